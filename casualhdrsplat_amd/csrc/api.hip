@@ -1,0 +1,210 @@
+// C ABI of libhdrsplat.so (see include/hdrsplat.h).  Host-side only: argument validation, workspace
+// carving and kernel sequencing.  Nothing here allocates device memory or synchronises.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "hs_common.h"
+
+namespace hs {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+int crf_partial_floats(int K);
+
+static int plan(const hs_dims& d, hs_sizes* sz, hs_layout* L) {
+    if (d.P < 0 || d.W <= 0 || d.H <= 0 || d.n_poses < 1 || d.capacity < 0 || d.M < 0) {
+        set_error("hs_plan: bad dims P=%d W=%d H=%d N=%d capacity=%lld", d.P, d.W, d.H, d.n_poses, (long long)d.capacity);
+        return HS_EINVAL;
+    }
+    const int64_t I = (int64_t)d.P * d.n_poses;
+    const int64_t gx = (d.W + kTile - 1) / kTile, gy = (d.H + kTile - 1) / kTile;
+    const int64_t vtiles = gx * gy * d.n_poses;
+    if (I >= (1ll << 31) || vtiles >= (1ll << 31) || d.capacity >= (1ll << 32)) {
+        set_error("hs_plan: problem too large for 32-bit instance / pair indices");
+        return HS_EINVAL;
+    }
+    const int64_t HW = (int64_t)d.W * d.H;
+    hs_layout l;
+    int64_t o = 0;
+    auto carve = [&o](int64_t bytes) { int64_t at = o; o = align_up(o + bytes, 256); return at; };
+    // geometry
+    l.counters = carve(sizeof(hs_counters));
+    l.rec = carve(I * kRecFloats * 4);
+    l.depth = carve(I * 4);
+    l.radii = carve(I * 4);
+    l.tiles_touched = carve(I * 4);
+    l.offsets = carve(I * 4);
+    l.cov3D = carve((int64_t)d.P * 6 * 4);
+    l.clamped = carve(I);
+    l.scan_spine = carve(((I + 1023) / 1024 + 1) * 4);
+    sz->geom_bytes = o;
+    // binning
+    o = 0;
+    l.keys_sorted = carve(d.capacity * 8);
+    l.point_list = carve(d.capacity * 4);
+    l.keys_unsorted = carve(d.capacity * 8);
+    l.vals_unsorted = carve(d.capacity * 4);
+    l.ranges = carve(vtiles * 8);
+    l.sort_tmp = carve(sort_tmp_bytes(d.capacity));
+    sz->binning_bytes = o;
+    // image
+    o = 0;
+    l.final_T = carve(HW * d.n_poses * 4);
+    l.n_contrib = carve(HW * d.n_poses * 4);
+    l.pose_hdr = carve(HW * 3 * 4 * (d.n_poses + (d.n_poses > 1 ? 1 : 0)));
+    sz->image_bytes = o;
+    // backward scratch
+    o = 0;
+    l.pair_grads = carve(d.capacity * kPairFloats * 4);
+    l.crf_partials = carve((int64_t)crf_partial_floats(4096) * 4);
+    sz->bwd_bytes = o;
+    if (L) *L = l;
+    return HS_OK;
+}
+
+static int check_common(const hs_dims& d, const float* means3D, const float* shs, const float* colors,
+                        const float* scales, const float* rots, const float* cov, const float* view,
+                        const float* proj, const float* campos, const float* bg, const char* who) {
+    if (!means3D || !view || !proj || !campos || !bg) { set_error("%s: null required pointer", who); return HS_EINVAL; }
+    if ((shs == nullptr) == (colors == nullptr)) { set_error("%s: provide exactly one of shs / colors_precomp", who); return HS_EINVAL; }
+    const bool sr = scales && rots;
+    if (sr == (cov != nullptr) || ((scales == nullptr) != (rots == nullptr))) {
+        set_error("%s: provide exactly one of (scales, rotations) / cov3D_precomp", who);
+        return HS_EINVAL;
+    }
+    if (shs) {
+        if (d.sh_degree < 0 || d.sh_degree > 3 || (d.sh_degree + 1) * (d.sh_degree + 1) > d.M) {
+            set_error("%s: sh_degree %d needs %d coefficients, M=%d", who, d.sh_degree, (d.sh_degree + 1) * (d.sh_degree + 1), d.M);
+            return HS_EINVAL;
+        }
+    }
+    if (rots && ((uintptr_t)rots & 15)) { set_error("%s: rotations must be 16-byte aligned", who); return HS_EINVAL; }
+    return HS_OK;
+}
+
+}  // namespace hs
+
+using namespace hs;
+
+extern "C" {
+
+int hs_version(void) { return HS_VERSION; }
+
+const char* hs_last_error(void) { return g_err; }
+
+int hs_plan(const hs_dims* dims, hs_sizes* sizes, hs_layout* layout) {
+    if (!dims || !sizes) { set_error("hs_plan: null argument"); return HS_EINVAL; }
+    return plan(*dims, sizes, layout);
+}
+
+int hs_forward(const hs_fwd_args* a, void* hip_stream) {
+    if (!a) { set_error("hs_forward: null args"); return HS_EINVAL; }
+    hipStream_t s = (hipStream_t)hip_stream;
+    hs_sizes sz; hs_layout L;
+    int rc = plan(a->dims, &sz, &L);
+    if (rc) return rc;
+    rc = check_common(a->dims, a->means3D, a->shs, a->colors_precomp, a->scales, a->rotations, a->cov3D_precomp,
+                      a->viewmatrices, a->projmatrices, a->camposes, a->bg, "hs_forward");
+    if (rc) return rc;
+    if (!a->opacities || !a->geom || !a->radii) { set_error("hs_forward: null opacities/geom/radii"); return HS_EINVAL; }
+    if ((a->flags & HS_FLAG_HDR) && (!a->exposure || !a->crf_table || a->crf_K < 2 || a->crf_K > 4096 || !(a->crf_umax > a->crf_umin))) {
+        set_error("hs_forward: HDR needs exposure, crf_table, 2 <= crf_K <= 4096 and umax > umin");
+        return HS_EINVAL;
+    }
+    if (((uintptr_t)a->geom & 255) || ((uintptr_t)a->binning & 255) || ((uintptr_t)a->image & 255)) {
+        set_error("hs_forward: workspaces must be 256-byte aligned");
+        return HS_EINVAL;
+    }
+    if (a->dims.P == 0) {
+        // nothing to rasterize: clear counters so the host sees R = 0, and paint the background
+        if (a->stages & HS_STAGE_PREPROCESS) HS_HIP_CHECK(hipMemsetAsync(a->geom, 0, sizeof(hs_counters), s));
+    }
+    if ((a->stages & HS_STAGE_PREPROCESS) && a->dims.P > 0) {
+        rc = launch_preprocess_fwd(*a, L, s);
+        if (rc) return rc;
+        rc = launch_scan(*a, L, s);
+        if (rc) return rc;
+    }
+    if (a->stages & HS_STAGE_BIN) {
+        if (!a->binning) { set_error("hs_forward: null binning workspace"); return HS_EINVAL; }
+        if (a->dims.P > 0) {
+            rc = launch_binning(*a, L, s);
+            if (rc) return rc;
+        } else {
+            const int64_t gx = (a->dims.W + kTile - 1) / kTile, gy = (a->dims.H + kTile - 1) / kTile;
+            HS_HIP_CHECK(hipMemsetAsync((char*)a->binning + L.ranges, 0, (size_t)(gx * gy * a->dims.n_poses * 8), s));
+        }
+    }
+    if (a->stages & HS_STAGE_RENDER) {
+        if (!a->binning || !a->image || !a->out_color) { set_error("hs_forward: null binning/image/out_color"); return HS_EINVAL; }
+        rc = launch_render_fwd(*a, L, s);
+        if (rc) return rc;
+    }
+    return HS_OK;
+}
+
+int hs_backward(const hs_bwd_args* a, void* hip_stream) {
+    if (!a) { set_error("hs_backward: null args"); return HS_EINVAL; }
+    hipStream_t s = (hipStream_t)hip_stream;
+    hs_sizes sz; hs_layout L;
+    int rc = plan(a->dims, &sz, &L);
+    if (rc) return rc;
+    rc = check_common(a->dims, a->means3D, a->shs, a->colors_precomp, a->scales, a->rotations, a->cov3D_precomp,
+                      a->viewmatrices, a->projmatrices, a->camposes, a->bg, "hs_backward");
+    if (rc) return rc;
+    if (!a->geom || !a->binning || !a->image || !a->bwd || !a->dL_dout_color) {
+        set_error("hs_backward: null workspace or dL_dout_color");
+        return HS_EINVAL;
+    }
+    if ((a->flags & HS_FLAG_HDR) && (!a->exposure || !a->crf_table || a->crf_K < 2 || a->crf_K > 4096)) {
+        set_error("hs_backward: HDR needs exposure and crf_table");
+        return HS_EINVAL;
+    }
+    if (a->dims.P == 0) return HS_OK;
+    rc = launch_render_bwd(*a, L, s);
+    if (rc) return rc;
+    return launch_preprocess_bwd(*a, L, s);
+}
+
+int hs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, uint8_t* visible, void* hip_stream) {
+    if (P < 0 || (P > 0 && (!means3D || !viewmatrix || !visible))) { set_error("hs_mark_visible: bad argument"); return HS_EINVAL; }
+    if (P == 0) return HS_OK;
+    return launch_mark_visible(P, means3D, viewmatrix, visible, (hipStream_t)hip_stream);
+}
+
+int64_t hs_sort_tmp_bytes(int64_t n) { return sort_tmp_bytes(n) + 256 + 2 * align_up(n * 8, 256) + 2 * align_up(n * 4, 256); }
+
+int hs_sort_pairs(const uint64_t* keys_in, const uint32_t* vals_in, uint64_t* keys_out, uint32_t* vals_out,
+                  int64_t n, int32_t nbits, void* tmp, void* hip_stream) {
+    if (n < 0 || nbits < 1 || nbits > 64 || (n > 0 && (!keys_in || !vals_in || !keys_out || !vals_out || !tmp))) {
+        set_error("hs_sort_pairs: bad argument");
+        return HS_EINVAL;
+    }
+    if (n == 0) return HS_OK;
+    hipStream_t s = (hipStream_t)hip_stream;
+    char* t = (char*)tmp;
+    uint32_t* n_dev = (uint32_t*)t; t += 256;
+    uint64_t* kb = (uint64_t*)t; t += align_up(n * 8, 256);
+    uint32_t* vb = (uint32_t*)t; t += align_up(n * 4, 256);
+    uint64_t* ka = (uint64_t*)t; t += align_up(n * 8, 256);
+    uint32_t* va = (uint32_t*)t; t += align_up(n * 4, 256);
+    HS_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)n_dev, (int)(uint32_t)n, 1, s));
+    HS_HIP_CHECK(hipMemcpyAsync(ka, keys_in, (size_t)n * 8, hipMemcpyDeviceToDevice, s));
+    HS_HIP_CHECK(hipMemcpyAsync(va, vals_in, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+    int rc = launch_radix_sort(ka, va, kb, vb, n_dev, n, nbits, t, s);
+    if (rc) return rc;
+    const bool in_a = sort_passes(nbits) % 2 == 0;
+    HS_HIP_CHECK(hipMemcpyAsync(keys_out, in_a ? ka : kb, (size_t)n * 8, hipMemcpyDeviceToDevice, s));
+    HS_HIP_CHECK(hipMemcpyAsync(vals_out, in_a ? va : vb, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+    return HS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,387 @@
+// Tile binning for gfx950: inclusive scan of tiles_touched (a5), duplicateWithKeys (a6),
+// stable LSD radix sort of (u64 key, u32 instance) pairs (a7) and tile ranges (a8).
+//
+// Rules: SURVEY.md 8(a).  All integer work -- results are bit-exact against oracle/hs_oracle.c.
+// The sort is a wave64 design: per 8-bit digit pass a 256-bin LDS histogram kernel, a 256-block
+// row scan, and a scatter kernel that ranks keys with 64-bit ballots (match-any over the digit
+// bits), reorders the 4096-key block through LDS and writes each digit's run contiguously.
+// Element counts are read from device memory (hs_counters.num_rendered) so the host never has
+// to know R to launch (grids are sized by capacity; surplus blocks exit on their first load).
+#include "hs_common.h"
+
+namespace hs {
+
+namespace {
+
+// ---------------------------------------------------------------- scan (a5)
+constexpr int kScanItems = 4;
+constexpr int kScanTile = 256 * kScanItems;
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(v, d);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// Block-wide inclusive scan of one value per thread (256 threads); returns the inclusive prefix and
+// the block total through *total.
+__device__ __forceinline__ uint32_t block_incl_scan(uint32_t v, uint32_t* s_wave /*[4]*/, uint32_t* total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = wave_incl_scan(v, lane);
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t add = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+        if (w < wave) add += s_wave[w];
+    *total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    __syncthreads();
+    return incl + add;
+}
+
+__global__ void __launch_bounds__(256) scan_reduce_kernel(const uint32_t* in, int64_t n, uint32_t* block_sums) {
+    __shared__ uint32_t s_wave[4];
+    const int64_t base = (int64_t)blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+    uint32_t v = 0;
+    if (base + kScanItems <= n) {
+        uint4 q = *reinterpret_cast<const uint4*>(in + base);
+        v = q.x + q.y + q.z + q.w;
+    } else {
+        for (int i = 0; i < kScanItems; ++i)
+            if (base + i < n) v += in[base + i];
+    }
+    uint32_t total;
+    block_incl_scan(v, s_wave, &total);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+// Single block: exclusive scan of block_sums in place; writes the grand total to *total_out.
+__global__ void __launch_bounds__(256) scan_spine_kernel(uint32_t* block_sums, int nblocks, uint32_t* total_out) {
+    __shared__ uint32_t s_wave[4];
+    uint32_t carry = 0;
+    for (int base = 0; base < nblocks; base += 256) {
+        int i = base + threadIdx.x;
+        uint32_t v = i < nblocks ? block_sums[i] : 0;
+        uint32_t total;
+        uint32_t incl = block_incl_scan(v, s_wave, &total);
+        if (i < nblocks) block_sums[i] = carry + incl - v;
+        carry += total;
+    }
+    if (threadIdx.x == 0) *total_out = carry;
+}
+
+__global__ void __launch_bounds__(256) scan_apply_kernel(const uint32_t* in, int64_t n, const uint32_t* block_sums,
+                                                         uint32_t* out) {
+    __shared__ uint32_t s_wave[4];
+    const int64_t base = (int64_t)blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+    uint32_t v[kScanItems];
+    uint32_t sum = 0;
+#pragma unroll
+    for (int i = 0; i < kScanItems; ++i) {
+        v[i] = base + i < n ? in[base + i] : 0;
+        sum += v[i];
+    }
+    uint32_t total;
+    uint32_t incl = block_incl_scan(sum, s_wave, &total);
+    uint32_t run = block_sums[blockIdx.x] + incl - sum;
+#pragma unroll
+    for (int i = 0; i < kScanItems; ++i) {
+        run += v[i];
+        if (base + i < n) out[base + i] = run;
+    }
+}
+
+// n_sort = R when it fits the binning capacity, else 0 (and the overflow flag is raised): every later
+// kernel of the forward reads n_sort, so an overflowing call degrades to an empty render instead of
+// writing out of bounds; the host sees counters.overflow and replays with a larger capacity.
+__global__ void bin_prepare_kernel(hs_counters* c, uint64_t capacity) {
+    const bool ok = (uint64_t)c->num_rendered <= capacity;
+    c->reserved[0] = ok ? c->num_rendered : 0u;
+    c->overflow = ok ? 0u : 1u;
+}
+
+// ---------------------------------------------------------------- duplicateWithKeys (a6)
+// One thread per instance.  The tile rectangle is recomputed from (pixel centre, radius) with exactly the
+// operations of preprocess (this TU is also built with -ffp-contract=off).
+__global__ void __launch_bounds__(256) duplicate_with_keys_kernel(int64_t I, int P, int W, int H, float4* rec,
+                                                                  const int* radii, const uint32_t* offsets,
+                                                                  uint64_t* keys, uint32_t* vals, uint64_t capacity,
+                                                                  hs_counters* counters) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= I) return;
+    if ((uint64_t)counters->num_rendered > capacity) return;  // overflow: bin_prepare_kernel flagged it
+    const int rad = radii[idx];
+    if (rad <= 0) return;
+    uint32_t off = idx == 0 ? 0u : offsets[idx - 1];
+    // start of this instance's pair slots: needed by render-backward to address its gradient records
+    reinterpret_cast<float*>(rec + 3 * idx + 2)[3] = __uint_as_float(off);
+    const float4 ra = rec[3 * idx];
+    const float depth = reinterpret_cast<const float*>(rec + 3 * idx + 2)[1];
+    const int gx = (W + kTile - 1) / kTile, gy = (H + kTile - 1) / kTile;
+    const int rminx = min(gx, max(0, (int)((ra.x - (float)rad) / (float)kTile)));
+    const int rminy = min(gy, max(0, (int)((ra.y - (float)rad) / (float)kTile)));
+    const int rmaxx = min(gx, max(0, (int)((ra.x + (float)rad + (float)(kTile - 1)) / (float)kTile)));
+    const int rmaxy = min(gy, max(0, (int)((ra.y + (float)rad + (float)(kTile - 1)) / (float)kTile)));
+    const uint32_t pose = (uint32_t)(idx / P);
+    const uint32_t tile_base = pose * (uint32_t)(gx * gy);
+    const uint64_t dbits = (uint64_t)__float_as_uint(depth);
+    for (int y = rminy; y < rmaxy; ++y)
+        for (int x = rminx; x < rmaxx; ++x) {
+            const uint64_t key = ((uint64_t)(tile_base + (uint32_t)(y * gx + x)) << 32) | dbits;
+            keys[off] = key;
+            vals[off] = (uint32_t)idx;
+            ++off;
+        }
+}
+
+// ---------------------------------------------------------------- radix sort (a7)
+__device__ __forceinline__ uint32_t digit_of(uint64_t k, int shift, uint32_t mask) {
+    return (uint32_t)(k >> shift) & mask;
+}
+
+// hist[digit * nblk + blk] = number of keys of block `blk` with that digit.
+__global__ void __launch_bounds__(kSortBlock) radix_hist_kernel(const uint64_t* keys, const uint32_t* n_dev, int shift,
+                                                                uint32_t mask, uint32_t* hist, int nblk) {
+    __shared__ uint32_t s_hist[256];
+    const int64_t n = *n_dev;
+    const int64_t base = (int64_t)blockIdx.x * kSortTile;
+    s_hist[threadIdx.x] = 0;
+    __syncthreads();
+    if (base < n) {
+#pragma unroll 4
+        for (int i = 0; i < kSortItems; ++i) {
+            const int64_t k = base + i * kSortBlock + threadIdx.x;
+            if (k < n) atomicAdd(&s_hist[digit_of(keys[k], shift, mask)], 1u);
+        }
+    }
+    __syncthreads();
+    hist[(int64_t)threadIdx.x * nblk + blockIdx.x] = s_hist[threadIdx.x];
+}
+
+// Digit totals (one block per digit), consumed by radix_scan_kernel.
+__global__ void __launch_bounds__(256) radix_totals_kernel(const uint32_t* hist, int nblk, uint32_t* totals) {
+    __shared__ uint32_t s_wave[4];
+    const int d = blockIdx.x;
+    const uint32_t* row = hist + (int64_t)d * nblk;
+    uint32_t acc = 0;
+    for (int i = threadIdx.x; i < nblk; i += 256) acc += row[i];
+    uint32_t total;
+    block_incl_scan(acc, s_wave, &total);
+    if (threadIdx.x == 0) totals[d] = total;
+}
+
+// One block per digit: exclusive scan of that digit's row over blocks, offset by the number of keys
+// with a smaller digit.
+__global__ void __launch_bounds__(256) radix_scan_kernel(uint32_t* hist, int nblk, const uint32_t* totals) {
+    __shared__ uint32_t s_wave[4];
+    const int d = blockIdx.x;
+    // exclusive prefix of digit totals below d
+    uint32_t mine = threadIdx.x < d ? totals[threadIdx.x] : 0;
+    uint32_t carry;
+    block_incl_scan(mine, s_wave, &carry);
+    uint32_t* row = hist + (int64_t)d * nblk;
+    for (int base = 0; base < nblk; base += 256) {
+        const int i = base + threadIdx.x;
+        const uint32_t v = i < nblk ? row[i] : 0;
+        uint32_t total;
+        const uint32_t incl = block_incl_scan(v, s_wave, &total);
+        if (i < nblk) row[i] = carry + incl - v;
+        carry += total;
+    }
+}
+
+// Scatter: stable within the block (wave w owns keys [w*1024, (w+1)*1024) of the block, processed in
+// 16 rounds of 64 consecutive keys), stable across blocks through the scanned histogram.
+__global__ void __launch_bounds__(kSortBlock) radix_scatter_kernel(const uint64_t* keys_in, const uint32_t* vals_in,
+                                                                   uint64_t* keys_out, uint32_t* vals_out,
+                                                                   const uint32_t* n_dev, int shift, uint32_t mask,
+                                                                   const uint32_t* hist, int nblk) {
+    __shared__ uint32_t s_cnt[4][256];    // per-wave digit counters -> per-wave exclusive offsets
+    __shared__ uint32_t s_dstart[256];    // block-local start of each digit's run
+    __shared__ uint32_t s_gbase[256];     // global start of this block's run of each digit
+    __shared__ uint64_t s_keys[kSortTile];
+    __shared__ uint32_t s_vals[kSortTile];
+
+    const int64_t n = *n_dev;
+    const int64_t base = (int64_t)blockIdx.x * kSortTile;
+    if (base >= n) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cnt_block = (int)min((int64_t)kSortTile, n - base);
+
+#pragma unroll
+    for (int w = 0; w < 4; ++w) s_cnt[w][threadIdx.x] = 0;
+    s_gbase[threadIdx.x] = hist[(int64_t)threadIdx.x * nblk + blockIdx.x];
+    __syncthreads();
+
+    uint64_t key[kSortItems];
+    uint32_t val[kSortItems];
+    uint16_t rank[kSortItems];
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    const int wbase = wave * (kSortTile / 4);
+#pragma unroll
+    for (int i = 0; i < kSortItems; ++i) {
+        const int loc = wbase + i * 64 + lane;
+        const bool valid = loc < cnt_block;
+        key[i] = valid ? keys_in[base + loc] : ~0ull;
+        val[i] = valid ? vals_in[base + loc] : 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < kSortItems; ++i) {
+        const int loc = wbase + i * 64 + lane;
+        const bool valid = loc < cnt_block;
+        const uint32_t d = digit_of(key[i], shift, mask);
+        // match-any: lanes holding the same digit
+        uint64_t peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const uint64_t m = __ballot((d >> b) & 1u);
+            peers &= ((d >> b) & 1u) ? m : ~m;
+        }
+        const uint32_t before = s_cnt[wave][d];
+        const uint32_t below = __popcll(peers & lt_mask);
+        rank[i] = (uint16_t)(before + below);
+        // the last peer publishes the new count (all peers read `before` first: same wave, in-order LDS)
+        if (valid && (peers >> lane) == 1ull) s_cnt[wave][d] = before + below + 1;
+    }
+    __syncthreads();
+    // per-digit: exclusive offsets over waves and the block-local run starts
+    {
+        const uint32_t c0 = s_cnt[0][threadIdx.x], c1 = s_cnt[1][threadIdx.x], c2 = s_cnt[2][threadIdx.x],
+                       c3 = s_cnt[3][threadIdx.x];
+        const uint32_t tot = c0 + c1 + c2 + c3;
+        s_cnt[0][threadIdx.x] = 0; s_cnt[1][threadIdx.x] = c0; s_cnt[2][threadIdx.x] = c0 + c1;
+        s_cnt[3][threadIdx.x] = c0 + c1 + c2;
+        __shared__ uint32_t s_wave[4];
+        uint32_t total;
+        const uint32_t incl = block_incl_scan(tot, s_wave, &total);
+        s_dstart[threadIdx.x] = incl - tot;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < kSortItems; ++i) {
+        const int loc = wbase + i * 64 + lane;
+        if (loc < cnt_block) {
+            const uint32_t d = digit_of(key[i], shift, mask);
+            const uint32_t pos = s_dstart[d] + s_cnt[wave][d] + rank[i];
+            s_keys[pos] = key[i];
+            s_vals[pos] = val[i];
+        }
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int i = 0; i < kSortItems; ++i) {
+        const int pos = i * kSortBlock + threadIdx.x;
+        if (pos < cnt_block) {
+            const uint64_t k = s_keys[pos];
+            const uint32_t d = digit_of(k, shift, mask);
+            const int64_t dst = (int64_t)s_gbase[d] + (pos - s_dstart[d]);
+            keys_out[dst] = k;
+            vals_out[dst] = s_vals[pos];
+        }
+    }
+}
+
+// ---------------------------------------------------------------- tile ranges (a8)
+__global__ void __launch_bounds__(256) tile_ranges_kernel(const uint64_t* keys, const uint32_t* n_dev, uint2* ranges) {
+    const int64_t n = *n_dev;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t t = (uint32_t)(keys[i] >> 32);
+    if (i == 0) ranges[t].x = 0;
+    else {
+        const uint32_t tp = (uint32_t)(keys[i - 1] >> 32);
+        if (t != tp) {
+            ranges[tp].y = (uint32_t)i;
+            ranges[t].x = (uint32_t)i;
+        }
+    }
+    if (i == n - 1) ranges[t].y = (uint32_t)n;
+}
+
+}  // namespace
+
+int64_t sort_tmp_bytes(int64_t n) {
+    const int64_t nblk = ceil_div(n > 0 ? n : 1, kSortTile);
+    return align_up(256 * nblk * 4, 256) + 256 * 4;
+}
+
+int launch_radix_sort(uint64_t* k0, uint32_t* v0, uint64_t* k1, uint32_t* v1, const uint32_t* n_dev,
+                      int64_t n_launch, int nbits, void* tmp, hipStream_t s) {
+    if (n_launch <= 0) return HS_OK;
+    const int nblk = ceil_div(n_launch, kSortTile);
+    uint32_t* hist = (uint32_t*)tmp;
+    uint32_t* totals = (uint32_t*)((char*)tmp + align_up(256 * (int64_t)nblk * 4, 256));
+    uint64_t* kin = k0; uint32_t* vin = v0; uint64_t* kout = k1; uint32_t* vout = v1;
+    for (int shift = 0; shift < nbits; shift += 8) {
+        const int w = nbits - shift < 8 ? nbits - shift : 8;
+        const uint32_t mask = (1u << w) - 1u;
+        radix_hist_kernel<<<nblk, kSortBlock, 0, s>>>(kin, n_dev, shift, mask, hist, nblk);
+        radix_totals_kernel<<<256, 256, 0, s>>>(hist, nblk, totals);
+        radix_scan_kernel<<<256, 256, 0, s>>>(hist, nblk, totals);
+        radix_scatter_kernel<<<nblk, kSortBlock, 0, s>>>(kin, vin, kout, vout, n_dev, shift, mask, hist, nblk);
+        HS_LAUNCH_CHECK();
+        uint64_t* tk = kin; kin = kout; kout = tk;
+        uint32_t* tv = vin; vin = vout; vout = tv;
+    }
+    return HS_OK;
+}
+
+int launch_scan(const hs_fwd_args& a, const hs_layout& L, hipStream_t s) {
+    const hs_dims& d = a.dims;
+    char* geom = (char*)a.geom;
+    const int64_t I = (int64_t)d.P * d.n_poses;
+    const int nblk = ceil_div(I, kScanTile);
+    const uint32_t* tiles = (const uint32_t*)(geom + L.tiles_touched);
+    uint32_t* offsets = (uint32_t*)(geom + L.offsets);
+    // the block-sum spine is carved from the geom workspace (binning may not be allocated yet)
+    uint32_t* spine = (uint32_t*)(geom + L.scan_spine);
+    hs_counters* counters = (hs_counters*)(geom + L.counters);
+    HS_HIP_CHECK(hipMemsetAsync(counters, 0, sizeof(hs_counters), s));
+    scan_reduce_kernel<<<nblk, 256, 0, s>>>(tiles, I, spine);
+    scan_spine_kernel<<<1, 256, 0, s>>>(spine, nblk, &counters->num_rendered);
+    scan_apply_kernel<<<nblk, 256, 0, s>>>(tiles, I, spine, offsets);
+    HS_LAUNCH_CHECK();
+    return HS_OK;
+}
+
+int launch_binning(const hs_fwd_args& a, const hs_layout& L, hipStream_t s) {
+    const hs_dims& d = a.dims;
+    char* geom = (char*)a.geom;
+    char* bin = (char*)a.binning;
+    const int64_t I = (int64_t)d.P * d.n_poses;
+    const int gx = (d.W + kTile - 1) / kTile, gy = (d.H + kTile - 1) / kTile;
+    const int64_t ntiles = (int64_t)gx * gy * d.n_poses;
+    const int nbits = 32 + tile_bits((uint32_t)ntiles);
+    const int passes = sort_passes(nbits);
+    hs_counters* counters = (hs_counters*)(geom + L.counters);
+    uint64_t* kA = (uint64_t*)(bin + L.keys_sorted);
+    uint32_t* vA = (uint32_t*)(bin + L.point_list);
+    uint64_t* kB = (uint64_t*)(bin + L.keys_unsorted);
+    uint32_t* vB = (uint32_t*)(bin + L.vals_unsorted);
+    // the sorted result must land in (kA, vA): start from A when the pass count is even
+    uint64_t* k0 = (passes % 2 == 0) ? kA : kB;
+    uint32_t* v0 = (passes % 2 == 0) ? vA : vB;
+    uint64_t* k1 = (passes % 2 == 0) ? kB : kA;
+    uint32_t* v1 = (passes % 2 == 0) ? vB : vA;
+    bin_prepare_kernel<<<1, 1, 0, s>>>(counters, (uint64_t)d.capacity);
+    duplicate_with_keys_kernel<<<ceil_div(I, 256), 256, 0, s>>>(
+        I, d.P, d.W, d.H, (float4*)(geom + L.rec), (const int*)(geom + L.radii), (const uint32_t*)(geom + L.offsets),
+        k0, v0, (uint64_t)d.capacity, counters);
+    HS_LAUNCH_CHECK();
+    void* tmp = bin + L.sort_tmp;
+    const uint32_t* n_sort = &counters->reserved[0];
+    int rc = launch_radix_sort(k0, v0, k1, v1, n_sort, d.capacity, nbits, tmp, s);
+    if (rc != HS_OK) return rc;
+    uint2* ranges = (uint2*)(bin + L.ranges);
+    HS_HIP_CHECK(hipMemsetAsync(ranges, 0, (size_t)ntiles * 8, s));
+    if (d.capacity > 0) {
+        tile_ranges_kernel<<<ceil_div(d.capacity, 256), 256, 0, s>>>(kA, n_sort, ranges);
+        HS_LAUNCH_CHECK();
+    }
+    return HS_OK;
+}
+
+}  // namespace hs

@@ -1,0 +1,67 @@
+// Internal declarations shared by the HIP translation units of libhdrsplat.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/hdrsplat.h"
+
+namespace hs {
+
+void set_error(const char* fmt, ...);
+
+#define HS_HIP_CHECK(expr)                                                                         \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            ::hs::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return HS_EHIP;                                                                        \
+        }                                                                                          \
+    } while (0)
+#define HS_LAUNCH_CHECK() HS_HIP_CHECK(hipGetLastError())
+
+constexpr int kTile = HS_TILE;
+constexpr int kRecFloats = 12;   // per-instance render record: 3 x float4
+constexpr int kPairFloats = 12;  // per-(tile,instance) gradient record: 9 used, padded to 3 x float4
+constexpr int kSortItems = 16;   // keys per thread per radix block
+constexpr int kSortBlock = 256;
+constexpr int kSortTile = kSortItems * kSortBlock;  // 4096 keys per block
+
+static inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// index of highest set bit + 1 (number of bits needed for values < n ... as upstream getHigherMsb)
+static inline int tile_bits(uint32_t n) {
+    int b = 0;
+    while (n) { ++b; n >>= 1; }
+    return b;
+}
+
+struct Views {
+    const float* view;  // [N,16]
+    const float* proj;  // [N,16]
+    const float* campos;  // [N,3]
+};
+
+// ---- launchers (each enqueues on `s`, returns HS_OK / HS_EHIP) ----
+int launch_preprocess_fwd(const hs_fwd_args& a, const hs_layout& L, hipStream_t s);
+int launch_scan(const hs_fwd_args& a, const hs_layout& L, hipStream_t s);
+int launch_binning(const hs_fwd_args& a, const hs_layout& L, hipStream_t s);
+int launch_render_fwd(const hs_fwd_args& a, const hs_layout& L, hipStream_t s);
+int launch_render_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s);
+int launch_preprocess_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s);
+int launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* vis, hipStream_t s);
+
+int64_t sort_tmp_bytes(int64_t n);
+// Sorts on bits [0,nbits); ping-pongs between (k0,v0) and (k1,v1); the result lands in (k0,v0) when the
+// number of 8-bit passes is even, else in (k1,v1) -- use sort_result_in_first().  `n_dev` points at the
+// device-resident element count (<= n_launch); hist must hold sort_tmp_bytes(n_launch).
+int launch_radix_sort(uint64_t* k0, uint32_t* v0, uint64_t* k1, uint32_t* v1, const uint32_t* n_dev,
+                      int64_t n_launch, int nbits, void* hist, hipStream_t s);
+static inline int sort_passes(int nbits) { return (nbits + 7) / 8; }
+
+// ---- small device helpers ----
+__device__ __forceinline__ float xform_row(const float* m, int i, float x, float y, float z) {
+    return ((m[i] * x + m[4 + i] * y) + m[8 + i] * z) + m[12 + i];
+}
+
+}  // namespace hs

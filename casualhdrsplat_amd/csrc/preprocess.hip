@@ -1,0 +1,524 @@
+// preprocess forward / backward and markVisible for gfx950.
+//
+// Rules: SURVEY.md 8(a) rows a4 (preprocess fwd), a11 (computeCov2D bwd), a12 (preprocess bwd),
+// a14 (markVisible).  No reference file exists to cite (/root/reference has no code).
+//
+// This translation unit is compiled with -ffp-contract=off: depth bits, pixel centre, conic,
+// radius and the tile rectangle feed integer decisions (sort keys, tile lists) that must be
+// bit-identical to the CPU oracle, so only IEEE + - * / sqrt ceil in a fixed order are used.
+// One thread per instance (pose, Gaussian); the kernels are pure streaming (HBM-bound on the SH
+// read/write), so loads are issued as wide as the [P,*] layouts allow.
+#include "hs_common.h"
+
+namespace hs {
+
+namespace {
+
+__device__ constexpr float SH_C0 = 0.28209479177387814f;
+__device__ constexpr float SH_C1 = 0.4886025119029199f;
+__device__ constexpr float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                       -1.0925484305920792f, 0.5462742152960396f};
+__device__ constexpr float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                       0.3731763325901154f,  -0.4570457994644658f, 1.445305721320277f,
+                                       -0.5900435899266435f};
+
+struct Ewa {
+    float tx, ty, tz;
+    bool clamp_x, clamp_y;
+    float a0[3], a1[3];
+    float fx, fy;
+};
+
+__device__ __forceinline__ void quat_to_R(const float* q, float* R) {
+    float r = q[0], x = q[1], y = q[2], z = q[3];
+    R[0] = 1.f - 2.f * (y * y + z * z); R[1] = 2.f * (x * y - r * z);       R[2] = 2.f * (x * z + r * y);
+    R[3] = 2.f * (x * y + r * z);       R[4] = 1.f - 2.f * (x * x + z * z); R[5] = 2.f * (y * z - r * x);
+    R[6] = 2.f * (x * z - r * y);       R[7] = 2.f * (y * z + r * x);       R[8] = 1.f - 2.f * (x * x + y * y);
+}
+
+// Sigma = R diag((mod*s)^2) R^T, upper triangle (xx,xy,xz,yy,yz,zz).
+__device__ __forceinline__ void cov3d_from_scale_rot(const float* scale, float mod, const float* q, float* c6) {
+    float R[9], M[9];
+    quat_to_R(q, R);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float s = mod * scale[k];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) M[3 * k + i] = s * R[3 * i + k];
+    }
+#define HS_SIG(i, j) ((M[0 + i] * M[0 + j] + M[3 + i] * M[3 + j]) + M[6 + i] * M[6 + j])
+    c6[0] = HS_SIG(0, 0); c6[1] = HS_SIG(0, 1); c6[2] = HS_SIG(0, 2);
+    c6[3] = HS_SIG(1, 1); c6[4] = HS_SIG(1, 2); c6[5] = HS_SIG(2, 2);
+#undef HS_SIG
+}
+
+__device__ __forceinline__ void ewa_setup(const float* V, int W, int H, float tanfovx, float tanfovy, float pvx,
+                                          float pvy, float pvz, Ewa& e) {
+    float fx = (float)W / (2.f * tanfovx);
+    float fy = (float)H / (2.f * tanfovy);
+    float limx = 1.3f * tanfovx, limy = 1.3f * tanfovy;
+    float txtz = pvx / pvz, tytz = pvy / pvz;
+    e.clamp_x = (txtz < -limx) || (txtz > limx);
+    e.clamp_y = (tytz < -limy) || (tytz > limy);
+    float tx = fminf(limx, fmaxf(-limx, txtz)) * pvz;
+    float ty = fminf(limy, fmaxf(-limy, tytz)) * pvz;
+    float tz = pvz;
+    float J00 = fx / tz, J02 = -(fx * tx) / (tz * tz);
+    float J11 = fy / tz, J12 = -(fy * ty) / (tz * tz);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        e.a0[j] = J00 * V[4 * j + 0] + J02 * V[4 * j + 2];
+        e.a1[j] = J11 * V[4 * j + 1] + J12 * V[4 * j + 2];
+    }
+    e.tx = tx; e.ty = ty; e.tz = tz; e.fx = fx; e.fy = fy;
+}
+
+__device__ __forceinline__ void sym_mul(const float* s6, const float* v, float* out) {
+    out[0] = (s6[0] * v[0] + s6[1] * v[1]) + s6[2] * v[2];
+    out[1] = (s6[1] * v[0] + s6[3] * v[1]) + s6[4] * v[2];
+    out[2] = (s6[2] * v[0] + s6[4] * v[1]) + s6[5] * v[2];
+}
+__device__ __forceinline__ float dot3(const float* a, const float* b) {
+    return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2];
+}
+
+template <int DEG>
+__device__ __forceinline__ void sh_basis(float x, float y, float z, float* b) {
+    b[0] = SH_C0;
+    if constexpr (DEG >= 1) {
+        b[1] = -SH_C1 * y; b[2] = SH_C1 * z; b[3] = -SH_C1 * x;
+    }
+    if constexpr (DEG >= 2) {
+        float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+        b[4] = SH_C2[0] * xy; b[5] = SH_C2[1] * yz; b[6] = SH_C2[2] * (2.f * zz - xx - yy);
+        b[7] = SH_C2[3] * xz; b[8] = SH_C2[4] * (xx - yy);
+        if constexpr (DEG >= 3) {
+            b[9] = SH_C3[0] * y * (3.f * xx - yy);
+            b[10] = SH_C3[1] * xy * z;
+            b[11] = SH_C3[2] * y * (4.f * zz - xx - yy);
+            b[12] = SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy);
+            b[13] = SH_C3[4] * x * (4.f * zz - xx - yy);
+            b[14] = SH_C3[5] * z * (xx - yy);
+            b[15] = SH_C3[6] * x * (xx - 3.f * yy);
+        }
+    }
+}
+
+// d b[k] / d(x,y,z), components treated as independent.
+template <int DEG>
+__device__ __forceinline__ void sh_basis_grad(float x, float y, float z, float (*g)[3]) {
+#pragma unroll
+    for (int k = 0; k < (DEG + 1) * (DEG + 1); ++k) g[k][0] = g[k][1] = g[k][2] = 0.f;
+    if constexpr (DEG >= 1) {
+        g[1][1] = -SH_C1; g[2][2] = SH_C1; g[3][0] = -SH_C1;
+    }
+    if constexpr (DEG >= 2) {
+        float xx = x * x, yy = y * y, zz = z * z;
+        g[4][0] = SH_C2[0] * y; g[4][1] = SH_C2[0] * x;
+        g[5][1] = SH_C2[1] * z; g[5][2] = SH_C2[1] * y;
+        g[6][0] = SH_C2[2] * -2.f * x; g[6][1] = SH_C2[2] * -2.f * y; g[6][2] = SH_C2[2] * 4.f * z;
+        g[7][0] = SH_C2[3] * z; g[7][2] = SH_C2[3] * x;
+        g[8][0] = SH_C2[4] * 2.f * x; g[8][1] = SH_C2[4] * -2.f * y;
+        if constexpr (DEG >= 3) {
+            g[9][0] = SH_C3[0] * 6.f * x * y; g[9][1] = SH_C3[0] * (3.f * xx - 3.f * yy);
+            g[10][0] = SH_C3[1] * y * z; g[10][1] = SH_C3[1] * x * z; g[10][2] = SH_C3[1] * x * y;
+            g[11][0] = SH_C3[2] * -2.f * x * y; g[11][1] = SH_C3[2] * (4.f * zz - xx - 3.f * yy);
+            g[11][2] = SH_C3[2] * 8.f * y * z;
+            g[12][0] = SH_C3[3] * -6.f * x * z; g[12][1] = SH_C3[3] * -6.f * y * z;
+            g[12][2] = SH_C3[3] * (6.f * zz - 3.f * xx - 3.f * yy);
+            g[13][0] = SH_C3[4] * (4.f * zz - 3.f * xx - yy); g[13][1] = SH_C3[4] * -2.f * x * y;
+            g[13][2] = SH_C3[4] * 8.f * x * z;
+            g[14][0] = SH_C3[5] * 2.f * x * z; g[14][1] = SH_C3[5] * -2.f * y * z; g[14][2] = SH_C3[5] * (xx - yy);
+            g[15][0] = SH_C3[6] * (3.f * xx - 3.f * yy); g[15][1] = SH_C3[6] * -6.f * x * y;
+        }
+    }
+}
+
+struct PreFwd {
+    int P, M, W, H, N;
+    float tanfovx, tanfovy, mod;
+    const float* view; const float* proj; const float* campos;
+    const float* means; const float* opac; const float* shs; const float* colors; const float* scales;
+    const float* rots; const float* cov_pre;
+    float4* rec; float* depth; int* radii_inst; uint32_t* tiles; float* cov3D; uint8_t* clamped;
+    int* radii_out;
+};
+
+// a4.  instance = pose * P + g.
+template <int DEG>
+__global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreFwd p) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)p.P * p.N) return;
+    const int pose = (int)(idx / p.P);
+    const int g = (int)(idx - (int64_t)pose * p.P);
+    const float* V = p.view + 16 * pose;
+    const float* PM = p.proj + 16 * pose;
+
+    int my_radius = 0;
+    uint32_t ntiles = 0;
+    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, rc = ra;
+    float depth = 0.f;
+    uint8_t clampbits = 0;
+
+    const float x = p.means[3 * g], y = p.means[3 * g + 1], z = p.means[3 * g + 2];
+    const float pvx = xform_row(V, 0, x, y, z), pvy = xform_row(V, 1, x, y, z), pvz = xform_row(V, 2, x, y, z);
+
+    float s6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (pose == 0 || pvz > 0.2f) {
+        if (p.cov_pre) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) s6[k] = p.cov_pre[6 * g + k];
+        } else {
+            float sc[3] = {p.scales[3 * g], p.scales[3 * g + 1], p.scales[3 * g + 2]};
+            float4 q4 = reinterpret_cast<const float4*>(p.rots)[g];
+            float q[4] = {q4.x, q4.y, q4.z, q4.w};
+            cov3d_from_scale_rot(sc, p.mod, q, s6);
+        }
+        if (pose == 0) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) p.cov3D[6 * (int64_t)g + k] = s6[k];
+        }
+    }
+
+    if (pvz > 0.2f) {
+        const float phx = xform_row(PM, 0, x, y, z), phy = xform_row(PM, 1, x, y, z), phw = xform_row(PM, 3, x, y, z);
+        const float pw = 1.0f / (phw + 0.0000001f);
+        const float ppx = phx * pw, ppy = phy * pw;
+
+        Ewa e;
+        ewa_setup(V, p.W, p.H, p.tanfovx, p.tanfovy, pvx, pvy, pvz, e);
+        float u0[3], u1[3];
+        sym_mul(s6, e.a0, u0);
+        sym_mul(s6, e.a1, u1);
+        const float ca = dot3(e.a0, u0) + 0.3f;
+        const float cb = dot3(e.a1, u0);
+        const float cc = dot3(e.a1, u1) + 0.3f;
+        const float det = ca * cc - cb * cb;
+        if (det != 0.0f) {
+            const float det_inv = 1.f / det;
+            const float conA = cc * det_inv, conB = -cb * det_inv, conC = ca * det_inv;
+            const float mid = 0.5f * (ca + cc);
+            const float disc = sqrtf(fmaxf(0.1f, mid * mid - det));
+            const float lam1 = mid + disc, lam2 = mid - disc;
+            const int rad = (int)ceilf(3.f * sqrtf(fmaxf(lam1, lam2)));
+            const float pix_x = ((ppx + 1.0f) * (float)p.W - 1.0f) * 0.5f;
+            const float pix_y = ((ppy + 1.0f) * (float)p.H - 1.0f) * 0.5f;
+            const int gx = (p.W + kTile - 1) / kTile, gy = (p.H + kTile - 1) / kTile;
+            const int rminx = min(gx, max(0, (int)((pix_x - (float)rad) / (float)kTile)));
+            const int rminy = min(gy, max(0, (int)((pix_y - (float)rad) / (float)kTile)));
+            const int rmaxx = min(gx, max(0, (int)((pix_x + (float)rad + (float)(kTile - 1)) / (float)kTile)));
+            const int rmaxy = min(gy, max(0, (int)((pix_y + (float)rad + (float)(kTile - 1)) / (float)kTile)));
+            const int area = (rmaxx - rminx) * (rmaxy - rminy);
+            if (area != 0) {
+                float col[3];
+                if (p.colors) {
+                    col[0] = p.colors[3 * g]; col[1] = p.colors[3 * g + 1]; col[2] = p.colors[3 * g + 2];
+                } else {
+                    const float* cp = p.campos + 3 * pose;
+                    const float dx = x - cp[0], dy = y - cp[1], dz = z - cp[2];
+                    const float len = sqrtf((dx * dx + dy * dy) + dz * dz);
+                    const float ux = dx / len, uy = dy / len, uz = dz / len;
+                    float b[(DEG + 1) * (DEG + 1)];
+                    sh_basis<DEG>(ux, uy, uz, b);
+                    const float* sh = p.shs + (int64_t)g * p.M * 3;
+                    float acc[3] = {b[0] * sh[0], b[0] * sh[1], b[0] * sh[2]};
+#pragma unroll
+                    for (int k = 1; k < (DEG + 1) * (DEG + 1); ++k) {
+                        acc[0] = acc[0] + b[k] * sh[3 * k + 0];
+                        acc[1] = acc[1] + b[k] * sh[3 * k + 1];
+                        acc[2] = acc[2] + b[k] * sh[3 * k + 2];
+                    }
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) {
+                        float v = acc[ch] + 0.5f;
+                        if (v < 0.f) clampbits |= (uint8_t)(1u << ch);
+                        col[ch] = fmaxf(v, 0.f);
+                    }
+                }
+                my_radius = rad;
+                ntiles = (uint32_t)area;
+                depth = pvz;
+                ra = make_float4(pix_x, pix_y, conA, conB);
+                rb = make_float4(conC, p.opac[g], col[0], col[1]);
+                rc = make_float4(col[2], pvz, __int_as_float(rad), 0.f);
+            }
+        }
+    }
+    p.rec[3 * idx + 0] = ra;
+    p.rec[3 * idx + 1] = rb;
+    p.rec[3 * idx + 2] = rc;
+    p.depth[idx] = depth;
+    p.radii_inst[idx] = my_radius;
+    p.tiles[idx] = ntiles;
+    p.clamped[idx] = clampbits;
+    if (p.N == 1) p.radii_out[g] = my_radius;
+    else if (my_radius > 0) atomicMax(p.radii_out + g, my_radius);
+}
+
+__global__ void mark_visible_kernel(int P, const float* means, const float* V, uint8_t* vis) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    vis[i] = xform_row(V, 2, means[3 * i], means[3 * i + 1], means[3 * i + 2]) > 0.2f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// a11 + a12 + the per-Gaussian segmented sum of the render-backward pair records.
+// One thread per Gaussian, looping over poses; sums are formed in a fixed order (pair slots
+// ascending, poses ascending) so the gradients are bitwise reproducible run to run.
+// ------------------------------------------------------------------------------------------------
+struct PreBwd {
+    int P, M, W, H, N;
+    float tanfovx, tanfovy, mod;
+    const float* view; const float* proj; const float* campos;
+    const float* means; const float* shs; const float* scales; const float* rots;
+    bool has_colors_precomp, has_cov_pre;
+    const float4* rec; const int* radii_inst; const uint32_t* tiles; const uint32_t* offsets; const float* cov3D;
+    const uint8_t* clamped;
+    const float4* pair_grads;
+    float* d_means3D; float* d_means2D; float* d_opac; float* d_shs; float* d_colors; float* d_scales;
+    float* d_rots; float* d_cov;
+};
+
+template <int DEG>
+__global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreBwd p) {
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= p.P) return;
+    constexpr int NC = (DEG + 1) * (DEG + 1);
+    const float x = p.means[3 * g], y = p.means[3 * g + 1], z = p.means[3 * g + 2];
+
+    float gm[3] = {0.f, 0.f, 0.f};
+    float gcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float gm2d[2] = {0.f, 0.f};
+    float gop = 0.f;
+    float gcol_pre[3] = {0.f, 0.f, 0.f};
+    float gsh[NC * 3];
+#pragma unroll
+    for (int k = 0; k < NC * 3; ++k) gsh[k] = 0.f;
+
+    float s6[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) s6[k] = p.cov3D[6 * (int64_t)g + k];
+
+    for (int pose = 0; pose < p.N; ++pose) {
+        const int64_t idx = (int64_t)pose * p.P + g;
+        if (p.radii_inst[idx] <= 0) continue;
+        // ---- segmented sum of this instance's (tile, instance) records ----
+        const uint32_t n = p.tiles[idx];
+        const uint32_t end = p.offsets[idx];
+        const uint32_t beg = end - n;
+        float r[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (uint32_t s = beg; s < end; ++s) {
+            const float4 q0 = p.pair_grads[3 * (int64_t)s + 0];
+            const float4 q1 = p.pair_grads[3 * (int64_t)s + 1];
+            const float4 q2 = p.pair_grads[3 * (int64_t)s + 2];
+            r[0] += q0.x; r[1] += q0.y; r[2] += q0.z; r[3] += q0.w;
+            r[4] += q1.x; r[5] += q1.y; r[6] += q1.z; r[7] += q1.w;
+            r[8] += q2.x;
+        }
+        // r = {dmean2D.x, dmean2D.y, dconic A, B, C, dopacity, dcolor r,g,b}
+        gm2d[0] += r[0]; gm2d[1] += r[1];
+        gop += r[5];
+
+        const float* V = p.view + 16 * pose;
+        const float* PM = p.proj + 16 * pose;
+        const float pvx = xform_row(V, 0, x, y, z), pvy = xform_row(V, 1, x, y, z), pvz = xform_row(V, 2, x, y, z);
+        Ewa e;
+        ewa_setup(V, p.W, p.H, p.tanfovx, p.tanfovy, pvx, pvy, pvz, e);
+        float u0[3], u1[3];
+        sym_mul(s6, e.a0, u0);
+        sym_mul(s6, e.a1, u1);
+        const float a = dot3(e.a0, u0) + 0.3f, b = dot3(e.a1, u0), cc = dot3(e.a1, u1) + 0.3f;
+        const float denom = a * cc - b * b;
+        const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+        const float gA = r[2], gB = r[3], gC = r[4];
+        if (denom2inv != 0.f) {
+            const float dLda = denom2inv * (-cc * cc * gA + b * cc * gB + (denom - a * cc) * gC);
+            const float dLdc = denom2inv * (-a * a * gC + a * b * gB + (denom - a * cc) * gA);
+            const float dLdb = denom2inv * (2.f * b * cc * gA - (denom + 2.f * b * b) * gB + 2.f * a * b * gC);
+            const float* pp = e.a0; const float* qq = e.a1;
+            gcov[0] += pp[0] * pp[0] * dLda + pp[0] * qq[0] * dLdb + qq[0] * qq[0] * dLdc;
+            gcov[3] += pp[1] * pp[1] * dLda + pp[1] * qq[1] * dLdb + qq[1] * qq[1] * dLdc;
+            gcov[5] += pp[2] * pp[2] * dLda + pp[2] * qq[2] * dLdb + qq[2] * qq[2] * dLdc;
+            gcov[1] += 2.f * pp[0] * pp[1] * dLda + (pp[0] * qq[1] + pp[1] * qq[0]) * dLdb + 2.f * qq[0] * qq[1] * dLdc;
+            gcov[2] += 2.f * pp[0] * pp[2] * dLda + (pp[0] * qq[2] + pp[2] * qq[0]) * dLdb + 2.f * qq[0] * qq[2] * dLdc;
+            gcov[4] += 2.f * pp[1] * pp[2] * dLda + (pp[1] * qq[2] + pp[2] * qq[1]) * dLdb + 2.f * qq[1] * qq[2] * dLdc;
+            float dJ00 = 0.f, dJ02 = 0.f, dJ11 = 0.f, dJ12 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const float ga0 = 2.f * dLda * u0[j] + dLdb * u1[j];
+                const float ga1 = 2.f * dLdc * u1[j] + dLdb * u0[j];
+                dJ00 += ga0 * V[4 * j + 0]; dJ02 += ga0 * V[4 * j + 2];
+                dJ11 += ga1 * V[4 * j + 1]; dJ12 += ga1 * V[4 * j + 2];
+            }
+            const float tz = 1.f / e.tz, tz2 = tz * tz, tz3 = tz2 * tz;
+            const float dtx = e.clamp_x ? 0.f : -e.fx * tz2 * dJ02;
+            const float dty = e.clamp_y ? 0.f : -e.fy * tz2 * dJ12;
+            const float dtz = -e.fx * tz2 * dJ00 - e.fy * tz2 * dJ11 + (2.f * e.fx * e.tx) * tz3 * dJ02 +
+                              (2.f * e.fy * e.ty) * tz3 * dJ12;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) gm[j] += V[4 * j + 0] * dtx + V[4 * j + 1] * dty + V[4 * j + 2] * dtz;
+        }
+        {
+            const float phx = xform_row(PM, 0, x, y, z), phy = xform_row(PM, 1, x, y, z),
+                        phw = xform_row(PM, 3, x, y, z);
+            const float mw = 1.0f / (phw + 0.0000001f);
+            const float mul1 = phx * mw * mw, mul2 = phy * mw * mw;
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                gm[j] += (PM[4 * j + 0] * mw - PM[4 * j + 3] * mul1) * r[0] +
+                         (PM[4 * j + 1] * mw - PM[4 * j + 3] * mul2) * r[1];
+        }
+        if (!p.has_colors_precomp) {
+            const float* cp = p.campos + 3 * pose;
+            const float dx = x - cp[0], dy = y - cp[1], dz = z - cp[2];
+            const float len = sqrtf((dx * dx + dy * dy) + dz * dz);
+            const float ux = dx / len, uy = dy / len, uz = dz / len;
+            float bs[NC];
+            sh_basis<DEG>(ux, uy, uz, bs);
+            const uint8_t cl = p.clamped[idx];
+            float gc[3];
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) gc[ch] = ((cl >> ch) & 1) ? 0.f : r[6 + ch];
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                gsh[3 * k + 0] += bs[k] * gc[0];
+                gsh[3 * k + 1] += bs[k] * gc[1];
+                gsh[3 * k + 2] += bs[k] * gc[2];
+            }
+            if constexpr (DEG >= 1) {
+                float gb[NC][3];
+                sh_basis_grad<DEG>(ux, uy, uz, gb);
+                const float* sh = p.shs + (int64_t)g * p.M * 3;
+                float gdir[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 1; k < NC; ++k) {
+                    const float w = (sh[3 * k] * gc[0] + sh[3 * k + 1] * gc[1]) + sh[3 * k + 2] * gc[2];
+                    gdir[0] += gb[k][0] * w; gdir[1] += gb[k][1] * w; gdir[2] += gb[k][2] * w;
+                }
+                const float dd = (ux * gdir[0] + uy * gdir[1]) + uz * gdir[2];
+                const float inv = 1.f / len;
+                gm[0] += (gdir[0] - ux * dd) * inv;
+                gm[1] += (gdir[1] - uy * dd) * inv;
+                gm[2] += (gdir[2] - uz * dd) * inv;
+            }
+        } else {
+            gcol_pre[0] += r[6]; gcol_pre[1] += r[7]; gcol_pre[2] += r[8];
+        }
+    }
+
+    // ---- Sigma -> scale / rotation (pose independent, applied once to the pose-summed gradient) ----
+    if (!p.has_cov_pre) {
+        float R[9], Mx[9], s[3];
+        const float4 q4 = reinterpret_cast<const float4*>(p.rots)[g];
+        const float q[4] = {q4.x, q4.y, q4.z, q4.w};
+        quat_to_R(q, R);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            s[k] = p.mod * p.scales[3 * g + k];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) Mx[3 * k + j] = s[k] * R[3 * j + k];
+        }
+        const float G[9] = {gcov[0], 0.5f * gcov[1], 0.5f * gcov[2], 0.5f * gcov[1], gcov[3],
+                            0.5f * gcov[4], 0.5f * gcov[2], 0.5f * gcov[4], gcov[5]};
+        float dR[9], dsc[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float ds = 0.f;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const float dM = 2.f * ((Mx[3 * k + 0] * G[0 + j] + Mx[3 * k + 1] * G[3 + j]) + Mx[3 * k + 2] * G[6 + j]);
+                ds += dM * R[3 * j + k];
+                dR[3 * j + k] = s[k] * dM;
+            }
+            dsc[k] = p.mod * ds;
+        }
+        const float r = q[0], qx = q[1], qy = q[2], qz = q[3];
+        if (p.d_scales) { p.d_scales[3 * g] = dsc[0]; p.d_scales[3 * g + 1] = dsc[1]; p.d_scales[3 * g + 2] = dsc[2]; }
+        if (p.d_rots) {
+            float4 o;
+            o.x = 2.f * (-qz * dR[1] + qy * dR[2] + qz * dR[3] - qx * dR[5] - qy * dR[6] + qx * dR[7]);
+            o.y = 2.f * (qy * dR[1] + qz * dR[2] + qy * dR[3] - 2.f * qx * dR[4] - r * dR[5] + qz * dR[6] + r * dR[7] - 2.f * qx * dR[8]);
+            o.z = 2.f * (-2.f * qy * dR[0] + qx * dR[1] + r * dR[2] + qx * dR[3] + qz * dR[5] - r * dR[6] + qz * dR[7] - 2.f * qy * dR[8]);
+            o.w = 2.f * (-2.f * qz * dR[0] - r * dR[1] + qx * dR[2] + r * dR[3] - 2.f * qz * dR[4] + qy * dR[5] + qx * dR[6] + qy * dR[7]);
+            reinterpret_cast<float4*>(p.d_rots)[g] = o;
+        }
+    } else if (p.d_cov) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) p.d_cov[6 * (int64_t)g + k] = gcov[k];
+    }
+    if (p.d_means3D) { p.d_means3D[3 * g] = gm[0]; p.d_means3D[3 * g + 1] = gm[1]; p.d_means3D[3 * g + 2] = gm[2]; }
+    if (p.d_means2D) { p.d_means2D[3 * g] = gm2d[0]; p.d_means2D[3 * g + 1] = gm2d[1]; p.d_means2D[3 * g + 2] = 0.f; }
+    if (p.d_opac) p.d_opac[g] = gop;
+    if (p.has_colors_precomp) {
+        if (p.d_colors) { p.d_colors[3 * g] = gcol_pre[0]; p.d_colors[3 * g + 1] = gcol_pre[1]; p.d_colors[3 * g + 2] = gcol_pre[2]; }
+    } else if (p.d_shs) {
+        float* o = p.d_shs + (int64_t)g * p.M * 3;
+#pragma unroll
+        for (int k = 0; k < NC * 3; ++k) o[k] = gsh[k];
+        for (int k = NC * 3; k < p.M * 3; ++k) o[k] = 0.f;
+    }
+}
+
+}  // namespace
+
+int launch_preprocess_fwd(const hs_fwd_args& a, const hs_layout& L, hipStream_t s) {
+    const hs_dims& d = a.dims;
+    char* geom = (char*)a.geom;
+    PreFwd p;
+    p.P = d.P; p.M = d.M; p.W = d.W; p.H = d.H; p.N = d.n_poses;
+    p.tanfovx = a.tanfovx; p.tanfovy = a.tanfovy; p.mod = a.scale_modifier;
+    p.view = a.viewmatrices; p.proj = a.projmatrices; p.campos = a.camposes;
+    p.means = a.means3D; p.opac = a.opacities; p.shs = a.shs; p.colors = a.colors_precomp; p.scales = a.scales;
+    p.rots = a.rotations; p.cov_pre = a.cov3D_precomp;
+    p.rec = (float4*)(geom + L.rec); p.depth = (float*)(geom + L.depth); p.radii_inst = (int*)(geom + L.radii);
+    p.tiles = (uint32_t*)(geom + L.tiles_touched); p.cov3D = (float*)(geom + L.cov3D);
+    p.clamped = (uint8_t*)(geom + L.clamped); p.radii_out = a.radii;
+    if (d.n_poses > 1) HS_HIP_CHECK(hipMemsetAsync(a.radii, 0, sizeof(int) * (size_t)d.P, s));
+    const int64_t I = (int64_t)d.P * d.n_poses;
+    const int grid = ceil_div(I, 256);
+    const int deg = a.colors_precomp ? 0 : d.sh_degree;
+    switch (deg) {
+        case 0: preprocess_fwd_kernel<0><<<grid, 256, 0, s>>>(p); break;
+        case 1: preprocess_fwd_kernel<1><<<grid, 256, 0, s>>>(p); break;
+        case 2: preprocess_fwd_kernel<2><<<grid, 256, 0, s>>>(p); break;
+        default: preprocess_fwd_kernel<3><<<grid, 256, 0, s>>>(p); break;
+    }
+    HS_LAUNCH_CHECK();
+    return HS_OK;
+}
+
+int launch_preprocess_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s) {
+    const hs_dims& d = a.dims;
+    const char* geom = (const char*)a.geom;
+    PreBwd p;
+    p.P = d.P; p.M = d.M; p.W = d.W; p.H = d.H; p.N = d.n_poses;
+    p.tanfovx = a.tanfovx; p.tanfovy = a.tanfovy; p.mod = a.scale_modifier;
+    p.view = a.viewmatrices; p.proj = a.projmatrices; p.campos = a.camposes;
+    p.means = a.means3D; p.shs = a.shs; p.scales = a.scales; p.rots = a.rotations;
+    p.has_colors_precomp = a.colors_precomp != nullptr; p.has_cov_pre = a.cov3D_precomp != nullptr;
+    p.rec = (const float4*)(geom + L.rec); p.radii_inst = (const int*)(geom + L.radii);
+    p.tiles = (const uint32_t*)(geom + L.tiles_touched); p.offsets = (const uint32_t*)(geom + L.offsets);
+    p.cov3D = (const float*)(geom + L.cov3D); p.clamped = (const uint8_t*)(geom + L.clamped);
+    p.pair_grads = (const float4*)((const char*)a.bwd + L.pair_grads);
+    p.d_means3D = a.dL_dmeans3D; p.d_means2D = a.dL_dmeans2D; p.d_opac = a.dL_dopacities; p.d_shs = a.dL_dshs;
+    p.d_colors = a.dL_dcolors_precomp; p.d_scales = a.dL_dscales; p.d_rots = a.dL_drotations;
+    p.d_cov = a.dL_dcov3D_precomp;
+    const int grid = ceil_div(d.P, 256);
+    const int deg = a.colors_precomp ? 0 : d.sh_degree;
+    switch (deg) {
+        case 0: preprocess_bwd_kernel<0><<<grid, 256, 0, s>>>(p); break;
+        case 1: preprocess_bwd_kernel<1><<<grid, 256, 0, s>>>(p); break;
+        case 2: preprocess_bwd_kernel<2><<<grid, 256, 0, s>>>(p); break;
+        default: preprocess_bwd_kernel<3><<<grid, 256, 0, s>>>(p); break;
+    }
+    HS_LAUNCH_CHECK();
+    return HS_OK;
+}
+
+int launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* vis, hipStream_t s) {
+    mark_visible_kernel<<<ceil_div(P, 256), 256, 0, s>>>(P, means3D, view, vis);
+    HS_LAUNCH_CHECK();
+    return HS_OK;
+}
+
+}  // namespace hs

@@ -1,0 +1,340 @@
+"""GaussianRasterizationSettings / GaussianRasterizer -- the drop-in Python boundary.
+
+BASELINE.json's north_star fixes this API as the boundary ("drops in behind CasualHDRSplat's
+GaussianRasterizer / GaussianRasterizationSettings Python API").  /root/reference holds no code
+(SURVEY.md section 0), so names, argument meaning and error behaviour follow the published
+diff_gaussian_rasterization package that API belongs to:
+
+  * GaussianRasterizationSettings is a NamedTuple with the upstream field order; matrices are
+    passed transposed (row-vector convention) and `projmatrix` is the full view*proj.
+  * GaussianRasterizer(raster_settings).forward(means3D, means2D, opacities, shs=None,
+    colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None) -> (color, radii);
+    exactly one of shs/colors_precomp and one of (scales, rotations)/cov3D_precomp, else an
+    Exception with the upstream message.
+  * backward returns gradients for (means3D, means2D, sh, colors_precomp, opacities, scales,
+    rotations, cov3Ds_precomp); grad of means2D is the NDC-scaled screen-space gradient used by
+    densification.
+
+HDR extension (image-formation order from /root/reference/assets/pipeline.png:
+H --(exposure, shared CRF)--> I --(average over virtual poses)--> B; Readme.md:54): optional
+settings fields `exposure`, `crf_table`, `crf_range`, `viewmatrices/projmatrices/camposes`
+(N virtual poses) and `blur_domain`.  With `crf_table` set, forward returns (ldr, radii, hdr).
+
+All compute happens in libhdrsplat.so (hand-written HIP for gfx950) through the C ABI of
+include/hdrsplat.h; PyTorch only owns memory and streams.  There is no fallback path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import NamedTuple, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool = False
+    debug: bool = False
+    antialiasing: bool = False
+    # ---- HDR / motion-blur extension (all optional) ----
+    exposure: Optional[torch.Tensor] = None       # scalar tensor, exposure time
+    crf_table: Optional[torch.Tensor] = None      # [3,K] camera response on log-exposure knots
+    crf_range: tuple = (-6.0, 3.0)                # (u_min, u_max) spanned by the K knots
+    viewmatrices: Optional[torch.Tensor] = None   # [N,4,4] virtual poses inside the exposure window
+    projmatrices: Optional[torch.Tensor] = None   # [N,4,4]
+    camposes: Optional[torch.Tensor] = None       # [N,3]
+    blur_domain: str = "ldr"                      # "ldr" (figure) or "hdr"
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _f32c(t: Optional[torch.Tensor], dev) -> Optional[torch.Tensor]:
+    if t is None:
+        return None
+    t = t.detach()
+    if t.dtype != torch.float32 or t.device != dev or not t.is_contiguous():
+        t = t.to(device=dev, dtype=torch.float32).contiguous()
+    if t.data_ptr() % 16:
+        t = t.clone()
+    return t
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+class _State:
+    """Everything the backward needs that is not a differentiable input (upstream: geomBuffer,
+    binningBuffer, imgBuffer, num_rendered)."""
+    __slots__ = ("dims", "layout", "geom", "binning", "image", "num_rendered", "flags", "views", "projs",
+                 "camposes", "bg", "tanfovx", "tanfovy", "scale_modifier", "crf_K", "crf_range", "W", "H",
+                 "pending")
+
+
+class _Pending:
+    """Deferred overflow check for the sync-free (fixed capacity) mode."""
+    def __init__(self, host, event, capacity):
+        self.host, self.event, self.capacity = host, event, capacity
+
+    def check(self):
+        self.event.synchronize()
+        if int(self.host[1]) != 0:
+            raise RuntimeError(
+                f"binning capacity {self.capacity} < num_rendered {int(self.host[0])}: the frame was rendered "
+                "empty; re-run with a larger `capacity` (or capacity=None for the synchronous mode)")
+        return int(self.host[0])
+
+
+def _run_forward(settings: GaussianRasterizationSettings, means3D, opacities, shs, colors_precomp, scales,
+                 rotations, cov3D_precomp, exposure, crf_table, capacity: Optional[int]):
+    lib = L.load()
+    dev = means3D.device
+    if dev.type != "cuda":
+        raise RuntimeError("casualhdrsplat_amd rasterizes on an MI355X only: tensors must live on a cuda (HIP) device")
+    P = means3D.shape[0]
+    W, H = int(settings.image_width), int(settings.image_height)
+    if settings.viewmatrices is not None:
+        views = _f32c(settings.viewmatrices, dev).reshape(-1, 16)
+        projs = _f32c(settings.projmatrices, dev).reshape(-1, 16)
+        campos = _f32c(settings.camposes, dev).reshape(-1, 3)
+    else:
+        views = _f32c(settings.viewmatrix, dev).reshape(1, 16)
+        projs = _f32c(settings.projmatrix, dev).reshape(1, 16)
+        campos = _f32c(settings.campos, dev).reshape(1, 3)
+    N = views.shape[0]
+    if projs.shape[0] != N or campos.shape[0] != N:
+        raise ValueError("viewmatrices, projmatrices and camposes must have the same leading dimension")
+    bg = _f32c(settings.bg, dev).reshape(3)
+    M = shs.shape[1] if shs is not None else 0
+    hdr = crf_table is not None
+    flags = 0
+    if hdr:
+        flags |= L.HS_FLAG_HDR
+        if exposure is None:
+            exposure = torch.ones((), device=dev)
+        if settings.blur_domain == "hdr":
+            flags |= L.HS_FLAG_BLUR_HDR
+        elif settings.blur_domain != "ldr":
+            raise ValueError("blur_domain must be 'ldr' or 'hdr'")
+    if settings.debug:
+        flags |= L.HS_FLAG_DEBUG
+    exposure = None if exposure is None else _f32c(exposure, dev).reshape(1)
+    crf_table = _f32c(crf_table, dev)
+    crf_K = int(crf_table.shape[1]) if hdr else 0
+
+    sync_mode = capacity is None
+    dims, sizes, layout = L.plan(P, M, int(settings.sh_degree), W, H, N, 0 if sync_mode else int(capacity))
+    geom = torch.empty(max(int(sizes.geom_bytes), 256), dtype=torch.uint8, device=dev)
+    out_color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
+    out_hdr = torch.empty(3, H, W, dtype=torch.float32, device=dev) if hdr else None
+    radii = torch.empty(P, dtype=torch.int32, device=dev)
+
+    a = L.hs_fwd_args()
+    a.dims = dims
+    a.tanfovx, a.tanfovy, a.scale_modifier = float(settings.tanfovx), float(settings.tanfovy), float(settings.scale_modifier)
+    a.flags = flags
+    a.crf_K, a.crf_umin, a.crf_umax = crf_K, float(settings.crf_range[0]), float(settings.crf_range[1])
+    a.bg, a.viewmatrices, a.projmatrices, a.camposes = _ptr(bg), _ptr(views), _ptr(projs), _ptr(campos)
+    a.means3D, a.opacities, a.shs, a.colors_precomp = _ptr(means3D), _ptr(opacities), _ptr(shs), _ptr(colors_precomp)
+    a.scales, a.rotations, a.cov3D_precomp = _ptr(scales), _ptr(rotations), _ptr(cov3D_precomp)
+    a.exposure, a.crf_table = _ptr(exposure), _ptr(crf_table)
+    a.geom = geom.data_ptr()
+    a.out_color, a.out_hdr, a.radii = out_color.data_ptr(), _ptr(out_hdr), radii.data_ptr()
+
+    st = _State()
+    st.pending = None
+    stream = _stream()
+    if sync_mode:
+        # upstream semantics: one host read of num_rendered between the scan and the binning
+        a.stages = L.HS_STAGE_PREPROCESS
+        L.check(lib.hs_forward(C.byref(a), stream), "hs_forward[preprocess]")
+        R = int(geom[:4].view(torch.int32).item()) & 0xFFFFFFFF if P > 0 else 0
+        dims, sizes, layout = L.plan(P, M, int(settings.sh_degree), W, H, N, R)
+        a.dims = dims
+        a.stages = L.HS_STAGE_BIN | L.HS_STAGE_RENDER
+    else:
+        R = -1
+        a.stages = L.HS_STAGE_ALL
+    binning = torch.empty(max(int(sizes.binning_bytes), 256), dtype=torch.uint8, device=dev)
+    image = torch.empty(max(int(sizes.image_bytes), 256), dtype=torch.uint8, device=dev)
+    a.binning, a.image = binning.data_ptr(), image.data_ptr()
+    L.check(lib.hs_forward(C.byref(a), stream), "hs_forward")
+    if not sync_mode:
+        host = torch.empty(2, dtype=torch.int32).pin_memory()
+        host.copy_(geom[:8].view(torch.int32), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        st.pending = _Pending(host, ev, int(capacity))
+
+    st.dims, st.layout, st.geom, st.binning, st.image = dims, layout, geom, binning, image
+    st.num_rendered, st.flags, st.views, st.projs, st.camposes, st.bg = R, flags, views, projs, campos, bg
+    st.tanfovx, st.tanfovy, st.scale_modifier = a.tanfovx, a.tanfovy, a.scale_modifier
+    st.crf_K, st.crf_range, st.W, st.H = crf_K, (a.crf_umin, a.crf_umax), W, H
+    return out_color, out_hdr, radii, st, exposure, crf_table
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                exposure, crf_table, raster_settings, capacity):
+        dev = means3D.device
+        m3 = _f32c(means3D, dev)
+        op = _f32c(opacities, dev)
+        shs = _f32c(sh, dev) if sh is not None and sh.numel() else None
+        cp = _f32c(colors_precomp, dev) if colors_precomp is not None and colors_precomp.numel() else None
+        sc = _f32c(scales, dev) if scales is not None and scales.numel() else None
+        ro = _f32c(rotations, dev) if rotations is not None and rotations.numel() else None
+        cv = _f32c(cov3Ds_precomp, dev) if cov3Ds_precomp is not None and cov3Ds_precomp.numel() else None
+        color, hdr, radii, st, exp_t, crf_t = _run_forward(raster_settings, m3, op, shs, cp, sc, ro, cv, exposure,
+                                                           crf_table, capacity)
+        ctx.st = st
+        ctx.exp_shape = None if exposure is None else tuple(exposure.shape)
+        ctx.has = (shs is not None, cp is not None, sc is not None, cv is not None, exposure is not None,
+                   crf_table is not None)
+        ctx.save_for_backward(m3, op, shs, cp, sc, ro, cv, exp_t, crf_t)
+        ctx.mark_non_differentiable(radii)
+        if hdr is None:
+            return color, radii
+        return color, radii, hdr
+
+    @staticmethod
+    def backward(ctx, grad_color, grad_radii=None, grad_hdr=None):
+        lib = L.load()
+        st: _State = ctx.st
+        m3, op, shs, cp, sc, ro, cv, exp_t, crf_t = ctx.saved_tensors
+        dev = m3.device
+        if st.pending is not None:
+            st.num_rendered = st.pending.check()
+            st.pending = None
+        P, M = st.dims.P, st.dims.M
+        gcol = _f32c(grad_color, dev)
+        ghdr = _f32c(grad_hdr, dev) if grad_hdr is not None else None
+        _, sizes, _ = L.plan(P, M, st.dims.sh_degree, st.W, st.H, st.dims.n_poses, st.dims.capacity)
+        bwd = torch.empty(max(int(sizes.bwd_bytes), 256), dtype=torch.uint8, device=dev)
+
+        def z(*shape):
+            return torch.empty(*shape, dtype=torch.float32, device=dev)
+
+        d_means3D, d_means2D, d_op = z(P, 3), z(P, 3), z(P, 1)
+        d_shs = z(P, M, 3) if shs is not None else None
+        d_cp = z(P, 3) if cp is not None else None
+        d_sc = z(P, 3) if sc is not None else None
+        d_ro = z(P, 4) if ro is not None else None
+        d_cv = z(P, 6) if cv is not None else None
+        hdr = bool(st.flags & L.HS_FLAG_HDR)
+        d_exp = torch.zeros(1, dtype=torch.float32, device=dev) if hdr else None
+        d_tab = torch.zeros(3, st.crf_K, dtype=torch.float32, device=dev) if hdr else None
+
+        a = L.hs_bwd_args()
+        a.dims = st.dims
+        a.tanfovx, a.tanfovy, a.scale_modifier = st.tanfovx, st.tanfovy, st.scale_modifier
+        a.flags, a.crf_K, a.crf_umin, a.crf_umax = st.flags, st.crf_K, st.crf_range[0], st.crf_range[1]
+        a.bg, a.viewmatrices, a.projmatrices, a.camposes = _ptr(st.bg), _ptr(st.views), _ptr(st.projs), _ptr(st.camposes)
+        a.means3D, a.opacities, a.shs, a.colors_precomp = _ptr(m3), _ptr(op), _ptr(shs), _ptr(cp)
+        a.scales, a.rotations, a.cov3D_precomp = _ptr(sc), _ptr(ro), _ptr(cv)
+        a.exposure, a.crf_table = _ptr(exp_t), _ptr(crf_t)
+        a.geom, a.binning, a.image, a.bwd = st.geom.data_ptr(), st.binning.data_ptr(), st.image.data_ptr(), bwd.data_ptr()
+        a.dL_dout_color, a.dL_dout_hdr = _ptr(gcol), _ptr(ghdr)
+        a.dL_dmeans3D, a.dL_dmeans2D, a.dL_dopacities = _ptr(d_means3D), _ptr(d_means2D), _ptr(d_op)
+        a.dL_dshs, a.dL_dcolors_precomp, a.dL_dscales = _ptr(d_shs), _ptr(d_cp), _ptr(d_sc)
+        a.dL_drotations, a.dL_dcov3D_precomp = _ptr(d_ro), _ptr(d_cv)
+        a.dL_dexposure, a.dL_dcrf_table = _ptr(d_exp), _ptr(d_tab)
+        if P > 0:
+            L.check(lib.hs_backward(C.byref(a), _stream()), "hs_backward")
+        has_sh, has_cp, has_sc, has_cv, has_exp, has_crf = ctx.has
+        return (d_means3D, d_means2D, d_shs if has_sh else None, d_cp if has_cp else None, d_op,
+                d_sc if has_sc else None, d_ro if has_sc else None, d_cv if has_cv else None,
+                d_exp.reshape(ctx.exp_shape) if (hdr and has_exp) else None, d_tab if has_crf else None, None, None)
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                        raster_settings, capacity=None):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                     cov3Ds_precomp, raster_settings.exposure, raster_settings.crf_table,
+                                     raster_settings, capacity)
+
+
+class GaussianRasterizer(nn.Module):
+    """Drop-in for diff_gaussian_rasterization.GaussianRasterizer.
+
+    `capacity` (extension): None = upstream behaviour (one host read of num_rendered per forward);
+    an int = sync-free mode with a fixed binning capacity in (tile, Gaussian) pairs, overflow is
+    detected lazily (at backward / `last_num_rendered`) and raises.
+    """
+
+    def __init__(self, raster_settings: GaussianRasterizationSettings, capacity: Optional[int] = None):
+        super().__init__()
+        self.raster_settings = raster_settings
+        self.capacity = capacity
+
+    def markVisible(self, positions: torch.Tensor) -> torch.Tensor:
+        lib = L.load()
+        with torch.no_grad():
+            pos = _f32c(positions, positions.device)
+            view = _f32c(self.raster_settings.viewmatrix, positions.device)
+            vis = torch.empty(pos.shape[0], dtype=torch.uint8, device=positions.device)
+            L.check(lib.hs_mark_visible(pos.shape[0], pos.data_ptr(), view.data_ptr(), vis.data_ptr(), _stream()),
+                    "hs_mark_visible")
+        return vis.bool()
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        rs = self.raster_settings
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+        empty = torch.Tensor([])
+        shs = empty if shs is None else shs
+        colors_precomp = empty if colors_precomp is None else colors_precomp
+        scales = empty if scales is None else scales
+        rotations = empty if rotations is None else rotations
+        cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                                   cov3D_precomp, rs, self.capacity)
+
+
+def inspect_state(out_tensor: torch.Tensor) -> dict:
+    """Test/profiling helper: the intermediates of the forward that produced `out_tensor` (a tensor
+    returned by GaussianRasterizer.forward with grad enabled), as views into the state workspaces."""
+    fn = out_tensor.grad_fn
+    st: _State = fn.st
+    lay, d = st.layout, st.dims
+    I = d.P * d.n_poses
+    gx, gy = (d.W + L.HS_TILE - 1) // L.HS_TILE, (d.H + L.HS_TILE - 1) // L.HS_TILE
+    vt = gx * gy * d.n_poses
+    R = st.num_rendered if st.num_rendered >= 0 else st.pending.check()
+
+    def view(buf, off, count, dtype):
+        nbytes = count * torch.empty((), dtype=dtype).element_size()
+        return buf[off:off + nbytes].view(dtype)
+
+    rec = view(st.geom, lay.rec, I * 12, torch.float32).reshape(I, 12)
+    return dict(
+        num_rendered=R,
+        rec=rec, xy=rec[:, 0:2], conic_opacity=torch.stack([rec[:, 2], rec[:, 3], rec[:, 4], rec[:, 5]], 1),
+        rgb=rec[:, 6:9], depths=view(st.geom, lay.depth, I, torch.float32),
+        radii=view(st.geom, lay.radii, I, torch.int32), tiles_touched=view(st.geom, lay.tiles_touched, I, torch.int32),
+        offsets=view(st.geom, lay.offsets, I, torch.int32), cov3D=view(st.geom, lay.cov3D, d.P * 6, torch.float32).reshape(d.P, 6),
+        clamped=view(st.geom, lay.clamped, I, torch.uint8),
+        keys_sorted=view(st.binning, lay.keys_sorted, R, torch.int64),
+        point_list=view(st.binning, lay.point_list, R, torch.int32),
+        ranges=view(st.binning, lay.ranges, vt * 2, torch.int32).reshape(vt, 2),
+        final_T=view(st.image, lay.final_T, d.n_poses * d.W * d.H, torch.float32).reshape(d.n_poses, d.H, d.W),
+        n_contrib=view(st.image, lay.n_contrib, d.n_poses * d.W * d.H, torch.int32).reshape(d.n_poses, d.H, d.W),
+    )

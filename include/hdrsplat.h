@@ -1,0 +1,179 @@
+/*
+ * hdrsplat.h -- C ABI of libhdrsplat.so, the MI355X (gfx950) differentiable Gaussian rasterizer.
+ *
+ * Boundary being replaced.  BASELINE.json's north_star fixes the drop-in boundary as the
+ * GaussianRasterizer / GaussianRasterizationSettings Python API.  /root/reference contains no
+ * code at all (Readme.md:1-58 + two figures), so there is no reference
+ * FFI file:line to cite.  The interface each entry point replaces is therefore the *published*
+ * binding of the third-party package that API belongs to (diff_gaussian_rasterization, not
+ * vendored/pinned by the reference -- SURVEY.md 2.3, 8b):
+ *
+ *   hs_forward       <-> _C.rasterize_gaussians           (pybind11, torch tensors)   [SURVEY 3.2]
+ *   hs_backward      <-> _C.rasterize_gaussians_backward                              [SURVEY 3.3]
+ *   hs_mark_visible  <-> _C.mark_visible                                              [SURVEY 2.3 a14]
+ *   hs_plan          <-> the resize-callback carving of geomBuffer/binningBuffer/imgBuffer [a13]
+ *
+ * Contract: plain C structs of raw DEVICE pointers and scalars; no torch types,
+ * no C++ exceptions across the ABI; the caller owns every byte (the library never allocates
+ * device memory and keeps no state between calls); all work is enqueued on the caller's HIP
+ * stream and nothing inside synchronises; return 0 = ok, negative = error, text through
+ * hs_last_error() (thread-local).
+ *
+ * "Instance" below means one (pose, Gaussian) pair: with n_poses = N the library renders N
+ * virtual sharp images in one launch (pose id folded into the tile sort key) and averages
+ * them (motion blur as N-pose render averaging, /root/reference/assets/pipeline.png "+").
+ */
+#ifndef HDRSPLAT_H
+#define HDRSPLAT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HS_VERSION 100
+
+#define HS_OK 0
+#define HS_EINVAL (-1)    /* bad argument (null pointer, bad shape, unsupported degree ...) */
+#define HS_EHIP (-2)      /* a HIP runtime call failed; see hs_last_error() */
+#define HS_EOVERFLOW (-3) /* binning capacity smaller than the number of (tile, instance) pairs */
+
+#define HS_TILE 16 /* binning tile edge in pixels (BLOCK_X = BLOCK_Y = 16 upstream) */
+
+/* hs_fwd_args.stages */
+#define HS_STAGE_PREPROCESS 1 /* preprocess + inclusive scan of tiles_touched; writes hs_counters */
+#define HS_STAGE_BIN 2        /* duplicateWithKeys + radix sort + tile ranges */
+#define HS_STAGE_RENDER 4     /* per-tile alpha blend (+ HDR epilogue, + N-pose resolve) */
+#define HS_STAGE_ALL 7
+
+/* flags */
+#define HS_FLAG_HDR 1          /* exposure * CRF tone-map epilogue; out_color = LDR, out_hdr = radiance */
+#define HS_FLAG_BLUR_HDR 2     /* N-pose average taken on radiance before the CRF (default: on LDR) */
+#define HS_FLAG_DEBUG 4
+
+typedef struct hs_dims {
+    int32_t P;         /* Gaussians */
+    int32_t M;         /* SH coefficients stored per Gaussian and channel (0 if colors_precomp) */
+    int32_t sh_degree; /* active degree, (sh_degree+1)^2 <= M */
+    int32_t W, H;
+    int32_t n_poses;   /* N >= 1 */
+    int64_t capacity;  /* binning capacity in (tile, instance) pairs */
+} hs_dims;
+
+typedef struct hs_sizes {
+    int64_t geom_bytes;    /* per-instance geometry state (a13 GeometryState) */
+    int64_t binning_bytes; /* keys/values double buffers, histograms, ranges (BinningState) */
+    int64_t image_bytes;   /* final_T, n_contrib, per-pose radiance (ImageState) */
+    int64_t bwd_bytes;     /* backward scratch: per-pair gradient records, CRF partials */
+} hs_sizes;
+
+/* First bytes of the geometry workspace; the host may read them after HS_STAGE_PREPROCESS. */
+typedef struct hs_counters {
+    uint32_t num_rendered; /* R = sum of tiles_touched over all instances */
+    uint32_t overflow;     /* set by HS_STAGE_BIN when R > capacity */
+    uint32_t reserved[6];  /* [0] = pairs actually binned (R, or 0 on overflow) */
+} hs_counters;
+
+typedef struct hs_fwd_args {
+    hs_dims dims;
+    float tanfovx, tanfovy, scale_modifier;
+    int32_t flags;
+    int32_t stages;
+    int32_t crf_K;               /* knots per channel of crf_table (HDR) */
+    float crf_umin, crf_umax;    /* log-exposure range spanned by the table */
+    /* device inputs */
+    const float* bg;             /* [3] */
+    const float* viewmatrices;   /* [N,16] flat "transposed": x' = m[0]x + m[4]y + m[8]z + m[12] */
+    const float* projmatrices;   /* [N,16] full view*proj, same convention */
+    const float* camposes;       /* [N,3] */
+    const float* means3D;        /* [P,3] */
+    const float* opacities;      /* [P] */
+    const float* shs;            /* [P,M,3] or NULL */
+    const float* colors_precomp; /* [P,3] or NULL */
+    const float* scales;         /* [P,3] or NULL */
+    const float* rotations;      /* [P,4] (w,x,y,z) or NULL */
+    const float* cov3D_precomp;  /* [P,6] or NULL */
+    const float* exposure;       /* [1] (HDR) or NULL */
+    const float* crf_table;      /* [3,crf_K] (HDR) or NULL */
+    /* caller-owned workspaces, sizes from hs_plan(), 256-byte aligned */
+    void* geom;
+    void* binning;
+    void* image;
+    /* device outputs */
+    float* out_color;            /* [3,H,W]; LDR when HS_FLAG_HDR */
+    float* out_hdr;              /* [3,H,W] linear radiance (HDR) or NULL */
+    int32_t* radii;              /* [P] max over poses */
+} hs_fwd_args;
+
+typedef struct hs_bwd_args {
+    hs_dims dims;
+    float tanfovx, tanfovy, scale_modifier;
+    int32_t flags;
+    int32_t crf_K;
+    float crf_umin, crf_umax;
+    const float* bg;
+    const float* viewmatrices;
+    const float* projmatrices;
+    const float* camposes;
+    const float* means3D;
+    const float* opacities;
+    const float* shs;
+    const float* colors_precomp;
+    const float* scales;
+    const float* rotations;
+    const float* cov3D_precomp;
+    const float* exposure;
+    const float* crf_table;
+    /* state produced by hs_forward (same buffers) */
+    const void* geom;
+    const void* binning;
+    const void* image;
+    void* bwd;                    /* scratch, hs_sizes.bwd_bytes */
+    /* upstream gradients */
+    const float* dL_dout_color;   /* [3,H,W] */
+    const float* dL_dout_hdr;     /* [3,H,W] or NULL */
+    /* outputs (each may be NULL when its input is absent) */
+    float* dL_dmeans3D;           /* [P,3] */
+    float* dL_dmeans2D;           /* [P,3] screen-space gradient (NDC-scaled), summed over poses */
+    float* dL_dopacities;         /* [P] */
+    float* dL_dshs;               /* [P,M,3] */
+    float* dL_dcolors_precomp;    /* [P,3] */
+    float* dL_dscales;            /* [P,3] */
+    float* dL_drotations;         /* [P,4] */
+    float* dL_dcov3D_precomp;     /* [P,6] */
+    float* dL_dexposure;          /* [1] (HDR) */
+    float* dL_dcrf_table;         /* [3,crf_K] (HDR) */
+} hs_bwd_args;
+
+/* Byte offsets of the arrays carved out of the three state workspaces, for tests, profilers and
+ * INTEGRATION.md-style bindings that want to inspect intermediates (keys, point_list, ranges...). */
+typedef struct hs_layout {
+    /* geom workspace; arrays are indexed by instance = pose * P + gaussian */
+    int64_t counters, rec, depth, radii, tiles_touched, offsets, cov3D, clamped, scan_spine;
+    /* binning workspace */
+    int64_t keys_sorted, point_list, keys_unsorted, vals_unsorted, ranges, sort_tmp;
+    /* image workspace */
+    int64_t final_T, n_contrib, pose_hdr;
+    /* bwd workspace */
+    int64_t pair_grads, crf_partials;
+} hs_layout;
+
+int hs_version(void);
+const char* hs_last_error(void);
+int hs_plan(const hs_dims* dims, hs_sizes* sizes, hs_layout* layout /* may be NULL */);
+int hs_forward(const hs_fwd_args* args, void* hip_stream);
+int hs_backward(const hs_bwd_args* args, void* hip_stream);
+int hs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, uint8_t* visible,
+                    void* hip_stream);
+
+/* Bench/test only: stable LSD radix sort of (u64 key, u32 value) pairs on bits [0, nbits), using the
+ * same kernels as HS_STAGE_BIN.  tmp must hold hs_sort_tmp_bytes(n).  Result in keys_out/vals_out. */
+int64_t hs_sort_tmp_bytes(int64_t n);
+int hs_sort_pairs(const uint64_t* keys_in, const uint32_t* vals_in, uint64_t* keys_out, uint32_t* vals_out,
+                  int64_t n, int32_t nbits, void* tmp, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HDRSPLAT_H */
