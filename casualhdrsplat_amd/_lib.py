@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("HS_LIB_PATH", os.path.join(_HERE, "libhdrsplat.so"))
 HS_OK, HS_EINVAL, HS_EHIP, HS_EOVERFLOW = 0, -1, -2, -3
 HS_STAGE_PREPROCESS, HS_STAGE_BIN, HS_STAGE_RENDER, HS_STAGE_ALL = 1, 2, 4, 7
 HS_FLAG_HDR, HS_FLAG_BLUR_HDR, HS_FLAG_DEBUG = 1, 2, 4
+HS_BWD_RENDER, HS_BWD_PREPROCESS, HS_BWD_ALL = 1, 2, 3
 HS_TILE = 16
 
 _fp = C.c_void_p  # device pointers travel as plain addresses
@@ -52,7 +53,8 @@ class hs_bwd_args(C.Structure):
     _fields_ = [
         ("dims", hs_dims),
         ("tanfovx", C.c_float), ("tanfovy", C.c_float), ("scale_modifier", C.c_float),
-        ("flags", C.c_int32), ("crf_K", C.c_int32), ("crf_umin", C.c_float), ("crf_umax", C.c_float),
+        ("flags", C.c_int32), ("stages", C.c_int32), ("crf_K", C.c_int32), ("crf_umin", C.c_float),
+        ("crf_umax", C.c_float),
         ("bg", _fp), ("viewmatrices", _fp), ("projmatrices", _fp), ("camposes", _fp),
         ("means3D", _fp), ("opacities", _fp), ("shs", _fp), ("colors_precomp", _fp), ("scales", _fp),
         ("rotations", _fp), ("cov3D_precomp", _fp), ("exposure", _fp), ("crf_table", _fp),

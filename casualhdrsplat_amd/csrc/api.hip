@@ -111,10 +111,13 @@ int hs_forward(const hs_fwd_args* a, void* hip_stream) {
     hs_sizes sz; hs_layout L;
     int rc = plan(a->dims, &sz, &L);
     if (rc) return rc;
-    rc = check_common(a->dims, a->means3D, a->shs, a->colors_precomp, a->scales, a->rotations, a->cov3D_precomp,
-                      a->viewmatrices, a->projmatrices, a->camposes, a->bg, "hs_forward");
-    if (rc) return rc;
-    if (!a->opacities || !a->geom || !a->radii) { set_error("hs_forward: null opacities/geom/radii"); return HS_EINVAL; }
+    if (a->dims.P > 0) {  // an empty cloud has no arrays to validate: it renders the background
+        rc = check_common(a->dims, a->means3D, a->shs, a->colors_precomp, a->scales, a->rotations, a->cov3D_precomp,
+                          a->viewmatrices, a->projmatrices, a->camposes, a->bg, "hs_forward");
+        if (rc) return rc;
+        if (!a->opacities || !a->radii) { set_error("hs_forward: null opacities/radii"); return HS_EINVAL; }
+    }
+    if (!a->geom || !a->bg) { set_error("hs_forward: null geom/bg"); return HS_EINVAL; }
     if ((a->flags & HS_FLAG_HDR) && (!a->exposure || !a->crf_table || a->crf_K < 2 || a->crf_K > 4096 || !(a->crf_umax > a->crf_umin))) {
         set_error("hs_forward: HDR needs exposure, crf_table, 2 <= crf_K <= 4096 and umax > umin");
         return HS_EINVAL;
@@ -169,9 +172,15 @@ int hs_backward(const hs_bwd_args* a, void* hip_stream) {
         return HS_EINVAL;
     }
     if (a->dims.P == 0) return HS_OK;
-    rc = launch_render_bwd(*a, L, s);
-    if (rc) return rc;
-    return launch_preprocess_bwd(*a, L, s);
+    if (a->stages & HS_BWD_RENDER) {
+        rc = launch_render_bwd(*a, L, s);
+        if (rc) return rc;
+    }
+    if (a->stages & HS_BWD_PREPROCESS) {
+        rc = launch_preprocess_bwd(*a, L, s);
+        if (rc) return rc;
+    }
+    return HS_OK;
 }
 
 int hs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, uint8_t* visible, void* hip_stream) {

@@ -1,7 +1,7 @@
 // Tile binning for gfx950: inclusive scan of tiles_touched (a5), duplicateWithKeys (a6),
 // stable LSD radix sort of (u64 key, u32 instance) pairs (a7) and tile ranges (a8).
 //
-// Rules: SURVEY.md 8(a).  All integer work -- results are bit-exact against oracle/hs_oracle.c.
+// Rules: SURVEY.md 8(a).  All integer work -- results are bit-exact against the CPU restatement under oracle/.
 // The sort is a wave64 design: per 8-bit digit pass a 256-bin LDS histogram kernel, a 256-block
 // row scan, and a scatter kernel that ranks keys with 64-bit ballots (match-any over the digit
 // bits), reorders the 4096-key block through LDS and writes each digit's run contiguously.

@@ -82,7 +82,7 @@ class _State:
     binningBuffer, imgBuffer, num_rendered)."""
     __slots__ = ("dims", "layout", "geom", "binning", "image", "num_rendered", "flags", "views", "projs",
                  "camposes", "bg", "tanfovx", "tanfovy", "scale_modifier", "crf_K", "crf_range", "W", "H",
-                 "pending")
+                 "pending", "fwd_args", "keep")
 
 
 class _Pending:
@@ -184,6 +184,9 @@ def _run_forward(settings: GaussianRasterizationSettings, means3D, opacities, sh
     st.num_rendered, st.flags, st.views, st.projs, st.camposes, st.bg = R, flags, views, projs, campos, bg
     st.tanfovx, st.tanfovy, st.scale_modifier = a.tanfovx, a.tanfovy, a.scale_modifier
     st.crf_K, st.crf_range, st.W, st.H = crf_K, (a.crf_umin, a.crf_umax), W, H
+    st.fwd_args = a
+    st.keep = (out_color, out_hdr, radii, exposure, crf_table, means3D, opacities, shs, colors_precomp, scales,
+               rotations, cov3D_precomp)
     return out_color, out_hdr, radii, st, exposure, crf_table
 
 
@@ -213,52 +216,97 @@ class _RasterizeGaussians(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_color, grad_radii=None, grad_hdr=None):
-        lib = L.load()
         st: _State = ctx.st
-        m3, op, shs, cp, sc, ro, cv, exp_t, crf_t = ctx.saved_tensors
-        dev = m3.device
-        if st.pending is not None:
-            st.num_rendered = st.pending.check()
-            st.pending = None
-        P, M = st.dims.P, st.dims.M
+        saved = ctx.saved_tensors
+        dev = saved[0].device
         gcol = _f32c(grad_color, dev)
         ghdr = _f32c(grad_hdr, dev) if grad_hdr is not None else None
-        _, sizes, _ = L.plan(P, M, st.dims.sh_degree, st.W, st.H, st.dims.n_poses, st.dims.capacity)
-        bwd = torch.empty(max(int(sizes.bwd_bytes), 256), dtype=torch.uint8, device=dev)
-
-        def z(*shape):
-            return torch.empty(*shape, dtype=torch.float32, device=dev)
-
-        d_means3D, d_means2D, d_op = z(P, 3), z(P, 3), z(P, 1)
-        d_shs = z(P, M, 3) if shs is not None else None
-        d_cp = z(P, 3) if cp is not None else None
-        d_sc = z(P, 3) if sc is not None else None
-        d_ro = z(P, 4) if ro is not None else None
-        d_cv = z(P, 6) if cv is not None else None
-        hdr = bool(st.flags & L.HS_FLAG_HDR)
-        d_exp = torch.zeros(1, dtype=torch.float32, device=dev) if hdr else None
-        d_tab = torch.zeros(3, st.crf_K, dtype=torch.float32, device=dev) if hdr else None
-
-        a = L.hs_bwd_args()
-        a.dims = st.dims
-        a.tanfovx, a.tanfovy, a.scale_modifier = st.tanfovx, st.tanfovy, st.scale_modifier
-        a.flags, a.crf_K, a.crf_umin, a.crf_umax = st.flags, st.crf_K, st.crf_range[0], st.crf_range[1]
-        a.bg, a.viewmatrices, a.projmatrices, a.camposes = _ptr(st.bg), _ptr(st.views), _ptr(st.projs), _ptr(st.camposes)
-        a.means3D, a.opacities, a.shs, a.colors_precomp = _ptr(m3), _ptr(op), _ptr(shs), _ptr(cp)
-        a.scales, a.rotations, a.cov3D_precomp = _ptr(sc), _ptr(ro), _ptr(cv)
-        a.exposure, a.crf_table = _ptr(exp_t), _ptr(crf_t)
-        a.geom, a.binning, a.image, a.bwd = st.geom.data_ptr(), st.binning.data_ptr(), st.image.data_ptr(), bwd.data_ptr()
-        a.dL_dout_color, a.dL_dout_hdr = _ptr(gcol), _ptr(ghdr)
-        a.dL_dmeans3D, a.dL_dmeans2D, a.dL_dopacities = _ptr(d_means3D), _ptr(d_means2D), _ptr(d_op)
-        a.dL_dshs, a.dL_dcolors_precomp, a.dL_dscales = _ptr(d_shs), _ptr(d_cp), _ptr(d_sc)
-        a.dL_drotations, a.dL_dcov3D_precomp = _ptr(d_ro), _ptr(d_cv)
-        a.dL_dexposure, a.dL_dcrf_table = _ptr(d_exp), _ptr(d_tab)
-        if P > 0:
-            L.check(lib.hs_backward(C.byref(a), _stream()), "hs_backward")
+        g = _launch_backward(st, saved, gcol, ghdr, L.HS_BWD_ALL)
+        if st.pending is not None:
+            # sync-free mode: the kernels are already queued; only now look at the forward's counters
+            st.num_rendered = st.pending.check()
+            st.pending = None
         has_sh, has_cp, has_sc, has_cv, has_exp, has_crf = ctx.has
-        return (d_means3D, d_means2D, d_shs if has_sh else None, d_cp if has_cp else None, d_op,
-                d_sc if has_sc else None, d_ro if has_sc else None, d_cv if has_cv else None,
-                d_exp.reshape(ctx.exp_shape) if (hdr and has_exp) else None, d_tab if has_crf else None, None, None)
+        hdr = bool(st.flags & L.HS_FLAG_HDR)
+        return (g["means3D"], g["means2D"], g["shs"] if has_sh else None, g["colors_precomp"] if has_cp else None,
+                g["opacities"], g["scales"] if has_sc else None, g["rotations"] if has_sc else None,
+                g["cov3D_precomp"] if has_cv else None,
+                g["exposure"].reshape(ctx.exp_shape) if (hdr and has_exp) else None,
+                g["crf_table"] if has_crf else None, None, None)
+
+
+def _launch_backward(st: "_State", saved, gcol, ghdr, stages: int) -> dict:
+    """Enqueue hs_backward.  All per-Gaussian gradients are carved out of ONE flat fp32 buffer (the
+    layout casualhdrsplat_amd.distributed all-reduces in a single RCCL call): [means3D | means2D |
+    opacities | sh | colors | scales | rotations | cov3D | exposure | crf_table]."""
+    lib = L.load()
+    m3, op, shs, cp, sc, ro, cv, exp_t, crf_t = saved
+    dev = m3.device
+    P, M = st.dims.P, st.dims.M
+    _, sizes, _ = L.plan(P, M, st.dims.sh_degree, st.W, st.H, st.dims.n_poses, st.dims.capacity)
+    bwd = torch.empty(max(int(sizes.bwd_bytes), 256), dtype=torch.uint8, device=dev)
+    hdr = bool(st.flags & L.HS_FLAG_HDR)
+    spec = [("means3D", (P, 3), True), ("means2D", (P, 3), True), ("opacities", (P, 1), True),
+            ("shs", (P, M, 3), shs is not None), ("colors_precomp", (P, 3), cp is not None),
+            ("scales", (P, 3), sc is not None), ("rotations", (P, 4), ro is not None),
+            ("cov3D_precomp", (P, 6), cv is not None), ("exposure", (1,), hdr), ("crf_table", (3, st.crf_K), hdr)]
+    total = 0
+    offs = {}
+    for name, shape, on in spec:
+        if on:
+            n = 1
+            for d in shape:
+                n *= d
+            offs[name] = (total, n, shape)
+            total += (n + 3) // 4 * 4  # keep every slice 16-byte aligned
+    flat = torch.empty(max(total, 4), dtype=torch.float32, device=dev)
+    g = {name: None for name, _, _ in spec}
+    for name, (o, n, shape) in offs.items():
+        g[name] = flat[o:o + n].view(shape)
+    if hdr:
+        g["exposure"].zero_()
+        g["crf_table"].zero_()
+    g["_flat"] = flat
+
+    a = L.hs_bwd_args()
+    a.dims = st.dims
+    a.tanfovx, a.tanfovy, a.scale_modifier = st.tanfovx, st.tanfovy, st.scale_modifier
+    a.flags, a.stages = st.flags, stages
+    a.crf_K, a.crf_umin, a.crf_umax = st.crf_K, st.crf_range[0], st.crf_range[1]
+    a.bg, a.viewmatrices, a.projmatrices, a.camposes = _ptr(st.bg), _ptr(st.views), _ptr(st.projs), _ptr(st.camposes)
+    a.means3D, a.opacities, a.shs, a.colors_precomp = _ptr(m3), _ptr(op), _ptr(shs), _ptr(cp)
+    a.scales, a.rotations, a.cov3D_precomp = _ptr(sc), _ptr(ro), _ptr(cv)
+    a.exposure, a.crf_table = _ptr(exp_t), _ptr(crf_t)
+    a.geom, a.binning, a.image, a.bwd = st.geom.data_ptr(), st.binning.data_ptr(), st.image.data_ptr(), bwd.data_ptr()
+    a.dL_dout_color, a.dL_dout_hdr = _ptr(gcol), _ptr(ghdr)
+    a.dL_dmeans3D, a.dL_dmeans2D, a.dL_dopacities = _ptr(g["means3D"]), _ptr(g["means2D"]), _ptr(g["opacities"])
+    a.dL_dshs, a.dL_dcolors_precomp, a.dL_dscales = _ptr(g["shs"]), _ptr(g["colors_precomp"]), _ptr(g["scales"])
+    a.dL_drotations, a.dL_dcov3D_precomp = _ptr(g["rotations"]), _ptr(g["cov3D_precomp"])
+    a.dL_dexposure, a.dL_dcrf_table = _ptr(g["exposure"]), _ptr(g["crf_table"])
+    if P > 0:
+        L.check(lib.hs_backward(C.byref(a), _stream()), "hs_backward")
+    else:
+        flat.zero_()
+    return g
+
+
+def replay_forward(out_tensor: torch.Tensor, stages: int = L.HS_STAGE_RENDER) -> None:
+    """Profiling helper: re-enqueue selected forward stages of the call that produced `out_tensor`
+    (same buffers, so the results are simply rewritten)."""
+    st: _State = out_tensor.grad_fn.st
+    a = st.fwd_args
+    a.stages = stages
+    L.check(L.load().hs_forward(C.byref(a), _stream()), "hs_forward[replay]")
+
+
+def replay_backward(out_tensor: torch.Tensor, grad_color: torch.Tensor, stages: int = L.HS_BWD_ALL,
+                    grad_hdr: Optional[torch.Tensor] = None) -> dict:
+    """Profiling helper (bench.py's per-kernel roofline leg): re-enqueue the selected half of the
+    backward of the forward call that produced `out_tensor`, outside autograd."""
+    fn = out_tensor.grad_fn
+    dev = out_tensor.device
+    return _launch_backward(fn.st, fn.saved_tensors, _f32c(grad_color, dev),
+                            None if grad_hdr is None else _f32c(grad_hdr, dev), stages)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,

@@ -47,6 +47,11 @@ extern "C" {
 #define HS_STAGE_RENDER 4     /* per-tile alpha blend (+ HDR epilogue, + N-pose resolve) */
 #define HS_STAGE_ALL 7
 
+/* hs_bwd_args.stages */
+#define HS_BWD_RENDER 1      /* per-pixel backward -> one gradient record per (tile, instance) pair */
+#define HS_BWD_PREPROCESS 2  /* per-instance record sum + computeCov2D/projection/SH/cov3D backward */
+#define HS_BWD_ALL 3
+
 /* flags */
 #define HS_FLAG_HDR 1          /* exposure * CRF tone-map epilogue; out_color = LDR, out_hdr = radiance */
 #define HS_FLAG_BLUR_HDR 2     /* N-pose average taken on radiance before the CRF (default: on LDR) */
@@ -110,6 +115,7 @@ typedef struct hs_bwd_args {
     hs_dims dims;
     float tanfovx, tanfovy, scale_modifier;
     int32_t flags;
+    int32_t stages;               /* HS_BWD_* bitmask; bench/profiling may run the two halves separately */
     int32_t crf_K;
     float crf_umin, crf_umax;
     const float* bg;

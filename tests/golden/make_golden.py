@@ -1,0 +1,82 @@
+"""Generates the committed golden fixtures (tests/golden/*.npz) with the CPU oracle.
+
+The reference ships no golden vectors (parity unpinned by the reference), so these
+are produced by this repo's own oracle (oracle/hs_oracle.c through oracle/c_oracle.py) after it has been
+pinned by tests/test_oracle_known_answers.py and tests/test_oracle_cross.py.  A fixture is data only:
+inputs, every integer intermediate, images and gradients for a fixed dL/dimage.
+
+    python tests/golden/make_golden.py        # rewrites tests/golden/*.npz
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import helpers as Hh  # noqa: E402
+from casualhdrsplat_amd import synthetic as S  # noqa: E402
+from oracle import c_oracle as O  # noqa: E402
+
+CASES = [
+    # name, P, W, H, deg, seed, hdr, n_poses, blur_domain
+    ("ldr_deg0_s0", 600, 96, 96, 0, 0, False, 1, "ldr"),
+    ("ldr_deg3_s1", 600, 96, 80, 3, 1, False, 1, "ldr"),
+    ("hdr_deg3_s2", 600, 96, 96, 3, 2, True, 1, "ldr"),
+    ("hdr_deg1_s3_n4_ldrblur", 400, 80, 64, 1, 3, True, 4, "ldr"),
+    ("hdr_deg1_s3_n4_hdrblur", 400, 80, 64, 1, 3, True, 4, "hdr"),
+]
+
+
+def scene_inputs(sc, cams):
+    d = dict(means3D=sc.means3D.numpy(), scales=sc.scales.numpy(), rotations=sc.rotations.numpy(),
+             opacities=sc.opacities.numpy(), shs=sc.shs.numpy(), bg=sc.bg.numpy(), dL_dimage=sc.dL_dimage.numpy(),
+             viewmatrices=np.stack([c.viewmatrix.numpy() for c in cams]),
+             projmatrices=np.stack([c.projmatrix.numpy() for c in cams]),
+             camposes=np.stack([c.campos.numpy() for c in cams]),
+             tanfov=np.array([sc.camera.tanfovx, sc.camera.tanfovy], np.float64))
+    if sc.crf_table is not None:
+        d.update(exposure=np.array(float(sc.exposure), np.float32), crf_table=sc.crf_table.numpy(),
+                 crf_range=np.array(sc.crf_range, np.float64))
+    return d
+
+
+def make(name, P, W, H, deg, seed, hdr, n_poses, dom):
+    sc = S.make_scene(P, W, H, deg, seed=seed, hdr=hdr)
+    cams = S.blur_poses(W, H, n_poses, step=0.02) if n_poses > 1 else [sc.camera]
+    out = scene_inputs(sc, cams)
+    out["meta"] = np.array([P, W, H, deg, seed, int(hdr), n_poses, int(dom == "hdr")], np.int64)
+    if not hdr:
+        f, b = Hh.run_oracle(O, sc)
+        for k in ("depths", "xy", "conic_opacity", "rgb", "radii", "tiles_touched", "offsets", "keys_sorted",
+                  "point_list", "ranges", "color", "final_T", "n_contrib"):
+            out["o_" + k] = f[k]
+        for _, k in Hh.GRAD_KEYS:
+            out["o_" + k] = b[k]
+    else:
+        r = Hh.run_oracle_hdr(O, sc, cams, dom)
+        out["o_color"], out["o_hdr"] = r["ldr"], r["hdr"]
+        out["o_point_list"] = np.concatenate([f["point_list"] + k * P for k, f in enumerate(r["fwd"])])
+        base, rr = 0, []
+        for f in r["fwd"]:  # the HIP path sorts all poses as one list: pose k's ranges are offset by sum R_<k
+            g = f["ranges"].astype(np.int64)
+            g[g[:, 1] > g[:, 0]] += base
+            rr.append(g)
+            base += f["R"]
+        out["o_ranges"] = np.concatenate(rr).astype(np.uint32)
+        out["o_num_rendered"] = np.array([f["R"] for f in r["fwd"]], np.int64)
+        out["o_n_contrib"] = np.stack([f["n_contrib"] for f in r["fwd"]])
+        for _, k in Hh.GRAD_KEYS:
+            out["o_" + k] = r[k]
+        out["o_dL_dcrf_table"], out["o_dL_dexposure"] = r["dL_dcrf_table"], np.array(r["dL_dexposure"], np.float64)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, {k: v.shape for k, v in out.items() if k.startswith("o_")})
+
+
+if __name__ == "__main__":
+    O.build()
+    for c in CASES:
+        make(*c)

@@ -122,3 +122,68 @@ def grad_floor(ref):
     ref = np.asarray(ref, np.float64)
     rms = float(np.sqrt((ref ** 2).mean())) if ref.size else 0.0
     return max(1e-3 * rms, 1e-30)
+
+
+def run_oracle_hdr(O, sc: S.Scene, cameras=None, blur_domain="ldr", dL_ldr=None, dL_hdr=None):
+    """HDR image formation with the C oracle: per pose H_k (a4..a9), tone-map (a15), average over poses;
+    backward chains tonemap_bwd into the rasterizer backward per pose and sums.  Returns dict of outputs
+    and gradients (numpy)."""
+    cams = cameras or [sc.camera]
+    N = len(cams)
+    dL_ldr = sc.dL_dimage.numpy() if dL_ldr is None else dL_ldr
+    dt = float(sc.exposure)
+    tab = sc.crf_table.numpy()
+    umin, umax = sc.crf_range
+    fs = [run_oracle(O, sc, cam=c, backward=False)[0] for c in cams]
+    Hs = [f["color"] for f in fs]
+    Hm = np.mean(np.stack(Hs), axis=0, dtype=np.float64).astype(np.float32)
+    if blur_domain == "ldr":
+        ldr = np.mean(np.stack([O.tonemap_fwd(h, dt, tab, umin, umax) for h in Hs]), axis=0, dtype=np.float64).astype(np.float32)
+    else:
+        ldr = O.tonemap_fwd(Hm, dt, tab, umin, umax)
+    out = {"ldr": ldr, "hdr": Hm, "fwd": fs}
+    gsum, dtab_sum, dexp_sum = None, np.zeros_like(tab, dtype=np.float64), 0.0
+    if blur_domain == "hdr":
+        dHm, dtab, dexp = O.tonemap_bwd(Hm, dt, tab, umin, umax, dL_ldr)
+        dtab_sum += dtab
+        dexp_sum += dexp
+    for k, c in enumerate(cams):
+        if blur_domain == "ldr":
+            dH, dtab, dexp = O.tonemap_bwd(Hs[k], dt, tab, umin, umax, dL_ldr / N)
+            dtab_sum += dtab
+            dexp_sum += dexp
+        else:
+            dH = dHm / N
+        if dL_hdr is not None:
+            dH = dH + dL_hdr / N
+        ocam = oracle_camera(O, sc, c)
+        b = O.backward(ocam, fs[k], dH.astype(np.float32), sc.means3D.numpy(), shs=sc.shs.numpy(),
+                       scales=sc.scales.numpy(), rotations=sc.rotations.numpy())
+        keys = ["dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dshs", "dL_dscales", "dL_drots"]
+        if gsum is None:
+            gsum = {q: b[q].astype(np.float64) for q in keys}
+        else:
+            for q in keys:
+                gsum[q] += b[q]
+    out.update({q: v.astype(np.float32) for q, v in gsum.items()})
+    out["dL_dcrf_table"] = dtab_sum.astype(np.float32)
+    out["dL_dexposure"] = float(dexp_sum)
+    return out
+
+
+GRAD_KEYS = [("means3D", "dL_dmeans3D"), ("means2D", "dL_dmeans2D"), ("opacities", "dL_dopacity"),
+             ("shs", "dL_dshs"), ("scales", "dL_dscales"), ("rotations", "dL_drots")]
+
+
+def assert_grads_close(got: dict, ref: dict, keys=GRAD_KEYS, frac_tol=1e-2, max_tol=5e-2, l2_tol=5e-5, what=""):
+    """Gradient parity: >= (1-frac_tol) of the elements within 1e-4 relative (floor 1e-3 * tensor RMS), the
+    fp32-ill-conditioned tail bounded by max_tol, and the whole tensor within l2_tol in relative L2."""
+    report = {}
+    for gk, rk in keys:
+        r = np.asarray(ref[rk])
+        g = np.asarray(got["d_" + gk]).reshape(r.shape)
+        mx, frac = rel_err(g, r, grad_floor(r))
+        l2 = float(np.linalg.norm(g.astype(np.float64) - r) / max(np.linalg.norm(r.astype(np.float64)), 1e-30))
+        report[gk] = (mx, frac, l2)
+        assert frac <= frac_tol and mx <= max_tol and l2 <= l2_tol, (what, gk, mx, frac, l2)
+    return report

@@ -1,0 +1,105 @@
+"""CPU-side checks of the C ABI: libhdrsplat.so builds, loads, and exports exactly what
+include/hdrsplat.h declares; hs_plan (pure host code) carves sane, aligned, non-overlapping
+workspaces; argument validation rejects bad calls before any HIP call is made."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "casualhdrsplat_amd", "csrc"), "-j4"])
+    from casualhdrsplat_amd import _lib
+    return _lib
+
+
+def header_functions():
+    txt = open(os.path.join(ROOT, "include", "hdrsplat.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(hs_[a-z_]+)\s*\(", txt)))
+
+
+def test_header_symbols_exported(lib):
+    names = header_functions()
+    assert set(names) == set(lib.EXPORTS)
+    dll = C.CDLL(lib.LIB_PATH)
+    for n in names:
+        assert hasattr(dll, n), n
+    out = subprocess.check_output(["nm", "-D", "--defined-only", lib.LIB_PATH]).decode()
+    for n in names:
+        assert re.search(rf"\bT {n}\b", out), n
+
+
+def test_struct_sizes_match_c(lib, tmp_path):
+    """ctypes mirrors must have the layout the C compiler gives include/hdrsplat.h."""
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include "hdrsplat.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n",'
+                   "sizeof(hs_dims),sizeof(hs_sizes),sizeof(hs_counters),sizeof(hs_fwd_args),sizeof(hs_bwd_args),"
+                   "sizeof(hs_layout));return 0;}\n")
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    want = [C.sizeof(t) for t in (lib.hs_dims, lib.hs_sizes, lib.hs_counters, lib.hs_fwd_args, lib.hs_bwd_args,
+                                  lib.hs_layout)]
+    assert got == want
+
+
+def test_version_and_plan(lib):
+    L = lib.load()
+    assert L.hs_version() == 100
+    d, sz, lay = lib.plan(1_000_000, 16, 3, 1920, 1080, 1, 7_000_000)
+    assert sz.geom_bytes > 1_000_000 * 48 and sz.binning_bytes > 7_000_000 * 24
+    assert sz.image_bytes >= 1920 * 1080 * (8 + 12) and sz.bwd_bytes >= 7_000_000 * 48
+    geom = [lay.counters, lay.rec, lay.depth, lay.radii, lay.tiles_touched, lay.offsets, lay.cov3D, lay.clamped,
+            lay.scan_spine]
+    assert geom == sorted(geom) and all(o % 256 == 0 for o in geom) and len(set(geom)) == len(geom)
+    binning = [lay.keys_sorted, lay.point_list, lay.keys_unsorted, lay.vals_unsorted, lay.ranges, lay.sort_tmp]
+    assert binning == sorted(binning) and all(o % 256 == 0 for o in binning)
+    # N poses scale the per-instance arrays
+    _, sz8, _ = lib.plan(1_000_000, 16, 3, 1920, 1080, 8, 7_000_000)
+    assert sz8.geom_bytes > 7 * sz.geom_bytes * 0.8 and sz8.image_bytes > 8 * 1920 * 1080 * 20
+
+
+def test_plan_rejects_bad_dims(lib):
+    L = lib.load()
+    d = lib.hs_dims(-1, 0, 0, 16, 16, 1, 0)
+    sz = lib.hs_sizes()
+    assert L.hs_plan(C.byref(d), C.byref(sz), None) == lib.HS_EINVAL
+    assert b"bad dims" in L.hs_last_error()
+    d = lib.hs_dims(10, 0, 0, 16, 16, 0, 0)
+    assert L.hs_plan(C.byref(d), C.byref(sz), None) == lib.HS_EINVAL
+    assert L.hs_plan(None, None, None) == lib.HS_EINVAL
+
+
+def test_forward_backward_validate_before_touching_the_gpu(lib):
+    L = lib.load()
+    assert L.hs_forward(None, None) == lib.HS_EINVAL
+    assert L.hs_backward(None, None) == lib.HS_EINVAL
+    a = lib.hs_fwd_args()
+    a.dims = lib.hs_dims(10, 1, 0, 32, 32, 1, 100)
+    assert L.hs_forward(C.byref(a), None) == lib.HS_EINVAL  # null pointers
+    assert b"null" in L.hs_last_error()
+    # both shs and colors_precomp present -> rejected (exactly-one-of rule of the reference API)
+    for f in ("means3D", "viewmatrices", "projmatrices", "camposes", "bg", "shs", "colors_precomp", "scales",
+              "rotations"):
+        setattr(a, f, 4096)
+    assert L.hs_forward(C.byref(a), None) == lib.HS_EINVAL
+    assert b"exactly one" in L.hs_last_error()
+    a.colors_precomp = None
+    a.dims.sh_degree = 3  # needs 16 coefficients, M = 1
+    assert L.hs_forward(C.byref(a), None) == lib.HS_EINVAL
+    assert b"sh_degree" in L.hs_last_error()
+    assert L.hs_mark_visible(-1, None, None, None, None) == lib.HS_EINVAL
+    assert L.hs_sort_pairs(None, None, None, None, 5, 40, None, None) == lib.HS_EINVAL
+
+
+def test_missing_library_is_a_hard_error(lib, monkeypatch):
+    monkeypatch.setattr(lib, "_lib", None)
+    monkeypatch.setattr(lib, "LIB_PATH", "/nonexistent/libhdrsplat.so")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        lib.load()

@@ -1,0 +1,88 @@
+"""The N>1 path on CPU: world_size-2 gloo.  Each rank holds the same Gaussians, renders its own view with
+the CPU oracle standing in for the MI355X kernels (the collective code is device-agnostic), packs the
+gradients the way rasterizer._launch_backward lays them out and all-reduces them with
+casualhdrsplat_amd.distributed; the result must equal the sum of the single-view gradients."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _view_grads(rank, world):
+    import helpers as Hh
+    from casualhdrsplat_amd import synthetic as S
+    from oracle import c_oracle as O
+    sc = S.make_scene(400, 96, 64, 1, seed=2)
+    cam = S.yaw_camera(96, 64, -5.0 + 10.0 * rank / max(world - 1, 1))
+    _, b = Hh.run_oracle(O, sc, cam=cam)
+    return [b["dL_dmeans3D"], b["dL_dmeans2D"], b["dL_dopacity"].reshape(-1, 1), b["dL_dshs"], b["dL_dscales"], b["dL_drots"]]
+
+
+def _worker(rank, world, port, shared_flat, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from casualhdrsplat_amd.distributed import all_reduce_gradients, init_from_env
+    r, w, _ = init_from_env("gloo")
+    assert (r, w) == (rank, world)
+    grads = [torch.from_numpy(g.copy()) for g in _view_grads(rank, world)]
+    params = []
+    if shared_flat:  # the rasterizer's layout: all gradients are views of one flat fp32 buffer
+        flat = torch.empty(sum((g.numel() + 3) // 4 * 4 for g in grads))
+        o = 0
+        for g in grads:
+            p = torch.zeros(g.shape, requires_grad=True)
+            flat[o:o + g.numel()] = g.reshape(-1)
+            p.grad = flat[o:o + g.numel()].view(g.shape)
+            o += (g.numel() + 3) // 4 * 4
+            params.append(p)
+    else:
+        for g in grads:
+            p = torch.zeros(g.shape, requires_grad=True)
+            p.grad = g
+            params.append(p)
+    n = all_reduce_gradients(params)
+    assert n >= sum(g.numel() for g in grads)
+    if rank == 0:
+        q.put([p.grad.numpy().copy() for p in params])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("shared_flat", [True, False])
+def test_allreduce_equals_sum_of_single_view_gradients(oracle, shared_flat):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, shared_flat, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    want = [sum(x) for x in zip(*[_view_grads(r, world) for r in range(world)])]
+    for g, w in zip(got, want):
+        assert np.allclose(g, w, rtol=1e-6, atol=1e-6 * np.abs(w).max())
+    assert np.abs(want[0]).max() > 0
+
+
+def test_single_process_is_a_noop():
+    from casualhdrsplat_amd.distributed import all_reduce_gradients
+    p = torch.zeros(3, requires_grad=True)
+    p.grad = torch.ones(3)
+    assert all_reduce_gradients([p]) == 0 and torch.equal(p.grad, torch.ones(3))

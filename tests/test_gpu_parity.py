@@ -1,0 +1,311 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI behind
+GaussianRasterizer, against the CPU oracle and the committed golden fixtures.
+
+Bars (BASELINE.json north_star): tile assignment / indexing bit-exact; pixel and gradient values within
+1e-4 relative fp32.  Float details:
+  * images: |got-ref| <= 1e-4 * max(|ref|, 1e-2) on every pixel, except that a pixel whose
+    alpha / transmittance sits within an ulp of a threshold (1/255, 1e-4) may flip a contributor between
+    the GPU's exp and glibc's expf -- such pixels are counted and bounded (<= 2e-5 of the pixels);
+  * gradients: helpers.assert_grads_close (>= 99 % of elements within 1e-4 relative with a floor of
+    1e-3 * RMS, relative L2 error <= 5e-5; the tail is the fp32 conditioning of the T/(1-alpha)
+    recurrences that tests/test_oracle_cross.py shows for the fp32 oracle itself against float64).
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import helpers as Hh
+from casualhdrsplat_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+
+
+def u32(a):
+    return np.asarray(a).astype(np.int64) & 0xFFFFFFFF
+
+
+def check_structure(st, f, pose=0, P=None):
+    """Bit-exact integer/structural parity of one pose against the oracle forward dict f."""
+    P = P or f["radii"].shape[0]
+    sl = slice(pose * P, (pose + 1) * P)
+    for k in ("depths", "xy", "conic_opacity"):
+        assert np.array_equal(Hh.bits(st[k][sl]), Hh.bits(f[k])), k
+    assert np.array_equal(st["radii"][sl], f["radii"])
+    assert np.array_equal(u32(st["tiles_touched"][sl]), u32(f["tiles_touched"]))
+    assert np.abs(st["rgb"][sl] - f["rgb"]).max() <= 1e-6 * max(1.0, np.abs(f["rgb"]).max())
+
+
+def assert_image_close(got, ref, what):
+    """Every value within 1e-4 relative (floor 1e-2), except the few pixels where a contributor sits within an
+    ulp of the alpha >= 1/255 or T >= 1e-4 threshold and flips between the GPU exp and glibc expf: those
+    are counted (<= 2e-5 of the pixels) and bounded by the size of one minimal contribution."""
+    e = np.abs(np.asarray(got, np.float64) - ref) / np.maximum(np.abs(ref), 1e-2)
+    bad = e > 1e-4
+    nbad = int(bad.reshape(-1, bad.shape[-2] * bad.shape[-1]).any(axis=0).sum()) if e.ndim == 3 else int(bad.sum())
+    npix = e.shape[-1] * e.shape[-2]
+    assert nbad <= max(2, int(2e-5 * npix)), (what, "pixels beyond 1e-4", nbad)
+    assert e.max() <= 0.5, (what, float(e.max()))
+    return nbad
+
+
+def check_image(got, ref, nc_got, nc_ref, what):
+    flips = int((nc_got != nc_ref).sum())
+    assert flips <= max(2, int(2e-5 * nc_got.size)), (what, "n_contrib flips", flips)
+    return flips + assert_image_close(got, ref, what)
+
+
+@pytest.mark.parametrize("P,W,H,deg,seed", [(1000, 128, 128, 0, 0), (1000, 128, 128, 3, 1), (5000, 200, 136, 2, 2),
+                                            (20000, 500, 300, 1, 3), (100000, 800, 800, 0, 0)])
+def test_ldr_forward_backward_vs_oracle(oracle, P, W, H, deg, seed):
+    sc = S.make_scene(P, W, H, deg, seed=seed)
+    g = Hh.run_hip(sc)
+    f, b = Hh.run_oracle(oracle, sc)
+    st = g["state"]
+    R = f["R"]
+    assert st["num_rendered"] == R
+    check_structure(st, f)
+    assert np.array_equal(u32(st["offsets"]), u32(f["offsets"]))
+    assert np.array_equal(st["keys_sorted"].view(np.uint64)[:R], f["keys_sorted"])
+    assert np.array_equal(u32(st["point_list"][:R]), u32(f["point_list"]))
+    assert np.array_equal(u32(st["ranges"]), u32(f["ranges"]))
+    assert np.array_equal(g["radii"], f["radii"])
+    nc = u32(st["n_contrib"][0])
+    flips = check_image(g["color"], f["color"], nc, u32(f["n_contrib"]), "color")
+    check_image(st["final_T"][0], f["final_T"], nc, u32(f["n_contrib"]), "final_T")
+    if flips == 0:
+        Hh.assert_grads_close(g, b, what=f"P={P}")
+    else:  # a flipped contributor perturbs the gradients of the Gaussians on that pixel
+        Hh.assert_grads_close(g, b, frac_tol=2e-2, max_tol=1.0, l2_tol=5e-3, what=f"P={P} (flips={flips})")
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
+def test_against_golden_fixtures(path):
+    from test_golden_cpu import scene_from_golden
+    z = np.load(path)
+    sc, cams, hdr, dom = scene_from_golden(z)
+    g = Hh.run_hip(sc, cameras=cams if len(cams) > 1 else None, hdr=hdr, blur_domain=dom)
+    st = g["state"]
+    assert np.array_equal(u32(st["point_list"][:st["num_rendered"]]), u32(z["o_point_list"]))
+    assert np.array_equal(u32(st["ranges"]), u32(z["o_ranges"]))
+    assert Hh.rel_err(g["color"], z["o_color"], 1e-2)[0] <= 1e-4
+    ref = {k: z["o_" + k] for _, k in Hh.GRAD_KEYS}
+    if hdr:
+        assert Hh.rel_err(g["hdr"], z["o_hdr"], 1e-2)[0] <= 1e-4
+        assert int((u32(st["n_contrib"]) != u32(z["o_n_contrib"])).sum()) == 0
+        tab = z["o_dL_dcrf_table"]
+        assert Hh.rel_err(g["d_crf_table"], tab, 1e3 * Hh.grad_floor(tab))[0] <= 2e-4
+        assert float(g["d_exposure"]) == pytest.approx(float(z["o_dL_dexposure"]), rel=2e-4, abs=1e-3)
+    else:
+        assert np.array_equal(st["keys_sorted"].view(np.uint64)[:st["num_rendered"]], z["o_keys_sorted"])
+        assert np.array_equal(Hh.bits(st["depths"]), Hh.bits(z["o_depths"]))
+    Hh.assert_grads_close(g, ref, what=os.path.basename(path))
+
+
+def test_precomputed_colors_and_covariance(oracle):
+    sc = S.make_scene(3000, 160, 112, 0, seed=7)
+    f0, _ = Hh.run_oracle(oracle, sc, backward=False)
+    cols = torch.rand(3000, 3, generator=torch.Generator().manual_seed(1))
+    cov = torch.from_numpy(f0["cov3D"].copy())
+    g = Hh.run_hip(sc, use_colors_precomp=cols, use_cov_precomp=cov)
+    f, b = Hh.run_oracle(oracle, sc, use_colors_precomp=cols, use_cov_precomp=cov)
+    st = g["state"]
+    check_structure(st, f)
+    assert np.array_equal(u32(st["point_list"][:f["R"]]), u32(f["point_list"]))
+    check_image(g["color"], f["color"], u32(st["n_contrib"][0]), u32(f["n_contrib"]), "color")
+    Hh.assert_grads_close(g, b, keys=[("means3D", "dL_dmeans3D"), ("opacities", "dL_dopacity"),
+                                      ("colors_precomp", "dL_dcolors_precomp"), ("cov3D_precomp", "dL_dcov3D")])
+    assert g["d_shs" if "d_shs" in g else "d_colors_precomp"] is not None
+
+
+def test_hdr_with_direct_radiance_gradient(oracle):
+    """Loss on both outputs: LDR (through the CRF) and the linear radiance image."""
+    sc = S.make_scene(4000, 192, 128, 3, seed=4, hdr=True)
+    gh = torch.randn(3, 128, 192, generator=torch.Generator().manual_seed(5))
+    g = Hh.run_hip(sc, hdr=True, grad_hdr=gh)
+    r = Hh.run_oracle_hdr(oracle, sc, dL_hdr=gh.numpy())
+    flips = assert_image_close(g["color"], r["ldr"], "ldr") + assert_image_close(g["hdr"], r["hdr"], "hdr")
+    if flips == 0:
+        Hh.assert_grads_close(g, r)
+    else:
+        Hh.assert_grads_close(g, r, frac_tol=2e-2, max_tol=1.0, l2_tol=5e-3)
+    assert float(g["d_exposure"]) == pytest.approx(r["dL_dexposure"], rel=1e-3)
+
+
+@pytest.mark.parametrize("dom", ["ldr", "hdr"])
+def test_motion_blur_n_poses(oracle, dom):
+    sc = S.make_scene(3000, 160, 96, 2, seed=6, hdr=True)
+    cams = S.blur_poses(160, 96, 8, step=0.02)
+    g = Hh.run_hip(sc, cameras=cams, hdr=True, blur_domain=dom)
+    r = Hh.run_oracle_hdr(oracle, sc, cams, dom)
+    st = g["state"]
+    for k, f in enumerate(r["fwd"]):
+        check_structure(st, f, pose=k, P=3000)
+    assert st["num_rendered"] == sum(f["R"] for f in r["fwd"])
+    assert np.array_equal(g["radii"], np.max(np.stack([f["radii"] for f in r["fwd"]]), axis=0))
+    flips = assert_image_close(g["color"], r["ldr"], "ldr") + assert_image_close(g["hdr"], r["hdr"], "hdr")
+    if flips == 0:
+        Hh.assert_grads_close(g, r)
+    else:
+        Hh.assert_grads_close(g, r, frac_tol=2e-2, max_tol=1.0, l2_tol=5e-3)
+    tab = r["dL_dcrf_table"]
+    assert Hh.rel_err(g["d_crf_table"], tab, 1e3 * Hh.grad_floor(tab))[0] <= 2e-4
+
+
+def test_n_identical_poses_equal_single_pose():
+    sc = S.make_scene(5000, 256, 144, 1, seed=8, hdr=True)
+    one = Hh.run_hip(sc, hdr=True)
+    four = Hh.run_hip(sc, cameras=[sc.camera] * 4, hdr=True)
+    assert np.allclose(one["color"], four["color"], rtol=1e-6, atol=1e-7)
+    for k in ("means3D", "shs", "scales", "rotations", "opacities"):
+        a, b = one["d_" + k], four["d_" + k]
+        assert np.allclose(a, b, rtol=1e-4, atol=1e-5 * np.abs(a).max()), k
+
+
+def test_non_hdr_multi_pose_average(oracle):
+    sc = S.make_scene(2000, 128, 80, 0, seed=3)
+    cams = S.blur_poses(128, 80, 3, step=0.03)
+    g = Hh.run_hip(sc, cameras=cams)
+    fs = [Hh.run_oracle(oracle, sc, cam=c, backward=False)[0] for c in cams]
+    want = np.mean(np.stack([f["color"] for f in fs]), axis=0)
+    assert_image_close(g["color"], want, "mean of poses")
+    acc = None
+    for c, f in zip(cams, fs):
+        b = oracle.backward(Hh.oracle_camera(oracle, sc, c), f, sc.dL_dimage.numpy() / 3, sc.means3D.numpy(),
+                            shs=sc.shs.numpy(), scales=sc.scales.numpy(), rotations=sc.rotations.numpy())
+        acc = b if acc is None else {k: (acc[k] + b[k] if isinstance(b[k], np.ndarray) and b[k].dtype == np.float32 else acc[k]) for k in acc}
+    Hh.assert_grads_close(g, acc)
+
+
+def test_edge_cases(oracle):
+    from casualhdrsplat_amd import GaussianRasterizer
+    dev = "cuda"
+    # (1) empty cloud: background only
+    sc = S.make_scene(10, 70, 50, 0, seed=0)
+    sc.bg = torch.tensor([0.2, 0.4, 0.6])
+    rs, _, _ = Hh.settings_from_scene(sc, dev)
+    r = GaussianRasterizer(rs)
+    e = torch.zeros(0, 3, device=dev)
+    color, radii = r(e, e, torch.zeros(0, 1, device=dev), shs=torch.zeros(0, 1, 3, device=dev), scales=e, rotations=torch.zeros(0, 4, device=dev))
+    assert radii.numel() == 0 and torch.allclose(color, sc.bg.to(dev)[:, None, None].expand(3, 50, 70))
+    # (2) everything behind the near plane
+    sc2 = S.make_scene(500, 70, 50, 1, seed=1)
+    sc2.means3D[:, 2] = -sc2.means3D[:, 2]
+    g = Hh.run_hip(sc2)
+    assert g["state"]["num_rendered"] == 0 and np.all(g["radii"] == 0) and np.all(g["color"] == 0)
+    assert all(np.all(g["d_" + k] == 0) for k in ("means3D", "shs", "scales", "rotations", "opacities"))
+    # (3) one Gaussian, ragged image (not a multiple of 16), bright background
+    sc3 = S.make_scene(1, 37, 23, 0, seed=2)
+    sc3.bg = torch.tensor([1.0, 0.5, 0.25])
+    g = Hh.run_hip(sc3)
+    f, b = Hh.run_oracle(oracle, sc3)
+    assert_image_close(g["color"], f["color"], "single")
+    Hh.assert_grads_close(g, b, frac_tol=0.05)
+    # (4) a huge Gaussian covering every tile + many tiny ones (ragged list lengths)
+    sc4 = S.make_scene(800, 208, 120, 0, seed=3)
+    sc4.scales[0] = 3.0
+    sc4.means3D[0] = torch.tensor([0.0, 0.0, 4.0])
+    g = Hh.run_hip(sc4)
+    f, b = Hh.run_oracle(oracle, sc4)
+    assert g["state"]["num_rendered"] == f["R"] and f["tiles_touched"][0] == 13 * 8
+    assert np.array_equal(u32(g["state"]["point_list"][:f["R"]]), u32(f["point_list"]))
+    check_image(g["color"], f["color"], u32(g["state"]["n_contrib"][0]), u32(f["n_contrib"]), "huge")
+    Hh.assert_grads_close(g, b)
+
+
+def test_mark_visible(oracle):
+    from casualhdrsplat_amd import GaussianRasterizer
+    sc = S.make_scene(5000, 64, 64, 0, seed=0)
+    sc.means3D[::3, 2] -= 3.0
+    rs, _, _ = Hh.settings_from_scene(sc, "cuda")
+    vis = GaussianRasterizer(rs).markVisible(sc.means3D.cuda()).cpu().numpy()
+    assert np.array_equal(vis, oracle.mark_visible(Hh.oracle_camera(oracle, sc), sc.means3D.numpy()))
+    assert 0 < vis.sum() < 5000
+
+
+def test_fixed_capacity_mode_and_overflow():
+    sc = S.make_scene(20000, 320, 200, 1, seed=5)
+    ref = Hh.run_hip(sc)
+    R = ref["state"]["num_rendered"]
+    ok = Hh.run_hip(sc, capacity=R + 1000)
+    assert ok["state"]["num_rendered"] == R
+    assert np.array_equal(ok["color"], ref["color"])
+    for k in ("means3D", "shs", "scales"):
+        assert np.array_equal(ok["d_" + k], ref["d_" + k]), k  # deterministic, capacity-independent
+    with pytest.raises(RuntimeError, match="binning capacity"):
+        Hh.run_hip(sc, capacity=R // 2)
+
+
+def test_run_to_run_bitwise_determinism():
+    sc = S.make_scene(50000, 640, 360, 3, seed=9, hdr=True)
+    a = Hh.run_hip(sc, hdr=True)
+    b = Hh.run_hip(sc, hdr=True)
+    assert np.array_equal(a["color"], b["color"]) and np.array_equal(a["hdr"], b["hdr"])
+    for k in ("means3D", "means2D", "opacities", "shs", "scales", "rotations"):
+        assert np.array_equal(a["d_" + k], b["d_" + k]), k
+
+
+def test_device_radix_sort_matches_stable_reference():
+    import ctypes as C
+    from casualhdrsplat_amd import _lib as L
+    lib = L.load()
+    gen = torch.Generator().manual_seed(0)
+    for n, nbits in [(1, 40), (63, 45), (4097, 45), (300001, 45), (1 << 20, 48), (50000, 33), (70000, 64)]:
+        hi = torch.randint(0, 1 << 16, (n,), generator=gen, dtype=torch.int64)
+        lo = torch.randint(0, 1 << 8, (n,), generator=gen, dtype=torch.int64)  # few distinct low bits: many ties
+        keys = ((hi << 32) | (lo << 12)) & ((1 << min(nbits, 62)) - 1)
+        vals = torch.arange(n, dtype=torch.int32)
+        kd, vd = keys.cuda(), vals.cuda()
+        ko, vo = torch.empty_like(kd), torch.empty_like(vd)
+        tmp = torch.empty(int(lib.hs_sort_tmp_bytes(n)), dtype=torch.uint8, device="cuda")
+        L.check(lib.hs_sort_pairs(kd.data_ptr(), vd.data_ptr(), ko.data_ptr(), vo.data_ptr(), n, nbits, tmp.data_ptr(),
+                                  torch.cuda.current_stream().cuda_stream), "hs_sort_pairs")
+        order = torch.sort(keys, stable=True).indices
+        assert torch.equal(ko.cpu(), keys[order]) and torch.equal(vo.cpu().long(), order), (n, nbits)
+
+
+def test_full_size_properties_c3():
+    """BASELINE c3 size (1M Gaussians, 1080p, deg 3, HDR): properties that need no oracle."""
+    from casualhdrsplat_amd import GaussianRasterizer, inspect_state
+    dev = "cuda"
+    P, W, H = 1_000_000, 1920, 1080
+    sc = S.make_scene(P, W, H, 3, seed=0, hdr=True)
+    rs, expo, crf = Hh.settings_from_scene(sc, dev, hdr=True, requires_grad=True)
+    leaves = [t.to(dev).requires_grad_(True) for t in (sc.means3D, torch.zeros(P, 3), sc.opacities, sc.shs, sc.scales, sc.rotations)]
+    rast = GaussianRasterizer(rs)
+
+    def run(dL):
+        for t in leaves + [expo, crf]:
+            t.grad = None
+        out = rast(leaves[0], leaves[1], leaves[2], shs=leaves[3], scales=leaves[4], rotations=leaves[5])
+        st = inspect_state(out[0])
+        torch.autograd.backward(out[0], grad_tensors=dL)
+        return out, st, [t.grad.clone() for t in leaves]
+
+    dL = sc.dL_dimage.to(dev)
+    out, st, g1 = run(dL)
+    R = st["num_rendered"]
+    keys = st["keys_sorted"][:R]
+    assert bool((keys[1:] >= keys[:-1]).all())                              # sortedness
+    assert R == int(st["tiles_touched"].to(torch.int64).sum())                # len(keys) == sum tiles_touched
+    rng = st["ranges"].to(torch.int64)
+    lens = rng[:, 1] - rng[:, 0]
+    assert int(lens.sum()) == R                                               # ranges partition [0, R)
+    nz = rng[lens > 0]
+    assert bool((nz[1:, 0] == nz[:-1, 1]).all()) and int(nz[0, 0]) == 0 and int(nz[-1, 1]) == R
+    tiles = keys >> 32
+    assert int(tiles.max()) < 120 * 68
+    pl = st["point_list"][:R].to(torch.int64)
+    assert int(torch.bincount(pl, minlength=P).sub(st["tiles_touched"].to(torch.int64)).abs().max()) == 0
+    assert bool(torch.isfinite(out[0]).all()) and bool((out[2] >= 0).all())
+    assert bool((st["n_contrib"].to(torch.int64)[0].reshape(-1) <= lens.max()).all())
+    # linearity of the backward in dL/dimage: grad(2*dL) == 2*grad(dL) bit for bit (power-of-two scaling)
+    _, _, g2 = run(2 * dL)
+    for a, b in zip(g1, g2):
+        assert torch.equal(2 * a, b)
+    # checksum of checksums stays finite and non-trivial
+    assert all(bool(torch.isfinite(a).all()) for a in g1) and float(g1[3].abs().sum()) > 0

@@ -1,0 +1,97 @@
+"""Host-side behaviour of the drop-in boundary that needs no GPU: the settings tuple, argument
+validation with the reference API's error messages, loud failure on CPU tensors, synthetic scenes."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from casualhdrsplat_amd import GaussianRasterizationSettings, GaussianRasterizer, synthetic as S
+
+
+def settings(W=32, H=32):
+    cam = S.make_camera(W, H)
+    return GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=torch.zeros(3), scale_modifier=1.0,
+        viewmatrix=cam.viewmatrix, projmatrix=cam.projmatrix, sh_degree=0, campos=cam.campos, prefiltered=False, debug=False)
+
+
+def test_settings_field_order_matches_reference_api():
+    names = GaussianRasterizationSettings._fields
+    assert names[:12] == ("image_height", "image_width", "tanfovx", "tanfovy", "bg", "scale_modifier", "viewmatrix",
+                          "projmatrix", "sh_degree", "campos", "prefiltered", "debug")
+    assert names[12] == "antialiasing"
+    rs = settings()
+    assert rs.exposure is None and rs.crf_table is None and rs.blur_domain == "ldr" and rs.viewmatrices is None
+
+
+def test_exactly_one_of_rules():
+    r = GaussianRasterizer(settings())
+    P = 4
+    m, o = torch.zeros(P, 3), torch.ones(P, 1)
+    sh, col = torch.zeros(P, 1, 3), torch.zeros(P, 3)
+    sc, ro, cov = torch.ones(P, 3), torch.zeros(P, 4), torch.zeros(P, 6)
+    with pytest.raises(Exception, match="SHs or precomputed colors"):
+        r(m, m, o, scales=sc, rotations=ro)
+    with pytest.raises(Exception, match="SHs or precomputed colors"):
+        r(m, m, o, shs=sh, colors_precomp=col, scales=sc, rotations=ro)
+    with pytest.raises(Exception, match="scale/rotation pair or precomputed 3D covariance"):
+        r(m, m, o, shs=sh)
+    with pytest.raises(Exception, match="scale/rotation pair or precomputed 3D covariance"):
+        r(m, m, o, shs=sh, scales=sc, rotations=ro, cov3D_precomp=cov)
+    with pytest.raises(Exception, match="scale/rotation pair or precomputed 3D covariance"):
+        r(m, m, o, shs=sh, scales=sc)
+
+
+def test_cpu_tensors_fail_loudly_no_fallback():
+    r = GaussianRasterizer(settings())
+    P = 4
+    with pytest.raises(RuntimeError, match="MI355X"):
+        r(torch.zeros(P, 3), torch.zeros(P, 3), torch.ones(P, 1), shs=torch.zeros(P, 1, 3), scales=torch.ones(P, 3),
+          rotations=torch.zeros(P, 4))
+
+
+def test_product_never_imports_the_oracle():
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "casualhdrsplat_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h")):
+                txt = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
+                assert "libhs_oracle" not in txt and "c_oracle" not in txt and "torch_rasterizer" not in txt, f
+
+
+def test_synthetic_scene_distribution_and_determinism():
+    a = S.make_scene(5000, 320, 180, 3, seed=0, hdr=True)
+    b = S.make_scene(5000, 320, 180, 3, seed=0, hdr=True)
+    c = S.make_scene(5000, 320, 180, 3, seed=1, hdr=True)
+    assert torch.equal(a.means3D, b.means3D) and torch.equal(a.shs, b.shs) and not torch.equal(a.means3D, c.means3D)
+    assert a.shs.shape == (5000, 16, 3) and a.crf_table.shape == (3, 256)
+    assert torch.allclose(a.rotations.norm(dim=1), torch.ones(5000), atol=1e-5)
+    z = a.means3D[:, 2]
+    assert z.min() >= 2 and z.max() <= 10
+    cam = a.camera
+    assert cam.tanfovx == pytest.approx(320 / (2 * 1000 * 320 / 1920))
+    # every mean projects inside the image
+    fx = 320 / (2 * cam.tanfovx)
+    px = fx * a.means3D[:, 0] / z + (320 - 1) / 2
+    py = fx * a.means3D[:, 1] / z + (180 - 1) / 2
+    assert px.min() > -1 and px.max() < 320 and py.min() > -1 and py.max() < 180
+    sig = a.scales.mean(dim=1) * fx / z
+    assert 0.3 < sig.min() and sig.max() < 14
+    assert torch.all(a.crf_table[:, 1:] > a.crf_table[:, :-1])  # monotone response
+    poses = S.blur_poses(320, 180, 8)
+    assert len(poses) == 8 and poses[3].campos[0] == pytest.approx(0.03)
+
+
+def test_yaw_camera_keeps_cloud_centre_fixed():
+    cam = S.yaw_camera(640, 360, 5.0, centre_depth=6.0)
+    w2c = cam.viewmatrix.t().double()
+    c = torch.tensor([0.0, 0.0, 6.0, 1.0], dtype=torch.float64)
+    assert torch.allclose((w2c @ c)[:3], c[:3], atol=1e-6)
+    R = w2c[:3, :3]
+    assert torch.allclose(R @ R.t(), torch.eye(3, dtype=torch.float64), atol=1e-6)
+    assert math.degrees(math.acos(float(R[0, 0]))) == pytest.approx(5.0, abs=1e-4)
