@@ -51,6 +51,38 @@ __device__ __forceinline__ float wave_sum_hi(float v) {
     v += dpp<0x143, 0xC>(v);  // row_bcast:31 -> rows 2,3
     return v;
 }
+// Halving steps of the 9-value wave reduction (gfx950 v_permlane{32,16}_swap): the sum of TWO registers over
+// one lane bit costs one swap + one add, and the result holds x's partial sums in the lanes whose bit is 0 and
+// y's in the lanes whose bit is 1.
+__device__ __forceinline__ float halve32(float x, float y) {  // lane bit 5
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float halve16(float x, float y) {  // lane bit 4 (x -> even rows, y -> odd rows)
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// Sum over the 16 lanes of each DPP row; every lane of the row receives the row total.
+__device__ __forceinline__ float row_sum(float v) {
+    v += dpp<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp<0x141>(v);  // row_half_mirror
+    v += dpp<0x140>(v);  // row_mirror
+    return v;
+}
+// Reduces g[0..8] over the wave.  Output: three registers whose 16-lane rows hold wave totals:
+//   q0 rows 0..3 = g0, g2, g1, g3 ; q1 rows 0..3 = g4, g6, g5, g7 ; q2 rows 0,1 = g8 (rows 2,3 = 0).
+__device__ __forceinline__ void wave_reduce9(const float* g, float& q0, float& q1, float& q2) {
+    const float r0 = halve32(g[0], g[1]);
+    const float r1 = halve32(g[2], g[3]);
+    const float r2 = halve32(g[4], g[5]);
+    const float r3 = halve32(g[6], g[7]);
+    const float r4 = halve32(g[8], 0.f);
+    q0 = row_sum(halve16(r0, r1));
+    q1 = row_sum(halve16(r2, r3));
+    q2 = row_sum(halve16(r4, r4));
+}
+
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d));
@@ -117,6 +149,24 @@ struct RenderFwd {
     const float* exposure;
 };
 
+// One compositing step of the forward for one staged entry (branch-free: predication instead of exec
+// juggling keeps the scalar unit out of the inner loop).
+struct PixF {
+    float T, C0, C1, C2;
+    uint32_t last;
+    bool done;
+};
+__device__ __forceinline__ void blend_fwd(PixF& s, float power, float alpha, float r, float g, float b, uint32_t idx1) {
+    const bool valid = !s.done && power <= 0.f && alpha >= kAlphaMin;
+    const float test_T = s.T * (1.f - alpha);
+    const bool upd = valid && !(test_T < kTmin);
+    s.done = s.done || (valid && test_T < kTmin);
+    const float w = upd ? alpha * s.T : 0.f;
+    s.C0 += r * w; s.C1 += g * w; s.C2 += b * w;
+    s.T = upd ? test_T : s.T;
+    s.last = upd ? idx1 : s.last;
+}
+
 __global__ void __launch_bounds__(256) render_fwd_kernel(RenderFwd p) {
     __shared__ float4 s_a[256];
     __shared__ float4 s_b[256];
@@ -137,13 +187,12 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(RenderFwd p) {
     const uint2 range = p.ranges[vt];
     const int n = (int)(range.y - range.x);
 
-    float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
-    uint32_t last = 0;
-    bool done = !inside;
+    PixF st;
+    st.T = 1.f; st.C0 = st.C1 = st.C2 = 0.f; st.last = 0; st.done = !inside;
 
     int it = 0;
     for (int base = 0; base < n; base += 256, ++it) {
-        const bool wave_alive = __ballot(!done) != 0ull;
+        const bool wave_alive = __ballot(!st.done) != 0ull;
         if (lane == 0) s_alive[it & 1][wave] = wave_alive;
         __syncthreads();  // also: everyone finished reading the previous batch
         if (!(s_alive[it & 1][0] | s_alive[it & 1][1] | s_alive[it & 1][2] | s_alive[it & 1][3])) break;
@@ -163,32 +212,30 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(RenderFwd p) {
             bool touch = false;
             if (jj < cnt) touch = subtile_may_touch(s_a[jj], s_b[jj], sxf, syf);
             uint64_t mask = __ballot(touch);
+            // two staged entries per trip: their power/exp/alpha are independent (ILP), only the blend is serial
             while (mask) {
-                const int bit = __builtin_ctzll(mask);
+                const int j0 = k * 64 + __builtin_ctzll(mask);
                 mask &= mask - 1;
-                const int j = k * 64 + bit;
-                if (!done) {
-                    const float4 a = s_a[j];
-                    const float4 b = s_b[j];
-                    const float dx = a.x - pxf, dy = a.y - pyf;
-                    const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-                    const float alpha = fminf(kAlphaMax, b.y * hs_exp(power));
-                    if (power <= 0.f && alpha >= kAlphaMin) {
-                        const float test_T = T * (1.f - alpha);
-                        if (test_T < kTmin) {
-                            done = true;
-                        } else {
-                            const float w = alpha * T;
-                            C0 += b.z * w; C1 += b.w * w; C2 += s_cb[j] * w;
-                            T = test_T;
-                            last = (uint32_t)(base + j + 1);
-                        }
-                    }
-                }
-                if (__ballot(!done) == 0ull) { mask = 0; k = 4; }
+                const bool two = mask != 0ull;
+                const int j1 = two ? k * 64 + __builtin_ctzll(mask) : j0;
+                mask &= mask - 1;
+                const float4 a0 = s_a[j0], b0 = s_b[j0];
+                const float4 a1 = s_a[j1], b1 = s_b[j1];
+                const float c0 = s_cb[j0], c1 = s_cb[j1];
+                const float dx0 = a0.x - pxf, dy0 = a0.y - pyf;
+                const float dx1 = a1.x - pxf, dy1 = a1.y - pyf;
+                const float pw0 = -0.5f * (a0.z * dx0 * dx0 + b0.x * dy0 * dy0) - a0.w * dx0 * dy0;
+                const float pw1 = -0.5f * (a1.z * dx1 * dx1 + b1.x * dy1 * dy1) - a1.w * dx1 * dy1;
+                const float al0 = fminf(kAlphaMax, b0.y * hs_exp(pw0));
+                const float al1 = fminf(kAlphaMax, b1.y * hs_exp(pw1));
+                blend_fwd(st, pw0, al0, b0.z, b0.w, c0, (uint32_t)(base + j0 + 1));
+                if (two) blend_fwd(st, pw1, al1, b1.z, b1.w, c1, (uint32_t)(base + j1 + 1));
+                if (__ballot(!st.done) == 0ull) { mask = 0; k = 4; }
             }
         }
     }
+    const float T = st.T, C0 = st.C0, C1 = st.C1, C2 = st.C2;
+    const uint32_t last = st.last;
 
     if (inside) {
         const int64_t HW = (int64_t)p.H * p.W;
@@ -349,39 +396,43 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(RenderBwd p) {
                     const float alpha = fminf(kAlphaMax, b.y * G);
                     const bool act = ((uint32_t)(base + j) < last) && (power <= 0.f) && (alpha >= kAlphaMin);
                     if (__ballot(act) == 0ull) continue;
+                    // branch-free per-lane update: inactive lanes keep their state and contribute zeros
+                    const float one_m = 1.f - alpha;
+                    const float rcp_one_m = __builtin_amdgcn_rcpf(one_m);
+                    const float Tn = T * rcp_one_m;
+                    T = act ? Tn : T;
+                    const float dch = act ? alpha * T : 0.f;
+                    const float la = act ? last_alpha : 0.f;  // la = 0 leaves accum_rec unchanged
+                    const float sel = act ? 1.f : 0.f;
+                    ar0 = la * lc0 + (1.f - la) * ar0;
+                    ar1 = la * lc1 + (1.f - la) * ar1;
+                    ar2 = la * lc2 + (1.f - la) * ar2;
+                    lc0 = act ? b.z : lc0; lc1 = act ? b.w : lc1; lc2 = act ? cb : lc2;
+                    last_alpha = act ? alpha : last_alpha;
+                    float dL_dalpha = ((b.z - ar0) * dL0 + (b.w - ar1) * dL1) + (cb - ar2) * dL2;
+                    dL_dalpha = dL_dalpha * T + (-T_final * rcp_one_m) * bg_dot;
+                    dL_dalpha *= sel;
+                    const float dL_dG = b.y * dL_dalpha;
+                    const float gdx = G * dx, gdy = G * dy;
+                    const float dG_ddelx = -gdx * a.z - gdy * a.w;
+                    const float dG_ddely = -gdy * b.x - gdx * a.w;
                     float g[9];
-                    if (act) {
-                        const float one_m = 1.f - alpha;
-                        T = T / one_m;
-                        const float dch = alpha * T;
-                        ar0 = last_alpha * lc0 + (1.f - last_alpha) * ar0;
-                        ar1 = last_alpha * lc1 + (1.f - last_alpha) * ar1;
-                        ar2 = last_alpha * lc2 + (1.f - last_alpha) * ar2;
-                        lc0 = b.z; lc1 = b.w; lc2 = cb;
-                        float dL_dalpha = ((b.z - ar0) * dL0 + (b.w - ar1) * dL1) + (cb - ar2) * dL2;
-                        dL_dalpha *= T;
-                        last_alpha = alpha;
-                        dL_dalpha += (-T_final / one_m) * bg_dot;
-                        const float dL_dG = b.y * dL_dalpha;
-                        const float gdx = G * dx, gdy = G * dy;
-                        const float dG_ddelx = -gdx * a.z - gdy * a.w;
-                        const float dG_ddely = -gdy * b.x - gdx * a.w;
-                        g[0] = dL_dG * dG_ddelx * ddelx_dx;
-                        g[1] = dL_dG * dG_ddely * ddely_dy;
-                        g[2] = -0.5f * gdx * dx * dL_dG;
-                        g[3] = -gdx * dy * dL_dG;
-                        g[4] = -0.5f * gdy * dy * dL_dG;
-                        g[5] = G * dL_dalpha;
-                        g[6] = dch * dL0; g[7] = dch * dL1; g[8] = dch * dL2;
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < 9; ++q) g[q] = 0.f;
-                    }
-#pragma unroll
-                    for (int q = 0; q < 9; ++q) g[q] = wave_sum_hi(g[q]);
-                    if (lane == 63) {
-#pragma unroll
-                        for (int q = 0; q < 9; ++q) s_acc[wave][q][j] = g[q];
+                    g[0] = dL_dG * dG_ddelx * ddelx_dx;
+                    g[1] = dL_dG * dG_ddely * ddely_dy;
+                    g[2] = -0.5f * gdx * dx * dL_dG;
+                    g[3] = -gdx * dy * dL_dG;
+                    g[4] = -0.5f * gdy * dy * dL_dG;
+                    g[5] = G * dL_dalpha;
+                    g[6] = dch * dL0; g[7] = dch * dL1; g[8] = dch * dL2;
+                    float q0, q1, q2;
+                    wave_reduce9(g, q0, q1, q2);
+                    // rows 0..3 of q0 hold totals of g0,g2,g1,g3; of q1: g4,g6,g5,g7; rows 0,1 of q2: g8
+                    if ((lane & 15) == 0) {
+                        const int row = lane >> 4;
+                        const int v0 = ((row & 1) << 1) | (row >> 1);
+                        s_acc[wave][v0][j] = q0;
+                        s_acc[wave][4 + v0][j] = q1;
+                        if (row == 0) s_acc[wave][8][j] = q2;
                     }
                     wrote |= 1ull << bit;
                 }
@@ -457,14 +508,19 @@ __global__ void __launch_bounds__(256) crf_grad_kernel(int64_t HW, int N, int fl
     for (int i = threadIdx.x; i < K3 + 1; i += 256) partials[(int64_t)blockIdx.x * (K3 + 1) + i] = s_tab[i];
 }
 
+// One wave per output element: lanes stride over the per-block partial rows (fixed order -> reproducible).
 __global__ void __launch_bounds__(256) crf_reduce_kernel(const float* partials, int nblk, int K3, float* d_table,
                                                          float* d_exposure) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     if (i > K3) return;
     float acc = 0.f;
-    for (int b = 0; b < nblk; ++b) acc += partials[(int64_t)b * (K3 + 1) + i];
-    if (i < K3) { if (d_table) d_table[i] = acc; }
-    else if (d_exposure) d_exposure[0] = acc;
+    for (int b = lane; b < nblk; b += 64) acc += partials[(int64_t)b * (K3 + 1) + i];
+    acc = wave_sum_hi(acc);
+    if (lane == 63) {
+        if (i < K3) { if (d_table) d_table[i] = acc; }
+        else if (d_exposure) d_exposure[0] = acc;
+    }
 }
 
 }  // namespace
@@ -521,7 +577,7 @@ int launch_render_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s) {
         const int K3 = 3 * a.crf_K;
         crf_grad_kernel<<<kCrfBlocks, 256, (K3 + 4) * sizeof(float), s>>>(HW, d.n_poses, a.flags, p.pose_hdr, p.crf,
                                                                          a.exposure, a.dL_dout_color, partials);
-        crf_reduce_kernel<<<ceil_div(K3 + 1, 256), 256, 0, s>>>(partials, kCrfBlocks, K3, a.dL_dcrf_table,
+        crf_reduce_kernel<<<ceil_div(K3 + 1, 4), 256, 0, s>>>(partials, kCrfBlocks, K3, a.dL_dcrf_table,
                                                                 a.dL_dexposure);
         HS_LAUNCH_CHECK();
     }
