@@ -1,24 +1,27 @@
 // Per-tile alpha-blend forward (a9) and per-pixel backward (a10) for gfx950, plus the HDR
 // epilogue / prologue and N-pose resolve (a15).  Rules: SURVEY.md 8(a); no reference code exists.
 //
-// CDNA4 design (not a translation of the CUDA 16x16-thread tile):
-//  * one 256-thread workgroup per 16x16 binning tile, but each of its four wave64s owns a compact
-//    8x8 sub-tile, so a wave's early termination and culling are spatially coherent;
-//  * the tile's sorted instance list is staged 256 entries at a time into LDS as three float4
-//    planes (one gather of a 48-byte record per thread), then read back with wave-uniform
-//    (broadcast) ds_read_b128 -- no bank conflicts, no VGPRs spent on the batch;
-//  * before touching a batch each wave tests the 256 staged Gaussians against its own sub-tile,
-//    one Gaussian per lane, and turns the result into four 64-bit ballot masks; the compositing loop
-//    then walks set bits only (s_ff1/s_flbit) -- Gaussians whose 1/255-alpha ellipse misses the
-//    sub-tile cost ~0.3 instructions instead of ~30;
-//  * backward: no global atomics.  Per (wave, Gaussian) the nine partial derivatives are reduced
-//    across the 64 lanes with DPP row operations, parked in a per-wave LDS plane, summed over the
-//    four waves in fixed order and written as ONE 48-byte record per (tile, instance) pair at the
-//    pair's duplicateWithKeys slot; preprocess-backward then sums each instance's contiguous
-//    slots.  Gradients are bitwise reproducible run to run.
+// CDNA4 design (not a translation of the CUDA 16x16-thread tile).  Measured on MI355X the loops are bound by
+// VALU issue (~4 cycles per wave64 VALU instruction, profiles/r01_valu_rate.txt), so the design minimises vector
+// instructions per (pixel, Gaussian) pair:
+//  * one 128-thread workgroup (two wave64) per 16x16 binning tile; each wave owns a 16x8 half tile and each lane
+//    TWO vertically adjacent pixels, so dx and every per-Gaussian term is shared by the pair and the rest is
+//    packed fp32 (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32);
+//  * the tile's sorted instance list is staged 128 entries at a time into LDS (one gather of a 48-byte record
+//    per thread, the next batch prefetched into registers), the conic pre-scaled by -0.5*log2(e) so the inner
+//    loop is  dx, dy -> two FMAs -> v_exp_f32;
+//  * before touching a batch each wave tests the staged Gaussians against its own half tile, one Gaussian per
+//    lane, and compacts the survivors into a per-wave LDS index list (ballot + mbcnt); the compositing loop
+//    walks that list with the entry index in a VGPR (broadcast ds_read_b128), keeping the scalar unit idle;
+//  * backward: no global atomics.  Per (wave, Gaussian) nine partial sums are formed in-lane over the pixel
+//    pair, reduced across the 64 lanes with v_permlane32_swap / v_permlane16_swap halving steps plus DPP row
+//    reductions (~29 instructions for all nine), parked in a per-wave LDS plane, combined over the two waves
+//    in fixed order and written as ONE 48-byte record per (tile, instance) pair at the pair's
+//    duplicateWithKeys slot; preprocess-backward then sums each instance's contiguous slots.  Gradients are
+//    bitwise reproducible run to run.
 //
-// This TU is compiled with FMA contraction on (the loops are VALU-bound); every integer decision it
-// makes (pair slot addressing) uses add/div-only expressions that contraction cannot change.
+// This TU is compiled with FMA contraction on; every integer decision it makes (pair slot addressing) uses
+// add/div-only expressions that contraction cannot change.
 #include "hs_common.h"
 
 namespace hs {
@@ -34,6 +37,15 @@ constexpr float kLogEps = 1e-8f;
 __device__ __forceinline__ float hs_exp(float x) { return expf(x); }
 #else
 __device__ __forceinline__ float hs_exp(float x) { return __expf(x); }
+#endif
+
+#ifdef HS_STATS
+// Development-only counters (never compiled into the shipped library): [0] (wave,entry) trips of the backward
+// loop, [1] trips with no active lane, [2] sum of active lanes, [3] culled by the sub-tile test, [4..7] same for fwd.
+__device__ unsigned long long g_stats[8];
+#define HS_STAT_ADD(i, v) do { const unsigned long long v_ = (unsigned long long)(v); if ((threadIdx.x & 63) == 0) atomicAdd(&g_stats[i], v_); } while (0)
+#else
+#define HS_STAT_ADD(i, v) do { } while (0)
 #endif
 
 // ---- DPP cross-lane helpers (wave64) ----
@@ -83,6 +95,11 @@ __device__ __forceinline__ void wave_reduce9(const float* g, float& q0, float& q
     q2 = row_sum(halve16(r4, r4));
 }
 
+// number of set bits of a wave-uniform 64-bit mask below this lane
+__device__ __forceinline__ int mask_prefix(uint64_t m) {
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d));
@@ -124,21 +141,32 @@ __device__ __forceinline__ float crf_grad_H(const Crf& c, int ch, float Hv, floa
     return g * (t[i + 1] - t[i]) * scale / xv * c.dt;
 }
 
-// One Gaussian per lane against the wave's 8x8 sub-tile [sx,sx+7]x[sy,sy+7] (pixel centres).
-// Returns false only when NO pixel of the sub-tile can pass `power <= 0 && alpha >= 1/255`:
-// alpha >= 1/255  <=>  q(d) = A dx^2 + 2B dx dy + C dy^2 <= tau = 2 ln(255 o); the axis-aligned
-// bounding box of that ellipse has half-extents sqrt(tau*C/det), sqrt(tau*A/det).  tau carries an
-// absolute safety margin of 0.05 (+1e-4 relative), orders of magnitude above fp32 evaluation
-// error of `power` for variance ratios up to ~1e5, so culling never changes a result.
-__device__ __forceinline__ bool subtile_may_touch(const float4 a, const float4 b, float sx, float sy) {
-    const float A = a.z, B = a.w, C = b.x, o = b.y;
+constexpr float kLog2e = 1.4426950408889634f;
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// Staged entry as the inner loops want it: a = {x, y, A2, B2}, b = {C2, opacity, r, g} with the conic
+// pre-scaled so that log2(G) = dx*(A2*dx + B2*dy) + C2*dy*dy :  A2 = -0.5*A*log2e, B2 = -B*log2e, C2 = -0.5*C*log2e.
+__device__ __forceinline__ void scale_entry(float4& a, float4& b) {
+    a.z *= -0.5f * kLog2e; a.w *= -kLog2e; b.x *= -0.5f * kLog2e;
+}
+
+// One Gaussian per lane against a half tile [sx, sx+15] x [sy, sy+7] (pixel centres).
+// Returns false only when NO pixel of it can pass `power <= 0 && alpha >= 1/255`:
+// alpha >= 1/255  <=>  q(d) = A dx^2 + 2B dx dy + C dy^2 <= tau = 2 ln(255 o); the axis-aligned bounding box of
+// that ellipse has half-extents sqrt(tau*C/det), sqrt(tau*A/det), det = AC - B^2.  In the scaled coefficients
+// C/det = -2 L C2 / (4 A2 C2 - B2^2) with L = log2e.  tau carries an absolute safety margin of 0.05 (+1e-4
+// relative), orders of magnitude above the fp32 evaluation error of `power` for variance ratios up to ~1e5,
+// so culling never changes a result.
+__device__ __forceinline__ bool halftile_may_touch(const float4 a, const float4 b, float sx, float sy) {
+    const float A2 = a.z, B2 = a.w, C2 = b.x, o = b.y;
     if (!(o >= kAlphaMin)) return false;
     const float tau = 2.f * __logf(255.f * o) * 1.0001f + 0.05f;
-    const float det = A * C - B * B;
+    const float det = 4.f * A2 * C2 - B2 * B2;
     if (!(det > 0.f)) return true;  // degenerate conic: let the exact test decide
-    const float k = tau / det;
-    const float hx = sqrtf(k * C) * 1.0001f, hy = sqrtf(k * A) * 1.0001f;
-    return (a.x + hx >= sx) && (a.x - hx <= sx + 7.f) && (a.y + hy >= sy) && (a.y - hy <= sy + 7.f);
+    const float k = tau * (-2.f * kLog2e) / det;
+    const float hx = sqrtf(k * C2) * 1.0001f, hy = sqrtf(k * A2) * 1.0001f;
+    return (a.x + hx >= sx) && (a.x - hx <= sx + 15.f) && (a.y + hy >= sy) && (a.y - hy <= sy + 7.f);
 }
 
 struct RenderFwd {
@@ -149,15 +177,19 @@ struct RenderFwd {
     const float* exposure;
 };
 
-// One compositing step of the forward for one staged entry (branch-free: predication instead of exec
-// juggling keeps the scalar unit out of the inner loop).
+constexpr int kBatch = 128;  // staged entries per trip = threads per workgroup
+
+__device__ __forceinline__ float hs_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// Per-pixel compositing state of the forward (two of these per lane).
 struct PixF {
     float T, C0, C1, C2;
     uint32_t last;
     bool done;
 };
-__device__ __forceinline__ void blend_fwd(PixF& s, float power, float alpha, float r, float g, float b, uint32_t idx1) {
-    const bool valid = !s.done && power <= 0.f && alpha >= kAlphaMin;
+// One compositing step (branch-free: predication keeps the scalar unit out of the inner loop).
+__device__ __forceinline__ void blend_fwd(PixF& s, float pw, float alpha, float r, float g, float b, uint32_t idx1) {
+    const bool valid = !s.done && pw <= 0.f && alpha >= kAlphaMin;
     const float test_T = s.T * (1.f - alpha);
     const bool upd = valid && !(test_T < kTmin);
     s.done = s.done || (valid && test_T < kTmin);
@@ -167,100 +199,113 @@ __device__ __forceinline__ void blend_fwd(PixF& s, float power, float alpha, flo
     s.last = upd ? idx1 : s.last;
 }
 
-__global__ void __launch_bounds__(256) render_fwd_kernel(RenderFwd p) {
-    __shared__ float4 s_a[256];
-    __shared__ float4 s_b[256];
-    __shared__ float s_cb[256];
-    __shared__ int s_alive[2][4];
+__device__ __forceinline__ void write_pixel_fwd(const RenderFwd& p, const PixF& st, int pose, int px, int py) {
+    const int64_t HW = (int64_t)p.H * p.W;
+    const int64_t pix = (int64_t)py * p.W + px;
+    p.final_T[(int64_t)pose * HW + pix] = st.T;
+    p.n_contrib[(int64_t)pose * HW + pix] = st.last;
+    const float H0 = st.C0 + st.T * p.bg[0], H1 = st.C1 + st.T * p.bg[1], H2 = st.C2 + st.T * p.bg[2];
+    const bool hdr = p.flags & HS_FLAG_HDR;
+    if (p.pose_hdr) {
+        float* ph = p.pose_hdr + (int64_t)pose * 3 * HW;
+        ph[pix] = H0; ph[HW + pix] = H1; ph[2 * HW + pix] = H2;
+    }
+    if (p.N == 1) {
+        if (hdr) {
+            Crf c = p.crf;
+            c.dt = p.exposure[0];
+            if (p.out_hdr) { p.out_hdr[pix] = H0; p.out_hdr[HW + pix] = H1; p.out_hdr[2 * HW + pix] = H2; }
+            p.out_color[pix] = crf_eval(c, 0, H0);
+            p.out_color[HW + pix] = crf_eval(c, 1, H1);
+            p.out_color[2 * HW + pix] = crf_eval(c, 2, H2);
+        } else {
+            p.out_color[pix] = H0; p.out_color[HW + pix] = H1; p.out_color[2 * HW + pix] = H2;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(kBatch) render_fwd_kernel(RenderFwd p) {
+    constexpr int KB = kBatch;
+    __shared__ float4 s_a[KB];
+    __shared__ float4 s_b[KB];
+    __shared__ float s_cb[KB];
+    __shared__ uint16_t s_list[2][KB];  // per-wave compacted list of staged entries that can touch its half tile
+    __shared__ int s_alive[2][2];
 
     const int vt = blockIdx.x;  // virtual tile = pose * ntiles + tile
     const int pose = vt / p.ntiles;
     const int tile = vt - pose * p.ntiles;
     const int tx = tile % p.gx, ty = tile / p.gx;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int sx = tx * kTile + (wave & 1) * 8, sy = ty * kTile + (wave >> 1) * 8;
-    const int px = sx + (lane & 7), py = sy + (lane >> 3);
-    const bool inside = px < p.W && py < p.H;
-    const float pxf = (float)px, pyf = (float)py;
+    const int sx = tx * kTile, sy = ty * kTile + wave * 8;
+    const int px = sx + (lane & 15), py0 = sy + 2 * (lane >> 4), py1 = py0 + 1;
+    const bool in0 = px < p.W && py0 < p.H, in1 = px < p.W && py1 < p.H;
+    const float pxf = (float)px;
+    const f2 pyf = {(float)py0, (float)py1};
     const float sxf = (float)sx, syf = (float)sy;
 
     const uint2 range = p.ranges[vt];
     const int n = (int)(range.y - range.x);
 
-    PixF st;
-    st.T = 1.f; st.C0 = st.C1 = st.C2 = 0.f; st.last = 0; st.done = !inside;
+    PixF s0, s1;
+    s0.T = s1.T = 1.f; s0.C0 = s0.C1 = s0.C2 = s1.C0 = s1.C1 = s1.C2 = 0.f; s0.last = s1.last = 0;
+    s0.done = !in0; s1.done = !in1;
 
+    // software pipeline of the staging gather: registers hold the NEXT batch while the current one is processed
+    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
+    float rcb = 0.f;
+    if ((int)threadIdx.x < n) {
+        const uint32_t id = p.point_list[range.x + threadIdx.x];
+        const float4* r = p.rec + 3 * (int64_t)id;
+        ra = r[0]; rb = r[1]; rcb = reinterpret_cast<const float*>(r + 2)[0];
+    }
     int it = 0;
-    for (int base = 0; base < n; base += 256, ++it) {
-        const bool wave_alive = __ballot(!st.done) != 0ull;
+    for (int base = 0; base < n; base += KB, ++it) {
+        const bool wave_alive = __ballot(!(s0.done && s1.done)) != 0ull;
         if (lane == 0) s_alive[it & 1][wave] = wave_alive;
         __syncthreads();  // also: everyone finished reading the previous batch
-        if (!(s_alive[it & 1][0] | s_alive[it & 1][1] | s_alive[it & 1][2] | s_alive[it & 1][3])) break;
-        const int cnt = min(256, n - base);
+        if (!(s_alive[it & 1][0] | s_alive[it & 1][1])) break;
+        const int cnt = min(KB, n - base);
         if ((int)threadIdx.x < cnt) {
-            const uint32_t id = p.point_list[range.x + base + threadIdx.x];
+            scale_entry(ra, rb);
+            s_a[threadIdx.x] = ra; s_b[threadIdx.x] = rb; s_cb[threadIdx.x] = rcb;
+        }
+        if (base + KB + (int)threadIdx.x < n) {
+            const uint32_t id = p.point_list[range.x + base + KB + threadIdx.x];
             const float4* r = p.rec + 3 * (int64_t)id;
-            s_a[threadIdx.x] = r[0];
-            s_b[threadIdx.x] = r[1];
-            s_cb[threadIdx.x] = reinterpret_cast<const float*>(r + 2)[0];
+            ra = r[0]; rb = r[1]; rcb = reinterpret_cast<const float*>(r + 2)[0];
         }
         __syncthreads();
         if (!wave_alive) continue;
-#pragma unroll 1
-        for (int k = 0; k < 4; ++k) {
+        // compaction: one staged Gaussian per lane against this wave's half tile, survivors appended in order
+        int n_t = 0;
+#pragma unroll
+        for (int k = 0; k < KB / 64; ++k) {
             const int jj = k * 64 + lane;
             bool touch = false;
-            if (jj < cnt) touch = subtile_may_touch(s_a[jj], s_b[jj], sxf, syf);
-            uint64_t mask = __ballot(touch);
-            // two staged entries per trip: their power/exp/alpha are independent (ILP), only the blend is serial
-            while (mask) {
-                const int j0 = k * 64 + __builtin_ctzll(mask);
-                mask &= mask - 1;
-                const bool two = mask != 0ull;
-                const int j1 = two ? k * 64 + __builtin_ctzll(mask) : j0;
-                mask &= mask - 1;
-                const float4 a0 = s_a[j0], b0 = s_b[j0];
-                const float4 a1 = s_a[j1], b1 = s_b[j1];
-                const float c0 = s_cb[j0], c1 = s_cb[j1];
-                const float dx0 = a0.x - pxf, dy0 = a0.y - pyf;
-                const float dx1 = a1.x - pxf, dy1 = a1.y - pyf;
-                const float pw0 = -0.5f * (a0.z * dx0 * dx0 + b0.x * dy0 * dy0) - a0.w * dx0 * dy0;
-                const float pw1 = -0.5f * (a1.z * dx1 * dx1 + b1.x * dy1 * dy1) - a1.w * dx1 * dy1;
-                const float al0 = fminf(kAlphaMax, b0.y * hs_exp(pw0));
-                const float al1 = fminf(kAlphaMax, b1.y * hs_exp(pw1));
-                blend_fwd(st, pw0, al0, b0.z, b0.w, c0, (uint32_t)(base + j0 + 1));
-                if (two) blend_fwd(st, pw1, al1, b1.z, b1.w, c1, (uint32_t)(base + j1 + 1));
-                if (__ballot(!st.done) == 0ull) { mask = 0; k = 4; }
-            }
+            if (jj < cnt) touch = halftile_may_touch(s_a[jj], s_b[jj], sxf, syf);
+            const uint64_t mask = __ballot(touch);
+            if (touch) s_list[wave][n_t + mask_prefix(mask)] = (uint16_t)jj;
+            n_t += __popcll(mask);
+        }
+        for (int i = 0; i < n_t; ++i) {
+            const int j = (int)s_list[wave][i];  // uniform across lanes -> broadcast LDS reads below
+            const float4 a = s_a[j], b = s_b[j];
+            const float cb = s_cb[j];
+            const float dx = a.x - pxf;
+            const f2 dy = a.y - pyf;
+            const float t = a.z * dx * dx, u = a.w * dx;
+            const f2 pw = dy * (b.x * dy + u) + t;  // log2 of the Gaussian falloff at the two pixels
+            const float al0 = fminf(kAlphaMax, b.y * hs_exp2(pw.x));
+            const float al1 = fminf(kAlphaMax, b.y * hs_exp2(pw.y));
+            const uint32_t idx1 = (uint32_t)(base + j + 1);
+            blend_fwd(s0, pw.x, al0, b.z, b.w, cb, idx1);
+            blend_fwd(s1, pw.y, al1, b.z, b.w, cb, idx1);
+            if (__ballot(!(s0.done && s1.done)) == 0ull) break;
         }
     }
-    const float T = st.T, C0 = st.C0, C1 = st.C1, C2 = st.C2;
-    const uint32_t last = st.last;
-
-    if (inside) {
-        const int64_t HW = (int64_t)p.H * p.W;
-        const int64_t pix = (int64_t)py * p.W + px;
-        p.final_T[(int64_t)pose * HW + pix] = T;
-        p.n_contrib[(int64_t)pose * HW + pix] = last;
-        const float H0 = C0 + T * p.bg[0], H1 = C1 + T * p.bg[1], H2 = C2 + T * p.bg[2];
-        const bool hdr = p.flags & HS_FLAG_HDR;
-        if (p.pose_hdr) {
-            float* ph = p.pose_hdr + (int64_t)pose * 3 * HW;
-            ph[pix] = H0; ph[HW + pix] = H1; ph[2 * HW + pix] = H2;
-        }
-        if (p.N == 1) {
-            if (hdr) {
-                Crf c = p.crf;
-                c.dt = p.exposure[0];
-                if (p.out_hdr) { p.out_hdr[pix] = H0; p.out_hdr[HW + pix] = H1; p.out_hdr[2 * HW + pix] = H2; }
-                p.out_color[pix] = crf_eval(c, 0, H0);
-                p.out_color[HW + pix] = crf_eval(c, 1, H1);
-                p.out_color[2 * HW + pix] = crf_eval(c, 2, H2);
-            } else {
-                p.out_color[pix] = H0; p.out_color[HW + pix] = H1; p.out_color[2 * HW + pix] = H2;
-            }
-        }
-    }
+    if (in0) write_pixel_fwd(p, s0, pose, px, py0);
+    if (in1) write_pixel_fwd(p, s1, pose, px, py1);
 }
 
 // N > 1: average the per-pose images.  LDR domain (default, follows assets/pipeline.png: the blur "+" is
@@ -316,147 +361,192 @@ __device__ __forceinline__ float pixel_grad(const RenderBwd& p, const Crf& c, in
     return out;
 }
 
-__global__ void __launch_bounds__(256) render_bwd_kernel(RenderBwd p) {
-    __shared__ float4 s_a[256];
-    __shared__ float4 s_b[256];
-    __shared__ float4 s_c[256];
-    __shared__ float s_acc[4][9][256];
-    __shared__ uint64_t s_mask[4][4];
-    __shared__ uint32_t s_max[4];
+// Per-pixel state of the backward replay (two per lane).
+struct PixB {
+    float T, T_final, R0, R1, R2, dL0, dL1, dL2, bg_dot;
+    uint32_t last;
+};
+
+__device__ __forceinline__ void load_pixel_bwd(const RenderBwd& p, PixB& s, bool inside, int pose, int px, int py) {
+    const int64_t HW = (int64_t)p.H * p.W;
+    const int64_t pix = (int64_t)py * p.W + px;
+    s.T_final = 0.f; s.dL0 = s.dL1 = s.dL2 = 0.f; s.last = 0;
+    if (inside) {
+        s.T_final = p.final_T[(int64_t)pose * HW + pix];
+        s.last = p.n_contrib[(int64_t)pose * HW + pix];
+        Crf c = p.crf;
+        if (p.flags & HS_FLAG_HDR) c.dt = p.exposure[0];
+        s.dL0 = pixel_grad(p, c, pose, 0, pix, HW);
+        s.dL1 = pixel_grad(p, c, pose, 1, pix, HW);
+        s.dL2 = pixel_grad(p, c, pose, 2, pix, HW);
+    }
+    s.bg_dot = (p.bg[0] * s.dL0 + p.bg[1] * s.dL1) + p.bg[2] * s.dL2;
+    s.T = s.T_final;
+    s.R0 = s.R1 = s.R2 = 0.f;  // colour accumulated behind the current entry ("accum_rec")
+}
+
+// One back-to-front step for one pixel.  Outputs s_ = dL/dG * G (weight of the geometric sums), the opacity
+// term G * dL/dalpha and dch = alpha * T (colour weight); inactive pixels give exact zeros and keep their state
+// (alpha_eff = 0 makes every update an identity), so no per-field selects are needed.
+__device__ __forceinline__ void step_bwd(PixB& s, bool act, float G, float alpha, float o, float r, float g, float b,
+                                         float& sw, float& dop, float& dch) {
+    const float ae = act ? alpha : 0.f;
+    const float one_m = 1.f - ae;
+    const float rcp = __builtin_amdgcn_rcpf(one_m);
+    s.T *= rcp;
+    dch = ae * s.T;
+    float dLa = ((r - s.R0) * s.dL0 + (g - s.R1) * s.dL1) + (b - s.R2) * s.dL2;
+    dLa = dLa * s.T - (s.T_final * rcp) * s.bg_dot;
+    dLa = act ? dLa : 0.f;
+    s.R0 = ae * r + one_m * s.R0;
+    s.R1 = ae * g + one_m * s.R1;
+    s.R2 = ae * b + one_m * s.R2;
+    dop = G * dLa;
+    sw = o * dop;
+}
+
+__global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
+    constexpr int KB = kBatch;
+    __shared__ float4 s_a[KB];
+    __shared__ float4 s_b[KB];
+    __shared__ float4 s_c[KB];
+    __shared__ float s_acc[2][9][KB];       // per-wave planes of reduced partials, summed in fixed order at write-out
+    __shared__ uint16_t s_list[2][KB];      // per-wave compacted list of touched staged entries
+    __shared__ uint64_t s_wrote[2][KB / 64];
+    __shared__ uint32_t s_max[2];
 
     const int vt = blockIdx.x;
     const int pose = vt / p.ntiles;
     const int tile = vt - pose * p.ntiles;
     const int tx = tile % p.gx, ty = tile / p.gx;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int sx = tx * kTile + (wave & 1) * 8, sy = ty * kTile + (wave >> 1) * 8;
-    const int px = sx + (lane & 7), py = sy + (lane >> 3);
-    const bool inside = px < p.W && py < p.H;
-    const float pxf = (float)px, pyf = (float)py;
+    const int sx = tx * kTile, sy = ty * kTile + wave * 8;
+    const int px = sx + (lane & 15), py0 = sy + 2 * (lane >> 4), py1 = py0 + 1;
+    const bool in0 = px < p.W && py0 < p.H, in1 = px < p.W && py1 < p.H;
+    const float pxf = (float)px;
+    const f2 pyf = {(float)py0, (float)py1};
     const float sxf = (float)sx, syf = (float)sy;
-    const int64_t HW = (int64_t)p.H * p.W;
-    const int64_t pix = (int64_t)py * p.W + px;
 
     const uint2 range = p.ranges[vt];
 
-    float T_final = 0.f, dL0 = 0.f, dL1 = 0.f, dL2 = 0.f;
-    uint32_t last = 0;
-    if (inside) {
-        T_final = p.final_T[(int64_t)pose * HW + pix];
-        last = p.n_contrib[(int64_t)pose * HW + pix];
-        Crf c = p.crf;
-        if (p.flags & HS_FLAG_HDR) c.dt = p.exposure[0];
-        dL0 = pixel_grad(p, c, pose, 0, pix, HW);
-        dL1 = pixel_grad(p, c, pose, 1, pix, HW);
-        dL2 = pixel_grad(p, c, pose, 2, pix, HW);
-    }
-    const float bg_dot = (p.bg[0] * dL0 + p.bg[1] * dL1) + p.bg[2] * dL2;
-    const float ddelx_dx = 0.5f * (float)p.W, ddely_dy = 0.5f * (float)p.H;
+    PixB s0, s1;
+    load_pixel_bwd(p, s0, in0, pose, px, py0);
+    load_pixel_bwd(p, s1, in1, pose, px, py1);
 
-    const uint32_t wave_max = wave_max_u32(last);
+    const uint32_t wave_max = wave_max_u32(max(s0.last, s1.last));
     if (lane == 0) s_max[wave] = wave_max;
     __syncthreads();
-    const int n_proc = (int)max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+    const int n_proc = (int)max(s_max[0], s_max[1]);
 
-    float T = T_final;
-    float ar0 = 0.f, ar1 = 0.f, ar2 = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, last_alpha = 0.f;
-
-    const int nb = (n_proc + 255) / 256;
-    for (int bi = nb - 1; bi >= 0; --bi) {
-        const int base = bi * 256;
-        const int cnt = min(256, n_proc - base);
-        __syncthreads();  // previous batch's write-out finished
-        if ((int)threadIdx.x < cnt) {
+    const int nb = (n_proc + KB - 1) / KB;
+    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, rc = ra;
+    if (nb > 0) {
+        const int base = (nb - 1) * KB;
+        if ((int)threadIdx.x < n_proc - base) {
             const uint32_t id = p.point_list[range.x + base + threadIdx.x];
             const float4* r = p.rec + 3 * (int64_t)id;
-            s_a[threadIdx.x] = r[0];
-            s_b[threadIdx.x] = r[1];
-            s_c[threadIdx.x] = r[2];
+            ra = r[0]; rb = r[1]; rc = r[2];
+        }
+    }
+    for (int bi = nb - 1; bi >= 0; --bi) {
+        const int base = bi * KB;
+        const int cnt = min(KB, n_proc - base);
+        __syncthreads();  // previous batch's write-out finished
+        if ((int)threadIdx.x < cnt) {
+            scale_entry(ra, rb);
+            s_a[threadIdx.x] = ra; s_b[threadIdx.x] = rb; s_c[threadIdx.x] = rc;
+        }
+        if (bi > 0) {  // batches below the top one are always full
+            const uint32_t id = p.point_list[range.x + base - KB + threadIdx.x];
+            const float4* r = p.rec + 3 * (int64_t)id;
+            ra = r[0]; rb = r[1]; rc = r[2];
         }
         __syncthreads();
-        uint64_t done_mask[4] = {0ull, 0ull, 0ull, 0ull};
+        uint64_t wrote[KB / 64];
+#pragma unroll
+        for (int k = 0; k < KB / 64; ++k) wrote[k] = 0ull;
         if (base < (int)wave_max) {
-#pragma unroll 1
-            for (int k = 3; k >= 0; --k) {
+            int n_t = 0;
+#pragma unroll
+            for (int k = 0; k < KB / 64; ++k) {
                 const int jj = k * 64 + lane;
                 bool touch = false;
-                if (jj < cnt && base + jj < (int)wave_max) touch = subtile_may_touch(s_a[jj], s_b[jj], sxf, syf);
-                uint64_t mask = __ballot(touch);
-                uint64_t wrote = 0ull;
-                while (mask) {
-                    const int bit = 63 - __builtin_clzll(mask);
-                    mask &= ~(1ull << bit);
-                    const int j = k * 64 + bit;
-                    const float4 a = s_a[j];
-                    const float4 b = s_b[j];
-                    const float cb = s_c[j].x;
-                    const float dx = a.x - pxf, dy = a.y - pyf;
-                    const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-                    const float G = hs_exp(power);
-                    const float alpha = fminf(kAlphaMax, b.y * G);
-                    const bool act = ((uint32_t)(base + j) < last) && (power <= 0.f) && (alpha >= kAlphaMin);
-                    if (__ballot(act) == 0ull) continue;
-                    // branch-free per-lane update: inactive lanes keep their state and contribute zeros
-                    const float one_m = 1.f - alpha;
-                    const float rcp_one_m = __builtin_amdgcn_rcpf(one_m);
-                    const float Tn = T * rcp_one_m;
-                    T = act ? Tn : T;
-                    const float dch = act ? alpha * T : 0.f;
-                    const float la = act ? last_alpha : 0.f;  // la = 0 leaves accum_rec unchanged
-                    const float sel = act ? 1.f : 0.f;
-                    ar0 = la * lc0 + (1.f - la) * ar0;
-                    ar1 = la * lc1 + (1.f - la) * ar1;
-                    ar2 = la * lc2 + (1.f - la) * ar2;
-                    lc0 = act ? b.z : lc0; lc1 = act ? b.w : lc1; lc2 = act ? cb : lc2;
-                    last_alpha = act ? alpha : last_alpha;
-                    float dL_dalpha = ((b.z - ar0) * dL0 + (b.w - ar1) * dL1) + (cb - ar2) * dL2;
-                    dL_dalpha = dL_dalpha * T + (-T_final * rcp_one_m) * bg_dot;
-                    dL_dalpha *= sel;
-                    const float dL_dG = b.y * dL_dalpha;
-                    const float gdx = G * dx, gdy = G * dy;
-                    const float dG_ddelx = -gdx * a.z - gdy * a.w;
-                    const float dG_ddely = -gdy * b.x - gdx * a.w;
-                    float g[9];
-                    g[0] = dL_dG * dG_ddelx * ddelx_dx;
-                    g[1] = dL_dG * dG_ddely * ddely_dy;
-                    g[2] = -0.5f * gdx * dx * dL_dG;
-                    g[3] = -gdx * dy * dL_dG;
-                    g[4] = -0.5f * gdy * dy * dL_dG;
-                    g[5] = G * dL_dalpha;
-                    g[6] = dch * dL0; g[7] = dch * dL1; g[8] = dch * dL2;
-                    float q0, q1, q2;
-                    wave_reduce9(g, q0, q1, q2);
-                    // rows 0..3 of q0 hold totals of g0,g2,g1,g3; of q1: g4,g6,g5,g7; rows 0,1 of q2: g8
-                    if ((lane & 15) == 0) {
-                        const int row = lane >> 4;
-                        const int v0 = ((row & 1) << 1) | (row >> 1);
-                        s_acc[wave][v0][j] = q0;
-                        s_acc[wave][4 + v0][j] = q1;
-                        if (row == 0) s_acc[wave][8][j] = q2;
-                    }
-                    wrote |= 1ull << bit;
+                if (jj < cnt && base + jj < (int)wave_max) touch = halftile_may_touch(s_a[jj], s_b[jj], sxf, syf);
+                const uint64_t mask = __ballot(touch);
+                HS_STAT_ADD(3, __popcll(__ballot(jj < cnt && base + jj < (int)wave_max && !touch)));
+                if (touch) s_list[wave][n_t + mask_prefix(mask)] = (uint16_t)jj;
+                n_t += __popcll(mask);
+            }
+            for (int i = n_t - 1; i >= 0; --i) {  // back to front
+                const int j = (int)s_list[wave][i];
+                const float4 a = s_a[j];
+                const float4 b = s_b[j];
+                const float cb = s_c[j].x;
+                const float dx = a.x - pxf;
+                const f2 dy = a.y - pyf;
+                const float t = a.z * dx * dx, u = a.w * dx;
+                const f2 pw = dy * (b.x * dy + u) + t;
+                const float G0 = hs_exp2(pw.x), G1 = hs_exp2(pw.y);
+                const float al0 = fminf(kAlphaMax, b.y * G0), al1 = fminf(kAlphaMax, b.y * G1);
+                const uint32_t idx = (uint32_t)(base + j);
+                const bool act0 = (idx < s0.last) && (pw.x <= 0.f) && (al0 >= kAlphaMin);
+                const bool act1 = (idx < s1.last) && (pw.y <= 0.f) && (al1 >= kAlphaMin);
+                HS_STAT_ADD(0, 1);
+                HS_STAT_ADD(2, __popcll(__ballot(act0)) + __popcll(__ballot(act1)));
+                if (__ballot(act0 || act1) == 0ull) { HS_STAT_ADD(1, 1); continue; }
+                float w0, w1, dop0, dop1, dch0, dch1;
+                step_bwd(s0, act0, G0, al0, b.y, b.z, b.w, cb, w0, dop0, dch0);
+                step_bwd(s1, act1, G1, al1, b.y, b.z, b.w, cb, w1, dop1, dch1);
+                // in-lane sums over the pixel pair (dx is shared):  S1 = sum w dx, S2 = sum w dy, S3 = sum w dx^2,
+                // S4 = sum w dx dy, S5 = sum w dy^2 ; the conic factors are applied once per entry at write-out
+                const float m0 = w0 * dy.x, m1 = w1 * dy.y;
+                float g[9];
+                g[0] = (w0 + w1) * dx;
+                g[1] = m0 + m1;
+                g[2] = g[0] * dx;
+                g[3] = g[1] * dx;
+                g[4] = m0 * dy.x + m1 * dy.y;
+                g[5] = dop0 + dop1;
+                g[6] = dch0 * s0.dL0 + dch1 * s1.dL0;
+                g[7] = dch0 * s0.dL1 + dch1 * s1.dL1;
+                g[8] = dch0 * s0.dL2 + dch1 * s1.dL2;
+                float q0, q1, q2;
+                wave_reduce9(g, q0, q1, q2);
+                // rows 0..3 of q0 hold totals of g0,g2,g1,g3; of q1: g4,g6,g5,g7; rows 0,1 of q2: g8
+                if ((lane & 15) == 0) {
+                    const int row = lane >> 4;
+                    const int v0 = ((row & 1) << 1) | (row >> 1);
+                    s_acc[wave][v0][j] = q0;
+                    s_acc[wave][4 + v0][j] = q1;
+                    if (row == 0) s_acc[wave][8][j] = q2;
                 }
-                done_mask[k] = wrote;
+                wrote[j >> 6] |= 1ull << (j & 63);
             }
         }
         if (lane == 0) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) s_mask[wave][k] = done_mask[k];
+            for (int k = 0; k < KB / 64; ++k) s_wrote[wave][k] = wrote[k];
         }
         __syncthreads();
         if ((int)threadIdx.x < cnt) {
             const int t = threadIdx.x;
             float v[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                if ((s_mask[w][t >> 6] >> (t & 63)) & 1ull) {
+            for (int w = 0; w < 2; ++w) {
+                if ((s_wrote[w][t >> 6] >> (t & 63)) & 1ull) {
 #pragma unroll
                     for (int q = 0; q < 9; ++q) v[q] += s_acc[w][q][t];
                 }
             }
-            // slot of the (tile, instance) pair in duplicateWithKeys order
             const float4 a = s_a[t];
             const float4 c = s_c[t];
+            // un-scale the conic: A = A2 * (-2/L), B = B2 * (-1/L), C = C2 * (-2/L)
+            const float A = a.z * (-2.f / kLog2e), B = a.w * (-1.f / kLog2e), C = s_b[t].x * (-2.f / kLog2e);
+            const float ddelx_dx = 0.5f * (float)p.W, ddely_dy = 0.5f * (float)p.H;
+            // dL/dmean2D = -(A S1 + B S2, C S2 + B S1) (NDC-scaled); dL/dconic = (-0.5 S3, -S4, -0.5 S5)
+            const float gmx = -(A * v[0] + B * v[1]) * ddelx_dx;
+            const float gmy = -(C * v[1] + B * v[0]) * ddely_dy;
+            // slot of the (tile, instance) pair in duplicateWithKeys order
             const int rad = __float_as_int(c.z);
             const uint32_t off = __float_as_uint(c.w);
             const int rminx = min(p.gx, max(0, (int)((a.x - (float)rad) / (float)kTile)));
@@ -464,8 +554,8 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(RenderBwd p) {
             const int rmaxx = min(p.gx, max(0, (int)((a.x + (float)rad + (float)(kTile - 1)) / (float)kTile)));
             const int64_t slot = (int64_t)off + (int64_t)(ty - rminy) * (rmaxx - rminx) + (tx - rminx);
             float4* o = p.pair_grads + 3 * slot;
-            o[0] = make_float4(v[0], v[1], v[2], v[3]);
-            o[1] = make_float4(v[4], v[5], v[6], v[7]);
+            o[0] = make_float4(gmx, gmy, -0.5f * v[2], -v[3]);
+            o[1] = make_float4(-0.5f * v[4], v[5], v[6], v[7]);
             o[2] = make_float4(v[8], 0.f, 0.f, 0.f);
         }
     }
@@ -525,6 +615,14 @@ __global__ void __launch_bounds__(256) crf_reduce_kernel(const float* partials, 
 
 }  // namespace
 
+#ifdef HS_STATS
+extern "C" int hs_debug_stats(unsigned long long* out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_stats), sizeof(unsigned long long) * 8) != hipSuccess) return -2;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_stats), z, sizeof z) != hipSuccess) return -2; }
+    return 0;
+}
+#endif
+
 constexpr int kCrfBlocks = 512;
 
 int launch_render_fwd(const hs_fwd_args& a, const hs_layout& L, hipStream_t s) {
@@ -542,7 +640,7 @@ int launch_render_fwd(const hs_fwd_args& a, const hs_layout& L, hipStream_t s) {
     p.pose_hdr = need_pose ? (float*)(img + L.pose_hdr) : nullptr;
     p.crf.table = a.crf_table; p.crf.K = a.crf_K; p.crf.umin = a.crf_umin; p.crf.umax = a.crf_umax; p.crf.dt = 1.f;
     p.exposure = a.exposure;
-    render_fwd_kernel<<<p.ntiles * d.n_poses, 256, 0, s>>>(p);
+    render_fwd_kernel<<<p.ntiles * d.n_poses, kBatch, 0, s>>>(p);
     HS_LAUNCH_CHECK();
     if (d.n_poses > 1) {
         const int64_t HW = (int64_t)d.W * d.H;
@@ -569,7 +667,7 @@ int launch_render_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s) {
     p.exposure = a.exposure;
     // pairs beyond a tile's deepest contributor are never visited: their records must read as zero
     HS_HIP_CHECK(hipMemsetAsync(p.pair_grads, 0, (size_t)d.capacity * kPairFloats * sizeof(float), s));
-    render_bwd_kernel<<<p.ntiles * d.n_poses, 256, 0, s>>>(p);
+    render_bwd_kernel<<<p.ntiles * d.n_poses, kBatch, 0, s>>>(p);
     HS_LAUNCH_CHECK();
     if ((a.flags & HS_FLAG_HDR) && (a.dL_dcrf_table || a.dL_dexposure)) {
         const int64_t HW = (int64_t)d.W * d.H;
