@@ -69,7 +69,7 @@ class hs_bwd_args(C.Structure):
 class hs_layout(C.Structure):
     _fields_ = [(n, C.c_int64) for n in (
         "counters", "rec", "depth", "radii", "tiles_touched", "offsets", "cov3D", "clamped", "scan_spine",
-        "keys_sorted", "point_list", "keys_unsorted", "vals_unsorted", "ranges", "sort_tmp",
+        "keys_sorted", "point_list", "keys_unsorted", "vals_unsorted", "ranges", "sort_tmp", "depth_keys", "depth_vals",
         "final_T", "n_contrib", "pose_hdr",
         "pair_grads", "crf_partials")]
 

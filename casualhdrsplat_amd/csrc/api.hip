@@ -48,12 +48,14 @@ static int plan(const hs_dims& d, hs_sizes* sz, hs_layout* L) {
     sz->geom_bytes = o;
     // binning
     o = 0;
-    l.keys_sorted = carve(d.capacity * 8);
+    l.keys_sorted = carve(d.capacity * 4);
     l.point_list = carve(d.capacity * 4);
-    l.keys_unsorted = carve(d.capacity * 8);
+    l.keys_unsorted = carve(d.capacity * 4);
     l.vals_unsorted = carve(d.capacity * 4);
     l.ranges = carve(vtiles * 8);
-    l.sort_tmp = carve(sort_tmp_bytes(d.capacity));
+    l.sort_tmp = carve(sort_tmp_bytes(d.capacity > I ? d.capacity : I));
+    l.depth_keys = carve(2 * I * 4);
+    l.depth_vals = carve(2 * I * 4);
     sz->binning_bytes = o;
     // image
     o = 0;

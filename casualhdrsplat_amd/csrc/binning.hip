@@ -1,12 +1,23 @@
-// Tile binning for gfx950: inclusive scan of tiles_touched (a5), duplicateWithKeys (a6),
-// stable LSD radix sort of (u64 key, u32 instance) pairs (a7) and tile ranges (a8).
+// Tile binning for gfx950: inclusive scan of tiles_touched (a5), duplicateWithKeys (a6), the stable
+// radix tile sort (a7) and tile ranges (a8).
 //
 // Rules: SURVEY.md 8(a).  All integer work -- results are bit-exact against the CPU restatement under oracle/.
-// The sort is a wave64 design: per 8-bit digit pass a 256-bin LDS histogram kernel, a 256-block
-// row scan, and a scatter kernel that ranks keys with 64-bit ballots (match-any over the digit
-// bits), reorders the 4096-key block through LDS and writes each digit's run contiguously.
-// Element counts are read from device memory (hs_counters.num_rendered) so the host never has
-// to know R to launch (grids are sized by capacity; surplus blocks exit on their first load).
+//
+// The published algorithm sorts R (tile<<32 | depth_bits) keys with one 64-bit radix sort.  The result of that
+// stable sort is reproduced here with ~4x less HBM traffic by splitting it:
+//   1. stable-sort the I = N*P instances by depth bits (32-bit keys, I << R);
+//   2. emit each instance's (tile, instance) pairs walking the instances in that depth order, so the pair stream
+//      is already depth-ordered (ties in depth keep ascending instance index, exactly the order in which the
+//      published duplicateWithKeys lays equal keys out);
+//   3. stable-sort the pairs by tile id alone (13..16 bits => two 8-bit passes on 8-byte pairs).
+// A stable sort by tile of a depth-ordered stream is the (tile, depth) order with ties by emission order, i.e.
+// bit for bit the order of the 64-bit sort.  Tests compare point_list / ranges / reconstructed 64-bit keys with
+// the oracle's single 64-bit stable sort.
+//
+// The radix passes are wave64 kernels: a 256-bin LDS histogram kernel (which also accumulates digit totals), a
+// 256-block row scan, and a scatter kernel that ranks keys with 64-bit ballots (match-any over the digit bits),
+// reorders the 4096-key block through LDS and writes each digit's run contiguously.  Element counts are read
+// from device memory so the host never has to know R to launch (grids are sized by capacity).
 #include "hs_common.h"
 
 namespace hs {
@@ -58,7 +69,7 @@ __global__ void __launch_bounds__(256) scan_reduce_kernel(const uint32_t* in, in
     if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
 }
 
-// Single block: exclusive scan of block_sums in place; writes the grand total to *total_out.
+// Single block: exclusive scan of block_sums in place; writes the grand total to *total_out (may be null).
 __global__ void __launch_bounds__(256) scan_spine_kernel(uint32_t* block_sums, int nblocks, uint32_t* total_out) {
     __shared__ uint32_t s_wave[4];
     uint32_t carry = 0;
@@ -70,7 +81,7 @@ __global__ void __launch_bounds__(256) scan_spine_kernel(uint32_t* block_sums, i
         if (i < nblocks) block_sums[i] = carry + incl - v;
         carry += total;
     }
-    if (threadIdx.x == 0) *total_out = carry;
+    if (threadIdx.x == 0 && total_out) *total_out = carry;
 }
 
 __global__ void __launch_bounds__(256) scan_apply_kernel(const uint32_t* in, int64_t n, const uint32_t* block_sums,
@@ -94,57 +105,36 @@ __global__ void __launch_bounds__(256) scan_apply_kernel(const uint32_t* in, int
     }
 }
 
+int scan_u32(const uint32_t* in, int64_t n, uint32_t* spine, uint32_t* out, uint32_t* total_out, hipStream_t s) {
+    const int nblk = ceil_div(n, kScanTile);
+    scan_reduce_kernel<<<nblk, 256, 0, s>>>(in, n, spine);
+    scan_spine_kernel<<<1, 256, 0, s>>>(spine, nblk, total_out);
+    scan_apply_kernel<<<nblk, 256, 0, s>>>(in, n, spine, out);
+    HS_LAUNCH_CHECK();
+    return HS_OK;
+}
+
 // n_sort = R when it fits the binning capacity, else 0 (and the overflow flag is raised): every later
 // kernel of the forward reads n_sort, so an overflowing call degrades to an empty render instead of
 // writing out of bounds; the host sees counters.overflow and replays with a larger capacity.
-__global__ void bin_prepare_kernel(hs_counters* c, uint64_t capacity) {
+__global__ void bin_prepare_kernel(hs_counters* c, uint64_t capacity, uint32_t n_inst) {
     const bool ok = (uint64_t)c->num_rendered <= capacity;
     c->reserved[0] = ok ? c->num_rendered : 0u;
+    c->reserved[1] = n_inst;
     c->overflow = ok ? 0u : 1u;
 }
 
-// ---------------------------------------------------------------- duplicateWithKeys (a6)
-// One thread per instance.  The tile rectangle is recomputed from (pixel centre, radius) with exactly the
-// operations of preprocess (this TU is also built with -ffp-contract=off).
-__global__ void __launch_bounds__(256) duplicate_with_keys_kernel(int64_t I, int P, int W, int H, float4* rec,
-                                                                  const int* radii, const uint32_t* offsets,
-                                                                  uint64_t* keys, uint32_t* vals, uint64_t capacity,
-                                                                  hs_counters* counters) {
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= I) return;
-    if ((uint64_t)counters->num_rendered > capacity) return;  // overflow: bin_prepare_kernel flagged it
-    const int rad = radii[idx];
-    if (rad <= 0) return;
-    uint32_t off = idx == 0 ? 0u : offsets[idx - 1];
-    // start of this instance's pair slots: needed by render-backward to address its gradient records
-    reinterpret_cast<float*>(rec + 3 * idx + 2)[3] = __uint_as_float(off);
-    const float4 ra = rec[3 * idx];
-    const float depth = reinterpret_cast<const float*>(rec + 3 * idx + 2)[1];
-    const int gx = (W + kTile - 1) / kTile, gy = (H + kTile - 1) / kTile;
-    const int rminx = min(gx, max(0, (int)((ra.x - (float)rad) / (float)kTile)));
-    const int rminy = min(gy, max(0, (int)((ra.y - (float)rad) / (float)kTile)));
-    const int rmaxx = min(gx, max(0, (int)((ra.x + (float)rad + (float)(kTile - 1)) / (float)kTile)));
-    const int rmaxy = min(gy, max(0, (int)((ra.y + (float)rad + (float)(kTile - 1)) / (float)kTile)));
-    const uint32_t pose = (uint32_t)(idx / P);
-    const uint32_t tile_base = pose * (uint32_t)(gx * gy);
-    const uint64_t dbits = (uint64_t)__float_as_uint(depth);
-    for (int y = rminy; y < rmaxy; ++y)
-        for (int x = rminx; x < rmaxx; ++x) {
-            const uint64_t key = ((uint64_t)(tile_base + (uint32_t)(y * gx + x)) << 32) | dbits;
-            keys[off] = key;
-            vals[off] = (uint32_t)idx;
-            ++off;
-        }
-}
-
-// ---------------------------------------------------------------- radix sort (a7)
-__device__ __forceinline__ uint32_t digit_of(uint64_t k, int shift, uint32_t mask) {
+// ---------------------------------------------------------------- radix sort passes (a7)
+template <typename K>
+__device__ __forceinline__ uint32_t digit_of(K k, int shift, uint32_t mask) {
     return (uint32_t)(k >> shift) & mask;
 }
 
-// hist[digit * nblk + blk] = number of keys of block `blk` with that digit.
-__global__ void __launch_bounds__(kSortBlock) radix_hist_kernel(const uint64_t* keys, const uint32_t* n_dev, int shift,
-                                                                uint32_t mask, uint32_t* hist, int nblk) {
+// hist[digit * nblk + blk] = number of keys of block `blk` with that digit; totals[digit] += the same.
+template <typename K>
+__global__ void __launch_bounds__(kSortBlock) radix_hist_kernel(const K* keys, const uint32_t* n_dev, int shift,
+                                                                uint32_t mask, uint32_t* hist, uint32_t* totals,
+                                                                int nblk) {
     __shared__ uint32_t s_hist[256];
     const int64_t n = *n_dev;
     const int64_t base = (int64_t)blockIdx.x * kSortTile;
@@ -154,23 +144,13 @@ __global__ void __launch_bounds__(kSortBlock) radix_hist_kernel(const uint64_t* 
 #pragma unroll 4
         for (int i = 0; i < kSortItems; ++i) {
             const int64_t k = base + i * kSortBlock + threadIdx.x;
-            if (k < n) atomicAdd(&s_hist[digit_of(keys[k], shift, mask)], 1u);
+            if (k < n) atomicAdd(&s_hist[digit_of<K>(keys[k], shift, mask)], 1u);
         }
     }
     __syncthreads();
-    hist[(int64_t)threadIdx.x * nblk + blockIdx.x] = s_hist[threadIdx.x];
-}
-
-// Digit totals (one block per digit), consumed by radix_scan_kernel.
-__global__ void __launch_bounds__(256) radix_totals_kernel(const uint32_t* hist, int nblk, uint32_t* totals) {
-    __shared__ uint32_t s_wave[4];
-    const int d = blockIdx.x;
-    const uint32_t* row = hist + (int64_t)d * nblk;
-    uint32_t acc = 0;
-    for (int i = threadIdx.x; i < nblk; i += 256) acc += row[i];
-    uint32_t total;
-    block_incl_scan(acc, s_wave, &total);
-    if (threadIdx.x == 0) totals[d] = total;
+    const uint32_t c = s_hist[threadIdx.x];
+    hist[(int64_t)threadIdx.x * nblk + blockIdx.x] = c;
+    if (c) atomicAdd(&totals[threadIdx.x], c);
 }
 
 // One block per digit: exclusive scan of that digit's row over blocks, offset by the number of keys
@@ -178,8 +158,7 @@ __global__ void __launch_bounds__(256) radix_totals_kernel(const uint32_t* hist,
 __global__ void __launch_bounds__(256) radix_scan_kernel(uint32_t* hist, int nblk, const uint32_t* totals) {
     __shared__ uint32_t s_wave[4];
     const int d = blockIdx.x;
-    // exclusive prefix of digit totals below d
-    uint32_t mine = threadIdx.x < d ? totals[threadIdx.x] : 0;
+    uint32_t mine = (int)threadIdx.x < d ? totals[threadIdx.x] : 0;
     uint32_t carry;
     block_incl_scan(mine, s_wave, &carry);
     uint32_t* row = hist + (int64_t)d * nblk;
@@ -195,15 +174,17 @@ __global__ void __launch_bounds__(256) radix_scan_kernel(uint32_t* hist, int nbl
 
 // Scatter: stable within the block (wave w owns keys [w*1024, (w+1)*1024) of the block, processed in
 // 16 rounds of 64 consecutive keys), stable across blocks through the scanned histogram.
-__global__ void __launch_bounds__(kSortBlock) radix_scatter_kernel(const uint64_t* keys_in, const uint32_t* vals_in,
-                                                                   uint64_t* keys_out, uint32_t* vals_out,
+template <typename K>
+__global__ void __launch_bounds__(kSortBlock) radix_scatter_kernel(const K* keys_in, const uint32_t* vals_in,
+                                                                   K* keys_out, uint32_t* vals_out,
                                                                    const uint32_t* n_dev, int shift, uint32_t mask,
                                                                    const uint32_t* hist, int nblk) {
     __shared__ uint32_t s_cnt[4][256];    // per-wave digit counters -> per-wave exclusive offsets
     __shared__ uint32_t s_dstart[256];    // block-local start of each digit's run
     __shared__ uint32_t s_gbase[256];     // global start of this block's run of each digit
-    __shared__ uint64_t s_keys[kSortTile];
+    __shared__ K s_keys[kSortTile];
     __shared__ uint32_t s_vals[kSortTile];
+    __shared__ uint32_t s_wave[4];
 
     const int64_t n = *n_dev;
     const int64_t base = (int64_t)blockIdx.x * kSortTile;
@@ -216,7 +197,7 @@ __global__ void __launch_bounds__(kSortBlock) radix_scatter_kernel(const uint64_
     s_gbase[threadIdx.x] = hist[(int64_t)threadIdx.x * nblk + blockIdx.x];
     __syncthreads();
 
-    uint64_t key[kSortItems];
+    K key[kSortItems];
     uint32_t val[kSortItems];
     uint16_t rank[kSortItems];
     const uint64_t lt_mask = (1ull << lane) - 1ull;
@@ -225,14 +206,14 @@ __global__ void __launch_bounds__(kSortBlock) radix_scatter_kernel(const uint64_
     for (int i = 0; i < kSortItems; ++i) {
         const int loc = wbase + i * 64 + lane;
         const bool valid = loc < cnt_block;
-        key[i] = valid ? keys_in[base + loc] : ~0ull;
+        key[i] = valid ? keys_in[base + loc] : (K) ~(K)0;
         val[i] = valid ? vals_in[base + loc] : 0u;
     }
 #pragma unroll
     for (int i = 0; i < kSortItems; ++i) {
         const int loc = wbase + i * 64 + lane;
         const bool valid = loc < cnt_block;
-        const uint32_t d = digit_of(key[i], shift, mask);
+        const uint32_t d = digit_of<K>(key[i], shift, mask);
         // match-any: lanes holding the same digit
         uint64_t peers = __ballot(valid);
 #pragma unroll
@@ -254,7 +235,6 @@ __global__ void __launch_bounds__(kSortBlock) radix_scatter_kernel(const uint64_
         const uint32_t tot = c0 + c1 + c2 + c3;
         s_cnt[0][threadIdx.x] = 0; s_cnt[1][threadIdx.x] = c0; s_cnt[2][threadIdx.x] = c0 + c1;
         s_cnt[3][threadIdx.x] = c0 + c1 + c2;
-        __shared__ uint32_t s_wave[4];
         uint32_t total;
         const uint32_t incl = block_incl_scan(tot, s_wave, &total);
         s_dstart[threadIdx.x] = incl - tot;
@@ -264,7 +244,7 @@ __global__ void __launch_bounds__(kSortBlock) radix_scatter_kernel(const uint64_
     for (int i = 0; i < kSortItems; ++i) {
         const int loc = wbase + i * 64 + lane;
         if (loc < cnt_block) {
-            const uint32_t d = digit_of(key[i], shift, mask);
+            const uint32_t d = digit_of<K>(key[i], shift, mask);
             const uint32_t pos = s_dstart[d] + s_cnt[wave][d] + rank[i];
             s_keys[pos] = key[i];
             s_vals[pos] = val[i];
@@ -275,8 +255,8 @@ __global__ void __launch_bounds__(kSortBlock) radix_scatter_kernel(const uint64_
     for (int i = 0; i < kSortItems; ++i) {
         const int pos = i * kSortBlock + threadIdx.x;
         if (pos < cnt_block) {
-            const uint64_t k = s_keys[pos];
-            const uint32_t d = digit_of(k, shift, mask);
+            const K k = s_keys[pos];
+            const uint32_t d = digit_of<K>(k, shift, mask);
             const int64_t dst = (int64_t)s_gbase[d] + (pos - s_dstart[d]);
             keys_out[dst] = k;
             vals_out[dst] = s_vals[pos];
@@ -284,15 +264,88 @@ __global__ void __launch_bounds__(kSortBlock) radix_scatter_kernel(const uint64_
     }
 }
 
+template <typename K>
+int radix_sort(K* k0, uint32_t* v0, K* k1, uint32_t* v1, const uint32_t* n_dev, int64_t n_launch, int nbits,
+               void* tmp, hipStream_t s) {
+    if (n_launch <= 0) return HS_OK;
+    const int nblk = ceil_div(n_launch, kSortTile);
+    const int passes = sort_passes(nbits);
+    uint32_t* hist = (uint32_t*)tmp;
+    uint32_t* totals = (uint32_t*)((char*)tmp + align_up(256 * (int64_t)nblk * 4, 256));  // [passes][256]
+    HS_HIP_CHECK(hipMemsetAsync(totals, 0, (size_t)passes * 256 * 4, s));
+    K* kin = k0; uint32_t* vin = v0; K* kout = k1; uint32_t* vout = v1;
+    int pass = 0;
+    for (int shift = 0; shift < nbits; shift += 8, ++pass) {
+        const int w = nbits - shift < 8 ? nbits - shift : 8;
+        const uint32_t mask = (1u << w) - 1u;
+        uint32_t* tot = totals + 256 * pass;
+        radix_hist_kernel<K><<<nblk, kSortBlock, 0, s>>>(kin, n_dev, shift, mask, hist, tot, nblk);
+        radix_scan_kernel<<<256, 256, 0, s>>>(hist, nblk, tot);
+        radix_scatter_kernel<K><<<nblk, kSortBlock, 0, s>>>(kin, vin, kout, vout, n_dev, shift, mask, hist, nblk);
+        HS_LAUNCH_CHECK();
+        K* tk = kin; kin = kout; kout = tk;
+        uint32_t* tv = vin; vin = vout; vout = tv;
+    }
+    return HS_OK;
+}
+
+// ---------------------------------------------------------------- split tile sort (a6 + a7)
+// Depth keys of the instances: culled instances get the largest key so they sort to the end.
+__global__ void __launch_bounds__(256) depth_keys_kernel(int64_t I, const float* depth, const int* radii, uint32_t* keys,
+                                                         uint32_t* vals) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= I) return;
+    keys[i] = radii[i] > 0 ? __float_as_uint(depth[i]) : 0xFFFFFFFFu;
+    vals[i] = (uint32_t)i;
+}
+
+__global__ void __launch_bounds__(256) gather_tiles_kernel(int64_t I, const uint32_t* inst_sorted, const uint32_t* tiles,
+                                                           uint32_t* out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= I) return;
+    out[i] = tiles[inst_sorted[i]];
+}
+
+// duplicateWithKeys walking the instances in depth order.  One thread per instance; the tile rectangle is
+// recomputed from (pixel centre, radius) with exactly the operations of preprocess (this TU is built with
+// -ffp-contract=off).  Also records where the instance's pair slots start (render-backward addresses its
+// gradient records with it; preprocess-backward sums them).
+__global__ void __launch_bounds__(256) emit_pairs_kernel(int64_t I, int P, int W, int H, float4* rec, const int* radii,
+                                                         const uint32_t* inst_sorted, const uint32_t* offs_sorted,
+                                                         uint32_t* tile_keys, uint32_t* vals, const hs_counters* counters) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= I) return;
+    if (counters->overflow) return;
+    const uint32_t idx = inst_sorted[i];
+    const int rad = radii[idx];
+    if (rad <= 0) return;
+    uint32_t off = i == 0 ? 0u : offs_sorted[i - 1];
+    reinterpret_cast<float*>(rec + 3 * (int64_t)idx + 2)[3] = __uint_as_float(off);
+    const float4 ra = rec[3 * (int64_t)idx];
+    const int gx = (W + kTile - 1) / kTile, gy = (H + kTile - 1) / kTile;
+    const int rminx = min(gx, max(0, (int)((ra.x - (float)rad) / (float)kTile)));
+    const int rminy = min(gy, max(0, (int)((ra.y - (float)rad) / (float)kTile)));
+    const int rmaxx = min(gx, max(0, (int)((ra.x + (float)rad + (float)(kTile - 1)) / (float)kTile)));
+    const int rmaxy = min(gy, max(0, (int)((ra.y + (float)rad + (float)(kTile - 1)) / (float)kTile)));
+    const uint32_t pose = idx / (uint32_t)P;
+    const uint32_t tile_base = pose * (uint32_t)(gx * gy);
+    for (int y = rminy; y < rmaxy; ++y)
+        for (int x = rminx; x < rmaxx; ++x) {
+            tile_keys[off] = tile_base + (uint32_t)(y * gx + x);
+            vals[off] = idx;
+            ++off;
+        }
+}
+
 // ---------------------------------------------------------------- tile ranges (a8)
-__global__ void __launch_bounds__(256) tile_ranges_kernel(const uint64_t* keys, const uint32_t* n_dev, uint2* ranges) {
+__global__ void __launch_bounds__(256) tile_ranges_kernel(const uint32_t* tiles, const uint32_t* n_dev, uint2* ranges) {
     const int64_t n = *n_dev;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const uint32_t t = (uint32_t)(keys[i] >> 32);
+    const uint32_t t = tiles[i];
     if (i == 0) ranges[t].x = 0;
     else {
-        const uint32_t tp = (uint32_t)(keys[i - 1] >> 32);
+        const uint32_t tp = tiles[i - 1];
         if (t != tp) {
             ranges[tp].y = (uint32_t)i;
             ranges[t].x = (uint32_t)i;
@@ -305,46 +358,23 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(const uint64_t* keys, 
 
 int64_t sort_tmp_bytes(int64_t n) {
     const int64_t nblk = ceil_div(n > 0 ? n : 1, kSortTile);
-    return align_up(256 * nblk * 4, 256) + 256 * 4;
+    return align_up(256 * nblk * 4, 256) + 8 * 256 * 4;
 }
 
 int launch_radix_sort(uint64_t* k0, uint32_t* v0, uint64_t* k1, uint32_t* v1, const uint32_t* n_dev,
                       int64_t n_launch, int nbits, void* tmp, hipStream_t s) {
-    if (n_launch <= 0) return HS_OK;
-    const int nblk = ceil_div(n_launch, kSortTile);
-    uint32_t* hist = (uint32_t*)tmp;
-    uint32_t* totals = (uint32_t*)((char*)tmp + align_up(256 * (int64_t)nblk * 4, 256));
-    uint64_t* kin = k0; uint32_t* vin = v0; uint64_t* kout = k1; uint32_t* vout = v1;
-    for (int shift = 0; shift < nbits; shift += 8) {
-        const int w = nbits - shift < 8 ? nbits - shift : 8;
-        const uint32_t mask = (1u << w) - 1u;
-        radix_hist_kernel<<<nblk, kSortBlock, 0, s>>>(kin, n_dev, shift, mask, hist, nblk);
-        radix_totals_kernel<<<256, 256, 0, s>>>(hist, nblk, totals);
-        radix_scan_kernel<<<256, 256, 0, s>>>(hist, nblk, totals);
-        radix_scatter_kernel<<<nblk, kSortBlock, 0, s>>>(kin, vin, kout, vout, n_dev, shift, mask, hist, nblk);
-        HS_LAUNCH_CHECK();
-        uint64_t* tk = kin; kin = kout; kout = tk;
-        uint32_t* tv = vin; vin = vout; vout = tv;
-    }
-    return HS_OK;
+    return radix_sort<uint64_t>(k0, v0, k1, v1, n_dev, n_launch, nbits, tmp, s);
 }
 
 int launch_scan(const hs_fwd_args& a, const hs_layout& L, hipStream_t s) {
     const hs_dims& d = a.dims;
     char* geom = (char*)a.geom;
     const int64_t I = (int64_t)d.P * d.n_poses;
-    const int nblk = ceil_div(I, kScanTile);
-    const uint32_t* tiles = (const uint32_t*)(geom + L.tiles_touched);
-    uint32_t* offsets = (uint32_t*)(geom + L.offsets);
-    // the block-sum spine is carved from the geom workspace (binning may not be allocated yet)
-    uint32_t* spine = (uint32_t*)(geom + L.scan_spine);
     hs_counters* counters = (hs_counters*)(geom + L.counters);
     HS_HIP_CHECK(hipMemsetAsync(counters, 0, sizeof(hs_counters), s));
-    scan_reduce_kernel<<<nblk, 256, 0, s>>>(tiles, I, spine);
-    scan_spine_kernel<<<1, 256, 0, s>>>(spine, nblk, &counters->num_rendered);
-    scan_apply_kernel<<<nblk, 256, 0, s>>>(tiles, I, spine, offsets);
-    HS_LAUNCH_CHECK();
-    return HS_OK;
+    // offsets (instance order) are kept for inspection; their total is R
+    return scan_u32((const uint32_t*)(geom + L.tiles_touched), I, (uint32_t*)(geom + L.scan_spine),
+                    (uint32_t*)(geom + L.offsets), &counters->num_rendered, s);
 }
 
 int launch_binning(const hs_fwd_args& a, const hs_layout& L, hipStream_t s) {
@@ -354,26 +384,44 @@ int launch_binning(const hs_fwd_args& a, const hs_layout& L, hipStream_t s) {
     const int64_t I = (int64_t)d.P * d.n_poses;
     const int gx = (d.W + kTile - 1) / kTile, gy = (d.H + kTile - 1) / kTile;
     const int64_t ntiles = (int64_t)gx * gy * d.n_poses;
-    const int nbits = 32 + tile_bits((uint32_t)ntiles);
-    const int passes = sort_passes(nbits);
     hs_counters* counters = (hs_counters*)(geom + L.counters);
-    uint64_t* kA = (uint64_t*)(bin + L.keys_sorted);
-    uint32_t* vA = (uint32_t*)(bin + L.point_list);
-    uint64_t* kB = (uint64_t*)(bin + L.keys_unsorted);
-    uint32_t* vB = (uint32_t*)(bin + L.vals_unsorted);
-    // the sorted result must land in (kA, vA): start from A when the pass count is even
-    uint64_t* k0 = (passes % 2 == 0) ? kA : kB;
-    uint32_t* v0 = (passes % 2 == 0) ? vA : vB;
-    uint64_t* k1 = (passes % 2 == 0) ? kB : kA;
-    uint32_t* v1 = (passes % 2 == 0) ? vB : vA;
-    bin_prepare_kernel<<<1, 1, 0, s>>>(counters, (uint64_t)d.capacity);
-    duplicate_with_keys_kernel<<<ceil_div(I, 256), 256, 0, s>>>(
-        I, d.P, d.W, d.H, (float4*)(geom + L.rec), (const int*)(geom + L.radii), (const uint32_t*)(geom + L.offsets),
-        k0, v0, (uint64_t)d.capacity, counters);
-    HS_LAUNCH_CHECK();
-    void* tmp = bin + L.sort_tmp;
     const uint32_t* n_sort = &counters->reserved[0];
-    int rc = launch_radix_sort(k0, v0, k1, v1, n_sort, d.capacity, nbits, tmp, s);
+    const uint32_t* n_inst = &counters->reserved[1];
+    bin_prepare_kernel<<<1, 1, 0, s>>>(counters, (uint64_t)d.capacity, (uint32_t)I);
+
+    // 1. instances by depth (stable, 32-bit keys -> 4 passes: result back in the first buffer pair)
+    uint32_t* dk0 = (uint32_t*)(bin + L.depth_keys);
+    uint32_t* dv0 = (uint32_t*)(bin + L.depth_vals);
+    uint32_t* dk1 = dk0 + I;
+    uint32_t* dv1 = dv0 + I;
+    void* tmp = bin + L.sort_tmp;
+    depth_keys_kernel<<<ceil_div(I, 256), 256, 0, s>>>(I, (const float*)(geom + L.depth), (const int*)(geom + L.radii),
+                                                       dk0, dv0);
+    int rc = radix_sort<uint32_t>(dk0, dv0, dk1, dv1, n_inst, I, 32, tmp, s);
+    if (rc != HS_OK) return rc;
+    const uint32_t* inst_sorted = dv0;
+    // 2. pair offsets in depth order, then emission
+    uint32_t* ts = dk1;      // tiles touched in depth order (reuses the depth-key scratch)
+    uint32_t* offs = dv1;    // inclusive scan of ts
+    gather_tiles_kernel<<<ceil_div(I, 256), 256, 0, s>>>(I, inst_sorted, (const uint32_t*)(geom + L.tiles_touched), ts);
+    rc = scan_u32(ts, I, (uint32_t*)(geom + L.scan_spine), offs, nullptr, s);
+    if (rc != HS_OK) return rc;
+    // the tile sort must end in (keys_sorted, point_list): start from A when the pass count is even
+    const int tbits = tile_bits((uint32_t)ntiles);
+    const int passes = sort_passes(tbits);
+    uint32_t* kA = (uint32_t*)(bin + L.keys_sorted);
+    uint32_t* vA = (uint32_t*)(bin + L.point_list);
+    uint32_t* kB = (uint32_t*)(bin + L.keys_unsorted);
+    uint32_t* vB = (uint32_t*)(bin + L.vals_unsorted);
+    uint32_t* k0 = (passes % 2 == 0) ? kA : kB;
+    uint32_t* v0 = (passes % 2 == 0) ? vA : vB;
+    uint32_t* k1 = (passes % 2 == 0) ? kB : kA;
+    uint32_t* v1 = (passes % 2 == 0) ? vB : vA;
+    emit_pairs_kernel<<<ceil_div(I, 256), 256, 0, s>>>(I, d.P, d.W, d.H, (float4*)(geom + L.rec),
+                                                       (const int*)(geom + L.radii), inst_sorted, offs, k0, v0, counters);
+    HS_LAUNCH_CHECK();
+    // 3. stable sort by tile id only
+    rc = radix_sort<uint32_t>(k0, v0, k1, v1, n_sort, d.capacity, tbits, tmp, s);
     if (rc != HS_OK) return rc;
     uint2* ranges = (uint2*)(bin + L.ranges);
     HS_HIP_CHECK(hipMemsetAsync(ranges, 0, (size_t)ntiles * 8, s));

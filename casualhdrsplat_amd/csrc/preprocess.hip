@@ -304,8 +304,8 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreBwd p) {
         if (p.radii_inst[idx] <= 0) continue;
         // ---- segmented sum of this instance's (tile, instance) records ----
         const uint32_t n = p.tiles[idx];
-        const uint32_t end = p.offsets[idx];
-        const uint32_t beg = end - n;
+        const uint32_t beg = __float_as_uint(reinterpret_cast<const float*>(p.rec + 3 * idx + 2)[3]);
+        const uint32_t end = beg + n;
         float r[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         for (uint32_t s = beg; s < end; ++s) {
             const float4 q0 = p.pair_grads[3 * (int64_t)s + 0];

@@ -152,21 +152,28 @@ __device__ __forceinline__ void scale_entry(float4& a, float4& b) {
 }
 
 // One Gaussian per lane against a half tile [sx, sx+15] x [sy, sy+7] (pixel centres).
-// Returns false only when NO pixel of it can pass `power <= 0 && alpha >= 1/255`:
-// alpha >= 1/255  <=>  q(d) = A dx^2 + 2B dx dy + C dy^2 <= tau = 2 ln(255 o); the axis-aligned bounding box of
-// that ellipse has half-extents sqrt(tau*C/det), sqrt(tau*A/det), det = AC - B^2.  In the scaled coefficients
-// C/det = -2 L C2 / (4 A2 C2 - B2^2) with L = log2e.  tau carries an absolute safety margin of 0.05 (+1e-4
-// relative), orders of magnitude above the fp32 evaluation error of `power` for variance ratios up to ~1e5,
-// so culling never changes a result.
+// Returns false only when NO point of that rectangle can pass `alpha >= 1/255`, i.e. when the maximum over the
+// rectangle of  log2 G(d) = dx (A2 dx + B2 dy) + C2 dy^2  (a concave quadratic centred on the Gaussian) stays below
+// log2(1/(255 o)).  For a centre outside the rectangle the maximum lies on one of the two edges facing it; both
+// candidates below (optimum along the nearest vertical line, optimum along the nearest horizontal line, each
+// clamped to the rectangle) are points of the rectangle and one of them is the constrained optimum, so the test is
+// exact up to rounding.  The threshold carries an absolute margin of 0.05 in log2 units (+1e-4 relative), orders
+// of magnitude above the fp32 evaluation error of the inner loops for variance ratios up to ~1e5, so culling
+// never changes a result.
 __device__ __forceinline__ bool halftile_may_touch(const float4 a, const float4 b, float sx, float sy) {
     const float A2 = a.z, B2 = a.w, C2 = b.x, o = b.y;
     if (!(o >= kAlphaMin)) return false;
-    const float tau = 2.f * __logf(255.f * o) * 1.0001f + 0.05f;
-    const float det = 4.f * A2 * C2 - B2 * B2;
-    if (!(det > 0.f)) return true;  // degenerate conic: let the exact test decide
-    const float k = tau * (-2.f * kLog2e) / det;
-    const float hx = sqrtf(k * C2) * 1.0001f, hy = sqrtf(k * A2) * 1.0001f;
-    return (a.x + hx >= sx) && (a.x - hx <= sx + 15.f) && (a.y + hy >= sy) && (a.y - hy <= sy + 7.f);
+    if (!(A2 < 0.f && C2 < 0.f && 4.f * A2 * C2 - B2 * B2 > 0.f)) return true;  // not positive definite: no culling
+    const float thr = -(__log2f(255.f * o) * 1.0001f + 0.05f);
+    // rectangle in d = g - pixel coordinates: dx in [a.x - (sx+15), a.x - sx], dy in [a.y - (sy+7), a.y - sy]
+    const float dx_lo = a.x - (sx + 15.f), dx_hi = a.x - sx, dy_lo = a.y - (sy + 7.f), dy_hi = a.y - sy;
+    const float dx_e = fminf(fmaxf(0.f, dx_lo), dx_hi);  // nearest rectangle x to the centre (0 if inside)
+    const float dy_e = fminf(fmaxf(0.f, dy_lo), dy_hi);
+    const float dy_s = fminf(fmaxf(-0.5f * B2 * dx_e / C2, dy_lo), dy_hi);
+    const float dx_s = fminf(fmaxf(-0.5f * B2 * dy_e / A2, dx_lo), dx_hi);
+    const float p1 = dx_e * (A2 * dx_e + B2 * dy_s) + C2 * dy_s * dy_s;
+    const float p2 = dx_s * (A2 * dx_s + B2 * dy_e) + C2 * dy_e * dy_e;
+    return fmaxf(p1, p2) >= thr;
 }
 
 struct RenderFwd {
@@ -456,16 +463,22 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
             scale_entry(ra, rb);
             s_a[threadIdx.x] = ra; s_b[threadIdx.x] = rb; s_c[threadIdx.x] = rc;
         }
+#ifndef HS_ABLATE_STAGE
         if (bi > 0) {  // batches below the top one are always full
             const uint32_t id = p.point_list[range.x + base - KB + threadIdx.x];
             const float4* r = p.rec + 3 * (int64_t)id;
             ra = r[0]; rb = r[1]; rc = r[2];
         }
+#endif
         __syncthreads();
         uint64_t wrote[KB / 64];
 #pragma unroll
         for (int k = 0; k < KB / 64; ++k) wrote[k] = 0ull;
+#ifdef HS_ABLATE_COMPACT
+        if (false) {
+#else
         if (base < (int)wave_max) {
+#endif
             int n_t = 0;
 #pragma unroll
             for (int k = 0; k < KB / 64; ++k) {
@@ -477,6 +490,9 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
                 if (touch) s_list[wave][n_t + mask_prefix(mask)] = (uint16_t)jj;
                 n_t += __popcll(mask);
             }
+#ifdef HS_ABLATE_LOOP
+            n_t = 0;
+#endif
             for (int i = n_t - 1; i >= 0; --i) {  // back to front
                 const int j = (int)s_list[wave][i];
                 const float4 a = s_a[j];
@@ -511,7 +527,11 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
                 g[7] = dch0 * s0.dL1 + dch1 * s1.dL1;
                 g[8] = dch0 * s0.dL2 + dch1 * s1.dL2;
                 float q0, q1, q2;
+#ifdef HS_ABLATE_REDUCE
+                q0 = g[0] + g[1] + g[2] + g[3]; q1 = g[4] + g[5] + g[6] + g[7]; q2 = g[8];
+#else
                 wave_reduce9(g, q0, q1, q2);
+#endif
                 // rows 0..3 of q0 hold totals of g0,g2,g1,g3; of q1: g4,g6,g5,g7; rows 0,1 of q2: g8
                 if ((lane & 15) == 0) {
                     const int row = lane >> 4;
@@ -527,6 +547,9 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
 #pragma unroll
             for (int k = 0; k < KB / 64; ++k) s_wrote[wave][k] = wrote[k];
         }
+#ifdef HS_ABLATE_WRITEOUT
+        if (blockIdx.x != 0x7fffffff) continue;
+#endif
         __syncthreads();
         if ((int)threadIdx.x < cnt) {
             const int t = threadIdx.x;

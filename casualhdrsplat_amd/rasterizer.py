@@ -373,15 +373,20 @@ def inspect_state(out_tensor: torch.Tensor) -> dict:
         return buf[off:off + nbytes].view(dtype)
 
     rec = view(st.geom, lay.rec, I * 12, torch.float32).reshape(I, 12)
+    depths = view(st.geom, lay.depth, I, torch.float32)
+    tile_sorted = view(st.binning, lay.keys_sorted, R, torch.int32).to(torch.int64) & 0xFFFFFFFF
+    pl = view(st.binning, lay.point_list, R, torch.int32)
+    # the published sort key (tile << 32) | depth_bits, rebuilt from the two halves the split sort keeps
+    dbits = depths.view(torch.int32).to(torch.int64)[pl.to(torch.int64)] & 0xFFFFFFFF
+    keys_sorted = (tile_sorted << 32) | dbits
     return dict(
         num_rendered=R,
         rec=rec, xy=rec[:, 0:2], conic_opacity=torch.stack([rec[:, 2], rec[:, 3], rec[:, 4], rec[:, 5]], 1),
-        rgb=rec[:, 6:9], depths=view(st.geom, lay.depth, I, torch.float32),
+        rgb=rec[:, 6:9], depths=depths,
         radii=view(st.geom, lay.radii, I, torch.int32), tiles_touched=view(st.geom, lay.tiles_touched, I, torch.int32),
         offsets=view(st.geom, lay.offsets, I, torch.int32), cov3D=view(st.geom, lay.cov3D, d.P * 6, torch.float32).reshape(d.P, 6),
         clamped=view(st.geom, lay.clamped, I, torch.uint8),
-        keys_sorted=view(st.binning, lay.keys_sorted, R, torch.int64),
-        point_list=view(st.binning, lay.point_list, R, torch.int32),
+        keys_sorted=keys_sorted, point_list=pl,
         ranges=view(st.binning, lay.ranges, vt * 2, torch.int32).reshape(vt, 2),
         final_T=view(st.image, lay.final_T, d.n_poses * d.W * d.H, torch.float32).reshape(d.n_poses, d.H, d.W),
         n_contrib=view(st.image, lay.n_contrib, d.n_poses * d.W * d.H, torch.int32).reshape(d.n_poses, d.H, d.W),

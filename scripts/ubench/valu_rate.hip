@@ -30,6 +30,16 @@ __global__ void __launch_bounds__(256) k(float* out, float seed) {
             if (KIND == 10) asm volatile("v_sub_f32 %0, %1, %0" : "+v"(v[i]) : "s"(seed));
             if (KIND == 11) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(w[i]) : "v"(float2_{a, a}));
             if (KIND == 12) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(v[i]) : "v"(a), "v"(b));
+            if (KIND == 13) asm volatile("v_add_f32 %0, %0, %1" : "+v"(v[i]) : "v"(a));
+            if (KIND == 14) asm volatile("v_cndmask_b32 %0, %0, %1, s[10:11]" : "+v"(v[i]) : "v"(a) : "s10", "s11");
+            if (KIND == 15) asm volatile("v_cmp_lt_f32 s[10:11], %0, %1" :: "v"(v[i]), "v"(a) : "s10", "s11");
+            if (KIND == 16) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(w[i]) : "v"(float2_{a, a}));
+            if (KIND == 17) asm volatile("v_mul_f32 %0, %0, %0" : "+v"(v[i]));
+            if (KIND == 18) asm volatile("v_max_f32 %0, %0, %1" : "+v"(v[i]) : "v"(a));
+            if (KIND == 19) asm volatile("v_mov_b32 %0, %1" : "=v"(v[i]) : "v"(a));
+            if (KIND == 20) { asm volatile("v_mul_f32 %0, %0, %1" : "+v"(v[i]) : "v"(a)); asm volatile("v_exp_f32 %0, %0" : "+v"(w[i].x)); }
+            if (KIND == 21) asm volatile("v_and_b32 %0, %0, %1" : "+v"(v[i]) : "v"(a));
+            if (KIND == 22) asm volatile("v_add_u32 %0, %0, %1" : "+v"(v[i]) : "v"(a));
         }
     }
     float s = 0.f;
@@ -57,11 +67,15 @@ double run(const char* name, float* d, int blocks) {
 
 int main() {
     float* d; hipMalloc(&d, 8192 * 256 * 4);
-    for (int blocks : {256, 2048}) {  // 1 and 8 waves per SIMD
+    for (int blocks : {2048, 4096}) {  // 1 and 8 waves per SIMD
         run<0>("v_fma_f32", d, blocks); run<12>("v_fmac_f32", d, blocks); run<1>("v_pk_fma_f32", d, blocks); run<2>("v_mul_f32", d, blocks);
         run<11>("v_pk_mul_f32", d, blocks); run<3>("v_exp_f32", d, blocks); run<8>("v_rcp_f32", d, blocks);
         run<4>("v_cndmask_b32 vcc", d, blocks); run<5>("v_cmp_lt_f32 vcc", d, blocks); run<9>("v_min_f32", d, blocks);
         run<10>("v_sub_f32 sgpr", d, blocks); run<6>("v_add_f32_dpp quad", d, blocks); run<7>("v_permlane32_swap", d, blocks);
+        run<13>("v_add_f32", d, blocks); run<14>("v_cndmask sgprmask", d, blocks); run<15>("v_cmp -> sgpr", d, blocks);
+        run<16>("v_pk_add_f32", d, blocks); run<17>("v_mul_f32 x,x,x", d, blocks); run<18>("v_max_f32", d, blocks);
+        run<19>("v_mov_b32", d, blocks); run<20>("v_mul + v_exp pair", d, blocks); run<21>("v_and_b32", d, blocks); run<22>("v_add_u32", d, blocks);
+        run<2>("v_mul_f32 (again)", d, blocks); run<0>("v_fma_f32 (again)", d, blocks);
     }
     return 0;
 }
