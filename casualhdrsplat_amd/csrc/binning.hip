@@ -144,7 +144,17 @@ __global__ void __launch_bounds__(kSortBlock) radix_hist_kernel(const K* keys, c
 #pragma unroll 4
         for (int i = 0; i < kSortItems; ++i) {
             const int64_t k = base + i * kSortBlock + threadIdx.x;
-            if (k < n) atomicAdd(&s_hist[digit_of<K>(keys[k], shift, mask)], 1u);
+            const bool valid = k < n;
+            const uint32_t d = valid ? digit_of<K>(keys[k], shift, mask) : 0u;
+            // digits that are (nearly) constant over a pass -- exponent bits of depth, high tile bits -- would
+            // serialise 64 LDS atomics on one bin: when the whole wave agrees, one lane adds the count
+            const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
+            const uint64_t vm = __ballot(valid);
+            if (__ballot(valid && d != d0) == 0ull) {
+                if ((threadIdx.x & 63) == 0 && vm) atomicAdd(&s_hist[d0], (uint32_t)__popcll(vm));
+            } else if (valid) {
+                atomicAdd(&s_hist[d], 1u);
+            }
         }
     }
     __syncthreads();

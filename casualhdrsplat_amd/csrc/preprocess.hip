@@ -279,12 +279,28 @@ struct PreBwd {
     float* d_rots; float* d_cov;
 };
 
+constexpr int kPreBwdBlock = 128;
+
+// The [P, M, 3] SH tensors (input coefficients and their gradient) are the bulk of this kernel's bytes.  A thread
+// owns one Gaussian = one 12*M-byte row, so direct per-thread access would touch 64 different rows per wave
+// instruction; instead the block's rows are moved between HBM and LDS with fully coalesced accesses and each thread
+// works on its row in LDS (row stride M*3+1 words: conflict-free).
 template <int DEG>
-__global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreBwd p) {
-    const int g = blockIdx.x * 256 + threadIdx.x;
-    if (g >= p.P) return;
+__global__ void __launch_bounds__(kPreBwdBlock) preprocess_bwd_kernel(PreBwd p) {
+    extern __shared__ float s_sh[];  // [kPreBwdBlock][M*3 + 1]
     constexpr int NC = (DEG + 1) * (DEG + 1);
-    const float x = p.means[3 * g], y = p.means[3 * g + 1], z = p.means[3 * g + 2];
+    const int g0 = blockIdx.x * kPreBwdBlock;
+    const int g = g0 + threadIdx.x;
+    const int M3 = p.M * 3, ld = M3 + 1;
+    const int rows = min(kPreBwdBlock, p.P - g0);
+    const bool stage_in = !p.has_colors_precomp && DEG >= 1;
+    if (stage_in) {
+        const float* src = p.shs + (int64_t)g0 * M3;
+        for (int i = threadIdx.x; i < rows * M3; i += kPreBwdBlock) s_sh[(i / M3) * ld + (i % M3)] = src[i];
+        __syncthreads();
+    }
+    const bool valid = g < p.P;
+    const float x = valid ? p.means[3 * g] : 0.f, y = valid ? p.means[3 * g + 1] : 0.f, z = valid ? p.means[3 * g + 2] : 0.f;
 
     float gm[3] = {0.f, 0.f, 0.f};
     float gcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -297,9 +313,9 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreBwd p) {
 
     float s6[6];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) s6[k] = p.cov3D[6 * (int64_t)g + k];
+    for (int k = 0; k < 6; ++k) s6[k] = valid ? p.cov3D[6 * (int64_t)g + k] : 0.f;
 
-    for (int pose = 0; pose < p.N; ++pose) {
+    for (int pose = 0; pose < (valid ? p.N : 0); ++pose) {
         const int64_t idx = (int64_t)pose * p.P + g;
         if (p.radii_inst[idx] <= 0) continue;
         // ---- segmented sum of this instance's (tile, instance) records ----
@@ -388,7 +404,7 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreBwd p) {
             if constexpr (DEG >= 1) {
                 float gb[NC][3];
                 sh_basis_grad<DEG>(ux, uy, uz, gb);
-                const float* sh = p.shs + (int64_t)g * p.M * 3;
+                const float* sh = s_sh + threadIdx.x * ld;
                 float gdir[3] = {0.f, 0.f, 0.f};
 #pragma unroll
                 for (int k = 1; k < NC; ++k) {
@@ -407,7 +423,7 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreBwd p) {
     }
 
     // ---- Sigma -> scale / rotation (pose independent, applied once to the pose-summed gradient) ----
-    if (!p.has_cov_pre) {
+    if (valid && !p.has_cov_pre) {
         float R[9], Mx[9], s[3];
         const float4 q4 = reinterpret_cast<const float4*>(p.rots)[g];
         const float q[4] = {q4.x, q4.y, q4.z, q4.w};
@@ -442,20 +458,27 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreBwd p) {
             o.w = 2.f * (-2.f * qz * dR[0] - r * dR[1] + qx * dR[2] + r * dR[3] - 2.f * qz * dR[4] + qy * dR[5] + qx * dR[6] + qy * dR[7]);
             reinterpret_cast<float4*>(p.d_rots)[g] = o;
         }
-    } else if (p.d_cov) {
+    } else if (valid && p.d_cov) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) p.d_cov[6 * (int64_t)g + k] = gcov[k];
     }
-    if (p.d_means3D) { p.d_means3D[3 * g] = gm[0]; p.d_means3D[3 * g + 1] = gm[1]; p.d_means3D[3 * g + 2] = gm[2]; }
-    if (p.d_means2D) { p.d_means2D[3 * g] = gm2d[0]; p.d_means2D[3 * g + 1] = gm2d[1]; p.d_means2D[3 * g + 2] = 0.f; }
-    if (p.d_opac) p.d_opac[g] = gop;
-    if (p.has_colors_precomp) {
-        if (p.d_colors) { p.d_colors[3 * g] = gcol_pre[0]; p.d_colors[3 * g + 1] = gcol_pre[1]; p.d_colors[3 * g + 2] = gcol_pre[2]; }
-    } else if (p.d_shs) {
-        float* o = p.d_shs + (int64_t)g * p.M * 3;
+    if (valid) {
+        if (p.d_means3D) { p.d_means3D[3 * g] = gm[0]; p.d_means3D[3 * g + 1] = gm[1]; p.d_means3D[3 * g + 2] = gm[2]; }
+        if (p.d_means2D) { p.d_means2D[3 * g] = gm2d[0]; p.d_means2D[3 * g + 1] = gm2d[1]; p.d_means2D[3 * g + 2] = 0.f; }
+        if (p.d_opac) p.d_opac[g] = gop;
+        if (p.has_colors_precomp && p.d_colors) {
+            p.d_colors[3 * g] = gcol_pre[0]; p.d_colors[3 * g + 1] = gcol_pre[1]; p.d_colors[3 * g + 2] = gcol_pre[2];
+        }
+    }
+    if (!p.has_colors_precomp && p.d_shs) {
+        if (stage_in) __syncthreads();  // every thread has finished reading its input row
+        float* row = s_sh + threadIdx.x * ld;
 #pragma unroll
-        for (int k = 0; k < NC * 3; ++k) o[k] = gsh[k];
-        for (int k = NC * 3; k < p.M * 3; ++k) o[k] = 0.f;
+        for (int k = 0; k < NC * 3; ++k) row[k] = gsh[k];
+        for (int k = NC * 3; k < M3; ++k) row[k] = 0.f;
+        __syncthreads();
+        float* dst = p.d_shs + (int64_t)g0 * M3;
+        for (int i = threadIdx.x; i < rows * M3; i += kPreBwdBlock) dst[i] = s_sh[(i / M3) * ld + (i % M3)];
     }
 }
 
@@ -503,13 +526,14 @@ int launch_preprocess_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t 
     p.d_means3D = a.dL_dmeans3D; p.d_means2D = a.dL_dmeans2D; p.d_opac = a.dL_dopacities; p.d_shs = a.dL_dshs;
     p.d_colors = a.dL_dcolors_precomp; p.d_scales = a.dL_dscales; p.d_rots = a.dL_drotations;
     p.d_cov = a.dL_dcov3D_precomp;
-    const int grid = ceil_div(d.P, 256);
+    const int grid = ceil_div(d.P, kPreBwdBlock);
     const int deg = a.colors_precomp ? 0 : d.sh_degree;
+    const size_t lds = (size_t)kPreBwdBlock * (d.M * 3 + 1) * sizeof(float);
     switch (deg) {
-        case 0: preprocess_bwd_kernel<0><<<grid, 256, 0, s>>>(p); break;
-        case 1: preprocess_bwd_kernel<1><<<grid, 256, 0, s>>>(p); break;
-        case 2: preprocess_bwd_kernel<2><<<grid, 256, 0, s>>>(p); break;
-        default: preprocess_bwd_kernel<3><<<grid, 256, 0, s>>>(p); break;
+        case 0: preprocess_bwd_kernel<0><<<grid, kPreBwdBlock, lds, s>>>(p); break;
+        case 1: preprocess_bwd_kernel<1><<<grid, kPreBwdBlock, lds, s>>>(p); break;
+        case 2: preprocess_bwd_kernel<2><<<grid, kPreBwdBlock, lds, s>>>(p); break;
+        default: preprocess_bwd_kernel<3><<<grid, kPreBwdBlock, lds, s>>>(p); break;
     }
     HS_LAUNCH_CHECK();
     return HS_OK;
