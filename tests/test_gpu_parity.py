@@ -309,3 +309,22 @@ def test_full_size_properties_c3():
         assert torch.equal(2 * a, b)
     # checksum of checksums stays finite and non-trivial
     assert all(bool(torch.isfinite(a).all()) for a in g1) and float(g1[3].abs().sum()) > 0
+
+
+def test_gradients_share_one_flat_buffer():
+    """The backward hands autograd views of ONE flat fp32 buffer, so the multi-GPU step can all-reduce it in
+    place (casualhdrsplat_amd.distributed._shared_flat)."""
+    from casualhdrsplat_amd import GaussianRasterizer
+    from casualhdrsplat_amd.distributed import _shared_flat
+    sc = S.make_scene(3000, 128, 96, 3, seed=1, hdr=True)
+    rs, expo, crf = Hh.settings_from_scene(sc, "cuda", hdr=True, requires_grad=True)
+    leaves = [t.cuda().requires_grad_(True) for t in (sc.means3D, torch.zeros(3000, 3), sc.opacities, sc.shs, sc.scales, sc.rotations)]
+    out = GaussianRasterizer(rs)(leaves[0], leaves[1], leaves[2], shs=leaves[3], scales=leaves[4], rotations=leaves[5])
+    torch.autograd.backward(out[0], grad_tensors=sc.dL_dimage.cuda())
+    grads = [t.grad for t in leaves + [expo, crf]]
+    assert all(g is not None for g in grads)
+    flat = _shared_flat(grads)
+    assert flat is not None and flat.numel() >= sum(g.numel() for g in grads)
+    before = leaves[3].grad.clone()
+    flat.mul_(2.0)   # what an in-place all-reduce would do
+    assert torch.equal(leaves[3].grad, 2 * before)
