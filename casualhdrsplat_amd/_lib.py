@@ -71,7 +71,7 @@ class hs_layout(C.Structure):
         "counters", "rec", "depth", "radii", "tiles_touched", "offsets", "cov3D", "clamped", "scan_spine",
         "keys_sorted", "point_list", "keys_unsorted", "vals_unsorted", "ranges", "sort_tmp", "depth_keys", "depth_vals",
         "final_T", "n_contrib", "pose_hdr",
-        "pair_grads", "crf_partials")]
+        "pair_grads", "crf_partials", "pair_flags", "inst_grads")]
 
 
 EXPORTS = ("hs_version", "hs_last_error", "hs_plan", "hs_forward", "hs_backward", "hs_mark_visible",

@@ -67,6 +67,8 @@ static int plan(const hs_dims& d, hs_sizes* sz, hs_layout* L) {
     o = 0;
     l.pair_grads = carve(d.capacity * kPairFloats * 4);
     l.crf_partials = carve((int64_t)crf_partial_floats(4096) * 4);
+    l.pair_flags = carve(d.capacity);
+    l.inst_grads = carve(I * 12 * 4);
     sz->bwd_bytes = o;
     if (L) *L = l;
     return HS_OK;

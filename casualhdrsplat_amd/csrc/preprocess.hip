@@ -266,6 +266,33 @@ __global__ void mark_visible_kernel(int P, const float* means, const float* V, u
 // One thread per Gaussian, looping over poses; sums are formed in a fixed order (pair slots
 // ascending, poses ascending) so the gradients are bitwise reproducible run to run.
 // ------------------------------------------------------------------------------------------------
+// Per-instance sum of the render-backward pair records.  Threads walk the instances in DEPTH order, the order
+// in which duplicateWithKeys laid the pair slots out, so neighbouring lanes read neighbouring slot runs (coalesced
+// through L1/L2) and each thread adds its own run front to back: a fixed order, hence bitwise reproducible sums.
+// Unflagged records were never written this backward (their tile's replay stopped before them): skipped by select.
+__global__ void __launch_bounds__(256) pair_segsum_kernel(int64_t I, const uint32_t* inst_sorted, const uint32_t* offs_sorted,
+                                                          const float4* pair_grads, const uint8_t* pair_flags,
+                                                          float4* inst_grads) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= I) return;
+    const uint32_t beg = i == 0 ? 0u : offs_sorted[i - 1];
+    const uint32_t end = offs_sorted[i];
+    float r[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (uint32_t s = beg; s < end; ++s) {
+        const bool on = pair_flags[s] != 0;
+        const float4 q0 = pair_grads[3 * (int64_t)s + 0];
+        const float4 q1 = pair_grads[3 * (int64_t)s + 1];
+        const float q2 = reinterpret_cast<const float*>(pair_grads + 3 * (int64_t)s + 2)[0];
+        r[0] += on ? q0.x : 0.f; r[1] += on ? q0.y : 0.f; r[2] += on ? q0.z : 0.f; r[3] += on ? q0.w : 0.f;
+        r[4] += on ? q1.x : 0.f; r[5] += on ? q1.y : 0.f; r[6] += on ? q1.z : 0.f; r[7] += on ? q1.w : 0.f;
+        r[8] += on ? q2 : 0.f;
+    }
+    float4* o = inst_grads + 3 * (int64_t)inst_sorted[i];
+    o[0] = make_float4(r[0], r[1], r[2], r[3]);
+    o[1] = make_float4(r[4], r[5], r[6], r[7]);
+    o[2] = make_float4(r[8], 0.f, 0.f, 0.f);
+}
+
 struct PreBwd {
     int P, M, W, H, N;
     float tanfovx, tanfovy, mod;
@@ -274,7 +301,7 @@ struct PreBwd {
     bool has_colors_precomp, has_cov_pre;
     const float4* rec; const int* radii_inst; const uint32_t* tiles; const uint32_t* offsets; const float* cov3D;
     const uint8_t* clamped;
-    const float4* pair_grads;
+    const float4* inst_grads;
     float* d_means3D; float* d_means2D; float* d_opac; float* d_shs; float* d_colors; float* d_scales;
     float* d_rots; float* d_cov;
 };
@@ -318,18 +345,12 @@ __global__ void __launch_bounds__(kPreBwdBlock) preprocess_bwd_kernel(PreBwd p) 
     for (int pose = 0; pose < (valid ? p.N : 0); ++pose) {
         const int64_t idx = (int64_t)pose * p.P + g;
         if (p.radii_inst[idx] <= 0) continue;
-        // ---- segmented sum of this instance's (tile, instance) records ----
-        const uint32_t n = p.tiles[idx];
-        const uint32_t beg = __float_as_uint(reinterpret_cast<const float*>(p.rec + 3 * idx + 2)[3]);
-        const uint32_t end = beg + n;
-        float r[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (uint32_t s = beg; s < end; ++s) {
-            const float4 q0 = p.pair_grads[3 * (int64_t)s + 0];
-            const float4 q1 = p.pair_grads[3 * (int64_t)s + 1];
-            const float4 q2 = p.pair_grads[3 * (int64_t)s + 2];
-            r[0] += q0.x; r[1] += q0.y; r[2] += q0.z; r[3] += q0.w;
-            r[4] += q1.x; r[5] += q1.y; r[6] += q1.z; r[7] += q1.w;
-            r[8] += q2.x;
+        // ---- this instance's summed pair records (pair_segsum_kernel) ----
+        float r[9];
+        {
+            const float4 q0 = p.inst_grads[3 * idx + 0], q1 = p.inst_grads[3 * idx + 1];
+            r[0] = q0.x; r[1] = q0.y; r[2] = q0.z; r[3] = q0.w; r[4] = q1.x; r[5] = q1.y; r[6] = q1.z; r[7] = q1.w;
+            r[8] = reinterpret_cast<const float*>(p.inst_grads + 3 * idx + 2)[0];
         }
         // r = {dmean2D.x, dmean2D.y, dconic A, B, C, dopacity, dcolor r,g,b}
         gm2d[0] += r[0]; gm2d[1] += r[1];
@@ -522,7 +543,16 @@ int launch_preprocess_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t 
     p.rec = (const float4*)(geom + L.rec); p.radii_inst = (const int*)(geom + L.radii);
     p.tiles = (const uint32_t*)(geom + L.tiles_touched); p.offsets = (const uint32_t*)(geom + L.offsets);
     p.cov3D = (const float*)(geom + L.cov3D); p.clamped = (const uint8_t*)(geom + L.clamped);
-    p.pair_grads = (const float4*)((const char*)a.bwd + L.pair_grads);
+    p.inst_grads = (const float4*)((const char*)a.bwd + L.inst_grads);
+    {
+        const int64_t I = (int64_t)d.P * d.n_poses;
+        const char* bin = (const char*)a.binning;
+        const uint32_t* dv0 = (const uint32_t*)(bin + L.depth_vals);
+        pair_segsum_kernel<<<ceil_div(I, 256), 256, 0, s>>>(I, dv0, dv0 + I, (const float4*)((const char*)a.bwd + L.pair_grads),
+                                                           (const uint8_t*)a.bwd + L.pair_flags,
+                                                           (float4*)((char*)a.bwd + L.inst_grads));
+        HS_LAUNCH_CHECK();
+    }
     p.d_means3D = a.dL_dmeans3D; p.d_means2D = a.dL_dmeans2D; p.d_opac = a.dL_dopacities; p.d_shs = a.dL_dshs;
     p.d_colors = a.dL_dcolors_precomp; p.d_scales = a.dL_dscales; p.d_rots = a.dL_drotations;
     p.d_cov = a.dL_dcov3D_precomp;

@@ -347,6 +347,7 @@ struct RenderBwd {
     const float* final_T; const uint32_t* n_contrib; const float* pose_hdr;
     const float* dL_dcolor; const float* dL_dhdr;
     float4* pair_grads;
+    uint8_t* pair_flags;
     Crf crf;
     const float* exposure;
 };
@@ -402,12 +403,14 @@ __device__ __forceinline__ void step_bwd(PixB& s, bool act, float G, float alpha
     const float rcp = __builtin_amdgcn_rcpf(one_m);
     s.T *= rcp;
     dch = ae * s.T;
-    float dLa = ((r - s.R0) * s.dL0 + (g - s.R1) * s.dL1) + (b - s.R2) * s.dL2;
+    const float d0 = r - s.R0, d1 = g - s.R1, d2 = b - s.R2;
+    float dLa = (d0 * s.dL0 + d1 * s.dL1) + d2 * s.dL2;
     dLa = dLa * s.T - (s.T_final * rcp) * s.bg_dot;
     dLa = act ? dLa : 0.f;
-    s.R0 = ae * r + one_m * s.R0;
-    s.R1 = ae * g + one_m * s.R1;
-    s.R2 = ae * b + one_m * s.R2;
+    // accum_rec <- alpha*c + (1-alpha)*accum_rec, written as one FMA per channel on the difference already formed
+    s.R0 += ae * d0;
+    s.R1 += ae * d1;
+    s.R2 += ae * d2;
     dop = G * dLa;
     sw = o * dop;
 }
@@ -576,6 +579,7 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
             const int rminy = min(p.gy, max(0, (int)((a.y - (float)rad) / (float)kTile)));
             const int rmaxx = min(p.gx, max(0, (int)((a.x + (float)rad + (float)(kTile - 1)) / (float)kTile)));
             const int64_t slot = (int64_t)off + (int64_t)(ty - rminy) * (rmaxx - rminx) + (tx - rminx);
+            p.pair_flags[slot] = 1;
             float4* o = p.pair_grads + 3 * slot;
             o[0] = make_float4(gmx, gmy, -0.5f * v[2], -v[3]);
             o[1] = make_float4(-0.5f * v[4], v[5], v[6], v[7]);
@@ -646,7 +650,7 @@ extern "C" int hs_debug_stats(unsigned long long* out8, int reset) {
 }
 #endif
 
-constexpr int kCrfBlocks = 512;
+constexpr int kCrfBlocks = 2048;
 
 int launch_render_fwd(const hs_fwd_args& a, const hs_layout& L, hipStream_t s) {
     const hs_dims& d = a.dims;
@@ -688,8 +692,9 @@ int launch_render_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s) {
     p.pair_grads = (float4*)((char*)a.bwd + L.pair_grads);
     p.crf.table = a.crf_table; p.crf.K = a.crf_K; p.crf.umin = a.crf_umin; p.crf.umax = a.crf_umax; p.crf.dt = 1.f;
     p.exposure = a.exposure;
-    // pairs beyond a tile's deepest contributor are never visited: their records must read as zero
-    HS_HIP_CHECK(hipMemsetAsync(p.pair_grads, 0, (size_t)d.capacity * kPairFloats * sizeof(float), s));
+    p.pair_flags = (uint8_t*)a.bwd + L.pair_flags;
+    // pairs beyond a tile's deepest contributor are never visited: only flagged records are summed later
+    HS_HIP_CHECK(hipMemsetAsync(p.pair_flags, 0, (size_t)d.capacity, s));
     render_bwd_kernel<<<p.ntiles * d.n_poses, kBatch, 0, s>>>(p);
     HS_LAUNCH_CHECK();
     if ((a.flags & HS_FLAG_HDR) && (a.dL_dcrf_table || a.dL_dexposure)) {

@@ -164,7 +164,9 @@ typedef struct hs_layout {
     /* image workspace */
     int64_t final_T, n_contrib, pose_hdr;
     /* bwd workspace */
-    int64_t pair_grads, crf_partials;
+    /* pair_flags: u8 per pair, 1 = record written this backward; inst_grads: 12 floats per instance, the
+     * per-instance sum of its pair records */
+    int64_t pair_grads, crf_partials, pair_flags, inst_grads;
 } hs_layout;
 
 int hs_version(void);
