@@ -273,12 +273,17 @@ __global__ void mark_visible_kernel(int P, const float* means, const float* V, u
 __global__ void __launch_bounds__(256) pair_segsum_kernel(int64_t I, const uint32_t* inst_sorted, const uint32_t* offs_sorted,
                                                           const float4* pair_grads, const uint8_t* pair_flags,
                                                           float4* inst_grads) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= I) return;
-    const uint32_t beg = i == 0 ? 0u : offs_sorted[i - 1];
-    const uint32_t end = offs_sorted[i];
+    // four lanes (one DPP quad) per instance: lane q adds records beg+q, beg+q+4, ...; the four partial sums are
+    // combined in a fixed butterfly, so the result does not depend on timing.  Quads shorten the longest run in a
+    // wave fourfold (run lengths are heavy-tailed) and make neighbouring lanes read neighbouring records.
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t i = t >> 2;
+    const int q = (int)(t & 3);
+    const bool valid = i < I;
+    const uint32_t beg = valid ? (i == 0 ? 0u : offs_sorted[i - 1]) : 0u;
+    const uint32_t end = valid ? offs_sorted[i] : 0u;
     float r[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (uint32_t s = beg; s < end; ++s) {
+    for (uint32_t s = beg + q; s < end; s += 4) {
         const bool on = pair_flags[s] != 0;
         const float4 q0 = pair_grads[3 * (int64_t)s + 0];
         const float4 q1 = pair_grads[3 * (int64_t)s + 1];
@@ -287,10 +292,17 @@ __global__ void __launch_bounds__(256) pair_segsum_kernel(int64_t I, const uint3
         r[4] += on ? q1.x : 0.f; r[5] += on ? q1.y : 0.f; r[6] += on ? q1.z : 0.f; r[7] += on ? q1.w : 0.f;
         r[8] += on ? q2 : 0.f;
     }
-    float4* o = inst_grads + 3 * (int64_t)inst_sorted[i];
-    o[0] = make_float4(r[0], r[1], r[2], r[3]);
-    o[1] = make_float4(r[4], r[5], r[6], r[7]);
-    o[2] = make_float4(r[8], 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        r[k] += __shfl_xor(r[k], 1);
+        r[k] += __shfl_xor(r[k], 2);
+    }
+    if (valid && q == 0) {
+        float4* o = inst_grads + 3 * (int64_t)inst_sorted[i];
+        o[0] = make_float4(r[0], r[1], r[2], r[3]);
+        o[1] = make_float4(r[4], r[5], r[6], r[7]);
+        o[2] = make_float4(r[8], 0.f, 0.f, 0.f);
+    }
 }
 
 struct PreBwd {
@@ -548,7 +560,7 @@ int launch_preprocess_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t 
         const int64_t I = (int64_t)d.P * d.n_poses;
         const char* bin = (const char*)a.binning;
         const uint32_t* dv0 = (const uint32_t*)(bin + L.depth_vals);
-        pair_segsum_kernel<<<ceil_div(I, 256), 256, 0, s>>>(I, dv0, dv0 + I, (const float4*)((const char*)a.bwd + L.pair_grads),
+        pair_segsum_kernel<<<ceil_div(4 * I, 256), 256, 0, s>>>(I, dv0, dv0 + I, (const float4*)((const char*)a.bwd + L.pair_grads),
                                                            (const uint8_t*)a.bwd + L.pair_flags,
                                                            (float4*)((char*)a.bwd + L.inst_grads));
         HS_LAUNCH_CHECK();
