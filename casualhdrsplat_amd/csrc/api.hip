@@ -17,10 +17,10 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-int64_t crf_partial_floats(int K, int64_t vtiles);
+int crf_partial_floats(int K);
 
 static int plan(const hs_dims& d, hs_sizes* sz, hs_layout* L) {
-    if (d.P < 0 || d.W <= 0 || d.H <= 0 || d.n_poses < 1 || d.capacity < 0 || d.M < 0 || d.crf_K < 0 || d.crf_K > 4096) {
+    if (d.P < 0 || d.W <= 0 || d.H <= 0 || d.n_poses < 1 || d.capacity < 0 || d.M < 0) {
         set_error("hs_plan: bad dims P=%d W=%d H=%d N=%d capacity=%lld", d.P, d.W, d.H, d.n_poses, (long long)d.capacity);
         return HS_EINVAL;
     }
@@ -66,7 +66,7 @@ static int plan(const hs_dims& d, hs_sizes* sz, hs_layout* L) {
     // backward scratch
     o = 0;
     l.pair_grads = carve(d.capacity * kPairFloats * 4);
-    l.crf_partials = carve(crf_partial_floats(d.crf_K, vtiles) * 4);
+    l.crf_partials = carve((int64_t)crf_partial_floats(4096) * 4);
     l.pair_flags = carve(d.capacity);
     l.inst_grads = carve(I * 12 * 4);
     sz->bwd_bytes = o;

@@ -348,33 +348,19 @@ struct RenderBwd {
     const float* dL_dcolor; const float* dL_dhdr;
     float4* pair_grads;
     uint8_t* pair_flags;
-    float* crf_partials;  // non-null: per-tile CRF-table / exposure partial sums are formed in this kernel
     Crf crf;
     const float* exposure;
 };
 
-// Upstream gradient w.r.t. this pose's radiance H_ch at one pixel (the HDR prologue).  With s_tab != nullptr the
-// CRF-table and exposure gradient terms of the pixel are accumulated into the workgroup's LDS table as well.
-__device__ __forceinline__ float pixel_grad(const RenderBwd& p, const Crf& c, int pose, int ch, int64_t pix, int64_t HW,
-                                            float* s_tab, float& gexp) {
+// Upstream gradient w.r.t. this pose's radiance H_ch at one pixel (the HDR prologue).
+__device__ __forceinline__ float pixel_grad(const RenderBwd& p, const Crf& c, int pose, int ch, int64_t pix, int64_t HW) {
     const float invN = 1.f / (float)p.N;
     float g = p.dL_dcolor[ch * HW + pix];
     if (!(p.flags & HS_FLAG_HDR)) return g * invN;
     float out = 0.f;
     if (p.N == 1 || !(p.flags & HS_FLAG_BLUR_HDR)) {
         const float Hv = p.pose_hdr[((int64_t)pose * 3 + ch) * HW + pix];
-        g *= invN;
-        int i; float f, xv; bool in;
-        crf_locate(c, Hv, i, f, xv, in);
-        const float* t = c.table + ch * c.K;
-        const float scale = (float)(c.K - 1) / (c.umax - c.umin);
-        const float gx = in ? g * (t[i + 1] - t[i]) * scale / xv : 0.f;  // dL/d(H*dt)
-        out = gx * c.dt;
-        if (s_tab) {
-            atomicAdd(&s_tab[ch * c.K + i], (1.f - f) * g);
-            atomicAdd(&s_tab[ch * c.K + i + 1], f * g);
-            gexp += gx * Hv;
-        }
+        out = crf_grad_H(c, ch, Hv, g * invN);
     } else {
         const float Hm = p.pose_hdr[((int64_t)p.N * 3 + ch) * HW + pix];
         out = crf_grad_H(c, ch, Hm, g) * invN;
@@ -389,8 +375,7 @@ struct PixB {
     uint32_t last;
 };
 
-__device__ __forceinline__ void load_pixel_bwd(const RenderBwd& p, PixB& s, bool inside, int pose, int px, int py,
-                                               float* s_tab, float& gexp) {
+__device__ __forceinline__ void load_pixel_bwd(const RenderBwd& p, PixB& s, bool inside, int pose, int px, int py) {
     const int64_t HW = (int64_t)p.H * p.W;
     const int64_t pix = (int64_t)py * p.W + px;
     s.T_final = 0.f; s.dL0 = s.dL1 = s.dL2 = 0.f; s.last = 0;
@@ -399,9 +384,9 @@ __device__ __forceinline__ void load_pixel_bwd(const RenderBwd& p, PixB& s, bool
         s.last = p.n_contrib[(int64_t)pose * HW + pix];
         Crf c = p.crf;
         if (p.flags & HS_FLAG_HDR) c.dt = p.exposure[0];
-        s.dL0 = pixel_grad(p, c, pose, 0, pix, HW, s_tab, gexp);
-        s.dL1 = pixel_grad(p, c, pose, 1, pix, HW, s_tab, gexp);
-        s.dL2 = pixel_grad(p, c, pose, 2, pix, HW, s_tab, gexp);
+        s.dL0 = pixel_grad(p, c, pose, 0, pix, HW);
+        s.dL1 = pixel_grad(p, c, pose, 1, pix, HW);
+        s.dL2 = pixel_grad(p, c, pose, 2, pix, HW);
     }
     s.bg_dot = (p.bg[0] * s.dL0 + p.bg[1] * s.dL1) + p.bg[2] * s.dL2;
     s.T = s.T_final;
@@ -455,27 +440,8 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
     const uint2 range = p.ranges[vt];
 
     PixB s0, s1;
-    {
-        // fused CRF-table / exposure gradient: the workgroup's partial table lives in (aliases) the s_acc planes,
-        // which are not used before the replay loop
-        float* s_tab = p.crf_partials ? &s_acc[0][0][0] : nullptr;
-        const int K3 = 3 * p.crf.K;
-        if (s_tab) {
-            for (int i = threadIdx.x; i <= K3; i += KB) s_tab[i] = 0.f;
-            __syncthreads();
-        }
-        float gexp = 0.f;
-        load_pixel_bwd(p, s0, in0, pose, px, py0, s_tab, gexp);
-        load_pixel_bwd(p, s1, in1, pose, px, py1, s_tab, gexp);
-        if (s_tab) {
-            gexp = wave_sum_hi(gexp);
-            if (lane == 63) atomicAdd(&s_tab[K3], gexp);
-            __syncthreads();
-            float* dst = p.crf_partials + (int64_t)vt * (K3 + 1);
-            for (int i = threadIdx.x; i <= K3; i += KB) dst[i] = s_tab[i];
-            __syncthreads();
-        }
-    }
+    load_pixel_bwd(p, s0, in0, pose, px, py0);
+    load_pixel_bwd(p, s1, in1, pose, px, py1);
 
     const uint32_t wave_max = wave_max_u32(max(s0.last, s1.last));
     if (lane == 0) s_max[wave] = wave_max;
@@ -659,26 +625,19 @@ __global__ void __launch_bounds__(256) crf_grad_kernel(int64_t HW, int N, int fl
     for (int i = threadIdx.x; i < K3 + 1; i += 256) partials[(int64_t)blockIdx.x * (K3 + 1) + i] = s_tab[i];
 }
 
-// Column sums of the partial rows [nrows][K3+1] in two fixed-order stages: stage 1 = 64 row chunks x coalesced
-// columns (lane = column), stage 2 = sum of the 64 chunk results.  Deterministic for a given nrows.
-constexpr int kCrfChunks = 64;
-__global__ void __launch_bounds__(256) crf_reduce1_kernel(const float* partials, int nrows, int K3, float* stage) {
-    const int col = blockIdx.x * 256 + threadIdx.x;
-    const int chunk = blockIdx.y;
-    if (col > K3) return;
-    const int per = (nrows + kCrfChunks - 1) / kCrfChunks;
-    const int r0 = chunk * per, r1 = min(nrows, r0 + per);
+// One wave per output element: lanes stride over the per-block partial rows (fixed order -> reproducible).
+__global__ void __launch_bounds__(256) crf_reduce_kernel(const float* partials, int nblk, int K3, float* d_table,
+                                                         float* d_exposure) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (i > K3) return;
     float acc = 0.f;
-    for (int r = r0; r < r1; ++r) acc += partials[(int64_t)r * (K3 + 1) + col];
-    stage[(int64_t)chunk * (K3 + 1) + col] = acc;
-}
-__global__ void __launch_bounds__(256) crf_reduce2_kernel(const float* stage, int K3, float* d_table, float* d_exposure) {
-    const int col = blockIdx.x * 256 + threadIdx.x;
-    if (col > K3) return;
-    float acc = 0.f;
-    for (int c = 0; c < kCrfChunks; ++c) acc += stage[(int64_t)c * (K3 + 1) + col];
-    if (col < K3) { if (d_table) d_table[col] = acc; }
-    else if (d_exposure) d_exposure[0] = acc;
+    for (int b = lane; b < nblk; b += 64) acc += partials[(int64_t)b * (K3 + 1) + i];
+    acc = wave_sum_hi(acc);
+    if (lane == 63) {
+        if (i < K3) { if (d_table) d_table[i] = acc; }
+        else if (d_exposure) d_exposure[0] = acc;
+    }
 }
 
 }  // namespace
@@ -734,37 +693,23 @@ int launch_render_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s) {
     p.crf.table = a.crf_table; p.crf.K = a.crf_K; p.crf.umin = a.crf_umin; p.crf.umax = a.crf_umax; p.crf.dt = 1.f;
     p.exposure = a.exposure;
     p.pair_flags = (uint8_t*)a.bwd + L.pair_flags;
-    // CRF-table / exposure gradients: fused into the replay kernel's prologue when the per-tile table fits the LDS
-    // it aliases (and the blur is not taken on mean radiance, whose table terms are per pixel, not per pose)
-    const bool want_crf = (a.flags & HS_FLAG_HDR) && (a.dL_dcrf_table || a.dL_dexposure);
-    const bool fuse_crf = want_crf && (3 * a.crf_K + 1 <= 2 * 9 * kBatch) && !((a.flags & HS_FLAG_BLUR_HDR) && d.n_poses > 1);
-    p.crf_partials = fuse_crf ? (float*)((char*)a.bwd + L.crf_partials) : nullptr;
     // pairs beyond a tile's deepest contributor are never visited: only flagged records are summed later
     HS_HIP_CHECK(hipMemsetAsync(p.pair_flags, 0, (size_t)d.capacity, s));
     render_bwd_kernel<<<p.ntiles * d.n_poses, kBatch, 0, s>>>(p);
     HS_LAUNCH_CHECK();
-    if (want_crf) {
+    if ((a.flags & HS_FLAG_HDR) && (a.dL_dcrf_table || a.dL_dexposure)) {
         const int64_t HW = (int64_t)d.W * d.H;
         float* partials = (float*)((char*)a.bwd + L.crf_partials);
         const int K3 = 3 * a.crf_K;
-        int nrows = p.ntiles * d.n_poses;
-        if (!fuse_crf) {
-            nrows = kCrfBlocks;
-            crf_grad_kernel<<<kCrfBlocks, 256, (K3 + 4) * sizeof(float), s>>>(HW, d.n_poses, a.flags, p.pose_hdr, p.crf,
-                                                                             a.exposure, a.dL_dout_color, partials);
-        }
-        float* stage = partials + (int64_t)nrows * (K3 + 1);
-        crf_reduce1_kernel<<<dim3(ceil_div(K3 + 1, 256), kCrfChunks), 256, 0, s>>>(partials, nrows, K3, stage);
-        crf_reduce2_kernel<<<ceil_div(K3 + 1, 256), 256, 0, s>>>(stage, K3, a.dL_dcrf_table, a.dL_dexposure);
+        crf_grad_kernel<<<kCrfBlocks, 256, (K3 + 4) * sizeof(float), s>>>(HW, d.n_poses, a.flags, p.pose_hdr, p.crf,
+                                                                         a.exposure, a.dL_dout_color, partials);
+        crf_reduce_kernel<<<ceil_div(K3 + 1, 4), 256, 0, s>>>(partials, kCrfBlocks, K3, a.dL_dcrf_table,
+                                                                a.dL_dexposure);
         HS_LAUNCH_CHECK();
     }
     return HS_OK;
 }
 
-int64_t crf_partial_floats(int K, int64_t vtiles) {
-    if (K <= 0) return 0;
-    const int64_t rows = (3 * K + 1 <= 2 * 9 * kBatch) ? (vtiles > kCrfBlocks ? vtiles : kCrfBlocks) : kCrfBlocks;
-    return (rows + kCrfChunks) * (3 * (int64_t)K + 1);
-}
+int crf_partial_floats(int K) { return kCrfBlocks * (3 * K + 1); }
 
 }  // namespace hs

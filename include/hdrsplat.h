@@ -63,7 +63,6 @@ typedef struct hs_dims {
     int32_t sh_degree; /* active degree, (sh_degree+1)^2 <= M */
     int32_t W, H;
     int32_t n_poses;   /* N >= 1 */
-    int32_t crf_K;     /* knots per channel of the CRF table (0 when not HDR); sizes the backward scratch */
     int64_t capacity;  /* binning capacity in (tile, instance) pairs */
 } hs_dims;
 
