@@ -131,19 +131,20 @@ __device__ __forceinline__ uint32_t digit_of(K k, int shift, uint32_t mask) {
 }
 
 // hist[digit * nblk + blk] = number of keys of block `blk` with that digit; totals[digit] += the same.
+constexpr int kHistThreads = 1024;  // one 4096-key sort tile per workgroup, 4 keys per thread: short dependent chains
 template <typename K>
-__global__ void __launch_bounds__(kSortBlock) radix_hist_kernel(const K* keys, const uint32_t* n_dev, int shift,
-                                                                uint32_t mask, uint32_t* hist, uint32_t* totals,
-                                                                int nblk) {
+__global__ void __launch_bounds__(kHistThreads) radix_hist_kernel(const K* keys, const uint32_t* n_dev, int shift,
+                                                                  uint32_t mask, uint32_t* hist, uint32_t* totals,
+                                                                  int nblk) {
     __shared__ uint32_t s_hist[256];
     const int64_t n = *n_dev;
     const int64_t base = (int64_t)blockIdx.x * kSortTile;
-    s_hist[threadIdx.x] = 0;
+    if (threadIdx.x < 256) s_hist[threadIdx.x] = 0;
     __syncthreads();
     if (base < n) {
-#pragma unroll 4
-        for (int i = 0; i < kSortItems; ++i) {
-            const int64_t k = base + i * kSortBlock + threadIdx.x;
+#pragma unroll
+        for (int i = 0; i < kSortTile / kHistThreads; ++i) {
+            const int64_t k = base + i * kHistThreads + threadIdx.x;
             const bool valid = k < n;
             const uint32_t d = valid ? digit_of<K>(keys[k], shift, mask) : 0u;
             // digits that are (nearly) constant over a pass -- exponent bits of depth, high tile bits -- would
@@ -158,9 +159,11 @@ __global__ void __launch_bounds__(kSortBlock) radix_hist_kernel(const K* keys, c
         }
     }
     __syncthreads();
-    const uint32_t c = s_hist[threadIdx.x];
-    hist[(int64_t)threadIdx.x * nblk + blockIdx.x] = c;
-    if (c) atomicAdd(&totals[threadIdx.x], c);
+    if (threadIdx.x < 256) {
+        const uint32_t c = s_hist[threadIdx.x];
+        hist[(int64_t)threadIdx.x * nblk + blockIdx.x] = c;
+        if (c) atomicAdd(&totals[threadIdx.x], c);
+    }
 }
 
 // One block per digit: exclusive scan of that digit's row over blocks, offset by the number of keys
@@ -289,7 +292,7 @@ int radix_sort(K* k0, uint32_t* v0, K* k1, uint32_t* v1, const uint32_t* n_dev, 
         const int w = nbits - shift < 8 ? nbits - shift : 8;
         const uint32_t mask = (1u << w) - 1u;
         uint32_t* tot = totals + 256 * pass;
-        radix_hist_kernel<K><<<nblk, kSortBlock, 0, s>>>(kin, n_dev, shift, mask, hist, tot, nblk);
+        radix_hist_kernel<K><<<nblk, kHistThreads, 0, s>>>(kin, n_dev, shift, mask, hist, tot, nblk);
         radix_scan_kernel<<<256, 256, 0, s>>>(hist, nblk, tot);
         radix_scatter_kernel<K><<<nblk, kSortBlock, 0, s>>>(kin, vin, kout, vout, n_dev, shift, mask, hist, nblk);
         HS_LAUNCH_CHECK();
@@ -324,27 +327,49 @@ __global__ void __launch_bounds__(256) emit_pairs_kernel(int64_t I, int P, int W
                                                          const uint32_t* inst_sorted, const uint32_t* offs_sorted,
                                                          uint32_t* tile_keys, uint32_t* vals, const hs_counters* counters) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= I) return;
+    const int lane = threadIdx.x & 63;
     if (counters->overflow) return;
-    const uint32_t idx = inst_sorted[i];
-    const int rad = radii[idx];
-    if (rad <= 0) return;
-    uint32_t off = i == 0 ? 0u : offs_sorted[i - 1];
-    reinterpret_cast<float*>(rec + 3 * (int64_t)idx + 2)[3] = __uint_as_float(off);
-    const float4 ra = rec[3 * (int64_t)idx];
+    uint32_t idx = 0, off = 0, tile_base = 0;
+    int rminx = 0, rminy = 0, w = 0, cnt = 0;
     const int gx = (W + kTile - 1) / kTile, gy = (H + kTile - 1) / kTile;
-    const int rminx = min(gx, max(0, (int)((ra.x - (float)rad) / (float)kTile)));
-    const int rminy = min(gy, max(0, (int)((ra.y - (float)rad) / (float)kTile)));
-    const int rmaxx = min(gx, max(0, (int)((ra.x + (float)rad + (float)(kTile - 1)) / (float)kTile)));
-    const int rmaxy = min(gy, max(0, (int)((ra.y + (float)rad + (float)(kTile - 1)) / (float)kTile)));
-    const uint32_t pose = idx / (uint32_t)P;
-    const uint32_t tile_base = pose * (uint32_t)(gx * gy);
-    for (int y = rminy; y < rmaxy; ++y)
-        for (int x = rminx; x < rmaxx; ++x) {
-            tile_keys[off] = tile_base + (uint32_t)(y * gx + x);
-            vals[off] = idx;
-            ++off;
+    if (i < I) {
+        idx = inst_sorted[i];
+        const int rad = radii[idx];
+        if (rad > 0) {
+            off = i == 0 ? 0u : offs_sorted[i - 1];
+            reinterpret_cast<float*>(rec + 3 * (int64_t)idx + 2)[3] = __uint_as_float(off);
+            const float4 ra = rec[3 * (int64_t)idx];
+            rminx = min(gx, max(0, (int)((ra.x - (float)rad) / (float)kTile)));
+            rminy = min(gy, max(0, (int)((ra.y - (float)rad) / (float)kTile)));
+            const int rmaxx = min(gx, max(0, (int)((ra.x + (float)rad + (float)(kTile - 1)) / (float)kTile)));
+            const int rmaxy = min(gy, max(0, (int)((ra.y + (float)rad + (float)(kTile - 1)) / (float)kTile)));
+            w = rmaxx - rminx;
+            cnt = w * (rmaxy - rminy);
+            tile_base = (idx / (uint32_t)P) * (uint32_t)(gx * gy);
         }
+    }
+    // rectangles are heavy-tailed: small ones are written by their own lane, big ones by the whole wave
+    // (row-major order within the rectangle either way)
+    constexpr int kSmall = 16;
+    if (cnt <= kSmall) {
+        for (int t = 0; t < cnt; ++t) {
+            const int y = rminy + t / w, x = rminx + t % w;
+            tile_keys[off + t] = tile_base + (uint32_t)(y * gx + x);
+            vals[off + t] = idx;
+        }
+    }
+    uint64_t big = __ballot(cnt > kSmall);
+    while (big) {
+        const int src = __builtin_ctzll(big);
+        big &= big - 1;
+        const uint32_t b_off = __shfl(off, src), b_idx = __shfl(idx, src), b_base = __shfl(tile_base, src);
+        const int b_cnt = __shfl(cnt, src), b_w = __shfl(w, src), b_x = __shfl(rminx, src), b_y = __shfl(rminy, src);
+        for (int t = lane; t < b_cnt; t += 64) {
+            const int y = b_y + t / b_w, x = b_x + t % b_w;
+            tile_keys[b_off + t] = b_base + (uint32_t)(y * gx + x);
+            vals[b_off + t] = b_idx;
+        }
+    }
 }
 
 // ---------------------------------------------------------------- tile ranges (a8)

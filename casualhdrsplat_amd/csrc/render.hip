@@ -599,24 +599,35 @@ __global__ void __launch_bounds__(256) crf_grad_kernel(int64_t HW, int N, int fl
     crf.dt = exposure[0];
     const bool blur_hdr = (flags & HS_FLAG_BLUR_HDR) && N > 1;
     const int npose = blur_hdr ? 1 : N;
-    const float invN = 1.f / (float)N;
+    const float gs = blur_hdr ? 1.f : 1.f / (float)N;
     const float scale = (float)(crf.K - 1) / (crf.umax - crf.umin);
     float gexp = 0.f;
-    const int64_t total = (int64_t)npose * 3 * HW;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int k = (int)(i / (3 * HW));
-        const int64_t r = i - (int64_t)k * 3 * HW;
-        const int ch = (int)(r / HW);
-        const int slot = blur_hdr ? N : k;
-        const float Hv = pose_hdr[(int64_t)slot * 3 * HW + r];
-        const float g = dL_dcolor[r] * (blur_hdr ? 1.f : invN);
-        int idx; float f, xv; bool in;
-        crf_locate(crf, Hv, idx, f, xv, in);
-        atomicAdd(&s_tab[ch * crf.K + idx], (1.f - f) * g);
-        atomicAdd(&s_tab[ch * crf.K + idx + 1], f * g);
-        if (in) {
-            const float* t = crf.table + ch * crf.K;
-            gexp += g * (t[idx + 1] - t[idx]) * scale / xv * Hv;
+    const int64_t per_pose = 3 * HW;
+    const int64_t total = (int64_t)npose * per_pose;
+    // the image is walked in float4 quads (HW % 4 == 0 is not required: the tail is handled per element)
+    for (int64_t i4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i4 < total; i4 += (int64_t)gridDim.x * 1024) {
+        float Hv[4], g[4];
+        int ch[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int64_t i = i4 + e;
+            const bool ok = i < total;
+            const int k = ok ? (int)(i / per_pose) : 0;
+            const int64_t r = ok ? i - (int64_t)k * per_pose : 0;
+            ch[e] = (int)(r / HW);
+            Hv[e] = ok ? pose_hdr[(int64_t)(blur_hdr ? N : k) * per_pose + r] : 0.f;
+            g[e] = ok ? dL_dcolor[r] * gs : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            int idx; float f, xv; bool in;
+            crf_locate(crf, Hv[e], idx, f, xv, in);
+            atomicAdd(&s_tab[ch[e] * crf.K + idx], (1.f - f) * g[e]);
+            atomicAdd(&s_tab[ch[e] * crf.K + idx + 1], f * g[e]);
+            if (in) {
+                const float* t = crf.table + ch[e] * crf.K;
+                gexp += g[e] * (t[idx + 1] - t[idx]) * scale * __builtin_amdgcn_rcpf(xv) * Hv[e];
+            }
         }
     }
     gexp = wave_sum_hi(gexp);
