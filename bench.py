@@ -248,7 +248,7 @@ def main():
             "kernel": "render_bwd_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
             "algorithmic_bytes": bytes_bwd, "avg_ms": bwd_ms, "median_ms": bwd_med,
-            "note": "launch = pair-record memset + render_bwd_kernel; kernel is VALU/exp-bound (SURVEY 7.4-4)",
+            "note": "stage = 7 MB pair-flag memset + render_bwd_kernel; the kernel is VALU-issue bound (DESIGN.md 4), not HBM bound",
             "fwd_bwd": {"kernels": "render_fwd_kernel + render_bwd_kernel", "algorithmic_bytes": bytes_fwd + bytes_bwd,
                         "avg_ms": fwd_ms + bwd_ms,
                         "achieved": (bytes_fwd + bytes_bwd) / ((fwd_ms + bwd_ms) * 1e-3) / 1e9,

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("HS_LIB_PATH", os.path.join(_HERE, "libhdrsplat.so"))
 HS_OK, HS_EINVAL, HS_EHIP, HS_EOVERFLOW = 0, -1, -2, -3
 HS_STAGE_PREPROCESS, HS_STAGE_BIN, HS_STAGE_RENDER, HS_STAGE_ALL = 1, 2, 4, 7
 HS_FLAG_HDR, HS_FLAG_BLUR_HDR, HS_FLAG_DEBUG = 1, 2, 4
-HS_BWD_RENDER, HS_BWD_PREPROCESS, HS_BWD_ALL = 1, 2, 3
+HS_BWD_RENDER, HS_BWD_PREPROCESS, HS_BWD_CRF, HS_BWD_ALL = 1, 2, 4, 7
 HS_TILE = 16
 
 _fp = C.c_void_p  # device pointers travel as plain addresses

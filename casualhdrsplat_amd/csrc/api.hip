@@ -180,6 +180,10 @@ int hs_backward(const hs_bwd_args* a, void* hip_stream) {
         rc = launch_render_bwd(*a, L, s);
         if (rc) return rc;
     }
+    if (a->stages & HS_BWD_CRF) {
+        rc = launch_crf_bwd(*a, L, s);
+        if (rc) return rc;
+    }
     if (a->stages & HS_BWD_PREPROCESS) {
         rc = launch_preprocess_bwd(*a, L, s);
         if (rc) return rc;

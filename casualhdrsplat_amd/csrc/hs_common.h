@@ -48,6 +48,7 @@ int launch_scan(const hs_fwd_args& a, const hs_layout& L, hipStream_t s);
 int launch_binning(const hs_fwd_args& a, const hs_layout& L, hipStream_t s);
 int launch_render_fwd(const hs_fwd_args& a, const hs_layout& L, hipStream_t s);
 int launch_render_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s);
+int launch_crf_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s);
 int launch_preprocess_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s);
 int launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* vis, hipStream_t s);
 

@@ -661,7 +661,6 @@ extern "C" int hs_debug_stats(unsigned long long* out8, int reset) {
 }
 #endif
 
-constexpr int kCrfBlocks = 1024;
 
 int launch_render_fwd(const hs_fwd_args& a, const hs_layout& L, hipStream_t s) {
     const hs_dims& d = a.dims;
@@ -689,6 +688,24 @@ int launch_render_fwd(const hs_fwd_args& a, const hs_layout& L, hipStream_t s) {
     return HS_OK;
 }
 
+constexpr int kCrfBlocks = 1024;
+
+int launch_crf_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s) {
+    const hs_dims& d = a.dims;
+    if (!((a.flags & HS_FLAG_HDR) && (a.dL_dcrf_table || a.dL_dexposure))) return HS_OK;
+    Crf crf;
+    crf.table = a.crf_table; crf.K = a.crf_K; crf.umin = a.crf_umin; crf.umax = a.crf_umax; crf.dt = 1.f;
+    const int64_t HW = (int64_t)d.W * d.H;
+    float* partials = (float*)((char*)a.bwd + L.crf_partials);
+    const float* pose_hdr = (const float*)((const char*)a.image + L.pose_hdr);
+    const int K3 = 3 * a.crf_K;
+    crf_grad_kernel<<<kCrfBlocks, 256, (K3 + 4) * sizeof(float), s>>>(HW, d.n_poses, a.flags, pose_hdr, crf, a.exposure,
+                                                                     a.dL_dout_color, partials);
+    crf_reduce_kernel<<<ceil_div(K3 + 1, 4), 256, 0, s>>>(partials, kCrfBlocks, K3, a.dL_dcrf_table, a.dL_dexposure);
+    HS_LAUNCH_CHECK();
+    return HS_OK;
+}
+
 int launch_render_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s) {
     const hs_dims& d = a.dims;
     RenderBwd p;
@@ -708,16 +725,6 @@ int launch_render_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s) {
     HS_HIP_CHECK(hipMemsetAsync(p.pair_flags, 0, (size_t)d.capacity, s));
     render_bwd_kernel<<<p.ntiles * d.n_poses, kBatch, 0, s>>>(p);
     HS_LAUNCH_CHECK();
-    if ((a.flags & HS_FLAG_HDR) && (a.dL_dcrf_table || a.dL_dexposure)) {
-        const int64_t HW = (int64_t)d.W * d.H;
-        float* partials = (float*)((char*)a.bwd + L.crf_partials);
-        const int K3 = 3 * a.crf_K;
-        crf_grad_kernel<<<kCrfBlocks, 256, (K3 + 4) * sizeof(float), s>>>(HW, d.n_poses, a.flags, p.pose_hdr, p.crf,
-                                                                         a.exposure, a.dL_dout_color, partials);
-        crf_reduce_kernel<<<ceil_div(K3 + 1, 4), 256, 0, s>>>(partials, kCrfBlocks, K3, a.dL_dcrf_table,
-                                                                a.dL_dexposure);
-        HS_LAUNCH_CHECK();
-    }
     return HS_OK;
 }
 

@@ -50,7 +50,8 @@ extern "C" {
 /* hs_bwd_args.stages */
 #define HS_BWD_RENDER 1      /* per-pixel backward -> one gradient record per (tile, instance) pair */
 #define HS_BWD_PREPROCESS 2  /* per-instance record sum + computeCov2D/projection/SH/cov3D backward */
-#define HS_BWD_ALL 3
+#define HS_BWD_CRF 4         /* CRF-table and exposure gradients (HDR only) */
+#define HS_BWD_ALL 7
 
 /* flags */
 #define HS_FLAG_HDR 1          /* exposure * CRF tone-map epilogue; out_color = LDR, out_hdr = radiance */
