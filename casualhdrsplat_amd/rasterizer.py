@@ -73,8 +73,24 @@ def _f32c(t: Optional[torch.Tensor], dev) -> Optional[torch.Tensor]:
     return t
 
 
-def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+def _stream(dev=None) -> int:
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+class _on_device:
+    """Make `dev` the current HIP device for the duration of a launch, only if it is not already."""
+    def __init__(self, dev):
+        self.ctx = None
+        if dev.type == "cuda" and dev.index is not None and dev.index != torch.cuda.current_device():
+            self.ctx = torch.cuda.device(dev)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *a):
+        if self.ctx is not None:
+            self.ctx.__exit__(*a)
 
 
 class _State:
@@ -202,8 +218,9 @@ class _RasterizeGaussians(torch.autograd.Function):
         sc = _f32c(scales, dev) if scales is not None and scales.numel() else None
         ro = _f32c(rotations, dev) if rotations is not None and rotations.numel() else None
         cv = _f32c(cov3Ds_precomp, dev) if cov3Ds_precomp is not None and cov3Ds_precomp.numel() else None
-        color, hdr, radii, st, exp_t, crf_t = _run_forward(raster_settings, m3, op, shs, cp, sc, ro, cv, exposure,
-                                                           crf_table, capacity)
+        with _on_device(dev):  # kernels are launched on the tensors' GPU, whatever the current device is
+            color, hdr, radii, st, exp_t, crf_t = _run_forward(raster_settings, m3, op, shs, cp, sc, ro, cv, exposure,
+                                                               crf_table, capacity)
         ctx.st = st
         ctx.exp_shape = None if exposure is None else tuple(exposure.shape)
         ctx.has = (shs is not None, cp is not None, sc is not None, cv is not None, exposure is not None,
@@ -221,7 +238,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         dev = saved[0].device
         gcol = _f32c(grad_color, dev)
         ghdr = _f32c(grad_hdr, dev) if grad_hdr is not None else None
-        g = _launch_backward(st, saved, gcol, ghdr, L.HS_BWD_ALL)
+        with _on_device(dev):
+            g = _launch_backward(st, saved, gcol, ghdr, L.HS_BWD_ALL)
         if st.pending is not None:
             # sync-free mode: the kernels are already queued; only now look at the forward's counters
             st.num_rendered = st.pending.check()
