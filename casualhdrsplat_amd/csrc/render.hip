@@ -466,22 +466,16 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
             scale_entry(ra, rb);
             s_a[threadIdx.x] = ra; s_b[threadIdx.x] = rb; s_c[threadIdx.x] = rc;
         }
-#ifndef HS_ABLATE_STAGE
         if (bi > 0) {  // batches below the top one are always full
             const uint32_t id = p.point_list[range.x + base - KB + threadIdx.x];
             const float4* r = p.rec + 3 * (int64_t)id;
             ra = r[0]; rb = r[1]; rc = r[2];
         }
-#endif
         __syncthreads();
         uint64_t wrote[KB / 64];
 #pragma unroll
         for (int k = 0; k < KB / 64; ++k) wrote[k] = 0ull;
-#ifdef HS_ABLATE_COMPACT
-        if (false) {
-#else
         if (base < (int)wave_max) {
-#endif
             int n_t = 0;
 #pragma unroll
             for (int k = 0; k < KB / 64; ++k) {
@@ -493,9 +487,6 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
                 if (touch) s_list[wave][n_t + mask_prefix(mask)] = (uint16_t)jj;
                 n_t += __popcll(mask);
             }
-#ifdef HS_ABLATE_LOOP
-            n_t = 0;
-#endif
             for (int i = n_t - 1; i >= 0; --i) {  // back to front
                 const int j = (int)s_list[wave][i];
                 const float4 a = s_a[j];
@@ -530,11 +521,7 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
                 g[7] = dch0 * s0.dL1 + dch1 * s1.dL1;
                 g[8] = dch0 * s0.dL2 + dch1 * s1.dL2;
                 float q0, q1, q2;
-#ifdef HS_ABLATE_REDUCE
-                q0 = g[0] + g[1] + g[2] + g[3]; q1 = g[4] + g[5] + g[6] + g[7]; q2 = g[8];
-#else
                 wave_reduce9(g, q0, q1, q2);
-#endif
                 // rows 0..3 of q0 hold totals of g0,g2,g1,g3; of q1: g4,g6,g5,g7; rows 0,1 of q2: g8
                 if ((lane & 15) == 0) {
                     const int row = lane >> 4;
@@ -550,9 +537,6 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
 #pragma unroll
             for (int k = 0; k < KB / 64; ++k) s_wrote[wave][k] = wrote[k];
         }
-#ifdef HS_ABLATE_WRITEOUT
-        if (blockIdx.x != 0x7fffffff) continue;
-#endif
         __syncthreads();
         if ((int)threadIdx.x < cnt) {
             const int t = threadIdx.x;
