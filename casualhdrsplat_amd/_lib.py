@@ -63,6 +63,7 @@ class hs_bwd_args(C.Structure):
         ("dL_dmeans3D", _fp), ("dL_dmeans2D", _fp), ("dL_dopacities", _fp), ("dL_dshs", _fp),
         ("dL_dcolors_precomp", _fp), ("dL_dscales", _fp), ("dL_drotations", _fp), ("dL_dcov3D_precomp", _fp),
         ("dL_dexposure", _fp), ("dL_dcrf_table", _fp),
+        ("dL_dviewmatrices", _fp), ("dL_dprojmatrices", _fp), ("dL_dcamposes", _fp),
     ]
 
 
@@ -71,7 +72,7 @@ class hs_layout(C.Structure):
         "counters", "rec", "depth", "radii", "tiles_touched", "offsets", "cov3D", "clamped", "scan_spine",
         "keys_sorted", "point_list", "keys_unsorted", "vals_unsorted", "ranges", "sort_tmp", "depth_keys", "depth_vals",
         "final_T", "n_contrib", "pose_hdr",
-        "pair_grads", "crf_partials", "pair_flags", "inst_grads")]
+        "pair_grads", "crf_partials", "pair_flags", "inst_grads", "pose_partials")]
 
 
 EXPORTS = ("hs_version", "hs_last_error", "hs_plan", "hs_forward", "hs_backward", "hs_mark_visible",

@@ -18,6 +18,7 @@ void set_error(const char* fmt, ...) {
 }
 
 int crf_partial_floats(int K);
+int64_t pose_partial_floats(int P, int N);
 
 static int plan(const hs_dims& d, hs_sizes* sz, hs_layout* L) {
     if (d.P < 0 || d.W <= 0 || d.H <= 0 || d.n_poses < 1 || d.capacity < 0 || d.M < 0) {
@@ -69,6 +70,7 @@ static int plan(const hs_dims& d, hs_sizes* sz, hs_layout* L) {
     l.crf_partials = carve((int64_t)crf_partial_floats(4096) * 4);
     l.pair_flags = carve(d.capacity);
     l.inst_grads = carve(I * 12 * 4);
+    l.pose_partials = carve(pose_partial_floats(d.P, d.n_poses) * 4);
     sz->bwd_bytes = o;
     if (L) *L = l;
     return HS_OK;
@@ -173,6 +175,11 @@ int hs_backward(const hs_bwd_args* a, void* hip_stream) {
     }
     if ((a->flags & HS_FLAG_HDR) && (!a->exposure || !a->crf_table || a->crf_K < 2 || a->crf_K > 4096)) {
         set_error("hs_backward: HDR needs exposure and crf_table");
+        return HS_EINVAL;
+    }
+    const int npose_out = (a->dL_dviewmatrices != nullptr) + (a->dL_dprojmatrices != nullptr) + (a->dL_dcamposes != nullptr);
+    if (npose_out != 0 && npose_out != 3) {
+        set_error("hs_backward: pose gradients need dL_dviewmatrices, dL_dprojmatrices and dL_dcamposes together");
         return HS_EINVAL;
     }
     if (a->dims.P == 0) return HS_OK;

@@ -316,7 +316,12 @@ struct PreBwd {
     const float4* inst_grads;
     float* d_means3D; float* d_means2D; float* d_opac; float* d_shs; float* d_colors; float* d_scales;
     float* d_rots; float* d_cov;
+    float* pose_partials;  // [blocks][N][kPoseVals] or null
 };
+
+// Camera-pose gradient terms per pose: 12 view-matrix entries (flat 4j+i, i<3), 12 projection entries (rows 0,1,3),
+// 3 camera-centre entries, padded to 28.
+constexpr int kPoseVals = 28;
 
 constexpr int kPreBwdBlock = 128;
 
@@ -324,9 +329,10 @@ constexpr int kPreBwdBlock = 128;
 // owns one Gaussian = one 12*M-byte row, so direct per-thread access would touch 64 different rows per wave
 // instruction; instead the block's rows are moved between HBM and LDS with fully coalesced accesses and each thread
 // works on its row in LDS (row stride M*3+1 words: conflict-free).
-template <int DEG>
+template <int DEG, bool POSE>
 __global__ void __launch_bounds__(kPreBwdBlock) preprocess_bwd_kernel(PreBwd p) {
     extern __shared__ float s_sh[];  // [kPreBwdBlock][M*3 + 1]
+    __shared__ float s_pose[kPreBwdBlock / 64][kPoseVals];
     constexpr int NC = (DEG + 1) * (DEG + 1);
     const int g0 = blockIdx.x * kPreBwdBlock;
     const int g = g0 + threadIdx.x;
@@ -354,9 +360,15 @@ __global__ void __launch_bounds__(kPreBwdBlock) preprocess_bwd_kernel(PreBwd p) 
 #pragma unroll
     for (int k = 0; k < 6; ++k) s6[k] = valid ? p.cov3D[6 * (int64_t)g + k] : 0.f;
 
-    for (int pose = 0; pose < (valid ? p.N : 0); ++pose) {
+    for (int pose = 0; pose < p.N; ++pose) {
         const int64_t idx = (int64_t)pose * p.P + g;
-        if (p.radii_inst[idx] <= 0) continue;
+        const bool on = valid && p.radii_inst[idx] > 0;
+        float pg[POSE ? kPoseVals : 1];
+        if constexpr (POSE) {
+#pragma unroll
+            for (int k = 0; k < kPoseVals; ++k) pg[k] = 0.f;
+        }
+        if (on) {
         // ---- this instance's summed pair records (pair_segsum_kernel) ----
         float r[9];
         {
@@ -392,10 +404,12 @@ __global__ void __launch_bounds__(kPreBwdBlock) preprocess_bwd_kernel(PreBwd p) 
             gcov[2] += 2.f * pp[0] * pp[2] * dLda + (pp[0] * qq[2] + pp[2] * qq[0]) * dLdb + 2.f * qq[0] * qq[2] * dLdc;
             gcov[4] += 2.f * pp[1] * pp[2] * dLda + (pp[1] * qq[2] + pp[2] * qq[1]) * dLdb + 2.f * qq[1] * qq[2] * dLdc;
             float dJ00 = 0.f, dJ02 = 0.f, dJ11 = 0.f, dJ12 = 0.f;
+            float ga0v[3], ga1v[3];
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 const float ga0 = 2.f * dLda * u0[j] + dLdb * u1[j];
                 const float ga1 = 2.f * dLdc * u1[j] + dLdb * u0[j];
+                ga0v[j] = ga0; ga1v[j] = ga1;
                 dJ00 += ga0 * V[4 * j + 0]; dJ02 += ga0 * V[4 * j + 2];
                 dJ11 += ga1 * V[4 * j + 1]; dJ12 += ga1 * V[4 * j + 2];
             }
@@ -406,6 +420,18 @@ __global__ void __launch_bounds__(kPreBwdBlock) preprocess_bwd_kernel(PreBwd p) 
                               (2.f * e.fy * e.ty) * tz3 * dJ12;
 #pragma unroll
             for (int j = 0; j < 3; ++j) gm[j] += V[4 * j + 0] * dtx + V[4 * j + 1] * dty + V[4 * j + 2] * dtz;
+            if constexpr (POSE) {
+                // t = Wv m + tv and A = J Wv:  dL/dWv_ij = dL/dt_i m_j + (row of A that uses Wv_i.)
+                const float J00 = e.fx * tz, J02 = -(e.fx * e.tx) * tz2, J11 = e.fy * tz, J12 = -(e.fy * e.ty) * tz2;
+                const float mm[3] = {x, y, z};
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {  // pg[3j+i] <-> viewmatrix flat[4j+i]
+                    pg[3 * j + 0] = dtx * mm[j] + ga0v[j] * J00;
+                    pg[3 * j + 1] = dty * mm[j] + ga1v[j] * J11;
+                    pg[3 * j + 2] = dtz * mm[j] + ga0v[j] * J02 + ga1v[j] * J12;
+                }
+                pg[9] = dtx; pg[10] = dty; pg[11] = dtz;
+            }
         }
         {
             const float phx = xform_row(PM, 0, x, y, z), phy = xform_row(PM, 1, x, y, z),
@@ -416,6 +442,17 @@ __global__ void __launch_bounds__(kPreBwdBlock) preprocess_bwd_kernel(PreBwd p) 
             for (int j = 0; j < 3; ++j)
                 gm[j] += (PM[4 * j + 0] * mw - PM[4 * j + 3] * mul1) * r[0] +
                          (PM[4 * j + 1] * mw - PM[4 * j + 3] * mul2) * r[1];
+            if constexpr (POSE) {
+                // ndc = (ph.x, ph.y) * mw :  d/dPV_row0 = g.x mw m~, d/dPV_row1 = g.y mw m~, d/dPV_row3 = -(g.ndc) mw m~
+                const float gw = -(r[0] * phx + r[1] * phy) * mw * mw;
+                const float mt[4] = {x, y, z, 1.f};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    pg[12 + 3 * j + 0] = r[0] * mw * mt[j];
+                    pg[12 + 3 * j + 1] = r[1] * mw * mt[j];
+                    pg[12 + 3 * j + 2] = gw * mt[j];
+                }
+            }
         }
         if (!p.has_colors_precomp) {
             const float* cp = p.campos + 3 * pose;
@@ -446,12 +483,32 @@ __global__ void __launch_bounds__(kPreBwdBlock) preprocess_bwd_kernel(PreBwd p) 
                 }
                 const float dd = (ux * gdir[0] + uy * gdir[1]) + uz * gdir[2];
                 const float inv = 1.f / len;
-                gm[0] += (gdir[0] - ux * dd) * inv;
-                gm[1] += (gdir[1] - uy * dd) * inv;
-                gm[2] += (gdir[2] - uz * dd) * inv;
+                const float gv0 = (gdir[0] - ux * dd) * inv, gv1 = (gdir[1] - uy * dd) * inv, gv2 = (gdir[2] - uz * dd) * inv;
+                gm[0] += gv0; gm[1] += gv1; gm[2] += gv2;
+                if constexpr (POSE) { pg[24] = -gv0; pg[25] = -gv1; pg[26] = -gv2; }  // v = m - campos
             }
         } else {
             gcol_pre[0] += r[6]; gcol_pre[1] += r[7]; gcol_pre[2] += r[8];
+        }
+    }  // if (on)
+        if constexpr (POSE) {
+            // workgroup sum of the 27 pose terms (all threads take part: `on` is per thread, `want_pose` uniform)
+            __syncthreads();  // s_sh rows are still being read above; the scratch below aliases nothing but keep order simple
+#pragma unroll
+            for (int k = 0; k < kPoseVals - 1; ++k) {
+                float v = pg[k];
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+                pg[k] = v;
+            }
+            if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+                for (int k = 0; k < kPoseVals - 1; ++k) s_pose[threadIdx.x >> 6][k] = pg[k];
+            }
+            __syncthreads();
+            if (threadIdx.x < kPoseVals - 1)
+                p.pose_partials[((int64_t)blockIdx.x * p.N + pose) * kPoseVals + threadIdx.x] =
+                    s_pose[0][threadIdx.x] + s_pose[1][threadIdx.x];
         }
     }
 
@@ -515,6 +572,36 @@ __global__ void __launch_bounds__(kPreBwdBlock) preprocess_bwd_kernel(PreBwd p) 
     }
 }
 
+// Pose-gradient partials [nblk][N*kPoseVals] -> column sums, two fixed-order stages (deterministic).
+constexpr int kPoseChunks = 64;
+__global__ void __launch_bounds__(256) pose_reduce1_kernel(const float* partials, int nblk, int cols, float* stage) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    const int chunk = blockIdx.y;
+    if (col >= cols) return;
+    const int per = (nblk + kPoseChunks - 1) / kPoseChunks;
+    const int r0 = chunk * per, r1 = min(nblk, r0 + per);
+    float acc = 0.f;
+    for (int r = r0; r < r1; ++r) acc += partials[(int64_t)r * cols + col];
+    stage[(int64_t)chunk * cols + col] = acc;
+}
+__global__ void __launch_bounds__(256) pose_reduce2_kernel(const float* stage, int N, float* d_view, float* d_proj,
+                                                           float* d_campos) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    const int cols = N * kPoseVals;
+    if (col >= cols) return;
+    float acc = 0.f;
+    for (int c = 0; c < kPoseChunks; ++c) acc += stage[(int64_t)c * cols + col];
+    const int pose = col / kPoseVals, k = col % kPoseVals;
+    if (k < 12) {  // pg[3j+i] <-> viewmatrix flat[4j+i], i < 3
+        d_view[16 * pose + 4 * (k / 3) + (k % 3)] = acc;
+    } else if (k < 24) {  // pg[12+3j+r] <-> projmatrix flat[4j + {0,1,3}[r]]
+        const int q = k - 12, r = q % 3;
+        d_proj[16 * pose + 4 * (q / 3) + (r == 2 ? 3 : r)] = acc;
+    } else if (k < 27) {
+        d_campos[3 * pose + (k - 24)] = acc;
+    }
+}
+
 }  // namespace
 
 int launch_preprocess_fwd(const hs_fwd_args& a, const hs_layout& L, hipStream_t s) {
@@ -571,14 +658,35 @@ int launch_preprocess_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t 
     const int grid = ceil_div(d.P, kPreBwdBlock);
     const int deg = a.colors_precomp ? 0 : d.sh_degree;
     const size_t lds = (size_t)kPreBwdBlock * (d.M * 3 + 1) * sizeof(float);
+    float* pose_partials = a.dL_dviewmatrices ? (float*)((char*)a.bwd + L.pose_partials) : nullptr;
+    p.pose_partials = pose_partials;
+#define HS_LAUNCH_PRE_BWD(DEG_)                                                                   \
+    if (pose_partials) preprocess_bwd_kernel<DEG_, true><<<grid, kPreBwdBlock, lds, s>>>(p);       \
+    else preprocess_bwd_kernel<DEG_, false><<<grid, kPreBwdBlock, lds, s>>>(p)
     switch (deg) {
-        case 0: preprocess_bwd_kernel<0><<<grid, kPreBwdBlock, lds, s>>>(p); break;
-        case 1: preprocess_bwd_kernel<1><<<grid, kPreBwdBlock, lds, s>>>(p); break;
-        case 2: preprocess_bwd_kernel<2><<<grid, kPreBwdBlock, lds, s>>>(p); break;
-        default: preprocess_bwd_kernel<3><<<grid, kPreBwdBlock, lds, s>>>(p); break;
+        case 0: HS_LAUNCH_PRE_BWD(0); break;
+        case 1: HS_LAUNCH_PRE_BWD(1); break;
+        case 2: HS_LAUNCH_PRE_BWD(2); break;
+        default: HS_LAUNCH_PRE_BWD(3); break;
     }
+#undef HS_LAUNCH_PRE_BWD
     HS_LAUNCH_CHECK();
+    if (pose_partials) {
+        const int cols = d.n_poses * kPoseVals;
+        float* stage = pose_partials + (int64_t)grid * cols;
+        // unused matrix entries (row 3 of the view matrix, row 2 of the projection) stay zero
+        HS_HIP_CHECK(hipMemsetAsync(a.dL_dviewmatrices, 0, sizeof(float) * 16 * d.n_poses, s));
+        HS_HIP_CHECK(hipMemsetAsync(a.dL_dprojmatrices, 0, sizeof(float) * 16 * d.n_poses, s));
+        pose_reduce1_kernel<<<dim3(ceil_div(cols, 256), kPoseChunks), 256, 0, s>>>(pose_partials, grid, cols, stage);
+        pose_reduce2_kernel<<<ceil_div(cols, 256), 256, 0, s>>>(stage, d.n_poses, a.dL_dviewmatrices, a.dL_dprojmatrices,
+                                                               a.dL_dcamposes);
+        HS_LAUNCH_CHECK();
+    }
     return HS_OK;
+}
+
+int64_t pose_partial_floats(int P, int N) {
+    return ((int64_t)ceil_div(P > 0 ? P : 1, kPreBwdBlock) + kPoseChunks) * N * kPoseVals;
 }
 
 int launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* vis, hipStream_t s) {

@@ -209,7 +209,7 @@ def _run_forward(settings: GaussianRasterizationSettings, means3D, opacities, sh
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                exposure, crf_table, raster_settings, capacity):
+                exposure, crf_table, viewmats, projmats, camposes, raster_settings, capacity):
         dev = means3D.device
         m3 = _f32c(means3D, dev)
         op = _f32c(opacities, dev)
@@ -223,6 +223,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                                                                crf_table, capacity)
         ctx.st = st
         ctx.exp_shape = None if exposure is None else tuple(exposure.shape)
+        ctx.pose_shapes = (tuple(viewmats.shape), tuple(projmats.shape), tuple(camposes.shape))
         ctx.has = (shs is not None, cp is not None, sc is not None, cv is not None, exposure is not None,
                    crf_table is not None)
         ctx.save_for_backward(m3, op, shs, cp, sc, ro, cv, exp_t, crf_t)
@@ -238,8 +239,9 @@ class _RasterizeGaussians(torch.autograd.Function):
         dev = saved[0].device
         gcol = _f32c(grad_color, dev)
         ghdr = _f32c(grad_hdr, dev) if grad_hdr is not None else None
+        want_pose = any(ctx.needs_input_grad[10:13])
         with _on_device(dev):
-            g = _launch_backward(st, saved, gcol, ghdr, L.HS_BWD_ALL)
+            g = _launch_backward(st, saved, gcol, ghdr, L.HS_BWD_ALL, want_pose)
         if st.pending is not None:
             # sync-free mode: the kernels are already queued; only now look at the forward's counters
             st.num_rendered = st.pending.check()
@@ -250,10 +252,13 @@ class _RasterizeGaussians(torch.autograd.Function):
                 g["opacities"], g["scales"] if has_sc else None, g["rotations"] if has_sc else None,
                 g["cov3D_precomp"] if has_cv else None,
                 g["exposure"].reshape(ctx.exp_shape) if (hdr and has_exp) else None,
-                g["crf_table"] if has_crf else None, None, None)
+                g["crf_table"] if has_crf else None,
+                g["viewmatrices"].reshape(ctx.pose_shapes[0]) if want_pose else None,
+                g["projmatrices"].reshape(ctx.pose_shapes[1]) if want_pose else None,
+                g["camposes"].reshape(ctx.pose_shapes[2]) if want_pose else None, None, None)
 
 
-def _launch_backward(st: "_State", saved, gcol, ghdr, stages: int) -> dict:
+def _launch_backward(st: "_State", saved, gcol, ghdr, stages: int, want_pose: bool = False) -> dict:
     """Enqueue hs_backward.  All per-Gaussian gradients are carved out of ONE flat fp32 buffer (the
     layout casualhdrsplat_amd.distributed all-reduces in a single RCCL call): [means3D | means2D |
     opacities | sh | colors | scales | rotations | cov3D | exposure | crf_table]."""
@@ -267,7 +272,9 @@ def _launch_backward(st: "_State", saved, gcol, ghdr, stages: int) -> dict:
     spec = [("means3D", (P, 3), True), ("means2D", (P, 3), True), ("opacities", (P, 1), True),
             ("shs", (P, M, 3), shs is not None), ("colors_precomp", (P, 3), cp is not None),
             ("scales", (P, 3), sc is not None), ("rotations", (P, 4), ro is not None),
-            ("cov3D_precomp", (P, 6), cv is not None), ("exposure", (1,), hdr), ("crf_table", (3, st.crf_K), hdr)]
+            ("cov3D_precomp", (P, 6), cv is not None), ("exposure", (1,), hdr), ("crf_table", (3, st.crf_K), hdr),
+            ("viewmatrices", (st.dims.n_poses, 16), want_pose), ("projmatrices", (st.dims.n_poses, 16), want_pose),
+            ("camposes", (st.dims.n_poses, 3), want_pose)]
     total = 0
     offs = {}
     for name, shape, on in spec:
@@ -301,6 +308,8 @@ def _launch_backward(st: "_State", saved, gcol, ghdr, stages: int) -> dict:
     a.dL_dshs, a.dL_dcolors_precomp, a.dL_dscales = _ptr(g["shs"]), _ptr(g["colors_precomp"]), _ptr(g["scales"])
     a.dL_drotations, a.dL_dcov3D_precomp = _ptr(g["rotations"]), _ptr(g["cov3D_precomp"])
     a.dL_dexposure, a.dL_dcrf_table = _ptr(g["exposure"]), _ptr(g["crf_table"])
+    a.dL_dviewmatrices, a.dL_dprojmatrices, a.dL_dcamposes = (_ptr(g["viewmatrices"]), _ptr(g["projmatrices"]),
+                                                              _ptr(g["camposes"]))
     if P > 0:
         L.check(lib.hs_backward(C.byref(a), _stream()), "hs_backward")
     else:
@@ -329,9 +338,14 @@ def replay_backward(out_tensor: torch.Tensor, grad_color: torch.Tensor, stages: 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                         raster_settings, capacity=None):
+    rs = raster_settings
+    multi = rs.viewmatrices is not None
+    # the camera tensors travel as autograd inputs so a trajectory model upstream receives pose gradients
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings.exposure, raster_settings.crf_table,
-                                     raster_settings, capacity)
+                                     cov3Ds_precomp, rs.exposure, rs.crf_table,
+                                     rs.viewmatrices if multi else rs.viewmatrix,
+                                     rs.projmatrices if multi else rs.projmatrix,
+                                     rs.camposes if multi else rs.campos, rs, capacity)
 
 
 class GaussianRasterizer(nn.Module):

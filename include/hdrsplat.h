@@ -151,6 +151,11 @@ typedef struct hs_bwd_args {
     float* dL_dcov3D_precomp;     /* [P,6] */
     float* dL_dexposure;          /* [1] (HDR) */
     float* dL_dcrf_table;         /* [3,crf_K] (HDR) */
+    /* camera-pose gradients (the reference optimises camera motion jointly, Readme.md:54);
+     * all three or none; same flat transposed layout as the inputs, unused entries are zero */
+    float* dL_dviewmatrices;      /* [N,16] or NULL */
+    float* dL_dprojmatrices;      /* [N,16] or NULL */
+    float* dL_dcamposes;          /* [N,3]  or NULL */
 } hs_bwd_args;
 
 /* Byte offsets of the arrays carved out of the three state workspaces, for tests, profilers and
@@ -167,7 +172,7 @@ typedef struct hs_layout {
     /* bwd workspace */
     /* pair_flags: u8 per pair, 1 = record written this backward; inst_grads: 12 floats per instance, the
      * per-instance sum of its pair records */
-    int64_t pair_grads, crf_partials, pair_flags, inst_grads;
+    int64_t pair_grads, crf_partials, pair_flags, inst_grads, pose_partials;
 } hs_layout;
 
 int hs_version(void);
