@@ -1,0 +1,108 @@
+"""Image-formation module: host-side SE(3)/CRF math on CPU; the end-to-end step on the GPU."""
+import math
+
+import pytest
+import torch
+
+from casualhdrsplat_amd import image_formation as IF
+from casualhdrsplat_amd import synthetic as S
+
+
+def test_se3_exp_log_roundtrip_and_group_properties():
+    torch.manual_seed(0)
+    xi = torch.randn(6, dtype=torch.float64) * 0.3
+    T = IF.se3_exp(xi)
+    R = T[:3, :3]
+    assert torch.allclose(R @ R.t(), torch.eye(3, dtype=torch.float64), atol=1e-12)
+    assert torch.det(R).item() == pytest.approx(1.0, abs=1e-12)
+    assert torch.allclose(IF.se3_log(T), xi, atol=1e-9)
+    assert torch.allclose(IF.se3_exp(torch.zeros(6, dtype=torch.float64)), torch.eye(4, dtype=torch.float64))
+    # one-parameter subgroup: exp(s xi) exp(t xi) = exp((s+t) xi)
+    assert torch.allclose(IF.se3_exp(0.3 * xi) @ IF.se3_exp(0.7 * xi), T, atol=1e-12)
+    # tiny rotations go through the series branch and stay differentiable
+    x = (torch.randn(6, dtype=torch.float64) * 1e-7).requires_grad_(True)
+    IF.se3_exp(x).sum().backward()
+    assert torch.isfinite(x.grad).all()
+
+
+def test_trajectory_samples_lie_between_knots():
+    knots = IF.knots_from_lookat(4, radius=0.2).double()
+    traj = IF.TrajectorySpline(knots).double()
+    P = traj.poses(1, 8)
+    assert P.shape == (8, 4, 4)
+    c = [-(p[:3, :3].t() @ p[:3, 3]) for p in P]                       # camera centres
+    c0 = -(knots[1][:3, :3].t() @ knots[1][:3, 3])
+    c1 = -(knots[2][:3, :3].t() @ knots[2][:3, 3])
+    xs = torch.stack(c)[:, 0]
+    assert torch.all(xs[1:] > xs[:-1]) and xs[0] > c0[0] and xs[-1] < c1[0]     # monotone along the arc, inside the window
+    for p in P:
+        assert torch.allclose(p[:3, :3] @ p[:3, :3].t(), torch.eye(3, dtype=torch.float64), atol=1e-10)
+    # a knot correction moves only the windows that touch the knot
+    with torch.no_grad():
+        traj.delta[3, 0] = 0.1
+    assert torch.allclose(traj.poses(1, 8), P) and not torch.allclose(traj.poses(2, 8), IF.TrajectorySpline(knots).double().poses(2, 8))
+
+
+def test_crf_table_is_monotone_and_normalised():
+    crf = IF.ImplicitCRF(K=64)
+    tab = crf.table()
+    assert tab.shape == (3, 64)
+    assert torch.all(tab[:, 1:] > tab[:, :-1])
+    assert torch.allclose(tab[:, 0], torch.zeros(3)) and torch.allclose(tab[:, -1], torch.ones(3), atol=1e-6)
+    tab.sum().backward()
+    assert all(p.grad is not None for p in crf.parameters())
+
+
+def test_camera_matrices_follow_the_rasterizer_convention():
+    W, H = 160, 96
+    cam = S.make_camera(W, H)
+    traj = IF.TrajectorySpline(torch.eye(4)[None].repeat(2, 1, 1))
+    model = IF.HDRBlurFormation(traj, 1, W, H, cam.tanfovx, cam.tanfovy, n_virtual=3, crf=IF.ImplicitCRF(K=16))
+    V, PV, C = model.cameras(0)
+    for k in range(3):  # identity trajectory == the synthetic default camera
+        assert torch.allclose(V[k], cam.viewmatrix, atol=1e-6)
+        assert torch.allclose(PV[k], cam.projmatrix, atol=1e-5)
+        assert torch.allclose(C[k], cam.campos, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_end_to_end_step_reaches_every_learnable():
+    """One HDR-deblur training step through the HIP rasterizer: the photometric loss back-propagates into the
+    Gaussians, the trajectory knots (camera motion), the exposure and the CRF network -- the four learnables of
+    /root/reference/assets/pipeline.png -- and a few Adam steps on (pose, exposure) reduce it."""
+    dev = "cuda"
+    W, H, P = 160, 96, 4000
+    sc = S.make_scene(P, W, H, 1, seed=21, hdr=True)
+    cam = sc.camera
+    knots = IF.knots_from_lookat(3, radius=0.03)
+    torch.manual_seed(0)
+
+    def build():
+        traj = IF.TrajectorySpline(knots)
+        m = IF.HDRBlurFormation(traj, 2, W, H, cam.tanfovx, cam.tanfovy, n_virtual=4, crf=IF.ImplicitCRF(K=64), sh_degree=1)
+        return m.to(dev)
+
+    leaves = {k: getattr(sc, k).to(dev).requires_grad_(True) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
+    target_model = build()
+    with torch.no_grad():
+        target_model.trajectory.delta[1, 0] = 0.02      # the "true" camera moved a little
+        target_model.log_exposure[0] = 0.3
+        target, _, _, _ = target_model(0, *[leaves[k].detach() for k in ("means3D", "opacities", "shs", "scales", "rotations")])
+    model = build()
+    model.crf.load_state_dict(target_model.crf.state_dict())
+    ldr, hdr, radii, m2d = model(0, leaves["means3D"], leaves["opacities"], leaves["shs"], leaves["scales"], leaves["rotations"])
+    assert ldr.shape == (3, H, W) and hdr.shape == (3, H, W) and int((radii > 0).sum()) > 0
+    loss0 = ((ldr - target) ** 2).mean()
+    loss0.backward()
+    assert all(torch.isfinite(v.grad).all() and v.grad.abs().sum() > 0 for v in leaves.values())
+    assert model.trajectory.delta.grad[:2].abs().sum() > 0 and torch.all(model.trajectory.delta.grad[2] == 0)
+    assert model.log_exposure.grad[0] != 0 and model.log_exposure.grad[1] == 0
+    assert sum(p.grad.abs().sum() for p in model.crf.parameters()) > 0
+    opt = torch.optim.Adam([model.trajectory.delta, model.log_exposure], lr=5e-3)
+    for _ in range(40):
+        opt.zero_grad()
+        ldr, _, _, _ = model(0, *[leaves[k].detach() for k in ("means3D", "opacities", "shs", "scales", "rotations")])
+        loss = ((ldr - target) ** 2).mean()
+        loss.backward()
+        opt.step()
+    assert loss.item() < 0.5 * loss0.item()
