@@ -134,8 +134,7 @@ __device__ __forceinline__ uint32_t digit_of(K k, int shift, uint32_t mask) {
 constexpr int kHistThreads = 1024;  // one 4096-key sort tile per workgroup, 4 keys per thread: short dependent chains
 template <typename K>
 __global__ void __launch_bounds__(kHistThreads) radix_hist_kernel(const K* keys, const uint32_t* n_dev, int shift,
-                                                                  uint32_t mask, uint32_t* hist, uint32_t* totals,
-                                                                  int nblk) {
+                                                                  uint32_t mask, uint32_t* hist, int nblk) {
     __shared__ uint32_t s_hist[256];
     const int64_t n = *n_dev;
     const int64_t base = (int64_t)blockIdx.x * kSortTile;
@@ -159,21 +158,15 @@ __global__ void __launch_bounds__(kHistThreads) radix_hist_kernel(const K* keys,
         }
     }
     __syncthreads();
-    if (threadIdx.x < 256) {
-        const uint32_t c = s_hist[threadIdx.x];
-        hist[(int64_t)threadIdx.x * nblk + blockIdx.x] = c;
-        if (c) atomicAdd(&totals[threadIdx.x], c);
-    }
+    if (threadIdx.x < 256) hist[(int64_t)threadIdx.x * nblk + blockIdx.x] = s_hist[threadIdx.x];
 }
 
-// One block per digit: exclusive scan of that digit's row over blocks, offset by the number of keys
-// with a smaller digit.
-__global__ void __launch_bounds__(256) radix_scan_kernel(uint32_t* hist, int nblk, const uint32_t* totals) {
+// One block per digit: exclusive scan of that digit's row over blocks (in place) and the digit's total.  The
+// offset of all smaller digits is added by the scatter kernel from totals[] (no global atomics, no grid sync).
+__global__ void __launch_bounds__(256) radix_scan_kernel(uint32_t* hist, int nblk, uint32_t* totals) {
     __shared__ uint32_t s_wave[4];
     const int d = blockIdx.x;
-    uint32_t mine = (int)threadIdx.x < d ? totals[threadIdx.x] : 0;
-    uint32_t carry;
-    block_incl_scan(mine, s_wave, &carry);
+    uint32_t carry = 0;
     uint32_t* row = hist + (int64_t)d * nblk;
     for (int base = 0; base < nblk; base += 256) {
         const int i = base + threadIdx.x;
@@ -183,6 +176,7 @@ __global__ void __launch_bounds__(256) radix_scan_kernel(uint32_t* hist, int nbl
         if (i < nblk) row[i] = carry + incl - v;
         carry += total;
     }
+    if (threadIdx.x == 0) totals[d] = carry;
 }
 
 // Scatter: stable within the block (wave w owns keys [w*1024, (w+1)*1024) of the block, processed in
@@ -191,7 +185,7 @@ template <typename K>
 __global__ void __launch_bounds__(kSortBlock) radix_scatter_kernel(const K* keys_in, const uint32_t* vals_in,
                                                                    K* keys_out, uint32_t* vals_out,
                                                                    const uint32_t* n_dev, int shift, uint32_t mask,
-                                                                   const uint32_t* hist, int nblk) {
+                                                                   const uint32_t* hist, const uint32_t* totals, int nblk) {
     __shared__ uint32_t s_cnt[4][256];    // per-wave digit counters -> per-wave exclusive offsets
     __shared__ uint32_t s_dstart[256];    // block-local start of each digit's run
     __shared__ uint32_t s_gbase[256];     // global start of this block's run of each digit
@@ -207,7 +201,12 @@ __global__ void __launch_bounds__(kSortBlock) radix_scatter_kernel(const K* keys
 
 #pragma unroll
     for (int w = 0; w < 4; ++w) s_cnt[w][threadIdx.x] = 0;
-    s_gbase[threadIdx.x] = hist[(int64_t)threadIdx.x * nblk + blockIdx.x];
+    {   // global start of this block's run of digit d = (keys with a smaller digit) + (same digit in earlier blocks)
+        const uint32_t tot = totals[threadIdx.x];
+        uint32_t all;
+        const uint32_t incl = block_incl_scan(tot, s_wave, &all);
+        s_gbase[threadIdx.x] = (incl - tot) + hist[(int64_t)threadIdx.x * nblk + blockIdx.x];
+    }
     __syncthreads();
 
     K key[kSortItems];
@@ -285,16 +284,16 @@ int radix_sort(K* k0, uint32_t* v0, K* k1, uint32_t* v1, const uint32_t* n_dev, 
     const int passes = sort_passes(nbits);
     uint32_t* hist = (uint32_t*)tmp;
     uint32_t* totals = (uint32_t*)((char*)tmp + align_up(256 * (int64_t)nblk * 4, 256));  // [passes][256]
-    HS_HIP_CHECK(hipMemsetAsync(totals, 0, (size_t)passes * 256 * 4, s));
+    (void)passes;
     K* kin = k0; uint32_t* vin = v0; K* kout = k1; uint32_t* vout = v1;
     int pass = 0;
     for (int shift = 0; shift < nbits; shift += 8, ++pass) {
         const int w = nbits - shift < 8 ? nbits - shift : 8;
         const uint32_t mask = (1u << w) - 1u;
         uint32_t* tot = totals + 256 * pass;
-        radix_hist_kernel<K><<<nblk, kHistThreads, 0, s>>>(kin, n_dev, shift, mask, hist, tot, nblk);
+        radix_hist_kernel<K><<<nblk, kHistThreads, 0, s>>>(kin, n_dev, shift, mask, hist, nblk);
         radix_scan_kernel<<<256, 256, 0, s>>>(hist, nblk, tot);
-        radix_scatter_kernel<K><<<nblk, kSortBlock, 0, s>>>(kin, vin, kout, vout, n_dev, shift, mask, hist, nblk);
+        radix_scatter_kernel<K><<<nblk, kSortBlock, 0, s>>>(kin, vin, kout, vout, n_dev, shift, mask, hist, tot, nblk);
         HS_LAUNCH_CHECK();
         K* tk = kin; kin = kout; kout = tk;
         uint32_t* tv = vin; vin = vout; vout = tv;
