@@ -69,8 +69,8 @@ class hs_bwd_args(C.Structure):
 
 class hs_layout(C.Structure):
     _fields_ = [(n, C.c_int64) for n in (
-        "counters", "rec", "depth", "radii", "tiles_touched", "offsets", "cov3D", "clamped", "scan_spine",
-        "keys_sorted", "point_list", "keys_unsorted", "vals_unsorted", "ranges", "sort_tmp", "depth_keys", "depth_vals",
+        "counters", "rec", "depth", "radii", "tiles_touched", "offsets", "cov3D", "clamped", "scan_spine", "binfo",
+        "keys_sorted", "point_list", "keys_unsorted", "vals_unsorted", "ranges", "sort_tmp", "depth_keys", "depth_vals", "srect",
         "final_T", "n_contrib", "pose_hdr",
         "pair_grads", "crf_partials", "pair_flags", "inst_grads", "pose_partials")]
 

@@ -46,6 +46,7 @@ static int plan(const hs_dims& d, hs_sizes* sz, hs_layout* L) {
     l.cov3D = carve((int64_t)d.P * 6 * 4);
     l.clamped = carve(I);
     l.scan_spine = carve(((I + 1023) / 1024 + 1) * 4);
+    l.binfo = carve(I * 8);
     sz->geom_bytes = o;
     // binning
     o = 0;
@@ -57,6 +58,7 @@ static int plan(const hs_dims& d, hs_sizes* sz, hs_layout* L) {
     l.sort_tmp = carve(sort_tmp_bytes(d.capacity > I ? d.capacity : I));
     l.depth_keys = carve(2 * I * 4);
     l.depth_vals = carve(2 * I * 4);
+    l.srect = carve(I * 8);
     sz->binning_bytes = o;
     // image
     o = 0;

@@ -311,63 +311,64 @@ __global__ void __launch_bounds__(256) depth_keys_kernel(int64_t I, const float*
     vals[i] = (uint32_t)i;
 }
 
-__global__ void __launch_bounds__(256) gather_tiles_kernel(int64_t I, const uint32_t* inst_sorted, const uint32_t* tiles,
-                                                           uint32_t* out) {
+// Tile rectangles and pair counts of the instances, gathered into depth order (one 8-byte gather per instance;
+// everything the emission needs afterwards is read coalesced).
+__global__ void __launch_bounds__(256) gather_binfo_kernel(int64_t I, const uint32_t* inst_sorted, const uint2* binfo,
+                                                           uint2* srect, uint32_t* ts) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= I) return;
-    out[i] = tiles[inst_sorted[i]];
+    const uint2 b = binfo[inst_sorted[i]];
+    srect[i] = b;
+    ts[i] = (b.y & 0xFFFFu) * (b.y >> 16);
 }
 
-// duplicateWithKeys walking the instances in depth order.  One thread per instance; the tile rectangle is
-// recomputed from (pixel centre, radius) with exactly the operations of preprocess (this TU is built with
-// -ffp-contract=off).  Also records where the instance's pair slots start (render-backward addresses its
-// gradient records with it; preprocess-backward sums them).
-__global__ void __launch_bounds__(256) emit_pairs_kernel(int64_t I, int P, int W, int H, float4* rec, const int* radii,
+// duplicateWithKeys walking the instances in depth order.  A wave owns 64 consecutive instances, whose pair slots
+// form ONE contiguous range; its lanes walk that range slot by slot (fully coalesced stores), finding each slot's
+// owner by binary search over the 64 slot starts in LDS and its tile from the owner's rectangle (row-major, the
+// published emission order).  Also records where each instance's slots start (render-backward addresses its
+// gradient records with it; the segmented sum walks them).
+__global__ void __launch_bounds__(256) emit_pairs_kernel(int64_t I, int P, int gx, int gy, float4* rec,
                                                          const uint32_t* inst_sorted, const uint32_t* offs_sorted,
-                                                         uint32_t* tile_keys, uint32_t* vals, const hs_counters* counters) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int lane = threadIdx.x & 63;
+                                                         const uint2* srect, uint32_t* tile_keys, uint32_t* vals,
+                                                         const hs_counters* counters) {
+    __shared__ uint32_t s_beg[4][64];
+    __shared__ uint2 s_rect[4][64];
+    __shared__ uint32_t s_inst[4][64];
     if (counters->overflow) return;
-    uint32_t idx = 0, off = 0, tile_base = 0;
-    int rminx = 0, rminy = 0, w = 0, cnt = 0;
-    const int gx = (W + kTile - 1) / kTile, gy = (H + kTile - 1) / kTile;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    uint32_t beg = 0, end = 0, inst = 0;
+    uint2 rc = make_uint2(0u, 0u);
     if (i < I) {
-        idx = inst_sorted[i];
-        const int rad = radii[idx];
-        if (rad > 0) {
-            off = i == 0 ? 0u : offs_sorted[i - 1];
-            reinterpret_cast<float*>(rec + 3 * (int64_t)idx + 2)[3] = __uint_as_float(off);
-            const float4 ra = rec[3 * (int64_t)idx];
-            rminx = min(gx, max(0, (int)((ra.x - (float)rad) / (float)kTile)));
-            rminy = min(gy, max(0, (int)((ra.y - (float)rad) / (float)kTile)));
-            const int rmaxx = min(gx, max(0, (int)((ra.x + (float)rad + (float)(kTile - 1)) / (float)kTile)));
-            const int rmaxy = min(gy, max(0, (int)((ra.y + (float)rad + (float)(kTile - 1)) / (float)kTile)));
-            w = rmaxx - rminx;
-            cnt = w * (rmaxy - rminy);
-            tile_base = (idx / (uint32_t)P) * (uint32_t)(gx * gy);
-        }
+        end = offs_sorted[i];
+        rc = srect[i];
+        beg = end - (rc.y & 0xFFFFu) * (rc.y >> 16);
+        inst = inst_sorted[i];
+        if (end > beg) reinterpret_cast<float*>(rec + 3 * (int64_t)inst + 2)[3] = __uint_as_float(beg);
     }
-    // rectangles are heavy-tailed: small ones are written by their own lane, big ones by the whole wave
-    // (row-major order within the rectangle either way)
-    constexpr int kSmall = 16;
-    if (cnt <= kSmall) {
-        for (int t = 0; t < cnt; ++t) {
-            const int y = rminy + t / w, x = rminx + t % w;
-            tile_keys[off + t] = tile_base + (uint32_t)(y * gx + x);
-            vals[off + t] = idx;
-        }
-    }
-    uint64_t big = __ballot(cnt > kSmall);
-    while (big) {
-        const int src = __builtin_ctzll(big);
-        big &= big - 1;
-        const uint32_t b_off = __shfl(off, src), b_idx = __shfl(idx, src), b_base = __shfl(tile_base, src);
-        const int b_cnt = __shfl(cnt, src), b_w = __shfl(w, src), b_x = __shfl(rminx, src), b_y = __shfl(rminy, src);
-        for (int t = lane; t < b_cnt; t += 64) {
-            const int y = b_y + t / b_w, x = b_x + t % b_w;
-            tile_keys[b_off + t] = b_base + (uint32_t)(y * gx + x);
-            vals[b_off + t] = b_idx;
-        }
+    // lanes past the end of the array inherit the running end so the range stays monotone
+    const uint32_t last_end = __shfl(end, 63 - __builtin_clzll(__ballot(i < I) | 1ull));
+    if (i >= I) beg = end = last_end;
+    s_beg[wave][lane] = beg;
+    s_rect[wave][lane] = rc;
+    s_inst[wave][lane] = inst;
+    const uint32_t first = __shfl(beg, 0);
+    const uint32_t total = last_end - first;
+    // same wave wrote and reads these LDS rows: no workgroup barrier needed (wave-private rows)
+    for (uint32_t p = lane; p < total; p += 64) {
+        const uint32_t pos = first + p;
+        int k = 0;
+#pragma unroll
+        for (int step = 32; step >= 1; step >>= 1)
+            if (s_beg[wave][k + step] <= pos) k += step;  // largest k with beg[k] <= pos (k + step <= 63)
+        const uint2 r = s_rect[wave][k];
+        const uint32_t t = pos - s_beg[wave][k];
+        const uint32_t w = r.y & 0xFFFFu;
+        const uint32_t ty = t / w, tx = t - ty * w;
+        const uint32_t idx = s_inst[wave][k];
+        const uint32_t tile_base = (idx / (uint32_t)P) * (uint32_t)(gx * gy);
+        tile_keys[pos] = tile_base + ((r.x >> 16) + ty) * (uint32_t)gx + (r.x & 0xFFFFu) + tx;
+        vals[pos] = idx;
     }
 }
 
@@ -437,7 +438,8 @@ int launch_binning(const hs_fwd_args& a, const hs_layout& L, hipStream_t s) {
     // 2. pair offsets in depth order, then emission
     uint32_t* ts = dk1;      // tiles touched in depth order (reuses the depth-key scratch)
     uint32_t* offs = dv1;    // inclusive scan of ts
-    gather_tiles_kernel<<<ceil_div(I, 256), 256, 0, s>>>(I, inst_sorted, (const uint32_t*)(geom + L.tiles_touched), ts);
+    uint2* srect = (uint2*)(bin + L.srect);
+    gather_binfo_kernel<<<ceil_div(I, 256), 256, 0, s>>>(I, inst_sorted, (const uint2*)(geom + L.binfo), srect, ts);
     rc = scan_u32(ts, I, (uint32_t*)(geom + L.scan_spine), offs, nullptr, s);
     if (rc != HS_OK) return rc;
     // the tile sort must end in (keys_sorted, point_list): start from A when the pass count is even
@@ -451,8 +453,8 @@ int launch_binning(const hs_fwd_args& a, const hs_layout& L, hipStream_t s) {
     uint32_t* v0 = (passes % 2 == 0) ? vA : vB;
     uint32_t* k1 = (passes % 2 == 0) ? kB : kA;
     uint32_t* v1 = (passes % 2 == 0) ? vB : vA;
-    emit_pairs_kernel<<<ceil_div(I, 256), 256, 0, s>>>(I, d.P, d.W, d.H, (float4*)(geom + L.rec),
-                                                       (const int*)(geom + L.radii), inst_sorted, offs, k0, v0, counters);
+    emit_pairs_kernel<<<ceil_div(I, 256), 256, 0, s>>>(I, d.P, gx, gy, (float4*)(geom + L.rec), inst_sorted, offs, srect,
+                                                       k0, v0, counters);
     HS_LAUNCH_CHECK();
     // 3. stable sort by tile id only
     rc = radix_sort<uint32_t>(k0, v0, k1, v1, n_sort, d.capacity, tbits, tmp, s);

@@ -141,6 +141,7 @@ struct PreFwd {
     const float* means; const float* opac; const float* shs; const float* colors; const float* scales;
     const float* rots; const float* cov_pre;
     float4* rec; float* depth; int* radii_inst; uint32_t* tiles; float* cov3D; uint8_t* clamped;
+    uint2* binfo;  // tile rectangle {min_x | min_y << 16, width | height << 16} for the pair emission
     int* radii_out;
 };
 
@@ -156,6 +157,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreFwd p) {
 
     int my_radius = 0;
     uint32_t ntiles = 0;
+    uint2 bi = make_uint2(0u, 0u);
     float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, rc = ra;
     float depth = 0.f;
     uint8_t clampbits = 0;
@@ -237,6 +239,8 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreFwd p) {
                 }
                 my_radius = rad;
                 ntiles = (uint32_t)area;
+                bi = make_uint2((uint32_t)rminx | ((uint32_t)rminy << 16),
+                                (uint32_t)(rmaxx - rminx) | ((uint32_t)(rmaxy - rminy) << 16));
                 depth = pvz;
                 ra = make_float4(pix_x, pix_y, conA, conB);
                 rb = make_float4(conC, p.opac[g], col[0], col[1]);
@@ -250,6 +254,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreFwd p) {
     p.depth[idx] = depth;
     p.radii_inst[idx] = my_radius;
     p.tiles[idx] = ntiles;
+    p.binfo[idx] = bi;
     p.clamped[idx] = clampbits;
     if (p.N == 1) p.radii_out[g] = my_radius;
     else if (my_radius > 0) atomicMax(p.radii_out + g, my_radius);
@@ -616,6 +621,7 @@ int launch_preprocess_fwd(const hs_fwd_args& a, const hs_layout& L, hipStream_t 
     p.rec = (float4*)(geom + L.rec); p.depth = (float*)(geom + L.depth); p.radii_inst = (int*)(geom + L.radii);
     p.tiles = (uint32_t*)(geom + L.tiles_touched); p.cov3D = (float*)(geom + L.cov3D);
     p.clamped = (uint8_t*)(geom + L.clamped); p.radii_out = a.radii;
+    p.binfo = (uint2*)(geom + L.binfo);
     if (d.n_poses > 1) HS_HIP_CHECK(hipMemsetAsync(a.radii, 0, sizeof(int) * (size_t)d.P, s));
     const int64_t I = (int64_t)d.P * d.n_poses;
     const int grid = ceil_div(I, 256);

@@ -162,11 +162,11 @@ typedef struct hs_bwd_args {
  * INTEGRATION.md-style bindings that want to inspect intermediates (keys, point_list, ranges...). */
 typedef struct hs_layout {
     /* geom workspace; arrays are indexed by instance = pose * P + gaussian */
-    int64_t counters, rec, depth, radii, tiles_touched, offsets, cov3D, clamped, scan_spine;
+    int64_t counters, rec, depth, radii, tiles_touched, offsets, cov3D, clamped, scan_spine, binfo;
     /* binning workspace: keys_sorted = u32 tile id of each sorted pair, point_list = u32 instance of each sorted
      * pair (the sort key of the published algorithm is (tile << 32) | depth_bits[instance]); depth_keys/depth_vals
      * = the instances sorted by depth (2 x I u32 each, second halves are scratch) */
-    int64_t keys_sorted, point_list, keys_unsorted, vals_unsorted, ranges, sort_tmp, depth_keys, depth_vals;
+    int64_t keys_sorted, point_list, keys_unsorted, vals_unsorted, ranges, sort_tmp, depth_keys, depth_vals, srect;
     /* image workspace */
     int64_t final_T, n_contrib, pose_hdr;
     /* bwd workspace */
