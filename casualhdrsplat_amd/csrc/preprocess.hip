@@ -150,8 +150,8 @@ template <int DEG>
 __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreFwd p) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (int64_t)p.P * p.N) return;
-    const int pose = (int)(idx / p.P);
-    const int g = (int)(idx - (int64_t)pose * p.P);
+    const int pose = (int)((uint32_t)idx / (uint32_t)p.P);  // I < 2^31 (hs_plan): 32-bit division
+    const int g = (int)((uint32_t)idx - (uint32_t)pose * (uint32_t)p.P);
     const float* V = p.view + 16 * pose;
     const float* PM = p.proj + 16 * pose;
 

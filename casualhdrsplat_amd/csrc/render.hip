@@ -574,6 +574,8 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
 
 // CRF-table and exposure gradients: fixed grid, LDS table per block, one partial row per block
 // ([3K] table + [1] exposure), reduced by crf_reduce_kernel.
+// grid = (blocks_x, 3 * npose): blockIdx.y selects the (pose, channel) image plane, x-blocks grid-stride over its
+// pixels in float4 quads -- no 64-bit integer division in the loop.
 __global__ void __launch_bounds__(256) crf_grad_kernel(int64_t HW, int N, int flags, const float* pose_hdr, Crf crf,
                                                        const float* exposure, const float* dL_dcolor, float* partials) {
     extern __shared__ float s_tab[];  // 3K + 4
@@ -582,42 +584,50 @@ __global__ void __launch_bounds__(256) crf_grad_kernel(int64_t HW, int N, int fl
     __syncthreads();
     crf.dt = exposure[0];
     const bool blur_hdr = (flags & HS_FLAG_BLUR_HDR) && N > 1;
-    const int npose = blur_hdr ? 1 : N;
     const float gs = blur_hdr ? 1.f : 1.f / (float)N;
     const float scale = (float)(crf.K - 1) / (crf.umax - crf.umin);
-    float gexp = 0.f;
-    const int64_t per_pose = 3 * HW;
-    const int64_t total = (int64_t)npose * per_pose;
-    // the image is walked in float4 quads (HW % 4 == 0 is not required: the tail is handled per element)
-    for (int64_t i4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i4 < total; i4 += (int64_t)gridDim.x * 1024) {
+    const int plane = blockIdx.y;            // pose * 3 + ch
+    const int pose = plane / 3, ch = plane - 3 * pose;
+    const float* Hp = pose_hdr + ((int64_t)(blur_hdr ? N : pose) * 3 + ch) * HW;
+    const float* gp = dL_dcolor + (int64_t)ch * HW;
+    const float* t = crf.table + ch * crf.K;
+    float* tab = s_tab + ch * crf.K;
+    float gexp = 0.f, g_lo = 0.f, g_hi = 0.f;
+    for (int64_t i4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i4 < HW; i4 += (int64_t)gridDim.x * 1024) {
         float Hv[4], g[4];
-        int ch[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int64_t i = i4 + e;
-            const bool ok = i < total;
-            const int k = ok ? (int)(i / per_pose) : 0;
-            const int64_t r = ok ? i - (int64_t)k * per_pose : 0;
-            ch[e] = (int)(r / HW);
-            Hv[e] = ok ? pose_hdr[(int64_t)(blur_hdr ? N : k) * per_pose + r] : 0.f;
-            g[e] = ok ? dL_dcolor[r] * gs : 0.f;
+            const bool ok = i4 + e < HW;
+            Hv[e] = ok ? Hp[i4 + e] : 0.f;
+            g[e] = ok ? gp[i4 + e] * gs : 0.f;
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             int idx; float f, xv; bool in;
             crf_locate(crf, Hv[e], idx, f, xv, in);
-            atomicAdd(&s_tab[ch[e] * crf.K + idx], (1.f - f) * g[e]);
-            atomicAdd(&s_tab[ch[e] * crf.K + idx + 1], f * g[e]);
-            if (in) {
-                const float* t = crf.table + ch[e] * crf.K;
-                gexp += g[e] * (t[idx + 1] - t[idx]) * scale * __builtin_amdgcn_rcpf(xv) * Hv[e];
+            // pixels clamped to an end of the table (black / saturated regions) would pile 64-way conflicts on
+            // one LDS word: they are summed in registers and added once per wave
+            const bool lo = idx == 0 && f == 0.f, hi = idx == crf.K - 2 && f == 1.f;
+            g_lo += lo ? g[e] : 0.f;
+            g_hi += hi ? g[e] : 0.f;
+            if (!lo && !hi) {
+                atomicAdd(&tab[idx], (1.f - f) * g[e]);
+                atomicAdd(&tab[idx + 1], f * g[e]);
             }
+            if (in) gexp += g[e] * (t[idx + 1] - t[idx]) * scale * __builtin_amdgcn_rcpf(xv) * Hv[e];
         }
     }
     gexp = wave_sum_hi(gexp);
-    if ((threadIdx.x & 63) == 63) atomicAdd(&s_tab[K3], gexp);
+    g_lo = wave_sum_hi(g_lo);
+    g_hi = wave_sum_hi(g_hi);
+    if ((threadIdx.x & 63) == 63) {
+        atomicAdd(&s_tab[K3], gexp);
+        atomicAdd(&tab[0], g_lo);
+        atomicAdd(&tab[crf.K - 1], g_hi);
+    }
     __syncthreads();
-    for (int i = threadIdx.x; i < K3 + 1; i += 256) partials[(int64_t)blockIdx.x * (K3 + 1) + i] = s_tab[i];
+    float* dst = partials + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (K3 + 1);
+    for (int i = threadIdx.x; i < K3 + 1; i += 256) dst[i] = s_tab[i];
 }
 
 // One wave per output element: lanes stride over the per-block partial rows (fixed order -> reproducible).
@@ -683,9 +693,12 @@ int launch_crf_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s) {
     float* partials = (float*)((char*)a.bwd + L.crf_partials);
     const float* pose_hdr = (const float*)((const char*)a.image + L.pose_hdr);
     const int K3 = 3 * a.crf_K;
-    crf_grad_kernel<<<kCrfBlocks, 256, (K3 + 4) * sizeof(float), s>>>(HW, d.n_poses, a.flags, pose_hdr, crf, a.exposure,
-                                                                     a.dL_dout_color, partials);
-    crf_reduce_kernel<<<ceil_div(K3 + 1, 4), 256, 0, s>>>(partials, kCrfBlocks, K3, a.dL_dcrf_table, a.dL_dexposure);
+    const bool blur_hdr = (a.flags & HS_FLAG_BLUR_HDR) && d.n_poses > 1;
+    const int planes = 3 * (blur_hdr ? 1 : d.n_poses);
+    const int bx = max(1, kCrfBlocks / planes);
+    crf_grad_kernel<<<dim3(bx, planes), 256, (K3 + 4) * sizeof(float), s>>>(HW, d.n_poses, a.flags, pose_hdr, crf,
+                                                                           a.exposure, a.dL_dout_color, partials);
+    crf_reduce_kernel<<<ceil_div(K3 + 1, 4), 256, 0, s>>>(partials, bx * planes, K3, a.dL_dcrf_table, a.dL_dexposure);
     HS_LAUNCH_CHECK();
     return HS_OK;
 }
