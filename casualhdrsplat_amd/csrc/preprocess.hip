@@ -289,13 +289,13 @@ __global__ void __launch_bounds__(256) pair_segsum_kernel(int64_t I, const uint3
     const uint32_t end = valid ? offs_sorted[i] : 0u;
     float r[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (uint32_t s = beg + q; s < end; s += 4) {
-        const bool on = pair_flags[s] != 0;
+        if (!pair_flags[s]) continue;  // never written this backward: skipping saves the 48-byte read (~55 % of pairs)
         const float4 q0 = pair_grads[3 * (int64_t)s + 0];
         const float4 q1 = pair_grads[3 * (int64_t)s + 1];
         const float q2 = reinterpret_cast<const float*>(pair_grads + 3 * (int64_t)s + 2)[0];
-        r[0] += on ? q0.x : 0.f; r[1] += on ? q0.y : 0.f; r[2] += on ? q0.z : 0.f; r[3] += on ? q0.w : 0.f;
-        r[4] += on ? q1.x : 0.f; r[5] += on ? q1.y : 0.f; r[6] += on ? q1.z : 0.f; r[7] += on ? q1.w : 0.f;
-        r[8] += on ? q2 : 0.f;
+        r[0] += q0.x; r[1] += q0.y; r[2] += q0.z; r[3] += q0.w;
+        r[4] += q1.x; r[5] += q1.y; r[6] += q1.z; r[7] += q1.w;
+        r[8] += q2;
     }
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
