@@ -406,12 +406,11 @@ __device__ __forceinline__ void step_bwd(PixB& s, bool act, float G, float alpha
     const float d0 = r - s.R0, d1 = g - s.R1, d2 = b - s.R2;
     float dLa = (d0 * s.dL0 + d1 * s.dL1) + d2 * s.dL2;
     dLa = dLa * s.T - (s.T_final * rcp) * s.bg_dot;
-    dLa = act ? dLa : 0.f;
     // accum_rec <- alpha*c + (1-alpha)*accum_rec, written as one FMA per channel on the difference already formed
     s.R0 += ae * d0;
     s.R1 += ae * d1;
     s.R2 += ae * d2;
-    dop = G * dLa;
+    dop = act ? G * dLa : 0.f;  // select AFTER the product: an indefinite conic can give G = inf at a skipped pixel
     sw = o * dop;
 }
 

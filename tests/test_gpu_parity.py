@@ -373,3 +373,27 @@ def test_camera_pose_gradients_vs_autograd(n_poses):
     # entries the projection never reads stay exactly zero
     assert np.all(got[0].reshape(n_poses, 16)[:, [3, 7, 11, 15]] == 0)
     assert np.all(got[1].reshape(n_poses, 16)[:, [2, 6, 10, 14]] == 0)
+
+
+def test_indefinite_precomputed_covariance_power_rule(oracle):
+    """A user-supplied cov3D_precomp need not be positive semi-definite; the resulting indefinite conic makes
+    `power > 0` reachable and the published rule (skip the pixel) must hold, also under sub-tile culling."""
+    sc = S.make_scene(1500, 144, 96, 0, seed=13)
+    f0, _ = Hh.run_oracle(oracle, sc, backward=False)
+    cov = torch.from_numpy(f0["cov3D"].copy())
+    gen = torch.Generator().manual_seed(3)
+    pick = torch.randperm(1500, generator=gen)[:300]
+    cov[pick, 0] *= -0.5     # negative xx variance: 2-D covariance keeps det != 0 but loses definiteness for many
+    cols = torch.rand(1500, 3, generator=gen)
+    g = Hh.run_hip(sc, use_colors_precomp=cols, use_cov_precomp=cov)
+    f, b = Hh.run_oracle(oracle, sc, use_colors_precomp=cols, use_cov_precomp=cov)
+    co = f["conic_opacity"]
+    indefinite = (co[:, 0] * co[:, 2] - co[:, 1] ** 2 <= 0) | (co[:, 0] <= 0)
+    assert int((indefinite & (f["radii"] > 0)).sum()) > 10          # the case is actually exercised
+    st = g["state"]
+    check_structure(st, f)
+    assert np.array_equal(u32(st["point_list"][:f["R"]]), u32(f["point_list"]))
+    flips = check_image(g["color"], f["color"], u32(st["n_contrib"][0]), u32(f["n_contrib"]), "indefinite")
+    Hh.assert_grads_close(g, b, keys=[("means3D", "dL_dmeans3D"), ("opacities", "dL_dopacity"),
+                                      ("colors_precomp", "dL_dcolors_precomp"), ("cov3D_precomp", "dL_dcov3D")],
+                          frac_tol=2e-2 if flips else 1e-2, max_tol=1.0 if flips else 5e-2, l2_tol=5e-3 if flips else 5e-5)
