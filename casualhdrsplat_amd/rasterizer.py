@@ -101,6 +101,9 @@ class _State:
                  "pending", "fwd_args", "keep")
 
 
+_PINNED_POOL: list = []  # recycled page-locked int32[2] buffers (hipHostMalloc per step is slow)
+
+
 class _Pending:
     """Deferred overflow check for the sync-free (fixed capacity) mode."""
     def __init__(self, host, event, capacity):
@@ -108,11 +111,14 @@ class _Pending:
 
     def check(self):
         self.event.synchronize()
-        if int(self.host[1]) != 0:
+        n, overflow = int(self.host[0]), int(self.host[1])
+        _PINNED_POOL.append(self.host)
+        self.host = None
+        if overflow != 0:
             raise RuntimeError(
-                f"binning capacity {self.capacity} < num_rendered {int(self.host[0])}: the frame was rendered "
+                f"binning capacity {self.capacity} < num_rendered {n}: the frame was rendered "
                 "empty; re-run with a larger `capacity` (or capacity=None for the synchronous mode)")
-        return int(self.host[0])
+        return n
 
 
 def _run_forward(settings: GaussianRasterizationSettings, means3D, opacities, shs, colors_precomp, scales,
@@ -190,7 +196,7 @@ def _run_forward(settings: GaussianRasterizationSettings, means3D, opacities, sh
     a.binning, a.image = binning.data_ptr(), image.data_ptr()
     L.check(lib.hs_forward(C.byref(a), stream), "hs_forward")
     if not sync_mode:
-        host = torch.empty(2, dtype=torch.int32).pin_memory()
+        host = _PINNED_POOL.pop() if _PINNED_POOL else torch.empty(2, dtype=torch.int32).pin_memory()
         host.copy_(geom[:8].view(torch.int32), non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
