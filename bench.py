@@ -174,9 +174,12 @@ def main():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback exists)")
     import torch.distributed as dist
     from casualhdrsplat_amd.distributed import init_from_env
-    rank, world, local = init_from_env("nccl")
+    # HS_BENCH_BACKEND=gloo is a plumbing check for boxes with fewer GPUs than ranks (ranks then share devices);
+    # measured runs use "nccl" (= RCCL over xGMI), one rank per GPU.
+    rank, world, local = init_from_env(os.environ.get("HS_BENCH_BACKEND", "nccl"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     cfg = CONFIGS[args.config]

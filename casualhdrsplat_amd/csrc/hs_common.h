@@ -36,12 +36,6 @@ static inline int tile_bits(uint32_t n) {
     return b;
 }
 
-struct Views {
-    const float* view;  // [N,16]
-    const float* proj;  // [N,16]
-    const float* campos;  // [N,3]
-};
-
 // ---- launchers (each enqueues on `s`, returns HS_OK / HS_EHIP) ----
 int launch_preprocess_fwd(const hs_fwd_args& a, const hs_layout& L, hipStream_t s);
 int launch_scan(const hs_fwd_args& a, const hs_layout& L, hipStream_t s);
@@ -53,9 +47,10 @@ int launch_preprocess_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t 
 int launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* vis, hipStream_t s);
 
 int64_t sort_tmp_bytes(int64_t n);
-// Sorts on bits [0,nbits); ping-pongs between (k0,v0) and (k1,v1); the result lands in (k0,v0) when the
-// number of 8-bit passes is even, else in (k1,v1) -- use sort_result_in_first().  `n_dev` points at the
-// device-resident element count (<= n_launch); hist must hold sort_tmp_bytes(n_launch).
+// Stable LSD radix sort of (u64 key, u32 value) pairs on bits [0,nbits) (hs_sort_pairs; the forward uses the u32-key
+// instantiation in binning.hip).  Ping-pongs between (k0,v0) and (k1,v1); the result lands in (k0,v0) when
+// sort_passes(nbits) is even, else in (k1,v1).  `n_dev` points at the device-resident element count (<= n_launch);
+// `hist` must hold sort_tmp_bytes(n_launch).
 int launch_radix_sort(uint64_t* k0, uint32_t* v0, uint64_t* k1, uint32_t* v1, const uint32_t* n_dev,
                       int64_t n_launch, int nbits, void* hist, hipStream_t s);
 static inline int sort_passes(int nbits) { return (nbits + 7) / 8; }

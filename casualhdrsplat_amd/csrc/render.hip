@@ -33,11 +33,6 @@ constexpr float kAlphaMax = 0.99f;
 constexpr float kTmin = 0.0001f;
 constexpr float kLogEps = 1e-8f;
 
-#ifdef HS_ACCURATE_EXP
-__device__ __forceinline__ float hs_exp(float x) { return expf(x); }
-#else
-__device__ __forceinline__ float hs_exp(float x) { return __expf(x); }
-#endif
 
 #ifdef HS_STATS
 // Development-only counters (never compiled into the shipped library): [0] (wave,entry) trips of the backward
@@ -74,25 +69,39 @@ __device__ __forceinline__ float halve16(float x, float y) {  // lane bit 4 (x -
     auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
-// Sum over the 16 lanes of each DPP row; every lane of the row receives the row total.
-__device__ __forceinline__ float row_sum(float v) {
-    v += dpp<0xB1>(v);   // quad_perm [1,0,3,2]
-    v += dpp<0x4E>(v);   // quad_perm [2,3,0,1]
-    v += dpp<0x141>(v);  // row_half_mirror
-    v += dpp<0x140>(v);  // row_mirror
-    return v;
+// In-row halving step on DPP bank masks: returns a register whose lanes with (lane & SHIFT) == 0 hold
+// x[l] + x[l + SHIFT] and whose other lanes hold y[l] + y[l - SHIFT] (SHIFT = 8 or 4 inside each 16-lane row).
+template <int SHIFT>
+__device__ __forceinline__ float halve_row(float x, float y) {
+    constexpr int lo_banks = SHIFT == 8 ? 0x3 : 0x5;  // banks (4-lane groups) whose lanes have the bit clear
+    constexpr int hi_banks = SHIFT == 8 ? 0xC : 0xA;
+    const float u = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(y), __float_as_int(x), 0x100 + SHIFT,
+                                                               0xF, lo_banks, false));  // row_shl: lane l <- x[l+SHIFT]
+    const float v = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(y), 0x110 + SHIFT,
+                                                               0xF, hi_banks, false));  // row_shr: lane l <- y[l-SHIFT]
+    return u + v;
 }
-// Reduces g[0..8] over the wave.  Output: three registers whose 16-lane rows hold wave totals:
-//   q0 rows 0..3 = g0, g2, g1, g3 ; q1 rows 0..3 = g4, g6, g5, g7 ; q2 rows 0,1 = g8 (rows 2,3 = 0).
-__device__ __forceinline__ void wave_reduce9(const float* g, float& q0, float& q1, float& q2) {
+
+// Reduces g[0..8] over the wave in ~26 instructions.  Halving steps keep the register count shrinking
+// (9 -> 5 -> 3 -> 2 -> 1); the result is ONE register in which, for DPP row r = lane >> 4 (0..3):
+//   lanes r*16 + 0..3   hold the wave total of g[{0,2,1,3}[r]],
+//   lanes r*16 + 8..11  hold the wave total of g[{4,6,5,7}[r]],
+//   lanes 4..7 (row 0)  hold the wave total of g[8].
+__device__ __forceinline__ float wave_reduce9(const float* g) {
     const float r0 = halve32(g[0], g[1]);
     const float r1 = halve32(g[2], g[3]);
     const float r2 = halve32(g[4], g[5]);
     const float r3 = halve32(g[6], g[7]);
     const float r4 = halve32(g[8], 0.f);
-    q0 = row_sum(halve16(r0, r1));
-    q1 = row_sum(halve16(r2, r3));
-    q2 = row_sum(halve16(r4, r4));
+    const float h0 = halve16(r0, r1);   // rows: g0, g2, g1, g3
+    const float h1 = halve16(r2, r3);   // rows: g4, g6, g5, g7
+    float h2 = halve16(r4, r4);         // rows: g8, g8, 0, 0
+    const float z = halve_row<8>(h0, h1);          // lanes 0-7: h0 over bit 3, lanes 8-15: h1 over bit 3
+    h2 += dpp<0x128>(h2);                           // row_ror:8 -> h2 over bit 3 in every lane
+    float w = halve_row<4>(z, h2);                  // quads 0,2: z over bit 2 ; quads 1,3: h2 over bit 2
+    w += dpp<0xB1>(w);                              // quad_perm [1,0,3,2]
+    w += dpp<0x4E>(w);                              // quad_perm [2,3,0,1]
+    return w;
 }
 
 // number of set bits of a wave-uniform 64-bit mask below this lane
@@ -447,6 +456,14 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
     __syncthreads();
     const int n_proc = (int)max(s_max[0], s_max[1]);
 
+    // which of the nine wave totals this lane holds after wave_reduce9 (-1: none)
+    int red_slot = -1;
+    {
+        const int row = lane >> 4, sub = lane & 15, v0 = ((row & 1) << 1) | (row >> 1);
+        if (sub == 0) red_slot = v0;
+        else if (sub == 8) red_slot = 4 + v0;
+        else if (lane == 4) red_slot = 8;
+    }
     const int nb = (n_proc + KB - 1) / KB;
     float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, rc = ra;
     if (nb > 0) {
@@ -519,16 +536,8 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
                 g[6] = dch0 * s0.dL0 + dch1 * s1.dL0;
                 g[7] = dch0 * s0.dL1 + dch1 * s1.dL1;
                 g[8] = dch0 * s0.dL2 + dch1 * s1.dL2;
-                float q0, q1, q2;
-                wave_reduce9(g, q0, q1, q2);
-                // rows 0..3 of q0 hold totals of g0,g2,g1,g3; of q1: g4,g6,g5,g7; rows 0,1 of q2: g8
-                if ((lane & 15) == 0) {
-                    const int row = lane >> 4;
-                    const int v0 = ((row & 1) << 1) | (row >> 1);
-                    s_acc[wave][v0][j] = q0;
-                    s_acc[wave][4 + v0][j] = q1;
-                    if (row == 0) s_acc[wave][8][j] = q2;
-                }
+                const float tot = wave_reduce9(g);
+                if (red_slot >= 0) s_acc[wave][red_slot][j] = tot;  // 9 lanes, one LDS store
                 wrote[j >> 6] |= 1ull << (j & 63);
             }
         }

@@ -110,15 +110,16 @@ class _Pending:
         self.host, self.event, self.capacity = host, event, capacity
 
     def check(self):
-        self.event.synchronize()
-        n, overflow = int(self.host[0]), int(self.host[1])
-        _PINNED_POOL.append(self.host)
-        self.host = None
-        if overflow != 0:
+        if self.host is not None:  # first call: wait for the copy, recycle the pinned buffer, remember the verdict
+            self.event.synchronize()
+            self.n, self.overflow = int(self.host[0]), int(self.host[1])
+            _PINNED_POOL.append(self.host)
+            self.host = None
+        if self.overflow != 0:
             raise RuntimeError(
-                f"binning capacity {self.capacity} < num_rendered {n}: the frame was rendered "
+                f"binning capacity {self.capacity} < num_rendered {self.n}: the frame was rendered "
                 "empty; re-run with a larger `capacity` (or capacity=None for the synchronous mode)")
-        return n
+        return self.n
 
 
 def _run_forward(settings: GaussianRasterizationSettings, means3D, opacities, shs, colors_precomp, scales,

@@ -204,7 +204,7 @@ def test_edge_cases(oracle):
     g = Hh.run_hip(sc3)
     f, b = Hh.run_oracle(oracle, sc3)
     assert_image_close(g["color"], f["color"], "single")
-    Hh.assert_grads_close(g, b, frac_tol=0.05)
+    Hh.assert_grads_close(g, b, frac_tol=0.34, max_tol=5e-4)  # 3-4 elements per tensor: bound every one at 5e-4
     # (4) a huge Gaussian covering every tile + many tiny ones (ragged list lengths)
     sc4 = S.make_scene(800, 208, 120, 0, seed=3)
     sc4.scales[0] = 3.0
