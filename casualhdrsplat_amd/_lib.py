@@ -59,7 +59,7 @@ class hs_bwd_args(C.Structure):
         ("means3D", _fp), ("opacities", _fp), ("shs", _fp), ("colors_precomp", _fp), ("scales", _fp),
         ("rotations", _fp), ("cov3D_precomp", _fp), ("exposure", _fp), ("crf_table", _fp),
         ("geom", _fp), ("binning", _fp), ("image", _fp), ("bwd", _fp),
-        ("dL_dout_color", _fp), ("dL_dout_hdr", _fp),
+        ("dL_dout_color", _fp), ("dL_dout_hdr", _fp), ("dL_dout_alpha", _fp),
         ("dL_dmeans3D", _fp), ("dL_dmeans2D", _fp), ("dL_dopacities", _fp), ("dL_dshs", _fp),
         ("dL_dcolors_precomp", _fp), ("dL_dscales", _fp), ("dL_drotations", _fp), ("dL_dcov3D_precomp", _fp),
         ("dL_dexposure", _fp), ("dL_dcrf_table", _fp),

@@ -354,7 +354,7 @@ struct RenderBwd {
     int W, H, gx, gy, ntiles, N, flags;
     const uint2* ranges; const uint32_t* point_list; const float4* rec; const float* bg;
     const float* final_T; const uint32_t* n_contrib; const float* pose_hdr;
-    const float* dL_dcolor; const float* dL_dhdr;
+    const float* dL_dcolor; const float* dL_dhdr; const float* dL_dalpha;
     float4* pair_grads;
     uint8_t* pair_flags;
     Crf crf;
@@ -398,6 +398,8 @@ __device__ __forceinline__ void load_pixel_bwd(const RenderBwd& p, PixB& s, bool
         s.dL2 = pixel_grad(p, c, pose, 2, pix, HW);
     }
     s.bg_dot = (p.bg[0] * s.dL0 + p.bg[1] * s.dL1) + p.bg[2] * s.dL2;
+    // accumulated opacity A = 1 - T_final: dA/dalpha_i = T_final / (1 - alpha_i), the background term with sign flipped
+    if (p.dL_dalpha && inside) s.bg_dot -= p.dL_dalpha[pix] / (float)p.N;
     s.T = s.T_final;
     s.R0 = s.R1 = s.R2 = 0.f;  // colour accumulated behind the current entry ("accum_rec")
 }
@@ -721,7 +723,7 @@ int launch_render_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s) {
     p.rec = (const float4*)(geom + L.rec); p.bg = a.bg;
     p.final_T = (const float*)(img + L.final_T); p.n_contrib = (const uint32_t*)(img + L.n_contrib);
     p.pose_hdr = (const float*)(img + L.pose_hdr);
-    p.dL_dcolor = a.dL_dout_color; p.dL_dhdr = a.dL_dout_hdr;
+    p.dL_dcolor = a.dL_dout_color; p.dL_dhdr = a.dL_dout_hdr; p.dL_dalpha = a.dL_dout_alpha;
     p.pair_grads = (float4*)((char*)a.bwd + L.pair_grads);
     p.crf.table = a.crf_table; p.crf.K = a.crf_K; p.crf.umin = a.crf_umin; p.crf.umax = a.crf_umax; p.crf.dt = 1.f;
     p.exposure = a.exposure;

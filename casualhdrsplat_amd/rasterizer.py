@@ -216,7 +216,7 @@ def _run_forward(settings: GaussianRasterizationSettings, means3D, opacities, sh
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                exposure, crf_table, viewmats, projmats, camposes, raster_settings, capacity):
+                exposure, crf_table, viewmats, projmats, camposes, raster_settings, capacity, return_alpha=False):
         dev = means3D.device
         m3 = _f32c(means3D, dev)
         op = _f32c(opacities, dev)
@@ -235,20 +235,29 @@ class _RasterizeGaussians(torch.autograd.Function):
                    crf_table is not None)
         ctx.save_for_backward(m3, op, shs, cp, sc, ro, cv, exp_t, crf_t)
         ctx.mark_non_differentiable(radii)
-        if hdr is None:
-            return color, radii
-        return color, radii, hdr
+        ctx.n_out = (hdr is not None, bool(return_alpha))
+        outs = (color, radii) + ((hdr,) if hdr is not None else ())
+        if return_alpha:
+            # accumulated opacity A = 1 - mean over poses of the final transmittance (newer rasterizers expose it)
+            d = st.dims
+            ft = st.image[st.layout.final_T:st.layout.final_T + 4 * d.n_poses * d.W * d.H].view(torch.float32)
+            outs = outs + (1.0 - ft.reshape(d.n_poses, d.H, d.W).mean(dim=0),)
+        return outs
 
     @staticmethod
-    def backward(ctx, grad_color, grad_radii=None, grad_hdr=None):
+    def backward(ctx, grad_color, grad_radii=None, *more):
+        has_hdr, has_alpha = ctx.n_out
+        grad_hdr = more[0] if has_hdr else None
+        grad_alpha = more[1 if has_hdr else 0] if has_alpha else None
         st: _State = ctx.st
         saved = ctx.saved_tensors
         dev = saved[0].device
         gcol = _f32c(grad_color, dev)
         ghdr = _f32c(grad_hdr, dev) if grad_hdr is not None else None
+        galpha = _f32c(grad_alpha, dev) if grad_alpha is not None else None
         want_pose = any(ctx.needs_input_grad[10:13])
         with _on_device(dev):
-            g = _launch_backward(st, saved, gcol, ghdr, L.HS_BWD_ALL, want_pose)
+            g = _launch_backward(st, saved, gcol, ghdr, L.HS_BWD_ALL, want_pose, galpha)
         if st.pending is not None:
             # sync-free mode: the kernels are already queued; only now look at the forward's counters
             st.num_rendered = st.pending.check()
@@ -262,10 +271,10 @@ class _RasterizeGaussians(torch.autograd.Function):
                 g["crf_table"] if has_crf else None,
                 g["viewmatrices"].reshape(ctx.pose_shapes[0]) if want_pose else None,
                 g["projmatrices"].reshape(ctx.pose_shapes[1]) if want_pose else None,
-                g["camposes"].reshape(ctx.pose_shapes[2]) if want_pose else None, None, None)
+                g["camposes"].reshape(ctx.pose_shapes[2]) if want_pose else None, None, None, None)
 
 
-def _launch_backward(st: "_State", saved, gcol, ghdr, stages: int, want_pose: bool = False) -> dict:
+def _launch_backward(st: "_State", saved, gcol, ghdr, stages: int, want_pose: bool = False, galpha=None) -> dict:
     """Enqueue hs_backward.  All per-Gaussian gradients are carved out of ONE flat fp32 buffer (the
     layout casualhdrsplat_amd.distributed all-reduces in a single RCCL call): [means3D | means2D |
     opacities | sh | colors | scales | rotations | cov3D | exposure | crf_table]."""
@@ -310,7 +319,7 @@ def _launch_backward(st: "_State", saved, gcol, ghdr, stages: int, want_pose: bo
     a.scales, a.rotations, a.cov3D_precomp = _ptr(sc), _ptr(ro), _ptr(cv)
     a.exposure, a.crf_table = _ptr(exp_t), _ptr(crf_t)
     a.geom, a.binning, a.image, a.bwd = st.geom.data_ptr(), st.binning.data_ptr(), st.image.data_ptr(), bwd.data_ptr()
-    a.dL_dout_color, a.dL_dout_hdr = _ptr(gcol), _ptr(ghdr)
+    a.dL_dout_color, a.dL_dout_hdr, a.dL_dout_alpha = _ptr(gcol), _ptr(ghdr), _ptr(galpha)
     a.dL_dmeans3D, a.dL_dmeans2D, a.dL_dopacities = _ptr(g["means3D"]), _ptr(g["means2D"]), _ptr(g["opacities"])
     a.dL_dshs, a.dL_dcolors_precomp, a.dL_dscales = _ptr(g["shs"]), _ptr(g["colors_precomp"]), _ptr(g["scales"])
     a.dL_drotations, a.dL_dcov3D_precomp = _ptr(g["rotations"]), _ptr(g["cov3D_precomp"])
@@ -344,7 +353,7 @@ def replay_backward(out_tensor: torch.Tensor, grad_color: torch.Tensor, stages: 
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                        raster_settings, capacity=None):
+                        raster_settings, capacity=None, return_alpha=False):
     rs = raster_settings
     multi = rs.viewmatrices is not None
     # the camera tensors travel as autograd inputs so a trajectory model upstream receives pose gradients
@@ -352,7 +361,7 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
                                      cov3Ds_precomp, rs.exposure, rs.crf_table,
                                      rs.viewmatrices if multi else rs.viewmatrix,
                                      rs.projmatrices if multi else rs.projmatrix,
-                                     rs.camposes if multi else rs.campos, rs, capacity)
+                                     rs.camposes if multi else rs.campos, rs, capacity, return_alpha)
 
 
 class GaussianRasterizer(nn.Module):
@@ -363,10 +372,12 @@ class GaussianRasterizer(nn.Module):
     detected lazily (at backward / `last_num_rendered`) and raises.
     """
 
-    def __init__(self, raster_settings: GaussianRasterizationSettings, capacity: Optional[int] = None):
+    def __init__(self, raster_settings: GaussianRasterizationSettings, capacity: Optional[int] = None,
+                 return_alpha: bool = False):
         super().__init__()
         self.raster_settings = raster_settings
         self.capacity = capacity
+        self.return_alpha = return_alpha  # extension: append the accumulated-opacity image [H,W] to the outputs
 
     def markVisible(self, positions: torch.Tensor) -> torch.Tensor:
         lib = L.load()
@@ -393,7 +404,7 @@ class GaussianRasterizer(nn.Module):
         rotations = empty if rotations is None else rotations
         cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
-                                   cov3D_precomp, rs, self.capacity)
+                                   cov3D_precomp, rs, self.capacity, self.return_alpha)
 
 
 def inspect_state(out_tensor: torch.Tensor) -> dict:

@@ -140,6 +140,7 @@ typedef struct hs_bwd_args {
     /* upstream gradients */
     const float* dL_dout_color;   /* [3,H,W] */
     const float* dL_dout_hdr;     /* [3,H,W] or NULL */
+    const float* dL_dout_alpha;   /* [H,W] or NULL: gradient w.r.t. the accumulated-opacity image 1 - mean_k final_T_k */
     /* outputs (each may be NULL when its input is absent) */
     float* dL_dmeans3D;           /* [P,3] */
     float* dL_dmeans2D;           /* [P,3] screen-space gradient (NDC-scaled), summed over poses */

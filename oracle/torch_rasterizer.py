@@ -215,7 +215,7 @@ def render(view: View, pre: dict, point_list, ranges, bg, tiles=None):
         last = torch.where(contrib, pos[None, :], torch.zeros_like(pos)[None, :]).amax(dim=1)
         out = C + Tf[:, None] * bg[None, :]
         color[:, y0:y0 + h, x0:x0 + w] = out.t().reshape(3, h, w)
-        final_T[y0:y0 + h, x0:x0 + w] = Tf.detach().reshape(h, w)
+        final_T[y0:y0 + h, x0:x0 + w] = Tf.reshape(h, w)  # differentiable: alpha image = 1 - final_T
         n_contrib[y0:y0 + h, x0:x0 + w] = last.reshape(h, w)
     return color, final_T, n_contrib
 

@@ -397,3 +397,32 @@ def test_indefinite_precomputed_covariance_power_rule(oracle):
     Hh.assert_grads_close(g, b, keys=[("means3D", "dL_dmeans3D"), ("opacities", "dL_dopacity"),
                                       ("colors_precomp", "dL_dcolors_precomp"), ("cov3D_precomp", "dL_dcov3D")],
                           frac_tol=2e-2 if flips else 1e-2, max_tol=1.0 if flips else 5e-2, l2_tol=5e-3 if flips else 5e-5)
+
+
+def test_accumulated_opacity_output_and_gradient():
+    """SURVEY.md 8(f) n3 (alpha part): optional A = 1 - final_T output with gradient, against fp64 autograd."""
+    from casualhdrsplat_amd import GaussianRasterizer
+    from oracle import torch_rasterizer as TR
+    P, W, H, deg = 800, 112, 80, 1
+    sc = S.make_scene(P, W, H, deg, seed=14)
+    sc.bg = torch.tensor([0.3, 0.1, 0.6])
+    rs, _, _ = Hh.settings_from_scene(sc, "cuda")
+    gen = torch.Generator().manual_seed(2)
+    gA = torch.randn(H, W, generator=gen)
+    leaves = {k: getattr(sc, k).cuda().requires_grad_(True) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
+    out = GaussianRasterizer(rs, return_alpha=True)(leaves["means3D"], torch.zeros(P, 3, device="cuda"), leaves["opacities"],
+                                                    shs=leaves["shs"], scales=leaves["scales"], rotations=leaves["rotations"])
+    assert len(out) == 3 and out[2].shape == (H, W)
+    ((out[0] * sc.dL_dimage.cuda()).sum() + (out[2] * gA.cuda()).sum()).backward()
+    dt = torch.float64
+    cam = sc.camera
+    view = TR.View(W, H, cam.tanfovx, cam.tanfovy, cam.viewmatrix.to(dt), cam.projmatrix.to(dt), cam.campos.to(dt))
+    ref = {k: getattr(sc, k).to(dt).clone().requires_grad_(True) for k in leaves}
+    color, st = TR.rasterize(view, ref["means3D"], ref["opacities"], deg, sc.bg, shs=ref["shs"], scales=ref["scales"],
+                             rotations=ref["rotations"], return_state=True)
+    alpha = 1.0 - st["final_T"]
+    ((color * sc.dL_dimage.to(dt)).sum() + (alpha * gA.to(dt)).sum()).backward()
+    assert Hh.rel_err(out[2].detach().cpu().numpy(), alpha.detach().numpy(), 1e-3)[0] <= 1e-4
+    got = {"d_" + k: v.grad.cpu().numpy() for k, v in leaves.items()}
+    want = {"dL_d" + k: v.grad.numpy() for k, v in ref.items()}
+    Hh.assert_grads_close(got, want, keys=[(k, "dL_d" + k) for k in leaves], frac_tol=2e-2, l2_tol=1e-4)
