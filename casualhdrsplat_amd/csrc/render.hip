@@ -467,28 +467,25 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
         else if (lane == 4) red_slot = 8;
     }
     const int nb = (n_proc + KB - 1) / KB;
-    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, rc = ra;
+    // only the instance id of the NEXT batch is prefetched (one register); its 48-byte record is gathered at the
+    // top of the batch -- keeping the three float4 in registers across the replay loop costs a wave of occupancy
+    uint32_t id_next = 0;
     if (nb > 0) {
         const int base = (nb - 1) * KB;
-        if ((int)threadIdx.x < n_proc - base) {
-            const uint32_t id = p.point_list[range.x + base + threadIdx.x];
-            const float4* r = p.rec + 3 * (int64_t)id;
-            ra = r[0]; rb = r[1]; rc = r[2];
-        }
+        if ((int)threadIdx.x < n_proc - base) id_next = p.point_list[range.x + base + threadIdx.x];
     }
     for (int bi = nb - 1; bi >= 0; --bi) {
         const int base = bi * KB;
         const int cnt = min(KB, n_proc - base);
         __syncthreads();  // previous batch's write-out finished
         if ((int)threadIdx.x < cnt) {
+            const float4* r = p.rec + 3 * (int64_t)id_next;
+            float4 ra = r[0], rb = r[1];
+            const float4 rc = r[2];
             scale_entry(ra, rb);
             s_a[threadIdx.x] = ra; s_b[threadIdx.x] = rb; s_c[threadIdx.x] = rc;
         }
-        if (bi > 0) {  // batches below the top one are always full
-            const uint32_t id = p.point_list[range.x + base - KB + threadIdx.x];
-            const float4* r = p.rec + 3 * (int64_t)id;
-            ra = r[0]; rb = r[1]; rc = r[2];
-        }
+        if (bi > 0) id_next = p.point_list[range.x + base - KB + threadIdx.x];  // batches below the top are full
         __syncthreads();
         uint64_t wrote[KB / 64];
 #pragma unroll
