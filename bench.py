@@ -94,7 +94,7 @@ def build_step(cfg, rank, world, dev):
                             scales=params["scales"], rotations=params["rotations"])
         torch.autograd.backward(out[0], grad_tensors=dL)
         if world > 1:
-            all_reduce_gradients(plist)
+            all_reduce_gradients(plist, algo="auto")
         state["out"] = out
         return out
 
@@ -192,6 +192,14 @@ def main():
     torch.cuda.synchronize()
     R, Rp, E, vtiles = derived_counts(out, W, H, n_poses)
     state["rast"] = make_rasterizer(int(R * 1.25) + 4096)
+    allreduce_info = None
+    if world > 1:
+        # measure, don't guess: library all-reduce vs the 1-hop all-to-all form on this node's links, once
+        from casualhdrsplat_amd.distributed import _ALGO, _shared_flat, autotune_all_reduce
+        flat = _shared_flat([p.grad for p in plist if p.grad is not None], multiple=world)
+        if flat is not None:
+            autotune_all_reduce(flat)
+        allreduce_info = dict(_ALGO, elements=None if flat is None else flat.numel())
 
     def barrier():
         if world > 1:
@@ -225,6 +233,8 @@ def main():
                    "binning": "sync-free fixed capacity 1.25*R"},
         "mpix_per_s": world * args.steps * W * H * n_poses / elapsed / 1e6,
     }
+    if allreduce_info is not None:
+        line["config"]["gradient_exchange"] = allreduce_info
 
     if rank == 0:
         from casualhdrsplat_amd import _lib as L

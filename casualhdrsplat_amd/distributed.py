@@ -37,8 +37,9 @@ def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
     return rank, world, local
 
 
-def _shared_flat(grads: Sequence[torch.Tensor]) -> torch.Tensor | None:
-    """If all gradients are contiguous slices of one storage, return a 1-D tensor spanning them."""
+def _shared_flat(grads: Sequence[torch.Tensor], multiple: int = 1) -> torch.Tensor | None:
+    """If all gradients are contiguous slices of one storage, return a 1-D tensor spanning them (its length
+    rounded up to `multiple` elements when the storage has the room: the rasterizer zero-pads its buffer)."""
     if not grads:
         return None
     st = grads[0].untyped_storage()
@@ -52,20 +53,82 @@ def _shared_flat(grads: Sequence[torch.Tensor]) -> torch.Tensor | None:
         hi = o + g.numel() if hi is None else max(hi, o + g.numel())
     if sum(g.numel() for g in grads) < 0.9 * (hi - lo):
         return None  # sparse cover: packing is cheaper than reducing the gaps
-    return torch.empty(0, dtype=torch.float32, device=grads[0].device).set_(st, lo, (hi - lo,))
+    n = hi - lo
+    if multiple > 1 and n % multiple:
+        n_up = (n + multiple - 1) // multiple * multiple
+        if (lo + n_up) * 4 <= st.nbytes():
+            n = n_up
+    return torch.empty(0, dtype=torch.float32, device=grads[0].device).set_(st, lo, (n,))
 
 
-def all_reduce_gradients(params: Iterable[torch.Tensor], group=None, average: bool = False) -> int:
-    """Sum (or average) `.grad` of `params` over all ranks with one collective.  Returns the number
-    of fp32 elements exchanged (0 when not distributed)."""
+def all_reduce_direct(flat: torch.Tensor, group=None) -> None:
+    """In-place sum of `flat` over the ranks as a 1-hop reduce-scatter + all-gather built from two all-to-alls.
+
+    xGMI on an 8 x MI355X node is a full mesh of point-to-point links (7 x ~153 GB/s per GPU), so a ring
+    all-reduce is bound by ONE link (2*(n-1)/n * bytes / link) while sending shard j straight to rank j uses
+    all seven links at once (~0.4 ms vs ~2.7 ms for 236 MB).  Every shard is summed by
+    exactly one rank in rank order and then broadcast, so all ranks end with bitwise identical results.
+    Requires flat.numel() % world == 0 (the rasterizer pads its gradient buffer accordingly)."""
+    world = dist.get_world_size(group)
+    n = flat.numel()
+    assert n % world == 0, (n, world)
+    chunk = n // world
+    recv = torch.empty_like(flat)
+    dist.all_to_all_single(recv, flat, group=group)              # recv[j*chunk:(j+1)*chunk] = rank j's copy of MY shard
+    mine = recv.view(world, chunk).sum(dim=0)                    # fixed summation order
+    send = mine.unsqueeze(0).expand(world, chunk).contiguous().view(-1)
+    dist.all_to_all_single(flat, send, group=group)              # flat[j*chunk:...] = rank j's reduced shard
+
+
+_ALGO = {"choice": "rccl"}
+
+
+def autotune_all_reduce(flat: torch.Tensor, group=None, iters: int = 3) -> str:
+    """Time the library all-reduce against all_reduce_direct on a scratch copy of `flat` and keep the faster one
+    for later all_reduce_gradients(..., algo="auto") calls.  The decision is taken on rank 0's maximum-over-ranks
+    timings, so every rank chooses the same algorithm."""
+    import time
+    world = dist.get_world_size(group)
+    if flat.numel() % world != 0:
+        _ALGO["choice"] = "rccl"
+        return "rccl"
+    scratch = torch.zeros_like(flat)
+    sync = torch.cuda.synchronize if flat.is_cuda else (lambda: None)
+    times = {}
+    for name, fn in (("rccl", lambda: dist.all_reduce(scratch, group=group)), ("direct", lambda: all_reduce_direct(scratch, group))):
+        fn()
+        dist.barrier(group)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        sync()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=flat.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        times[name] = float(t.item()) / iters
+    _ALGO["choice"] = "direct" if times["direct"] < times["rccl"] else "rccl"
+    _ALGO["times_ms"] = {k: v * 1e3 for k, v in times.items()}
+    return _ALGO["choice"]
+
+
+def all_reduce_gradients(params: Iterable[torch.Tensor], group=None, average: bool = False, algo: str = "rccl") -> int:
+    """Sum (or average) `.grad` of `params` over all ranks with one exchange.  Returns the number of fp32 elements
+    exchanged (0 when not distributed).  algo: "rccl" = torch.distributed.all_reduce, "direct" = all_reduce_direct,
+    "auto" = whichever autotune_all_reduce measured faster."""
     grads = [p.grad for p in params if p is not None and p.grad is not None]
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return 0
-    flat = _shared_flat(grads)
+    world = dist.get_world_size(group)
+    if algo == "auto":
+        algo = _ALGO["choice"]
+    flat = _shared_flat(grads, multiple=world)
     if flat is not None:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        if algo == "direct" and flat.numel() % world == 0:
+            all_reduce_direct(flat, group)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
         if average:
-            flat.div_(dist.get_world_size(group))
+            flat.div_(world)
         return flat.numel()
     packed = torch.cat([g.reshape(-1) for g in grads])
     dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)

@@ -300,7 +300,8 @@ def _launch_backward(st: "_State", saved, gcol, ghdr, stages: int, want_pose: bo
                 n *= d
             offs[name] = (total, n, shape)
             total += (n + 3) // 4 * 4  # keep every slice 16-byte aligned
-    flat = torch.empty(max(total, 4), dtype=torch.float32, device=dev)
+    padded = (max(total, 4) + 1023) // 1024 * 1024  # room for the N-rank shard split of distributed.all_reduce_direct
+    flat = torch.empty(padded, dtype=torch.float32, device=dev)  # the pad is never read back: left uninitialised
     g = {name: None for name, _, _ in spec}
     for name, (o, n, shape) in offs.items():
         g[name] = flat[o:o + n].view(shape)

@@ -30,7 +30,7 @@ def _view_grads(rank, world):
     return [b["dL_dmeans3D"], b["dL_dmeans2D"], b["dL_dopacity"].reshape(-1, 1), b["dL_dshs"], b["dL_dscales"], b["dL_drots"]]
 
 
-def _worker(rank, world, port, shared_flat, q):
+def _worker(rank, world, port, shared_flat, q, algo="rccl"):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
@@ -41,7 +41,7 @@ def _worker(rank, world, port, shared_flat, q):
     grads = [torch.from_numpy(g.copy()) for g in _view_grads(rank, world)]
     params = []
     if shared_flat:  # the rasterizer's layout: all gradients are views of one flat fp32 buffer
-        flat = torch.empty(sum((g.numel() + 3) // 4 * 4 for g in grads))
+        flat = torch.zeros((sum((g.numel() + 3) // 4 * 4 for g in grads) + 1023) // 1024 * 1024)
         o = 0
         for g in grads:
             p = torch.zeros(g.shape, requires_grad=True)
@@ -54,7 +54,7 @@ def _worker(rank, world, port, shared_flat, q):
             p = torch.zeros(g.shape, requires_grad=True)
             p.grad = g
             params.append(p)
-    n = all_reduce_gradients(params)
+    n = all_reduce_gradients(params, algo=algo)
     assert n >= sum(g.numel() for g in grads)
     if rank == 0:
         q.put([p.grad.numpy().copy() for p in params])
@@ -62,13 +62,13 @@ def _worker(rank, world, port, shared_flat, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("shared_flat", [True, False])
-def test_allreduce_equals_sum_of_single_view_gradients(oracle, shared_flat):
+@pytest.mark.parametrize("shared_flat,algo", [(True, "rccl"), (False, "rccl"), (True, "direct")])
+def test_allreduce_equals_sum_of_single_view_gradients(oracle, shared_flat, algo):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, shared_flat, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, shared_flat, q, algo)) for r in range(world)]
     for p in procs:
         p.start()
     got = q.get(timeout=120)
