@@ -46,7 +46,7 @@ CONFIGS = {
 
 def build_step(cfg, rank, world, dev):
     from casualhdrsplat_amd import GaussianRasterizationSettings, GaussianRasterizer, synthetic as S
-    from casualhdrsplat_amd.distributed import all_reduce_gradients
+    from casualhdrsplat_amd.distributed import all_reduce_gradients, exchange_view_gradients
     P, W, H, deg, hdr, n_poses = cfg
     sc = S.make_scene(P, W, H, deg, seed=0, hdr=hdr)
     # one view per rank: yaw in [-5, +5] degrees about the cloud centre; rank 0 of a
@@ -82,19 +82,29 @@ def build_step(cfg, rank, world, dev):
     dL = sc.dL_dimage.to(dev)
     plist = list(params.values()) + ([exposure, crf] if hdr else [])
 
-    def make_rasterizer(capacity):
-        return GaussianRasterizer(rs, capacity=capacity)
+    non_sh = [p for k, p in params.items() if k != "shs"] + ([exposure, crf] if hdr else [])
 
-    state = {"rast": make_rasterizer(None), "out": None}
+    def make_rasterizer(capacity):
+        # two front ends over the same kernels: plain, and with the SH gradient deferred to the view exchange
+        return {"allreduce": GaussianRasterizer(rs, capacity=capacity),
+                "views": GaussianRasterizer(rs, capacity=capacity, defer_sh_grad=True)}
+
+    # exchange = (what goes on the wire, all-reduce algorithm); chosen by measurement in main() when world > 1
+    state = {"rast": make_rasterizer(None), "out": None, "exchange": ("allreduce", "rccl")}
 
     def step():
+        mode, algo = state["exchange"]
+        rast = state["rast"][mode if world > 1 else "allreduce"]
         for p in plist:
             p.grad = None
-        out = state["rast"](params["means3D"], params["means2D"], params["opacities"], shs=params["shs"],
-                            scales=params["scales"], rotations=params["rotations"])
+        out = rast(params["means3D"], params["means2D"], params["opacities"], shs=params["shs"],
+                   scales=params["scales"], rotations=params["rotations"])
         torch.autograd.backward(out[0], grad_tensors=dL)
         if world > 1:
-            all_reduce_gradients(plist, algo="auto")
+            if mode == "views":
+                exchange_view_gradients(non_sh, params["shs"], rast.deferred, algo=algo)
+            else:
+                all_reduce_gradients(plist, algo=algo)
         state["out"] = out
         return out
 
@@ -192,19 +202,33 @@ def main():
     torch.cuda.synchronize()
     R, Rp, E, vtiles = derived_counts(out, W, H, n_poses)
     state["rast"] = make_rasterizer(int(R * 1.25) + 4096)
-    allreduce_info = None
-    if world > 1:
-        # measure, don't guess: library all-reduce vs the 1-hop all-to-all form on this node's links, once
-        from casualhdrsplat_amd.distributed import _ALGO, _shared_flat, autotune_all_reduce
-        flat = _shared_flat([p.grad for p in plist if p.grad is not None], multiple=world)
-        if flat is not None:
-            autotune_all_reduce(flat)
-        allreduce_info = dict(_ALGO, elements=None if flat is None else flat.numel())
-
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    allreduce_info = None
+    if world > 1:
+        # measure, don't guess: time a few whole steps with each gradient exchange on this node's links and keep the
+        # fastest (max over ranks, so every rank takes the same decision).  "allreduce" = all-reduce of the flat
+        # per-Gaussian gradient buffer; "views" = all-reduce of the non-SH part + all-gather of per-view colour
+        # gradients with the SH gradient rebuilt locally; "rccl" / "direct" = library ring vs 1-hop all-to-all form
+        times = {}
+        for mode in ("allreduce", "views"):
+            for algo in ("rccl", "direct"):
+                state["exchange"] = (mode, algo)
+                step()
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    step()
+                barrier()
+                t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                times[f"{mode}/{algo}"] = float(t.item()) / 3 * 1e3
+        best = min(times, key=times.get)
+        state["exchange"] = tuple(best.split("/"))
+        allreduce_info = {"choice": best, "step_ms": times}
 
     for _ in range(args.warmup):
         step()
@@ -228,7 +252,7 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.config}: {P} Gaussians, {W}x{H}, SH degree {deg}, "
                                f"{'HDR radiance + CRF tone-map' if hdr else 'LDR'}, {n_poses} pose(s)/view, "
-                               f"{world} view(s)/step (one per GPU)" + (", RCCL all-reduce of per-Gaussian grads" if world > 1 else ""),
+                               f"{world} view(s)/step (one per GPU)" + (", gradients summed over views (config.gradient_exchange)" if world > 1 else ""),
                    "num_rendered_R": R, "R_prime": Rp, "pixel_pair_evals_E": E,
                    "binning": "sync-free fixed capacity 1.25*R"},
         "mpix_per_s": world * args.steps * W * H * n_poses / elapsed / 1e6,
@@ -242,7 +266,7 @@ def main():
         # a fresh forward whose autograd graph is kept (never .backward()-ed) so its stages can be replayed
         for p_ in plist:
             p_.grad = None
-        out = state["rast"](*[plist[i] for i in (0, 1, 2)], shs=plist[3], scales=plist[4], rotations=plist[5])
+        out = state["rast"]["allreduce"](*[plist[i] for i in (0, 1, 2)], shs=plist[3], scales=plist[4], rotations=plist[5])
         R, Rp, E, vtiles = derived_counts(out, W, H, n_poses)
         WH = W * H * n_poses
         bwd_ms, bwd_med = time_stage(lambda: replay_backward(out[0], dL, L.HS_BWD_RENDER), args.kernel_iters)

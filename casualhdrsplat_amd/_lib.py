@@ -64,6 +64,7 @@ class hs_bwd_args(C.Structure):
         ("dL_dcolors_precomp", _fp), ("dL_dscales", _fp), ("dL_drotations", _fp), ("dL_dcov3D_precomp", _fp),
         ("dL_dexposure", _fp), ("dL_dcrf_table", _fp),
         ("dL_dviewmatrices", _fp), ("dL_dprojmatrices", _fp), ("dL_dcamposes", _fp),
+        ("dL_dview_colors", _fp),
     ]
 
 
@@ -76,7 +77,7 @@ class hs_layout(C.Structure):
 
 
 EXPORTS = ("hs_version", "hs_last_error", "hs_plan", "hs_forward", "hs_backward", "hs_mark_visible",
-           "hs_sort_tmp_bytes", "hs_sort_pairs")
+           "hs_sh_backward_views", "hs_sort_tmp_bytes", "hs_sort_pairs")
 
 _lib = None
 
@@ -105,6 +106,9 @@ def load() -> C.CDLL:
     lib.hs_backward.restype = C.c_int
     lib.hs_mark_visible.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.hs_mark_visible.restype = C.c_int
+    lib.hs_sh_backward_views.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p]
+    lib.hs_sh_backward_views.restype = C.c_int
     lib.hs_sort_tmp_bytes.argtypes = [C.c_int64]
     lib.hs_sort_tmp_bytes.restype = C.c_int64
     lib.hs_sort_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,

@@ -206,6 +206,17 @@ int hs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, ui
     return launch_mark_visible(P, means3D, viewmatrix, visible, (hipStream_t)hip_stream);
 }
 
+int hs_sh_backward_views(int32_t P, int32_t M, int32_t sh_degree, int32_t V, const float* means3D, const float* camposes,
+                         const float* dL_dview_colors, float* dL_dshs, void* hip_stream) {
+    if (P < 0 || V < 1 || sh_degree < 0 || sh_degree > 3 || M < (sh_degree + 1) * (sh_degree + 1) || M > 16 ||
+        (P > 0 && (!means3D || !camposes || !dL_dview_colors || !dL_dshs))) {
+        set_error("hs_sh_backward_views: bad argument");
+        return HS_EINVAL;
+    }
+    if (P == 0) return HS_OK;
+    return launch_sh_backward_views(P, M, sh_degree, V, means3D, camposes, dL_dview_colors, dL_dshs, (hipStream_t)hip_stream);
+}
+
 int64_t hs_sort_tmp_bytes(int64_t n) { return sort_tmp_bytes(n) + 256 + 2 * align_up(n * 8, 256) + 2 * align_up(n * 4, 256); }
 
 int hs_sort_pairs(const uint64_t* keys_in, const uint32_t* vals_in, uint64_t* keys_out, uint32_t* vals_out,

@@ -45,6 +45,8 @@ int launch_render_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s);
 int launch_crf_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s);
 int launch_preprocess_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s);
 int launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* vis, hipStream_t s);
+int launch_sh_backward_views(int P, int M, int deg, int V, const float* means3D, const float* camposes,
+                             const float* view_colors, float* d_shs, hipStream_t s);
 
 int64_t sort_tmp_bytes(int64_t n);
 // Stable LSD radix sort of (u64 key, u32 value) pairs on bits [0,nbits) (hs_sort_pairs; the forward uses the u32-key

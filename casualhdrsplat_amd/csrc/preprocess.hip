@@ -321,6 +321,7 @@ struct PreBwd {
     const float4* inst_grads;
     float* d_means3D; float* d_means2D; float* d_opac; float* d_shs; float* d_colors; float* d_scales;
     float* d_rots; float* d_cov;
+    float* d_view_colors;  // [N][P][3] or null: masked colour gradient per instance (hs_sh_backward_views input)
     float* pose_partials;  // [blocks][N][kPoseVals] or null
 };
 
@@ -334,7 +335,8 @@ constexpr int kPreBwdBlock = 128;
 // owns one Gaussian = one 12*M-byte row, so direct per-thread access would touch 64 different rows per wave
 // instruction; instead the block's rows are moved between HBM and LDS with fully coalesced accesses and each thread
 // works on its row in LDS (row stride M*3+1 words: conflict-free).
-template <int DEG, bool POSE>
+// SHG = false: the SH-coefficient gradient is not formed here (view-parallel exchange, hs_sh_backward_views).
+template <int DEG, bool POSE, bool SHG>
 __global__ void __launch_bounds__(kPreBwdBlock) preprocess_bwd_kernel(PreBwd p) {
     extern __shared__ float s_sh[];  // [kPreBwdBlock][M*3 + 1]
     __shared__ float s_pose[kPreBwdBlock / 64][kPoseVals];
@@ -357,9 +359,11 @@ __global__ void __launch_bounds__(kPreBwdBlock) preprocess_bwd_kernel(PreBwd p) 
     float gm2d[2] = {0.f, 0.f};
     float gop = 0.f;
     float gcol_pre[3] = {0.f, 0.f, 0.f};
-    float gsh[NC * 3];
+    float gsh[SHG ? NC * 3 : 1];
+    if constexpr (SHG) {
 #pragma unroll
-    for (int k = 0; k < NC * 3; ++k) gsh[k] = 0.f;
+        for (int k = 0; k < NC * 3; ++k) gsh[k] = 0.f;
+    }
 
     float s6[6];
 #pragma unroll
@@ -372,6 +376,9 @@ __global__ void __launch_bounds__(kPreBwdBlock) preprocess_bwd_kernel(PreBwd p) 
         if constexpr (POSE) {
 #pragma unroll
             for (int k = 0; k < kPoseVals; ++k) pg[k] = 0.f;
+        }
+        if (!on && valid && p.d_view_colors) {
+            p.d_view_colors[3 * idx] = 0.f; p.d_view_colors[3 * idx + 1] = 0.f; p.d_view_colors[3 * idx + 2] = 0.f;
         }
         if (on) {
         // ---- this instance's summed pair records (pair_segsum_kernel) ----
@@ -470,11 +477,16 @@ __global__ void __launch_bounds__(kPreBwdBlock) preprocess_bwd_kernel(PreBwd p) 
             float gc[3];
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) gc[ch] = ((cl >> ch) & 1) ? 0.f : r[6 + ch];
+            if (p.d_view_colors) {
+                p.d_view_colors[3 * idx] = gc[0]; p.d_view_colors[3 * idx + 1] = gc[1]; p.d_view_colors[3 * idx + 2] = gc[2];
+            }
+            if constexpr (SHG) {
 #pragma unroll
-            for (int k = 0; k < NC; ++k) {
-                gsh[3 * k + 0] += bs[k] * gc[0];
-                gsh[3 * k + 1] += bs[k] * gc[1];
-                gsh[3 * k + 2] += bs[k] * gc[2];
+                for (int k = 0; k < NC; ++k) {
+                    gsh[3 * k + 0] += bs[k] * gc[0];
+                    gsh[3 * k + 1] += bs[k] * gc[1];
+                    gsh[3 * k + 2] += bs[k] * gc[2];
+                }
             }
             if constexpr (DEG >= 1) {
                 float gb[NC][3];
@@ -565,16 +577,60 @@ __global__ void __launch_bounds__(kPreBwdBlock) preprocess_bwd_kernel(PreBwd p) 
             p.d_colors[3 * g] = gcol_pre[0]; p.d_colors[3 * g + 1] = gcol_pre[1]; p.d_colors[3 * g + 2] = gcol_pre[2];
         }
     }
-    if (!p.has_colors_precomp && p.d_shs) {
-        if (stage_in) __syncthreads();  // every thread has finished reading its input row
-        float* row = s_sh + threadIdx.x * ld;
+    if constexpr (SHG) {
+        if (!p.has_colors_precomp && p.d_shs) {
+            if (stage_in) __syncthreads();  // every thread has finished reading its input row
+            float* row = s_sh + threadIdx.x * ld;
 #pragma unroll
-        for (int k = 0; k < NC * 3; ++k) row[k] = gsh[k];
-        for (int k = NC * 3; k < M3; ++k) row[k] = 0.f;
-        __syncthreads();
-        float* dst = p.d_shs + (int64_t)g0 * M3;
-        for (int i = threadIdx.x; i < rows * M3; i += kPreBwdBlock) dst[i] = s_sh[(i / M3) * ld + (i % M3)];
+            for (int k = 0; k < NC * 3; ++k) row[k] = gsh[k];
+            for (int k = NC * 3; k < M3; ++k) row[k] = 0.f;
+            __syncthreads();
+            float* dst = p.d_shs + (int64_t)g0 * M3;
+            for (int i = threadIdx.x; i < rows * M3; i += kPreBwdBlock) dst[i] = s_sh[(i / M3) * ld + (i % M3)];
+        }
     }
+}
+
+// dL/dsh[g] = sum over views of basis(dir_v(g)) (x) colour gradient of view v (hs_sh_backward_views): one thread per
+// Gaussian, views in ascending order, rows leave through LDS so the [P, M, 3] store is coalesced.
+template <int DEG>
+__global__ void __launch_bounds__(kPreBwdBlock) sh_views_kernel(int P, int M, int V, const float* means, const float* campos,
+                                                                const float* view_colors, float* d_shs) {
+    extern __shared__ float s_sh[];  // [kPreBwdBlock][M*3 + 1]
+    constexpr int NC = (DEG + 1) * (DEG + 1);
+    const int g0 = blockIdx.x * kPreBwdBlock;
+    const int g = g0 + threadIdx.x;
+    const int M3 = M * 3, ld = M3 + 1;
+    const int rows = min(kPreBwdBlock, P - g0);
+    float gsh[NC * 3];
+#pragma unroll
+    for (int k = 0; k < NC * 3; ++k) gsh[k] = 0.f;
+    if (g < P) {
+        const float x = means[3 * g], y = means[3 * g + 1], z = means[3 * g + 2];
+        for (int v = 0; v < V; ++v) {
+            const float* gcp = view_colors + 3 * ((int64_t)v * P + g);
+            const float gc[3] = {gcp[0], gcp[1], gcp[2]};
+            const float* cp = campos + 3 * v;
+            const float dx = x - cp[0], dy = y - cp[1], dz = z - cp[2];
+            const float len = sqrtf((dx * dx + dy * dy) + dz * dz);
+            const float ux = dx / len, uy = dy / len, uz = dz / len;
+            float bs[NC];
+            sh_basis<DEG>(ux, uy, uz, bs);
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                gsh[3 * k + 0] += bs[k] * gc[0];
+                gsh[3 * k + 1] += bs[k] * gc[1];
+                gsh[3 * k + 2] += bs[k] * gc[2];
+            }
+        }
+    }
+    float* row = s_sh + threadIdx.x * ld;
+#pragma unroll
+    for (int k = 0; k < NC * 3; ++k) row[k] = gsh[k];
+    for (int k = NC * 3; k < M3; ++k) row[k] = 0.f;
+    __syncthreads();
+    float* dst = d_shs + (int64_t)g0 * M3;
+    for (int i = threadIdx.x; i < rows * M3; i += kPreBwdBlock) dst[i] = s_sh[(i / M3) * ld + (i % M3)];
 }
 
 // Pose-gradient partials [nblk][N*kPoseVals] -> column sums, two fixed-order stages (deterministic).
@@ -661,14 +717,18 @@ int launch_preprocess_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t 
     p.d_means3D = a.dL_dmeans3D; p.d_means2D = a.dL_dmeans2D; p.d_opac = a.dL_dopacities; p.d_shs = a.dL_dshs;
     p.d_colors = a.dL_dcolors_precomp; p.d_scales = a.dL_dscales; p.d_rots = a.dL_drotations;
     p.d_cov = a.dL_dcov3D_precomp;
+    p.d_view_colors = a.colors_precomp ? nullptr : a.dL_dview_colors;
+    const bool shg = p.d_shs != nullptr;
     const int grid = ceil_div(d.P, kPreBwdBlock);
     const int deg = a.colors_precomp ? 0 : d.sh_degree;
     const size_t lds = (size_t)kPreBwdBlock * (d.M * 3 + 1) * sizeof(float);
     float* pose_partials = a.dL_dviewmatrices ? (float*)((char*)a.bwd + L.pose_partials) : nullptr;
     p.pose_partials = pose_partials;
-#define HS_LAUNCH_PRE_BWD(DEG_)                                                                   \
-    if (pose_partials) preprocess_bwd_kernel<DEG_, true><<<grid, kPreBwdBlock, lds, s>>>(p);       \
-    else preprocess_bwd_kernel<DEG_, false><<<grid, kPreBwdBlock, lds, s>>>(p)
+#define HS_LAUNCH_PRE_BWD(DEG_)                                                                              \
+    if (pose_partials && shg) preprocess_bwd_kernel<DEG_, true, true><<<grid, kPreBwdBlock, lds, s>>>(p);       \
+    else if (pose_partials) preprocess_bwd_kernel<DEG_, true, false><<<grid, kPreBwdBlock, lds, s>>>(p);        \
+    else if (shg) preprocess_bwd_kernel<DEG_, false, true><<<grid, kPreBwdBlock, lds, s>>>(p);                  \
+    else preprocess_bwd_kernel<DEG_, false, false><<<grid, kPreBwdBlock, lds, s>>>(p)
     switch (deg) {
         case 0: HS_LAUNCH_PRE_BWD(0); break;
         case 1: HS_LAUNCH_PRE_BWD(1); break;
@@ -693,6 +753,20 @@ int launch_preprocess_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t 
 
 int64_t pose_partial_floats(int P, int N) {
     return ((int64_t)ceil_div(P > 0 ? P : 1, kPreBwdBlock) + kPoseChunks) * N * kPoseVals;
+}
+
+int launch_sh_backward_views(int P, int M, int deg, int V, const float* means3D, const float* camposes,
+                             const float* view_colors, float* d_shs, hipStream_t s) {
+    const int grid = ceil_div(P, kPreBwdBlock);
+    const size_t lds = (size_t)kPreBwdBlock * (M * 3 + 1) * sizeof(float);
+    switch (deg) {
+        case 0: sh_views_kernel<0><<<grid, kPreBwdBlock, lds, s>>>(P, M, V, means3D, camposes, view_colors, d_shs); break;
+        case 1: sh_views_kernel<1><<<grid, kPreBwdBlock, lds, s>>>(P, M, V, means3D, camposes, view_colors, d_shs); break;
+        case 2: sh_views_kernel<2><<<grid, kPreBwdBlock, lds, s>>>(P, M, V, means3D, camposes, view_colors, d_shs); break;
+        default: sh_views_kernel<3><<<grid, kPreBwdBlock, lds, s>>>(P, M, V, means3D, camposes, view_colors, d_shs); break;
+    }
+    HS_LAUNCH_CHECK();
+    return HS_OK;
 }
 
 int launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* vis, hipStream_t s) {

@@ -10,6 +10,12 @@ per-Gaussian gradients (P x 59 fp32 at SH degree 3, plus the CRF-table and expos
 The rasterizer's backward writes every gradient into one flat fp32 buffer
 (rasterizer._launch_backward), so when the `.grad`s of the Gaussian parameters are still views of
 that buffer the reduction is a single in-place collective with no packing copy.
+
+`exchange_view_gradients` is the cheaper exchange for SH-coloured Gaussians: the SH gradient row of a
+Gaussian is the outer product of its view's RGB gradient (3 floats) with the SH basis of its view
+direction (M floats), so ranks all-gather the 3 floats and the camera centres and rebuild the summed
+[P, M, 3] gradient locally -- 12 B instead of 12*M B per Gaussian and view on the wire (at SH degree 3
+and 8 views: 56 MB all-reduced + 12 MB all-gathered per rank instead of 236 MB all-reduced).
 """
 from __future__ import annotations
 
@@ -140,3 +146,37 @@ def all_reduce_gradients(params: Iterable[torch.Tensor], group=None, average: bo
         g.copy_(packed[o:o + n].view_as(g))
         o += n
     return packed.numel()
+
+
+def exchange_view_gradients(params: Iterable[torch.Tensor], shs: torch.Tensor, deferred: dict, group=None,
+                            average: bool = False, algo: str = "rccl", sh_backward=None) -> dict:
+    """Gradient exchange of one view-parallel step when the rasterizer ran with `defer_sh_grad=True`.
+
+    params   -- the non-SH parameters (their `.grad`s are summed over ranks by all_reduce_gradients);
+    shs      -- the SH parameter [P, M, 3]; its `.grad` is set to the gradient summed over ALL ranks' views;
+    deferred -- `GaussianRasterizer.deferred` after backward (this rank's view colour gradients [N, P, 3], camera
+                centres [N, 3], means3D, M, sh_degree).
+    Works at world size 1 too (no collective, same kernel).  `sh_backward` lets CPU tests inject a reference for
+    the HIP kernel; the product default is rasterizer.sh_backward_views, which raises without the extension.
+    Returns the element counts put on the wire."""
+    if not deferred or "view_colors" not in deferred:
+        raise RuntimeError("exchange_view_gradients: run backward through GaussianRasterizer(..., defer_sh_grad=True) first")
+    vc, cams = deferred["view_colors"], deferred["camposes"].reshape(-1, 3)
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    reduced = all_reduce_gradients(params, group=group, average=average, algo=algo)
+    gathered = 0
+    if world > 1:
+        # rank-major concatenation along dim 0 (the layout every backend accepts)
+        vc_all = torch.empty((world * vc.shape[0],) + tuple(vc.shape[1:]), dtype=vc.dtype, device=vc.device)
+        cams_all = torch.empty((world * cams.shape[0], 3), dtype=cams.dtype, device=cams.device)
+        dist.all_gather_into_tensor(vc_all, vc.contiguous(), group=group)
+        dist.all_gather_into_tensor(cams_all, cams.contiguous(), group=group)
+        gathered = vc_all.numel() + cams_all.numel()
+        vc, cams = vc_all, cams_all
+    if sh_backward is None:
+        from .rasterizer import sh_backward_views as sh_backward
+    g = sh_backward(deferred["means3D"], cams, vc, deferred["M"], deferred["sh_degree"])
+    if average:
+        g = g / world
+    shs.grad = g if shs.grad is None else shs.grad + g
+    return {"all_reduced": reduced, "all_gathered": gathered}

@@ -208,15 +208,17 @@ def _run_forward(settings: GaussianRasterizationSettings, means3D, opacities, sh
     st.tanfovx, st.tanfovy, st.scale_modifier = a.tanfovx, a.tanfovy, a.scale_modifier
     st.crf_K, st.crf_range, st.W, st.H = crf_K, (a.crf_umin, a.crf_umax), W, H
     st.fwd_args = a
-    st.keep = (out_color, out_hdr, radii, exposure, crf_table, means3D, opacities, shs, colors_precomp, scales,
-               rotations, cov3D_precomp)
+    # inputs only: an OUTPUT here would close a cycle output -> grad_fn -> ctx.st -> output through the C++ autograd
+    # node, which Python's collector cannot see, and leak the whole state (~340 MB per step at 1M Gaussians / 1080p)
+    st.keep = (exposure, crf_table, means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp)
     return out_color, out_hdr, radii, st, exposure, crf_table
 
 
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                exposure, crf_table, viewmats, projmats, camposes, raster_settings, capacity, return_alpha=False):
+                exposure, crf_table, viewmats, projmats, camposes, raster_settings, capacity, return_alpha=False,
+                deferred=None):
         dev = means3D.device
         m3 = _f32c(means3D, dev)
         op = _f32c(opacities, dev)
@@ -229,6 +231,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             color, hdr, radii, st, exp_t, crf_t = _run_forward(raster_settings, m3, op, shs, cp, sc, ro, cv, exposure,
                                                                crf_table, capacity)
         ctx.st = st
+        ctx.deferred = deferred if shs is not None else None
         ctx.exp_shape = None if exposure is None else tuple(exposure.shape)
         ctx.pose_shapes = (tuple(viewmats.shape), tuple(projmats.shape), tuple(camposes.shape))
         ctx.has = (shs is not None, cp is not None, sc is not None, cv is not None, exposure is not None,
@@ -257,7 +260,12 @@ class _RasterizeGaussians(torch.autograd.Function):
         galpha = _f32c(grad_alpha, dev) if grad_alpha is not None else None
         want_pose = any(ctx.needs_input_grad[10:13])
         with _on_device(dev):
-            g = _launch_backward(st, saved, gcol, ghdr, L.HS_BWD_ALL, want_pose, galpha)
+            g = _launch_backward(st, saved, gcol, ghdr, L.HS_BWD_ALL, want_pose, galpha,
+                                 defer_sh=ctx.deferred is not None)
+        if ctx.deferred is not None:
+            # view-parallel exchange: hand the per-view colour gradients to distributed.exchange_view_gradients
+            ctx.deferred.update(view_colors=g["view_colors"], camposes=st.camposes, means3D=saved[0],
+                                M=st.dims.M, sh_degree=st.dims.sh_degree, flat=g["_flat"])
         if st.pending is not None:
             # sync-free mode: the kernels are already queued; only now look at the forward's counters
             st.num_rendered = st.pending.check()
@@ -271,10 +279,11 @@ class _RasterizeGaussians(torch.autograd.Function):
                 g["crf_table"] if has_crf else None,
                 g["viewmatrices"].reshape(ctx.pose_shapes[0]) if want_pose else None,
                 g["projmatrices"].reshape(ctx.pose_shapes[1]) if want_pose else None,
-                g["camposes"].reshape(ctx.pose_shapes[2]) if want_pose else None, None, None, None)
+                g["camposes"].reshape(ctx.pose_shapes[2]) if want_pose else None, None, None, None, None)
 
 
-def _launch_backward(st: "_State", saved, gcol, ghdr, stages: int, want_pose: bool = False, galpha=None) -> dict:
+def _launch_backward(st: "_State", saved, gcol, ghdr, stages: int, want_pose: bool = False, galpha=None,
+                     defer_sh: bool = False) -> dict:
     """Enqueue hs_backward.  All per-Gaussian gradients are carved out of ONE flat fp32 buffer (the
     layout casualhdrsplat_amd.distributed all-reduces in a single RCCL call): [means3D | means2D |
     opacities | sh | colors | scales | rotations | cov3D | exposure | crf_table]."""
@@ -286,7 +295,7 @@ def _launch_backward(st: "_State", saved, gcol, ghdr, stages: int, want_pose: bo
     bwd = torch.empty(max(int(sizes.bwd_bytes), 256), dtype=torch.uint8, device=dev)
     hdr = bool(st.flags & L.HS_FLAG_HDR)
     spec = [("means3D", (P, 3), True), ("means2D", (P, 3), True), ("opacities", (P, 1), True),
-            ("shs", (P, M, 3), shs is not None), ("colors_precomp", (P, 3), cp is not None),
+            ("shs", (P, M, 3), shs is not None and not defer_sh), ("colors_precomp", (P, 3), cp is not None),
             ("scales", (P, 3), sc is not None), ("rotations", (P, 4), ro is not None),
             ("cov3D_precomp", (P, 6), cv is not None), ("exposure", (1,), hdr), ("crf_table", (3, st.crf_K), hdr),
             ("viewmatrices", (st.dims.n_poses, 16), want_pose), ("projmatrices", (st.dims.n_poses, 16), want_pose),
@@ -309,6 +318,9 @@ def _launch_backward(st: "_State", saved, gcol, ghdr, stages: int, want_pose: bo
         g["exposure"].zero_()
         g["crf_table"].zero_()
     g["_flat"] = flat
+    # deferred SH gradient: the per-view colour gradients live outside the flat (all-reduced) buffer
+    g["view_colors"] = (torch.empty(st.dims.n_poses, P, 3, dtype=torch.float32, device=dev)
+                        if defer_sh and shs is not None else None)
 
     a = L.hs_bwd_args()
     a.dims = st.dims
@@ -327,6 +339,7 @@ def _launch_backward(st: "_State", saved, gcol, ghdr, stages: int, want_pose: bo
     a.dL_dexposure, a.dL_dcrf_table = _ptr(g["exposure"]), _ptr(g["crf_table"])
     a.dL_dviewmatrices, a.dL_dprojmatrices, a.dL_dcamposes = (_ptr(g["viewmatrices"]), _ptr(g["projmatrices"]),
                                                               _ptr(g["camposes"]))
+    a.dL_dview_colors = _ptr(g["view_colors"])
     if P > 0:
         L.check(lib.hs_backward(C.byref(a), _stream()), "hs_backward")
     else:
@@ -340,6 +353,11 @@ def replay_forward(out_tensor: torch.Tensor, stages: int = L.HS_STAGE_RENDER) ->
     st: _State = out_tensor.grad_fn.st
     a = st.fwd_args
     a.stages = stages
+    # the state keeps no reference to the outputs: colour goes back into `out_tensor`, the rest into scratch
+    a.out_color = out_tensor.data_ptr()
+    scratch_hdr = torch.empty_like(out_tensor) if (st.flags & L.HS_FLAG_HDR) else None
+    scratch_radii = torch.empty(max(st.dims.P, 1), dtype=torch.int32, device=out_tensor.device)
+    a.out_hdr, a.radii = _ptr(scratch_hdr), scratch_radii.data_ptr()
     L.check(L.load().hs_forward(C.byref(a), _stream()), "hs_forward[replay]")
 
 
@@ -353,8 +371,26 @@ def replay_backward(out_tensor: torch.Tensor, grad_color: torch.Tensor, stages: 
                             None if grad_hdr is None else _f32c(grad_hdr, dev), stages)
 
 
+def sh_backward_views(means3D: torch.Tensor, camposes: torch.Tensor, view_colors: torch.Tensor, M: int,
+                      sh_degree: int) -> torch.Tensor:
+    """dL/dsh [P,M,3] from per-view colour gradients [V,P,3] and the V camera centres [V,3] (hs_sh_backward_views):
+    the local half of the view-parallel gradient exchange (distributed.exchange_view_gradients)."""
+    dev = means3D.device
+    if dev.type != "cuda":
+        raise RuntimeError("casualhdrsplat_amd runs on an MI355X only: tensors must live on a cuda (HIP) device")
+    m3, cp, vc = _f32c(means3D.detach(), dev), _f32c(camposes.detach(), dev).reshape(-1, 3), _f32c(view_colors, dev)
+    P, V = m3.shape[0], cp.shape[0]
+    if tuple(vc.shape) != (V, P, 3):
+        raise ValueError(f"view_colors must be [V={V}, P={P}, 3], got {tuple(vc.shape)}")
+    out = torch.empty(P, M, 3, dtype=torch.float32, device=dev)
+    with _on_device(dev):
+        L.check(L.load().hs_sh_backward_views(P, M, sh_degree, V, _ptr(m3), _ptr(cp), _ptr(vc), _ptr(out), _stream()),
+                "hs_sh_backward_views")
+    return out
+
+
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                        raster_settings, capacity=None, return_alpha=False):
+                        raster_settings, capacity=None, return_alpha=False, deferred=None):
     rs = raster_settings
     multi = rs.viewmatrices is not None
     # the camera tensors travel as autograd inputs so a trajectory model upstream receives pose gradients
@@ -362,7 +398,7 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
                                      cov3Ds_precomp, rs.exposure, rs.crf_table,
                                      rs.viewmatrices if multi else rs.viewmatrix,
                                      rs.projmatrices if multi else rs.projmatrix,
-                                     rs.camposes if multi else rs.campos, rs, capacity, return_alpha)
+                                     rs.camposes if multi else rs.campos, rs, capacity, return_alpha, deferred)
 
 
 class GaussianRasterizer(nn.Module):
@@ -374,11 +410,16 @@ class GaussianRasterizer(nn.Module):
     """
 
     def __init__(self, raster_settings: GaussianRasterizationSettings, capacity: Optional[int] = None,
-                 return_alpha: bool = False):
+                 return_alpha: bool = False, defer_sh_grad: bool = False):
         super().__init__()
         self.raster_settings = raster_settings
         self.capacity = capacity
         self.return_alpha = return_alpha  # extension: append the accumulated-opacity image [H,W] to the outputs
+        # extension for view-parallel training: backward leaves `shs.grad` unset and instead fills `self.deferred`
+        # with this view's per-Gaussian colour gradients; distributed.exchange_view_gradients all-gathers those
+        # (12 B per Gaussian and view instead of 12*M) and forms the summed SH gradient locally
+        self.defer_sh_grad = defer_sh_grad
+        self.deferred: Optional[dict] = None
 
     def markVisible(self, positions: torch.Tensor) -> torch.Tensor:
         lib = L.load()
@@ -404,8 +445,9 @@ class GaussianRasterizer(nn.Module):
         scales = empty if scales is None else scales
         rotations = empty if rotations is None else rotations
         cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
+        self.deferred = {} if self.defer_sh_grad else None
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
-                                   cov3D_precomp, rs, self.capacity, self.return_alpha)
+                                   cov3D_precomp, rs, self.capacity, self.return_alpha, self.deferred)
 
 
 def inspect_state(out_tensor: torch.Tensor) -> dict:

@@ -157,6 +157,10 @@ typedef struct hs_bwd_args {
     float* dL_dviewmatrices;      /* [N,16] or NULL */
     float* dL_dprojmatrices;      /* [N,16] or NULL */
     float* dL_dcamposes;          /* [N,3]  or NULL */
+    /* view-parallel exchange: when non-NULL, the colour gradient of every instance AFTER the SH clamp
+     * mask (zero for culled instances) is written here, [N,P,3]; dL_dshs may then be NULL, and the SH-coefficient
+     * gradient is formed later from the views of ALL ranks by hs_sh_backward_views */
+    float* dL_dview_colors;
 } hs_bwd_args;
 
 /* Byte offsets of the arrays carved out of the three state workspaces, for tests, profilers and
@@ -183,6 +187,15 @@ int hs_forward(const hs_fwd_args* args, void* hip_stream);
 int hs_backward(const hs_bwd_args* args, void* hip_stream);
 int hs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, uint8_t* visible,
                     void* hip_stream);
+
+/* SH-coefficient gradient from per-view colour gradients (the multi-GPU exchange of SURVEY.md 8e, where ranks
+ * all-gather 12 bytes per Gaussian and view instead of all-reducing the 12*M-byte SH gradient rows):
+ *   dL_dshs[g, k, c] = sum_{v < V} Y_k(normalize(means3D[g] - camposes[v])) * dL_dview_colors[v, g, c],
+ * views added in ascending order, k < (sh_degree+1)^2, rows k >= that are zeroed.  Same basis and per-view
+ * arithmetic as the SH part of hs_backward, so V = 1 reproduces its dL_dshs bit for bit. */
+int hs_sh_backward_views(int32_t P, int32_t M, int32_t sh_degree, int32_t V, const float* means3D,
+                         const float* camposes /* [V,3] */, const float* dL_dview_colors /* [V,P,3] */,
+                         float* dL_dshs /* [P,M,3] */, void* hip_stream);
 
 /* Bench/test only: stable LSD radix sort of (u64 key, u32 value) pairs on bits [0, nbits), using the
  * same kernels as HS_STAGE_BIN.  tmp must hold hs_sort_tmp_bytes(n).  Result in keys_out/vals_out. */

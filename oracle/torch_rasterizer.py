@@ -63,6 +63,19 @@ def sh_basis(deg, d):
     return torch.stack(b, dim=1)  # [P, (deg+1)^2]
 
 
+def sh_backward_views(means3D, camposes, view_colors, M, sh_degree):
+    """Checker for hs_sh_backward_views: dL/dsh[g,k,c] = sum_v Y_k(normalize(mean_g - campos_v)) * view_colors[v,g,c]
+    (rows k >= (sh_degree+1)^2 zero).  Plain tensor algebra; tests pin it against autograd of `preprocess`."""
+    P = means3D.shape[0]
+    out = torch.zeros(P, M, 3, dtype=view_colors.dtype, device=view_colors.device)
+    nc = (sh_degree + 1) ** 2
+    for v in range(camposes.shape[0]):
+        d = means3D.detach().to(view_colors.dtype) - camposes[v].to(view_colors.dtype)[None, :]
+        d = d / d.norm(dim=1, keepdim=True)
+        out[:, :nc, :] += sh_basis(sh_degree, d)[:, :, None] * view_colors[v][:, None, :]
+    return out
+
+
 def quat_to_R(q):
     r, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
     R = torch.stack([

@@ -30,6 +30,66 @@ def _view_grads(rank, world):
     return [b["dL_dmeans3D"], b["dL_dmeans2D"], b["dL_dopacity"].reshape(-1, 1), b["dL_dshs"], b["dL_dscales"], b["dL_drots"]]
 
 
+def _view_deferred(rank, world):
+    """What GaussianRasterizer(..., defer_sh_grad=True) leaves after backward, built from the CPU oracle: the non-SH
+    gradients plus this view's colour gradient after the SH clamp mask."""
+    import helpers as Hh
+    from casualhdrsplat_amd import synthetic as S
+    from oracle import c_oracle as O
+    sc = S.make_scene(400, 96, 64, 2, seed=2)
+    cam = S.yaw_camera(96, 64, -5.0 + 10.0 * rank / max(world - 1, 1))
+    f, b = Hh.run_oracle(O, sc, cam=cam)
+    vc = b["dL_dcolor"] * (1 - f["clamped"].astype(np.float32))
+    vc[f["radii"] <= 0] = 0
+    rest = [b["dL_dmeans3D"], b["dL_dmeans2D"], b["dL_dopacity"].reshape(-1, 1), b["dL_dscales"], b["dL_drots"]]
+    return sc, cam, vc, rest, b["dL_dshs"]
+
+
+def _worker_views(rank, world, port, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from casualhdrsplat_amd.distributed import exchange_view_gradients, init_from_env
+    from oracle import torch_rasterizer as TR
+    init_from_env("gloo")
+    sc, cam, vc, rest, _ = _view_deferred(rank, world)
+    params = []
+    for g in rest:
+        p = torch.zeros(g.shape, requires_grad=True)
+        p.grad = torch.from_numpy(g.copy())
+        params.append(p)
+    shs = torch.zeros(sc.shs.shape, requires_grad=True)
+    deferred = dict(view_colors=torch.from_numpy(vc.copy())[None], camposes=cam.campos.reshape(1, 3).clone(),
+                    means3D=sc.means3D, M=sc.shs.shape[1], sh_degree=sc.sh_degree)
+    n = exchange_view_gradients(params, shs, deferred, sh_backward=TR.sh_backward_views)
+    assert n["all_gathered"] == world * (vc.size + 3) and n["all_reduced"] >= sum(g.size for g in rest)
+    if rank == 0:
+        q.put([p.grad.numpy().copy() for p in params] + [shs.grad.numpy().copy()])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_view_exchange_equals_sum_of_single_view_gradients(oracle):
+    """all-gather of per-view colour gradients + local SH outer product == all-reduce of the SH gradient rows."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_views, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    views = [_view_deferred(r, world) for r in range(world)]
+    want = [sum(x) for x in zip(*[v[3] for v in views])] + [sum(v[4] for v in views)]
+    for g, w in zip(got, want):
+        assert np.allclose(g, w, rtol=1e-5, atol=2e-6 * np.abs(w).max())
+    assert np.abs(want[-1][:, 1:]).max() > 0  # higher SH bands are exercised
+
+
 def _worker(rank, world, port, shared_flat, q, algo="rccl"):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
