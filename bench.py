@@ -217,13 +217,19 @@ def main():
         for mode in ("allreduce", "views"):
             for algo in ("rccl", "direct"):
                 state["exchange"] = (mode, algo)
-                step()
-                barrier()
-                t0 = time.perf_counter()
-                for _ in range(3):
+                try:  # a backend that lacks a collective raises on every rank alike: skip that strategy
                     step()
-                barrier()
-                t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+                    barrier()
+                    t0 = time.perf_counter()
+                    for _ in range(3):
+                        step()
+                    barrier()
+                    dt_ = time.perf_counter() - t0
+                except RuntimeError as e:
+                    if rank == 0:
+                        print(f"[bench] exchange {mode}/{algo} unavailable: {e}", file=sys.stderr)
+                    continue
+                t = torch.tensor([dt_], dtype=torch.float64, device=dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 times[f"{mode}/{algo}"] = float(t.item()) / 3 * 1e3
         best = min(times, key=times.get)
