@@ -59,6 +59,7 @@ static int plan(const hs_dims& d, hs_sizes* sz, hs_layout* L) {
     l.depth_keys = carve(2 * I * 4);
     l.depth_vals = carve(2 * I * 4);
     l.srect = carve(I * 8);
+    l.pair_flags = carve(d.capacity);  // cleared by the pair emission, set by the render backward
     sz->binning_bytes = o;
     // image
     o = 0;
@@ -70,7 +71,6 @@ static int plan(const hs_dims& d, hs_sizes* sz, hs_layout* L) {
     o = 0;
     l.pair_grads = carve(d.capacity * kPairFloats * 4);
     l.crf_partials = carve((int64_t)crf_partial_floats(4096) * 4);
-    l.pair_flags = carve(d.capacity);
     l.inst_grads = carve(I * 12 * 4);
     l.pose_partials = carve(pose_partial_floats(d.P, d.n_poses) * 4);
     sz->bwd_bytes = o;

@@ -117,11 +117,17 @@ int scan_u32(const uint32_t* in, int64_t n, uint32_t* spine, uint32_t* out, uint
 // n_sort = R when it fits the binning capacity, else 0 (and the overflow flag is raised): every later
 // kernel of the forward reads n_sort, so an overflowing call degrades to an empty render instead of
 // writing out of bounds; the host sees counters.overflow and replays with a larger capacity.
-__global__ void bin_prepare_kernel(hs_counters* c, uint64_t capacity, uint32_t n_inst) {
-    const bool ok = (uint64_t)c->num_rendered <= capacity;
-    c->reserved[0] = ok ? c->num_rendered : 0u;
-    c->reserved[1] = n_inst;
-    c->overflow = ok ? 0u : 1u;
+// The same launch clears the tile ranges (tiles without pairs must read (0,0)).
+__global__ void __launch_bounds__(256) bin_prepare_kernel(hs_counters* c, uint64_t capacity, uint32_t n_inst, uint2* ranges,
+                                                          int64_t ntiles) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < ntiles) ranges[i] = make_uint2(0u, 0u);
+    if (i == 0) {
+        const bool ok = (uint64_t)c->num_rendered <= capacity;
+        c->reserved[0] = ok ? c->num_rendered : 0u;
+        c->reserved[1] = n_inst;
+        c->overflow = ok ? 0u : 1u;
+    }
 }
 
 // ---------------------------------------------------------------- radix sort passes (a7)
@@ -330,7 +336,7 @@ __global__ void __launch_bounds__(256) gather_binfo_kernel(int64_t I, const uint
 __global__ void __launch_bounds__(256) emit_pairs_kernel(int64_t I, int P, int gx, int gy, float4* rec,
                                                          const uint32_t* inst_sorted, const uint32_t* offs_sorted,
                                                          const uint2* srect, uint32_t* tile_keys, uint32_t* vals,
-                                                         const hs_counters* counters) {
+                                                         uint8_t* pair_flags, const hs_counters* counters) {
     __shared__ uint32_t s_beg[4][64];
     __shared__ uint2 s_rect[4][64];
     __shared__ uint32_t s_inst[4][64];
@@ -369,6 +375,7 @@ __global__ void __launch_bounds__(256) emit_pairs_kernel(int64_t I, int P, int g
         const uint32_t tile_base = (idx / (uint32_t)P) * (uint32_t)(gx * gy);
         tile_keys[pos] = tile_base + ((r.x >> 16) + ty) * (uint32_t)gx + (r.x & 0xFFFFu) + tx;
         vals[pos] = idx;
+        pair_flags[pos] = 0;  // "gradient record written" flag of this slot, set by the render backward
     }
 }
 
@@ -406,7 +413,7 @@ int launch_scan(const hs_fwd_args& a, const hs_layout& L, hipStream_t s) {
     char* geom = (char*)a.geom;
     const int64_t I = (int64_t)d.P * d.n_poses;
     hs_counters* counters = (hs_counters*)(geom + L.counters);
-    HS_HIP_CHECK(hipMemsetAsync(counters, 0, sizeof(hs_counters), s));
+    // no clearing of the counters: num_rendered is written by the scan, the rest by bin_prepare_kernel
     // offsets (instance order) are kept for inspection; their total is R
     return scan_u32((const uint32_t*)(geom + L.tiles_touched), I, (uint32_t*)(geom + L.scan_spine),
                     (uint32_t*)(geom + L.offsets), &counters->num_rendered, s);
@@ -422,7 +429,8 @@ int launch_binning(const hs_fwd_args& a, const hs_layout& L, hipStream_t s) {
     hs_counters* counters = (hs_counters*)(geom + L.counters);
     const uint32_t* n_sort = &counters->reserved[0];
     const uint32_t* n_inst = &counters->reserved[1];
-    bin_prepare_kernel<<<1, 1, 0, s>>>(counters, (uint64_t)d.capacity, (uint32_t)I);
+    uint2* ranges = (uint2*)(bin + L.ranges);
+    bin_prepare_kernel<<<ceil_div(ntiles, 256), 256, 0, s>>>(counters, (uint64_t)d.capacity, (uint32_t)I, ranges, ntiles);
 
     // 1. instances by depth (stable, 32-bit keys -> 4 passes: result back in the first buffer pair)
     uint32_t* dk0 = (uint32_t*)(bin + L.depth_keys);
@@ -454,13 +462,11 @@ int launch_binning(const hs_fwd_args& a, const hs_layout& L, hipStream_t s) {
     uint32_t* k1 = (passes % 2 == 0) ? kB : kA;
     uint32_t* v1 = (passes % 2 == 0) ? vB : vA;
     emit_pairs_kernel<<<ceil_div(I, 256), 256, 0, s>>>(I, d.P, gx, gy, (float4*)(geom + L.rec), inst_sorted, offs, srect,
-                                                       k0, v0, counters);
+                                                       k0, v0, (uint8_t*)(bin + L.pair_flags), counters);
     HS_LAUNCH_CHECK();
     // 3. stable sort by tile id only
     rc = radix_sort<uint32_t>(k0, v0, k1, v1, n_sort, d.capacity, tbits, tmp, s);
     if (rc != HS_OK) return rc;
-    uint2* ranges = (uint2*)(bin + L.ranges);
-    HS_HIP_CHECK(hipMemsetAsync(ranges, 0, (size_t)ntiles * 8, s));
     if (d.capacity > 0) {
         tile_ranges_kernel<<<ceil_div(d.capacity, 256), 256, 0, s>>>(kA, n_sort, ranges);
         HS_LAUNCH_CHECK();

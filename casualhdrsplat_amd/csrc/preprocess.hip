@@ -277,14 +277,15 @@ __global__ void mark_visible_kernel(int P, const float* means, const float* V, u
 // Unflagged records were never written this backward (their tile's replay stopped before them): skipped by select.
 __global__ void __launch_bounds__(256) pair_segsum_kernel(int64_t I, const uint32_t* inst_sorted, const uint32_t* offs_sorted,
                                                           const float4* pair_grads, const uint8_t* pair_flags,
-                                                          float4* inst_grads) {
+                                                          float4* inst_grads, const hs_counters* counters) {
     // four lanes (one DPP quad) per instance: lane q adds records beg+q, beg+q+4, ...; the four partial sums are
     // combined in a fixed butterfly, so the result does not depend on timing.  Quads shorten the longest run in a
     // wave fourfold (run lengths are heavy-tailed) and make neighbouring lanes read neighbouring records.
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t i = t >> 2;
     const int q = (int)(t & 3);
-    const bool valid = i < I;
+    // binning overflow (sync-free mode): nothing was emitted or rendered, and slots past the capacity do not exist
+    const bool valid = i < I && !counters->overflow;
     const uint32_t beg = valid ? (i == 0 ? 0u : offs_sorted[i - 1]) : 0u;
     const uint32_t end = valid ? offs_sorted[i] : 0u;
     float r[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -302,7 +303,7 @@ __global__ void __launch_bounds__(256) pair_segsum_kernel(int64_t I, const uint3
         r[k] += __shfl_xor(r[k], 1);
         r[k] += __shfl_xor(r[k], 2);
     }
-    if (valid && q == 0) {
+    if (i < I && q == 0) {
         float4* o = inst_grads + 3 * (int64_t)inst_sorted[i];
         o[0] = make_float4(r[0], r[1], r[2], r[3]);
         o[1] = make_float4(r[4], r[5], r[6], r[7]);
@@ -710,8 +711,9 @@ int launch_preprocess_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t 
         const char* bin = (const char*)a.binning;
         const uint32_t* dv0 = (const uint32_t*)(bin + L.depth_vals);
         pair_segsum_kernel<<<ceil_div(4 * I, 256), 256, 0, s>>>(I, dv0, dv0 + I, (const float4*)((const char*)a.bwd + L.pair_grads),
-                                                           (const uint8_t*)a.bwd + L.pair_flags,
-                                                           (float4*)((char*)a.bwd + L.inst_grads));
+                                                           (const uint8_t*)bin + L.pair_flags,
+                                                           (float4*)((char*)a.bwd + L.inst_grads),
+                                                           (const hs_counters*)(geom + L.counters));
         HS_LAUNCH_CHECK();
     }
     p.d_means3D = a.dL_dmeans3D; p.d_means2D = a.dL_dmeans2D; p.d_opac = a.dL_dopacities; p.d_shs = a.dL_dshs;

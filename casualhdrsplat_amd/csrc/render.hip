@@ -724,9 +724,10 @@ int launch_render_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s) {
     p.pair_grads = (float4*)((char*)a.bwd + L.pair_grads);
     p.crf.table = a.crf_table; p.crf.K = a.crf_K; p.crf.umin = a.crf_umin; p.crf.umax = a.crf_umax; p.crf.dt = 1.f;
     p.exposure = a.exposure;
-    p.pair_flags = (uint8_t*)a.bwd + L.pair_flags;
-    // pairs beyond a tile's deepest contributor are never visited: only flagged records are summed later
-    HS_HIP_CHECK(hipMemsetAsync(p.pair_flags, 0, (size_t)d.capacity, s));
+    // pairs beyond a tile's deepest contributor are never visited: only flagged records are summed later.  The flags
+    // were cleared by the forward's pair emission; which records get written depends on the forward state alone,
+    // so replays of this stage set the same flags again.
+    p.pair_flags = (uint8_t*)a.binning + L.pair_flags;
     render_bwd_kernel<<<p.ntiles * d.n_poses, kBatch, 0, s>>>(p);
     HS_LAUNCH_CHECK();
     return HS_OK;

@@ -231,6 +231,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             color, hdr, radii, st, exp_t, crf_t = _run_forward(raster_settings, m3, op, shs, cp, sc, ro, cv, exposure,
                                                                crf_table, capacity)
         ctx.st = st
+        ctx.set_materialize_grads(False)  # an unused output (e.g. the radiance image) must not cost a zero image
         ctx.deferred = deferred if shs is not None else None
         ctx.exp_shape = None if exposure is None else tuple(exposure.shape)
         ctx.pose_shapes = (tuple(viewmats.shape), tuple(projmats.shape), tuple(camposes.shape))
@@ -255,6 +256,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         st: _State = ctx.st
         saved = ctx.saved_tensors
         dev = saved[0].device
+        if grad_color is None:  # the loss used only the other outputs
+            grad_color = torch.zeros(3, st.H, st.W, dtype=torch.float32, device=dev)
         gcol = _f32c(grad_color, dev)
         ghdr = _f32c(grad_hdr, dev) if grad_hdr is not None else None
         galpha = _f32c(grad_alpha, dev) if grad_alpha is not None else None
@@ -314,8 +317,8 @@ def _launch_backward(st: "_State", saved, gcol, ghdr, stages: int, want_pose: bo
     g = {name: None for name, _, _ in spec}
     for name, (o, n, shape) in offs.items():
         g[name] = flat[o:o + n].view(shape)
-    if hdr:
-        g["exposure"].zero_()
+    if hdr and not (stages & L.HS_BWD_CRF):
+        g["exposure"].zero_()   # otherwise both are fully written by the CRF stage
         g["crf_table"].zero_()
     g["_flat"] = flat
     # deferred SH gradient: the per-view colour gradients live outside the flat (all-reduced) buffer

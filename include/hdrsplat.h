@@ -172,12 +172,14 @@ typedef struct hs_layout {
      * pair (the sort key of the published algorithm is (tile << 32) | depth_bits[instance]); depth_keys/depth_vals
      * = the instances sorted by depth (2 x I u32 each, second halves are scratch) */
     int64_t keys_sorted, point_list, keys_unsorted, vals_unsorted, ranges, sort_tmp, depth_keys, depth_vals, srect;
+    /* pair_flags (binning workspace): u8 per pair slot, cleared by the forward's pair emission, set to 1 by the
+     * render backward for the records it wrote */
+    int64_t pair_flags;
     /* image workspace */
     int64_t final_T, n_contrib, pose_hdr;
     /* bwd workspace */
-    /* pair_flags: u8 per pair, 1 = record written this backward; inst_grads: 12 floats per instance, the
-     * per-instance sum of its pair records */
-    int64_t pair_grads, crf_partials, pair_flags, inst_grads, pose_partials;
+    /* inst_grads: 12 floats per instance, the per-instance sum of its (flagged) pair records */
+    int64_t pair_grads, crf_partials, inst_grads, pose_partials;
 } hs_layout;
 
 int hs_version(void);
