@@ -600,29 +600,48 @@ __global__ void __launch_bounds__(256) crf_grad_kernel(int64_t HW, int N, int fl
     const float* t = crf.table + ch * crf.K;
     float* tab = s_tab + ch * crf.K;
     float gexp = 0.f, g_lo = 0.f, g_hi = 0.f;
-    for (int64_t i4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i4 < HW; i4 += (int64_t)gridDim.x * 1024) {
-        float Hv[4], g[4];
+    // Each thread walks 16 consecutive pixels (four float4 loads per array in flight) and merges the run of pixels
+    // that fall between the same two knots in registers: neighbouring pixels of a natural image mostly share a
+    // knot interval, and same-address LDS atomics of one wave serialise, so merging runs removes most of them.
+    for (int64_t i16 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 16; i16 < HW; i16 += (int64_t)gridDim.x * 4096) {
+        float Hv[16], g[16];
+        if (i16 + 16 <= HW && (HW & 3) == 0) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const bool ok = i4 + e < HW;
-            Hv[e] = ok ? Hp[i4 + e] : 0.f;
-            g[e] = ok ? gp[i4 + e] * gs : 0.f;
+            for (int q = 0; q < 4; ++q) {
+                const float4 h4 = reinterpret_cast<const float4*>(Hp + i16)[q];
+                const float4 g4 = reinterpret_cast<const float4*>(gp + i16)[q];
+                Hv[4 * q] = h4.x; Hv[4 * q + 1] = h4.y; Hv[4 * q + 2] = h4.z; Hv[4 * q + 3] = h4.w;
+                g[4 * q] = g4.x * gs; g[4 * q + 1] = g4.y * gs; g[4 * q + 2] = g4.z * gs; g[4 * q + 3] = g4.w * gs;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const bool ok = i16 + e < HW;
+                Hv[e] = ok ? Hp[i16 + e] : 0.f;
+                g[e] = ok ? gp[i16 + e] * gs : 0.f;
+            }
         }
+        int run = -1;            // knot interval of the pending run (-1: none)
+        float r0 = 0.f, r1 = 0.f;  // pending contributions to tab[run], tab[run + 1]
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < 16; ++e) {
             int idx; float f, xv; bool in;
             crf_locate(crf, Hv[e], idx, f, xv, in);
-            // pixels clamped to an end of the table (black / saturated regions) would pile 64-way conflicts on
-            // one LDS word: they are summed in registers and added once per wave
+            // pixels clamped to an end of the table (black / saturated regions) are summed per thread
             const bool lo = idx == 0 && f == 0.f, hi = idx == crf.K - 2 && f == 1.f;
             g_lo += lo ? g[e] : 0.f;
             g_hi += hi ? g[e] : 0.f;
             if (!lo && !hi) {
-                atomicAdd(&tab[idx], (1.f - f) * g[e]);
-                atomicAdd(&tab[idx + 1], f * g[e]);
+                if (idx != run) {
+                    if (run >= 0) { atomicAdd(&tab[run], r0); atomicAdd(&tab[run + 1], r1); }
+                    run = idx; r0 = 0.f; r1 = 0.f;
+                }
+                r0 += (1.f - f) * g[e];
+                r1 += f * g[e];
             }
             if (in) gexp += g[e] * (t[idx + 1] - t[idx]) * scale * __builtin_amdgcn_rcpf(xv) * Hv[e];
         }
+        if (run >= 0) { atomicAdd(&tab[run], r0); atomicAdd(&tab[run + 1], r1); }
     }
     gexp = wave_sum_hi(gexp);
     g_lo = wave_sum_hi(g_lo);

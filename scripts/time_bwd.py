@@ -18,4 +18,5 @@ def tm(fn, n=10):
 print(os.environ.get("HS_LIB_PATH", "default").split("/")[-1], "render_bwd(+memset+crf) ms", round(tm(lambda: replay_backward(out[0], dL, L.HS_BWD_RENDER)), 4),
       "render_fwd ms", round(tm(lambda: replay_forward(out[0], L.HS_STAGE_RENDER)), 4),
       "preprocess_bwd ms", round(tm(lambda: replay_backward(out[0], dL, L.HS_BWD_PREPROCESS)), 4),
-      "bin ms", round(tm(lambda: replay_forward(out[0], L.HS_STAGE_BIN)), 4))
+      "bin ms", round(tm(lambda: replay_forward(out[0], L.HS_STAGE_BIN)), 4),
+      "crf ms", round(tm(lambda: replay_backward(out[0], dL, L.HS_BWD_CRF)), 4))
