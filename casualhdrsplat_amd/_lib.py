@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("HS_LIB_PATH", os.path.join(_HERE, "libhdrsplat.so"))
 
 HS_OK, HS_EINVAL, HS_EHIP, HS_EOVERFLOW = 0, -1, -2, -3
 HS_STAGE_PREPROCESS, HS_STAGE_BIN, HS_STAGE_RENDER, HS_STAGE_ALL = 1, 2, 4, 7
-HS_FLAG_HDR, HS_FLAG_BLUR_HDR, HS_FLAG_DEBUG = 1, 2, 4
+HS_FLAG_HDR, HS_FLAG_BLUR_HDR, HS_FLAG_DEBUG, HS_FLAG_ANTIALIAS = 1, 2, 4, 8
 HS_BWD_RENDER, HS_BWD_PREPROCESS, HS_BWD_CRF, HS_BWD_ALL = 1, 2, 4, 7
 HS_TILE = 16
 
@@ -45,7 +45,7 @@ class hs_fwd_args(C.Structure):
         ("means3D", _fp), ("opacities", _fp), ("shs", _fp), ("colors_precomp", _fp), ("scales", _fp),
         ("rotations", _fp), ("cov3D_precomp", _fp), ("exposure", _fp), ("crf_table", _fp),
         ("geom", _fp), ("binning", _fp), ("image", _fp),
-        ("out_color", _fp), ("out_hdr", _fp), ("radii", _fp),
+        ("out_color", _fp), ("out_hdr", _fp), ("radii", _fp), ("out_invdepth", _fp),
     ]
 
 
@@ -64,7 +64,7 @@ class hs_bwd_args(C.Structure):
         ("dL_dcolors_precomp", _fp), ("dL_dscales", _fp), ("dL_drotations", _fp), ("dL_dcov3D_precomp", _fp),
         ("dL_dexposure", _fp), ("dL_dcrf_table", _fp),
         ("dL_dviewmatrices", _fp), ("dL_dprojmatrices", _fp), ("dL_dcamposes", _fp),
-        ("dL_dview_colors", _fp),
+        ("dL_dview_colors", _fp), ("dL_dout_invdepth", _fp),
     ]
 
 

@@ -143,6 +143,7 @@ struct PreFwd {
     float4* rec; float* depth; int* radii_inst; uint32_t* tiles; float* cov3D; uint8_t* clamped;
     uint2* binfo;  // tile rectangle {min_x | min_y << 16, width | height << 16} for the pair emission
     int* radii_out;
+    bool antialias;
 };
 
 // a4.  instance = pose * P + g.
@@ -243,7 +244,12 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreFwd p) {
                                 (uint32_t)(rmaxx - rminx) | ((uint32_t)(rmaxy - rminy) << 16));
                 depth = pvz;
                 ra = make_float4(pix_x, pix_y, conA, conB);
-                rb = make_float4(conC, p.opac[g], col[0], col[1]);
+                float opac = p.opac[g];
+                if (p.antialias) {  // energy compensation of the 0.3-pixel dilation (newer published rasterizer)
+                    const float det0 = (ca - 0.3f) * (cc - 0.3f) - cb * cb;
+                    opac = opac * sqrtf(fmaxf(0.000025f, det0 / det));
+                }
+                rb = make_float4(conC, opac, col[0], col[1]);
                 rc = make_float4(col[2], pvz, __int_as_float(rad), 0.f);
             }
         }
@@ -288,18 +294,18 @@ __global__ void __launch_bounds__(256) pair_segsum_kernel(int64_t I, const uint3
     const bool valid = i < I && !counters->overflow;
     const uint32_t beg = valid ? (i == 0 ? 0u : offs_sorted[i - 1]) : 0u;
     const uint32_t end = valid ? offs_sorted[i] : 0u;
-    float r[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float r[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (uint32_t s = beg + q; s < end; s += 4) {
         if (!pair_flags[s]) continue;  // never written this backward: skipping saves the 48-byte read (~55 % of pairs)
         const float4 q0 = pair_grads[3 * (int64_t)s + 0];
         const float4 q1 = pair_grads[3 * (int64_t)s + 1];
-        const float q2 = reinterpret_cast<const float*>(pair_grads + 3 * (int64_t)s + 2)[0];
+        const float2 q2 = reinterpret_cast<const float2*>(pair_grads + 3 * (int64_t)s + 2)[0];
         r[0] += q0.x; r[1] += q0.y; r[2] += q0.z; r[3] += q0.w;
         r[4] += q1.x; r[5] += q1.y; r[6] += q1.z; r[7] += q1.w;
-        r[8] += q2;
+        r[8] += q2.x; r[9] += q2.y;
     }
 #pragma unroll
-    for (int k = 0; k < 9; ++k) {
+    for (int k = 0; k < 10; ++k) {
         r[k] += __shfl_xor(r[k], 1);
         r[k] += __shfl_xor(r[k], 2);
     }
@@ -307,7 +313,7 @@ __global__ void __launch_bounds__(256) pair_segsum_kernel(int64_t I, const uint3
         float4* o = inst_grads + 3 * (int64_t)inst_sorted[i];
         o[0] = make_float4(r[0], r[1], r[2], r[3]);
         o[1] = make_float4(r[4], r[5], r[6], r[7]);
-        o[2] = make_float4(r[8], 0.f, 0.f, 0.f);
+        o[2] = make_float4(r[8], r[9], 0.f, 0.f);
     }
 }
 
@@ -315,8 +321,8 @@ struct PreBwd {
     int P, M, W, H, N;
     float tanfovx, tanfovy, mod;
     const float* view; const float* proj; const float* campos;
-    const float* means; const float* shs; const float* scales; const float* rots;
-    bool has_colors_precomp, has_cov_pre;
+    const float* means; const float* shs; const float* scales; const float* rots; const float* opac;
+    bool has_colors_precomp, has_cov_pre, antialias;
     const float4* rec; const int* radii_inst; const uint32_t* tiles; const uint32_t* offsets; const float* cov3D;
     const uint8_t* clamped;
     const float4* inst_grads;
@@ -389,9 +395,10 @@ __global__ void __launch_bounds__(kPreBwdBlock) preprocess_bwd_kernel(PreBwd p) 
             r[0] = q0.x; r[1] = q0.y; r[2] = q0.z; r[3] = q0.w; r[4] = q1.x; r[5] = q1.y; r[6] = q1.z; r[7] = q1.w;
             r[8] = reinterpret_cast<const float*>(p.inst_grads + 3 * idx + 2)[0];
         }
-        // r = {dmean2D.x, dmean2D.y, dconic A, B, C, dopacity, dcolor r,g,b}
+        // r = {dmean2D.x, dmean2D.y, dconic A, B, C, dopacity, dcolor r,g,b}; r9 = d(inverse depth)
+        const float r9 = reinterpret_cast<const float*>(p.inst_grads + 3 * idx + 2)[1];
         gm2d[0] += r[0]; gm2d[1] += r[1];
-        gop += r[5];
+        if (!p.antialias) gop += r[5];
 
         const float* V = p.view + 16 * pose;
         const float* PM = p.proj + 16 * pose;
@@ -405,10 +412,24 @@ __global__ void __launch_bounds__(kPreBwdBlock) preprocess_bwd_kernel(PreBwd p) 
         const float denom = a * cc - b * b;
         const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
         const float gA = r[2], gB = r[3], gC = r[4];
+        // antialiasing: opacity_eff = opacity * s, s = sqrt(max(eps, q)), q = det(cov - 0.3 I) / det(cov)
+        float aa_da = 0.f, aa_db = 0.f, aa_dc = 0.f;
+        if (p.antialias) {
+            const float det0 = (a - 0.3f) * (cc - 0.3f) - b * b;
+            const float q = det0 / denom;
+            const float sfac = sqrtf(fmaxf(0.000025f, q));
+            gop += r[5] * sfac;
+            if (q > 0.000025f) {
+                const float k = r[5] * p.opac[g] * 0.5f / sfac / (denom * denom);  // dL/dq / denom^2
+                aa_da = k * ((cc - 0.3f) * denom - det0 * cc);
+                aa_dc = k * ((a - 0.3f) * denom - det0 * a);
+                aa_db = k * (2.f * b * (det0 - denom));
+            }
+        }
         if (denom2inv != 0.f) {
-            const float dLda = denom2inv * (-cc * cc * gA + b * cc * gB + (denom - a * cc) * gC);
-            const float dLdc = denom2inv * (-a * a * gC + a * b * gB + (denom - a * cc) * gA);
-            const float dLdb = denom2inv * (2.f * b * cc * gA - (denom + 2.f * b * b) * gB + 2.f * a * b * gC);
+            const float dLda = denom2inv * (-cc * cc * gA + b * cc * gB + (denom - a * cc) * gC) + aa_da;
+            const float dLdc = denom2inv * (-a * a * gC + a * b * gB + (denom - a * cc) * gA) + aa_dc;
+            const float dLdb = denom2inv * (2.f * b * cc * gA - (denom + 2.f * b * b) * gB + 2.f * a * b * gC) + aa_db;
             const float* pp = e.a0; const float* qq = e.a1;
             gcov[0] += pp[0] * pp[0] * dLda + pp[0] * qq[0] * dLdb + qq[0] * qq[0] * dLdc;
             gcov[3] += pp[1] * pp[1] * dLda + pp[1] * qq[1] * dLdb + qq[1] * qq[1] * dLdc;
@@ -444,6 +465,17 @@ __global__ void __launch_bounds__(kPreBwdBlock) preprocess_bwd_kernel(PreBwd p) 
                     pg[3 * j + 2] = dtz * mm[j] + ga0v[j] * J02 + ga1v[j] * J12;
                 }
                 pg[9] = dtx; pg[10] = dty; pg[11] = dtz;
+            }
+        }
+        if (r9 != 0.f) {  // inverse depth 1 / z, z = row 2 of the view transform
+            const float dz = -r9 / (pvz * pvz);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) gm[j] += V[4 * j + 2] * dz;
+            if constexpr (POSE) {
+                const float mm[3] = {x, y, z};
+#pragma unroll
+                for (int j = 0; j < 3; ++j) pg[3 * j + 2] += dz * mm[j];
+                pg[11] += dz;
             }
         }
         {
@@ -679,6 +711,7 @@ int launch_preprocess_fwd(const hs_fwd_args& a, const hs_layout& L, hipStream_t 
     p.tiles = (uint32_t*)(geom + L.tiles_touched); p.cov3D = (float*)(geom + L.cov3D);
     p.clamped = (uint8_t*)(geom + L.clamped); p.radii_out = a.radii;
     p.binfo = (uint2*)(geom + L.binfo);
+    p.antialias = (a.flags & HS_FLAG_ANTIALIAS) != 0;
     if (d.n_poses > 1) HS_HIP_CHECK(hipMemsetAsync(a.radii, 0, sizeof(int) * (size_t)d.P, s));
     const int64_t I = (int64_t)d.P * d.n_poses;
     const int grid = ceil_div(I, 256);
@@ -700,7 +733,8 @@ int launch_preprocess_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t 
     p.P = d.P; p.M = d.M; p.W = d.W; p.H = d.H; p.N = d.n_poses;
     p.tanfovx = a.tanfovx; p.tanfovy = a.tanfovy; p.mod = a.scale_modifier;
     p.view = a.viewmatrices; p.proj = a.projmatrices; p.campos = a.camposes;
-    p.means = a.means3D; p.shs = a.shs; p.scales = a.scales; p.rots = a.rotations;
+    p.means = a.means3D; p.shs = a.shs; p.scales = a.scales; p.rots = a.rotations; p.opac = a.opacities;
+    p.antialias = (a.flags & HS_FLAG_ANTIALIAS) != 0;
     p.has_colors_precomp = a.colors_precomp != nullptr; p.has_cov_pre = a.cov3D_precomp != nullptr;
     p.rec = (const float4*)(geom + L.rec); p.radii_inst = (const int*)(geom + L.radii);
     p.tiles = (const uint32_t*)(geom + L.tiles_touched); p.offsets = (const uint32_t*)(geom + L.offsets);

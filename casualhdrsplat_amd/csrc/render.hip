@@ -189,6 +189,7 @@ struct RenderFwd {
     int W, H, gx, ntiles, N, flags;
     const uint2* ranges; const uint32_t* point_list; const float4* rec; const float* bg;
     float* out_color; float* out_hdr; float* final_T; uint32_t* n_contrib; float* pose_hdr;
+    float* out_invdepth;  // [N,H,W] or null
     Crf crf;
     const float* exposure;
 };
@@ -199,18 +200,22 @@ __device__ __forceinline__ float hs_exp2(float x) { return __builtin_amdgcn_exp2
 
 // Per-pixel compositing state of the forward (two of these per lane).
 struct PixF {
-    float T, C0, C1, C2;
+    float T, C0, C1, C2, D;
     uint32_t last;
     bool done;
 };
 // One compositing step (branch-free: predication keeps the scalar unit out of the inner loop).
-__device__ __forceinline__ void blend_fwd(PixF& s, float pw, float alpha, float r, float g, float b, uint32_t idx1) {
+// DEPTH: also accumulate the expected inverse depth sum alpha T / z.
+template <bool DEPTH>
+__device__ __forceinline__ void blend_fwd(PixF& s, float pw, float alpha, float r, float g, float b, float invd,
+                                          uint32_t idx1) {
     const bool valid = !s.done && pw <= 0.f && alpha >= kAlphaMin;
     const float test_T = s.T * (1.f - alpha);
     const bool upd = valid && !(test_T < kTmin);
     s.done = s.done || (valid && test_T < kTmin);
     const float w = upd ? alpha * s.T : 0.f;
     s.C0 += r * w; s.C1 += g * w; s.C2 += b * w;
+    if constexpr (DEPTH) s.D += invd * w;
     s.T = upd ? test_T : s.T;
     s.last = upd ? idx1 : s.last;
 }
@@ -240,11 +245,13 @@ __device__ __forceinline__ void write_pixel_fwd(const RenderFwd& p, const PixF& 
     }
 }
 
+template <bool DEPTH>
 __global__ void __launch_bounds__(kBatch) render_fwd_kernel(RenderFwd p) {
     constexpr int KB = kBatch;
     __shared__ float4 s_a[KB];
     __shared__ float4 s_b[KB];
     __shared__ float s_cb[KB];
+    __shared__ float s_id[DEPTH ? KB : 1];  // 1 / depth of the staged entries
     __shared__ uint16_t s_list[2][KB];  // per-wave compacted list of staged entries that can touch its half tile
     __shared__ int s_alive[2][2];
 
@@ -265,15 +272,17 @@ __global__ void __launch_bounds__(kBatch) render_fwd_kernel(RenderFwd p) {
 
     PixF s0, s1;
     s0.T = s1.T = 1.f; s0.C0 = s0.C1 = s0.C2 = s1.C0 = s1.C1 = s1.C2 = 0.f; s0.last = s1.last = 0;
+    s0.D = s1.D = 0.f;
     s0.done = !in0; s1.done = !in1;
 
     // software pipeline of the staging gather: registers hold the NEXT batch while the current one is processed
     float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
-    float rcb = 0.f;
+    float rcb = 0.f, rdepth = 1.f;
     if ((int)threadIdx.x < n) {
         const uint32_t id = p.point_list[range.x + threadIdx.x];
         const float4* r = p.rec + 3 * (int64_t)id;
         ra = r[0]; rb = r[1]; rcb = reinterpret_cast<const float*>(r + 2)[0];
+        if constexpr (DEPTH) rdepth = reinterpret_cast<const float*>(r + 2)[1];
     }
     int it = 0;
     for (int base = 0; base < n; base += KB, ++it) {
@@ -285,11 +294,13 @@ __global__ void __launch_bounds__(kBatch) render_fwd_kernel(RenderFwd p) {
         if ((int)threadIdx.x < cnt) {
             scale_entry(ra, rb);
             s_a[threadIdx.x] = ra; s_b[threadIdx.x] = rb; s_cb[threadIdx.x] = rcb;
+            if constexpr (DEPTH) s_id[threadIdx.x] = 1.f / rdepth;
         }
         if (base + KB + (int)threadIdx.x < n) {
             const uint32_t id = p.point_list[range.x + base + KB + threadIdx.x];
             const float4* r = p.rec + 3 * (int64_t)id;
             ra = r[0]; rb = r[1]; rcb = reinterpret_cast<const float*>(r + 2)[0];
+            if constexpr (DEPTH) rdepth = reinterpret_cast<const float*>(r + 2)[1];
         }
         __syncthreads();
         if (!wave_alive) continue;
@@ -315,13 +326,19 @@ __global__ void __launch_bounds__(kBatch) render_fwd_kernel(RenderFwd p) {
             const float al0 = fminf(kAlphaMax, b.y * hs_exp2(pw.x));
             const float al1 = fminf(kAlphaMax, b.y * hs_exp2(pw.y));
             const uint32_t idx1 = (uint32_t)(base + j + 1);
-            blend_fwd(s0, pw.x, al0, b.z, b.w, cb, idx1);
-            blend_fwd(s1, pw.y, al1, b.z, b.w, cb, idx1);
+            const float invd = DEPTH ? s_id[j] : 0.f;
+            blend_fwd<DEPTH>(s0, pw.x, al0, b.z, b.w, cb, invd, idx1);
+            blend_fwd<DEPTH>(s1, pw.y, al1, b.z, b.w, cb, invd, idx1);
             if (__ballot(!(s0.done && s1.done)) == 0ull) break;
         }
     }
     if (in0) write_pixel_fwd(p, s0, pose, px, py0);
     if (in1) write_pixel_fwd(p, s1, pose, px, py1);
+    if constexpr (DEPTH) {
+        const int64_t HW = (int64_t)p.H * p.W;
+        if (in0) p.out_invdepth[(int64_t)pose * HW + (int64_t)py0 * p.W + px] = s0.D;
+        if (in1) p.out_invdepth[(int64_t)pose * HW + (int64_t)py1 * p.W + px] = s1.D;
+    }
 }
 
 // N > 1: average the per-pose images.  LDR domain (default, follows assets/pipeline.png: the blur "+" is
@@ -354,7 +371,7 @@ struct RenderBwd {
     int W, H, gx, gy, ntiles, N, flags;
     const uint2* ranges; const uint32_t* point_list; const float4* rec; const float* bg;
     const float* final_T; const uint32_t* n_contrib; const float* pose_hdr;
-    const float* dL_dcolor; const float* dL_dhdr; const float* dL_dalpha;
+    const float* dL_dcolor; const float* dL_dhdr; const float* dL_dalpha; const float* dL_dinvdepth;
     float4* pair_grads;
     uint8_t* pair_flags;
     Crf crf;
@@ -381,6 +398,7 @@ __device__ __forceinline__ float pixel_grad(const RenderBwd& p, const Crf& c, in
 // Per-pixel state of the backward replay (two per lane).
 struct PixB {
     float T, T_final, R0, R1, R2, dL0, dL1, dL2, bg_dot;
+    float Rd, dLd;  // inverse-depth channel (DEPTH kernels only): value accumulated behind, upstream gradient
     uint32_t last;
 };
 
@@ -402,13 +420,16 @@ __device__ __forceinline__ void load_pixel_bwd(const RenderBwd& p, PixB& s, bool
     if (p.dL_dalpha && inside) s.bg_dot -= p.dL_dalpha[pix] / (float)p.N;
     s.T = s.T_final;
     s.R0 = s.R1 = s.R2 = 0.f;  // colour accumulated behind the current entry ("accum_rec")
+    s.Rd = 0.f;
+    s.dLd = (p.dL_dinvdepth && inside) ? p.dL_dinvdepth[pix] / (float)p.N : 0.f;
 }
 
 // One back-to-front step for one pixel.  Outputs s_ = dL/dG * G (weight of the geometric sums), the opacity
 // term G * dL/dalpha and dch = alpha * T (colour weight); inactive pixels give exact zeros and keep their state
 // (alpha_eff = 0 makes every update an identity), so no per-field selects are needed.
+template <bool DEPTH>
 __device__ __forceinline__ void step_bwd(PixB& s, bool act, float G, float alpha, float o, float r, float g, float b,
-                                         float& sw, float& dop, float& dch) {
+                                         float invd, float& sw, float& dop, float& dch) {
     const float ae = act ? alpha : 0.f;
     const float one_m = 1.f - ae;
     const float rcp = __builtin_amdgcn_rcpf(one_m);
@@ -416,6 +437,11 @@ __device__ __forceinline__ void step_bwd(PixB& s, bool act, float G, float alpha
     dch = ae * s.T;
     const float d0 = r - s.R0, d1 = g - s.R1, d2 = b - s.R2;
     float dLa = (d0 * s.dL0 + d1 * s.dL1) + d2 * s.dL2;
+    if constexpr (DEPTH) {  // the inverse-depth image is a fourth blended channel without background
+        const float dd = invd - s.Rd;
+        dLa += dd * s.dLd;
+        s.Rd += ae * dd;
+    }
     dLa = dLa * s.T - (s.T_final * rcp) * s.bg_dot;
     // accum_rec <- alpha*c + (1-alpha)*accum_rec, written as one FMA per channel on the difference already formed
     s.R0 += ae * d0;
@@ -425,12 +451,14 @@ __device__ __forceinline__ void step_bwd(PixB& s, bool act, float G, float alpha
     sw = o * dop;
 }
 
+template <bool DEPTH>
 __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
     constexpr int KB = kBatch;
+    constexpr int NV = DEPTH ? 10 : 9;      // reduced values per (tile, entry): nine published sums (+ d inverse depth)
     __shared__ float4 s_a[KB];
     __shared__ float4 s_b[KB];
     __shared__ float4 s_c[KB];
-    __shared__ float s_acc[2][9][KB];       // per-wave planes of reduced partials, summed in fixed order at write-out
+    __shared__ float s_acc[2][NV][KB];      // per-wave planes of reduced partials, summed in fixed order at write-out
     __shared__ uint16_t s_list[2][KB];      // per-wave compacted list of touched staged entries
     __shared__ uint64_t s_wrote[2][KB / 64];
     __shared__ uint32_t s_max[2];
@@ -481,7 +509,8 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
         if ((int)threadIdx.x < cnt) {
             const float4* r = p.rec + 3 * (int64_t)id_next;
             float4 ra = r[0], rb = r[1];
-            const float4 rc = r[2];
+            float4 rc = r[2];
+            if constexpr (DEPTH) rc.y = 1.f / rc.y;  // depth -> inverse depth
             scale_entry(ra, rb);
             s_a[threadIdx.x] = ra; s_b[threadIdx.x] = rb; s_c[threadIdx.x] = rc;
         }
@@ -507,6 +536,7 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
                 const float4 a = s_a[j];
                 const float4 b = s_b[j];
                 const float cb = s_c[j].x;
+                const float invd = DEPTH ? s_c[j].y : 0.f;  // staged as 1 / depth in DEPTH kernels
                 const float dx = a.x - pxf;
                 const f2 dy = a.y - pyf;
                 const float t = a.z * dx * dx, u = a.w * dx;
@@ -520,8 +550,8 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
                 HS_STAT_ADD(2, __popcll(__ballot(act0)) + __popcll(__ballot(act1)));
                 if (__ballot(act0 || act1) == 0ull) { HS_STAT_ADD(1, 1); continue; }
                 float w0, w1, dop0, dop1, dch0, dch1;
-                step_bwd(s0, act0, G0, al0, b.y, b.z, b.w, cb, w0, dop0, dch0);
-                step_bwd(s1, act1, G1, al1, b.y, b.z, b.w, cb, w1, dop1, dch1);
+                step_bwd<DEPTH>(s0, act0, G0, al0, b.y, b.z, b.w, cb, invd, w0, dop0, dch0);
+                step_bwd<DEPTH>(s1, act1, G1, al1, b.y, b.z, b.w, cb, invd, w1, dop1, dch1);
                 // in-lane sums over the pixel pair (dx is shared):  S1 = sum w dx, S2 = sum w dy, S3 = sum w dx^2,
                 // S4 = sum w dx dy, S5 = sum w dy^2 ; the conic factors are applied once per entry at write-out
                 const float m0 = w0 * dy.x, m1 = w1 * dy.y;
@@ -537,6 +567,10 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
                 g[8] = dch0 * s0.dL2 + dch1 * s1.dL2;
                 const float tot = wave_reduce9(g);
                 if (red_slot >= 0) s_acc[wave][red_slot][j] = tot;  // 9 lanes, one LDS store
+                if constexpr (DEPTH) {
+                    const float gd = wave_sum_hi(dch0 * s0.dLd + dch1 * s1.dLd);
+                    if (lane == 63) s_acc[wave][9][j] = gd;
+                }
                 wrote[j >> 6] |= 1ull << (j & 63);
             }
         }
@@ -547,12 +581,12 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
         __syncthreads();
         if ((int)threadIdx.x < cnt) {
             const int t = threadIdx.x;
-            float v[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            float v[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int w = 0; w < 2; ++w) {
                 if ((s_wrote[w][t >> 6] >> (t & 63)) & 1ull) {
 #pragma unroll
-                    for (int q = 0; q < 9; ++q) v[q] += s_acc[w][q][t];
+                    for (int q = 0; q < NV; ++q) v[q] += s_acc[w][q][t];
                 }
             }
             const float4 a = s_a[t];
@@ -574,7 +608,7 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
             float4* o = p.pair_grads + 3 * slot;
             o[0] = make_float4(gmx, gmy, -0.5f * v[2], -v[3]);
             o[1] = make_float4(-0.5f * v[4], v[5], v[6], v[7]);
-            o[2] = make_float4(v[8], 0.f, 0.f, 0.f);
+            o[2] = make_float4(v[8], v[9], 0.f, 0.f);
         }
     }
 }
@@ -697,7 +731,9 @@ int launch_render_fwd(const hs_fwd_args& a, const hs_layout& L, hipStream_t s) {
     p.pose_hdr = need_pose ? (float*)(img + L.pose_hdr) : nullptr;
     p.crf.table = a.crf_table; p.crf.K = a.crf_K; p.crf.umin = a.crf_umin; p.crf.umax = a.crf_umax; p.crf.dt = 1.f;
     p.exposure = a.exposure;
-    render_fwd_kernel<<<p.ntiles * d.n_poses, kBatch, 0, s>>>(p);
+    p.out_invdepth = a.out_invdepth;
+    if (a.out_invdepth) render_fwd_kernel<true><<<p.ntiles * d.n_poses, kBatch, 0, s>>>(p);
+    else render_fwd_kernel<false><<<p.ntiles * d.n_poses, kBatch, 0, s>>>(p);
     HS_LAUNCH_CHECK();
     if (d.n_poses > 1) {
         const int64_t HW = (int64_t)d.W * d.H;
@@ -740,6 +776,7 @@ int launch_render_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s) {
     p.final_T = (const float*)(img + L.final_T); p.n_contrib = (const uint32_t*)(img + L.n_contrib);
     p.pose_hdr = (const float*)(img + L.pose_hdr);
     p.dL_dcolor = a.dL_dout_color; p.dL_dhdr = a.dL_dout_hdr; p.dL_dalpha = a.dL_dout_alpha;
+    p.dL_dinvdepth = a.dL_dout_invdepth;
     p.pair_grads = (float4*)((char*)a.bwd + L.pair_grads);
     p.crf.table = a.crf_table; p.crf.K = a.crf_K; p.crf.umin = a.crf_umin; p.crf.umax = a.crf_umax; p.crf.dt = 1.f;
     p.exposure = a.exposure;
@@ -747,7 +784,8 @@ int launch_render_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s) {
     // were cleared by the forward's pair emission; which records get written depends on the forward state alone,
     // so replays of this stage set the same flags again.
     p.pair_flags = (uint8_t*)a.binning + L.pair_flags;
-    render_bwd_kernel<<<p.ntiles * d.n_poses, kBatch, 0, s>>>(p);
+    if (a.dL_dout_invdepth) render_bwd_kernel<true><<<p.ntiles * d.n_poses, kBatch, 0, s>>>(p);
+    else render_bwd_kernel<false><<<p.ntiles * d.n_poses, kBatch, 0, s>>>(p);
     HS_LAUNCH_CHECK();
     return HS_OK;
 }

@@ -123,7 +123,7 @@ class _Pending:
 
 
 def _run_forward(settings: GaussianRasterizationSettings, means3D, opacities, shs, colors_precomp, scales,
-                 rotations, cov3D_precomp, exposure, crf_table, capacity: Optional[int]):
+                 rotations, cov3D_precomp, exposure, crf_table, capacity: Optional[int], want_invdepth: bool = False):
     lib = L.load()
     dev = means3D.device
     if dev.type != "cuda":
@@ -155,6 +155,8 @@ def _run_forward(settings: GaussianRasterizationSettings, means3D, opacities, sh
             raise ValueError("blur_domain must be 'ldr' or 'hdr'")
     if settings.debug:
         flags |= L.HS_FLAG_DEBUG
+    if settings.antialiasing:
+        flags |= L.HS_FLAG_ANTIALIAS
     exposure = None if exposure is None else _f32c(exposure, dev).reshape(1)
     crf_table = _f32c(crf_table, dev)
     crf_K = int(crf_table.shape[1]) if hdr else 0
@@ -165,6 +167,7 @@ def _run_forward(settings: GaussianRasterizationSettings, means3D, opacities, sh
     out_color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
     out_hdr = torch.empty(3, H, W, dtype=torch.float32, device=dev) if hdr else None
     radii = torch.empty(P, dtype=torch.int32, device=dev)
+    invdepth = torch.empty(N, H, W, dtype=torch.float32, device=dev) if want_invdepth else None
 
     a = L.hs_fwd_args()
     a.dims = dims
@@ -177,6 +180,7 @@ def _run_forward(settings: GaussianRasterizationSettings, means3D, opacities, sh
     a.exposure, a.crf_table = _ptr(exposure), _ptr(crf_table)
     a.geom = geom.data_ptr()
     a.out_color, a.out_hdr, a.radii = out_color.data_ptr(), _ptr(out_hdr), radii.data_ptr()
+    a.out_invdepth = _ptr(invdepth)
 
     st = _State()
     st.pending = None
@@ -211,14 +215,14 @@ def _run_forward(settings: GaussianRasterizationSettings, means3D, opacities, sh
     # inputs only: an OUTPUT here would close a cycle output -> grad_fn -> ctx.st -> output through the C++ autograd
     # node, which Python's collector cannot see, and leak the whole state (~340 MB per step at 1M Gaussians / 1080p)
     st.keep = (exposure, crf_table, means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp)
-    return out_color, out_hdr, radii, st, exposure, crf_table
+    return out_color, out_hdr, radii, st, exposure, crf_table, invdepth
 
 
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                 exposure, crf_table, viewmats, projmats, camposes, raster_settings, capacity, return_alpha=False,
-                deferred=None):
+                deferred=None, return_invdepth=False):
         dev = means3D.device
         m3 = _f32c(means3D, dev)
         op = _f32c(opacities, dev)
@@ -228,8 +232,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         ro = _f32c(rotations, dev) if rotations is not None and rotations.numel() else None
         cv = _f32c(cov3Ds_precomp, dev) if cov3Ds_precomp is not None and cov3Ds_precomp.numel() else None
         with _on_device(dev):  # kernels are launched on the tensors' GPU, whatever the current device is
-            color, hdr, radii, st, exp_t, crf_t = _run_forward(raster_settings, m3, op, shs, cp, sc, ro, cv, exposure,
-                                                               crf_table, capacity)
+            color, hdr, radii, st, exp_t, crf_t, invd = _run_forward(raster_settings, m3, op, shs, cp, sc, ro, cv,
+                                                                     exposure, crf_table, capacity, return_invdepth)
         ctx.st = st
         ctx.set_materialize_grads(False)  # an unused output (e.g. the radiance image) must not cost a zero image
         ctx.deferred = deferred if shs is not None else None
@@ -239,20 +243,25 @@ class _RasterizeGaussians(torch.autograd.Function):
                    crf_table is not None)
         ctx.save_for_backward(m3, op, shs, cp, sc, ro, cv, exp_t, crf_t)
         ctx.mark_non_differentiable(radii)
-        ctx.n_out = (hdr is not None, bool(return_alpha))
+        ctx.n_out = (hdr is not None, bool(return_alpha), bool(return_invdepth))
         outs = (color, radii) + ((hdr,) if hdr is not None else ())
         if return_alpha:
             # accumulated opacity A = 1 - mean over poses of the final transmittance (newer rasterizers expose it)
             d = st.dims
             ft = st.image[st.layout.final_T:st.layout.final_T + 4 * d.n_poses * d.W * d.H].view(torch.float32)
             outs = outs + (1.0 - ft.reshape(d.n_poses, d.H, d.W).mean(dim=0),)
+        if return_invdepth:
+            # expected inverse depth sum_i alpha_i T_i / z_i, averaged over the poses (newer rasterizers' third output)
+            outs = outs + (invd[0] if invd.shape[0] == 1 else invd.mean(dim=0),)
         return outs
 
     @staticmethod
     def backward(ctx, grad_color, grad_radii=None, *more):
-        has_hdr, has_alpha = ctx.n_out
-        grad_hdr = more[0] if has_hdr else None
-        grad_alpha = more[1 if has_hdr else 0] if has_alpha else None
+        has_hdr, has_alpha, has_invd = ctx.n_out
+        more = list(more)
+        grad_hdr = more.pop(0) if has_hdr else None
+        grad_alpha = more.pop(0) if has_alpha else None
+        grad_invd = more.pop(0) if has_invd else None
         st: _State = ctx.st
         saved = ctx.saved_tensors
         dev = saved[0].device
@@ -261,10 +270,11 @@ class _RasterizeGaussians(torch.autograd.Function):
         gcol = _f32c(grad_color, dev)
         ghdr = _f32c(grad_hdr, dev) if grad_hdr is not None else None
         galpha = _f32c(grad_alpha, dev) if grad_alpha is not None else None
+        ginvd = _f32c(grad_invd, dev) if grad_invd is not None else None
         want_pose = any(ctx.needs_input_grad[10:13])
         with _on_device(dev):
             g = _launch_backward(st, saved, gcol, ghdr, L.HS_BWD_ALL, want_pose, galpha,
-                                 defer_sh=ctx.deferred is not None)
+                                 defer_sh=ctx.deferred is not None, ginvd=ginvd)
         if ctx.deferred is not None:
             # view-parallel exchange: hand the per-view colour gradients to distributed.exchange_view_gradients
             ctx.deferred.update(view_colors=g["view_colors"], camposes=st.camposes, means3D=saved[0],
@@ -282,11 +292,11 @@ class _RasterizeGaussians(torch.autograd.Function):
                 g["crf_table"] if has_crf else None,
                 g["viewmatrices"].reshape(ctx.pose_shapes[0]) if want_pose else None,
                 g["projmatrices"].reshape(ctx.pose_shapes[1]) if want_pose else None,
-                g["camposes"].reshape(ctx.pose_shapes[2]) if want_pose else None, None, None, None, None)
+                g["camposes"].reshape(ctx.pose_shapes[2]) if want_pose else None, None, None, None, None, None)
 
 
 def _launch_backward(st: "_State", saved, gcol, ghdr, stages: int, want_pose: bool = False, galpha=None,
-                     defer_sh: bool = False) -> dict:
+                     defer_sh: bool = False, ginvd=None) -> dict:
     """Enqueue hs_backward.  All per-Gaussian gradients are carved out of ONE flat fp32 buffer (the
     layout casualhdrsplat_amd.distributed all-reduces in a single RCCL call): [means3D | means2D |
     opacities | sh | colors | scales | rotations | cov3D | exposure | crf_table]."""
@@ -343,6 +353,7 @@ def _launch_backward(st: "_State", saved, gcol, ghdr, stages: int, want_pose: bo
     a.dL_dviewmatrices, a.dL_dprojmatrices, a.dL_dcamposes = (_ptr(g["viewmatrices"]), _ptr(g["projmatrices"]),
                                                               _ptr(g["camposes"]))
     a.dL_dview_colors = _ptr(g["view_colors"])
+    a.dL_dout_invdepth = _ptr(ginvd)
     if P > 0:
         L.check(lib.hs_backward(C.byref(a), _stream()), "hs_backward")
     else:
@@ -360,7 +371,7 @@ def replay_forward(out_tensor: torch.Tensor, stages: int = L.HS_STAGE_RENDER) ->
     a.out_color = out_tensor.data_ptr()
     scratch_hdr = torch.empty_like(out_tensor) if (st.flags & L.HS_FLAG_HDR) else None
     scratch_radii = torch.empty(max(st.dims.P, 1), dtype=torch.int32, device=out_tensor.device)
-    a.out_hdr, a.radii = _ptr(scratch_hdr), scratch_radii.data_ptr()
+    a.out_hdr, a.radii, a.out_invdepth = _ptr(scratch_hdr), scratch_radii.data_ptr(), None
     L.check(L.load().hs_forward(C.byref(a), _stream()), "hs_forward[replay]")
 
 
@@ -393,7 +404,7 @@ def sh_backward_views(means3D: torch.Tensor, camposes: torch.Tensor, view_colors
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                        raster_settings, capacity=None, return_alpha=False, deferred=None):
+                        raster_settings, capacity=None, return_alpha=False, deferred=None, return_invdepth=False):
     rs = raster_settings
     multi = rs.viewmatrices is not None
     # the camera tensors travel as autograd inputs so a trajectory model upstream receives pose gradients
@@ -401,7 +412,8 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
                                      cov3Ds_precomp, rs.exposure, rs.crf_table,
                                      rs.viewmatrices if multi else rs.viewmatrix,
                                      rs.projmatrices if multi else rs.projmatrix,
-                                     rs.camposes if multi else rs.campos, rs, capacity, return_alpha, deferred)
+                                     rs.camposes if multi else rs.campos, rs, capacity, return_alpha, deferred,
+                                     return_invdepth)
 
 
 class GaussianRasterizer(nn.Module):
@@ -413,8 +425,11 @@ class GaussianRasterizer(nn.Module):
     """
 
     def __init__(self, raster_settings: GaussianRasterizationSettings, capacity: Optional[int] = None,
-                 return_alpha: bool = False, defer_sh_grad: bool = False):
+                 return_alpha: bool = False, defer_sh_grad: bool = False, return_invdepth: bool = False):
         super().__init__()
+        # extension (newer published rasterizers return (color, radii, invdepths)): append the expected inverse
+        # depth image [H,W] = sum_i alpha_i T_i / z_i to the outputs, differentiable
+        self.return_invdepth = return_invdepth
         self.raster_settings = raster_settings
         self.capacity = capacity
         self.return_alpha = return_alpha  # extension: append the accumulated-opacity image [H,W] to the outputs
@@ -450,7 +465,8 @@ class GaussianRasterizer(nn.Module):
         cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
         self.deferred = {} if self.defer_sh_grad else None
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
-                                   cov3D_precomp, rs, self.capacity, self.return_alpha, self.deferred)
+                                   cov3D_precomp, rs, self.capacity, self.return_alpha, self.deferred,
+                                   self.return_invdepth)
 
 
 def inspect_state(out_tensor: torch.Tensor) -> dict:

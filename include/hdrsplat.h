@@ -57,6 +57,8 @@ extern "C" {
 #define HS_FLAG_HDR 1          /* exposure * CRF tone-map epilogue; out_color = LDR, out_hdr = radiance */
 #define HS_FLAG_BLUR_HDR 2     /* N-pose average taken on radiance before the CRF (default: on LDR) */
 #define HS_FLAG_DEBUG 4
+#define HS_FLAG_ANTIALIAS 8    /* newer published rasterizer's `antialiasing`: opacity *= sqrt(max(0.000025,
+                                  det(cov2D) / det(cov2D + 0.3 I))), with its gradient */
 
 typedef struct hs_dims {
     int32_t P;         /* Gaussians */
@@ -110,6 +112,8 @@ typedef struct hs_fwd_args {
     float* out_color;            /* [3,H,W]; LDR when HS_FLAG_HDR */
     float* out_hdr;              /* [3,H,W] linear radiance (HDR) or NULL */
     int32_t* radii;              /* [P] max over poses */
+    float* out_invdepth;         /* [N,H,W] or NULL: expected inverse depth sum_i alpha_i T_i / z_i per pose
+                                    (the caller averages the poses) */
 } hs_fwd_args;
 
 typedef struct hs_bwd_args {
@@ -161,6 +165,7 @@ typedef struct hs_bwd_args {
      * mask (zero for culled instances) is written here, [N,P,3]; dL_dshs may then be NULL, and the SH-coefficient
      * gradient is formed later from the views of ALL ranks by hs_sh_backward_views */
     float* dL_dview_colors;
+    const float* dL_dout_invdepth; /* [H,W] or NULL: gradient w.r.t. the pose-averaged inverse-depth image */
 } hs_bwd_args;
 
 /* Byte offsets of the arrays carved out of the three state workspaces, for tests, profilers and

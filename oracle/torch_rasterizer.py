@@ -86,8 +86,10 @@ def quat_to_R(q):
 
 
 def preprocess(view: View, means3D, opacities, sh_degree, shs=None, colors_precomp=None, scales=None,
-               rotations=None, cov3D_precomp=None, scale_modifier=1.0, means2D=None):
-    """a4.  Returns a dict; differentiable w.r.t. every float input.  Culled Gaussians have radii == 0."""
+               rotations=None, cov3D_precomp=None, scale_modifier=1.0, means2D=None, antialiasing=False):
+    """a4.  Returns a dict; differentiable w.r.t. every float input.  Culled Gaussians have radii == 0.
+    antialiasing (newer published rasterizer): opacity is scaled by sqrt(max(0.000025, det(cov2D) / det(cov2D +
+    0.3 I))), compensating the energy the 0.3-pixel dilation adds to small splats."""
     dt = means3D.dtype
     V = view.viewmatrix.to(dt)
     PM = view.projmatrix.to(dt)
@@ -152,7 +154,11 @@ def preprocess(view: View, means3D, opacities, sh_degree, shs=None, colors_preco
         clamped = raw < 0
         rgb = torch.clamp_min(raw, 0.0)
     radii = torch.where(ok, radius, torch.zeros_like(radius)).to(torch.int32)
-    return dict(xy=pix, conic=conic, opacity=opacities.reshape(-1), rgb=rgb, depth=pv[:, 2], radii=radii,
+    opac = opacities.reshape(-1)
+    if antialiasing:
+        det0 = (a - 0.3) * (c - 0.3) - b * b
+        opac = opac * torch.sqrt(torch.clamp(det0 / det_s, min=0.000025))
+    return dict(xy=pix, conic=conic, opacity=opac, rgb=rgb, depth=pv[:, 2], radii=radii,
                 rect=torch.stack([rminx, rminy, rmaxx, rmaxy], dim=1), tiles_touched=torch.where(ok, area, torch.zeros_like(area)),
                 clamped=clamped, visible=ok)
 
@@ -185,9 +191,10 @@ def bin_tiles(view: View, pre: dict):
     return point_list, ranges, keys_sorted
 
 
-def render(view: View, pre: dict, point_list, ranges, bg, tiles=None):
+def render(view: View, pre: dict, point_list, ranges, bg, tiles=None, want_invdepth=False):
     """a9.  Returns (color[3,H,W], final_T[H,W], n_contrib[H,W]); tiles = optional iterable of tile ids to
-    render (others stay at bg / T=1) -- used to time a bounded sample of a large frame."""
+    render (others stay at bg / T=1) -- used to time a bounded sample of a large frame.  want_invdepth appends the
+    expected inverse depth image sum_i alpha_i T_i / z_i (no background term), as newer published rasterizers do."""
     W, H = view.W, view.H
     dt = pre["xy"].dtype
     gx, gy = (W + TILE - 1) // TILE, (H + TILE - 1) // TILE
@@ -195,6 +202,7 @@ def render(view: View, pre: dict, point_list, ranges, bg, tiles=None):
     color = bg[:, None, None].expand(3, H, W).clone()
     final_T = torch.ones(H, W, dtype=dt)
     n_contrib = torch.zeros(H, W, dtype=torch.int64)
+    invdepth = torch.zeros(H, W, dtype=dt)
     oy, ox = torch.meshgrid(torch.arange(TILE), torch.arange(TILE), indexing="ij")
     tile_ids = range(gx * gy) if tiles is None else tiles
     xy, conic, opac, rgb = pre["xy"], pre["conic"], pre["opacity"], pre["rgb"]
@@ -223,6 +231,8 @@ def render(view: View, pre: dict, point_list, ranges, bg, tiles=None):
         T_before = T_incl / one_m
         wgt = torch.where(contrib, alpha * T_before, torch.zeros_like(alpha))
         C = wgt @ rgb[ids]
+        if want_invdepth:
+            invdepth[y0:y0 + h, x0:x0 + w] = (wgt @ (1.0 / pre["depth"][ids])).reshape(h, w)
         Tf = torch.where(alive, one_m, torch.ones_like(one_m)).prod(dim=1)
         pos = torch.arange(1, ids.numel() + 1)
         last = torch.where(contrib, pos[None, :], torch.zeros_like(pos)[None, :]).amax(dim=1)
@@ -230,6 +240,8 @@ def render(view: View, pre: dict, point_list, ranges, bg, tiles=None):
         color[:, y0:y0 + h, x0:x0 + w] = out.t().reshape(3, h, w)
         final_T[y0:y0 + h, x0:x0 + w] = Tf.reshape(h, w)  # differentiable: alpha image = 1 - final_T
         n_contrib[y0:y0 + h, x0:x0 + w] = last.reshape(h, w)
+    if want_invdepth:
+        return color, final_T, n_contrib, invdepth
     return color, final_T, n_contrib
 
 
@@ -249,15 +261,16 @@ def tonemap(hdr, exposure, table, u_range, eps=1e-8):
 
 
 def rasterize(view: View, means3D, opacities, sh_degree, bg, shs=None, colors_precomp=None, scales=None,
-              rotations=None, cov3D_precomp=None, scale_modifier=1.0, means2D=None, tiles=None, return_state=False):
+              rotations=None, cov3D_precomp=None, scale_modifier=1.0, means2D=None, tiles=None, return_state=False,
+              antialiasing=False):
     pre = preprocess(view, means3D, opacities, sh_degree, shs, colors_precomp, scales, rotations, cov3D_precomp,
-                     scale_modifier, means2D)
+                     scale_modifier, means2D, antialiasing)
     point_list, ranges, keys_sorted = bin_tiles(view, pre)
-    color, final_T, n_contrib = render(view, pre, point_list, ranges, bg, tiles)
     if return_state:
+        color, final_T, n_contrib, invdepth = render(view, pre, point_list, ranges, bg, tiles, want_invdepth=True)
         return color, dict(pre=pre, point_list=point_list, ranges=ranges, keys_sorted=keys_sorted, final_T=final_T,
-                           n_contrib=n_contrib)
-    return color
+                           n_contrib=n_contrib, invdepth=invdepth)
+    return render(view, pre, point_list, ranges, bg, tiles)[0]
 
 
 def rasterize_hdr(views, means3D, opacities, sh_degree, bg, exposure, crf_table, crf_range, blur_domain="ldr", **kw):

@@ -516,3 +516,56 @@ def test_steps_do_not_leak_device_memory():
     a = steps(3)
     b = steps(6)
     assert b <= a, (a, b)
+
+
+@pytest.mark.parametrize("antialiasing,n_poses", [(False, 1), (True, 1), (True, 3)])
+def test_inverse_depth_output_and_antialiasing_vs_autograd(antialiasing, n_poses):
+    """expected inverse-depth image (third output of newer published rasterizers) with gradient,
+    and the `antialiasing` opacity compensation, against float64 autograd through the pure-PyTorch rasterizer
+    (poses averaged).  Camera-pose gradients of the depth term are covered through the view matrices."""
+    from casualhdrsplat_amd import GaussianRasterizationSettings, GaussianRasterizer
+    from oracle import torch_rasterizer as TR
+    P, W, H, deg = 700, 112, 80, 1
+    sc = S.make_scene(P, W, H, deg, seed=21)
+    cams = [S.yaw_camera(W, H, 1.5 * k - 1.0) for k in range(n_poses)]
+    dev = "cuda"
+    V = torch.stack([c.viewmatrix for c in cams]).to(dev).requires_grad_(True)
+    PV = torch.stack([c.projmatrix for c in cams]).to(dev).requires_grad_(True)
+    C = torch.stack([c.campos for c in cams]).to(dev).requires_grad_(True)
+    rs = GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=cams[0].tanfovx, tanfovy=cams[0].tanfovy, bg=sc.bg.to(dev),
+        scale_modifier=1.0, viewmatrix=V[0], projmatrix=PV[0], sh_degree=deg, campos=C[0], prefiltered=False,
+        debug=False, antialiasing=antialiasing,
+        **(dict(viewmatrices=V, projmatrices=PV, camposes=C) if n_poses > 1 else {}))
+    gen = torch.Generator().manual_seed(4)
+    gD = torch.randn(H, W, generator=gen) * 5
+    names = ("means3D", "opacities", "shs", "scales", "rotations")
+    leaves = {k: getattr(sc, k).to(dev).requires_grad_(True) for k in names}
+    out = GaussianRasterizer(rs, return_invdepth=True)(leaves["means3D"], torch.zeros(P, 3, device=dev), leaves["opacities"],
+                                                       shs=leaves["shs"], scales=leaves["scales"], rotations=leaves["rotations"])
+    assert len(out) == 3 and out[2].shape == (H, W)
+    ((out[0] * sc.dL_dimage.to(dev)).sum() + (out[2] * gD.to(dev)).sum()).backward()
+
+    dt = torch.float64
+    ref = {k: getattr(sc, k).to(dt).clone().requires_grad_(True) for k in names}
+    Vr = torch.stack([c.viewmatrix for c in cams]).to(dt).requires_grad_(True)
+    PVr = torch.stack([c.projmatrix for c in cams]).to(dt).requires_grad_(True)
+    Cr = torch.stack([c.campos for c in cams]).to(dt).requires_grad_(True)
+    cols, invs = [], []
+    for k in range(n_poses):
+        view = TR.View(W, H, cams[k].tanfovx, cams[k].tanfovy, Vr[k], PVr[k], Cr[k])
+        color, st = TR.rasterize(view, ref["means3D"], ref["opacities"], deg, sc.bg, shs=ref["shs"], scales=ref["scales"],
+                                 rotations=ref["rotations"], return_state=True, antialiasing=antialiasing)
+        cols.append(color)
+        invs.append(st["invdepth"])
+    color, invd = torch.stack(cols).mean(dim=0), torch.stack(invs).mean(dim=0)
+    ((color * sc.dL_dimage.to(dt)).sum() + (invd * gD.to(dt)).sum()).backward()
+    assert Hh.rel_err(out[0].detach().cpu().numpy(), color.detach().numpy(), 1e-2)[0] <= 1e-4
+    assert Hh.rel_err(out[2].detach().cpu().numpy(), invd.detach().numpy(), 1e-3)[0] <= 1e-4
+    assert float(invd.detach().max()) > 0.05
+    got = {"d_" + k: v.grad.cpu().numpy() for k, v in leaves.items()}
+    want = {"dL_d" + k: v.grad.numpy() for k, v in ref.items()}
+    Hh.assert_grads_close(got, want, keys=[(k, "dL_d" + k) for k in names], frac_tol=2e-2, l2_tol=1e-4)
+    for name, g, w in (("viewmatrix", V.grad, Vr.grad), ("projmatrix", PV.grad, PVr.grad), ("campos", C.grad, Cr.grad)):
+        g, w = g.cpu().double().numpy(), w.numpy()
+        assert np.abs(g - w).max() <= 3e-4 * np.abs(w).max(), (name, float(np.abs(g - w).max() / np.abs(w).max()))
