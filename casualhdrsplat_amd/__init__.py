@@ -6,8 +6,8 @@ casualhdrsplat_amd/libhdrsplat.so (hand-written HIP, gfx950) reached through the
 include/hdrsplat.h; importing the package does not load the library, calling it does, and a
 missing library is a hard error (no CPU fallback).
 """
-from .rasterizer import (GaussianRasterizationSettings, GaussianRasterizer, inspect_state,
+from .rasterizer import (DensifyStats, GaussianRasterizationSettings, GaussianRasterizer, inspect_state,
                          rasterize_gaussians)
 
-__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "inspect_state"]
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "DensifyStats", "rasterize_gaussians", "inspect_state"]
 __version__ = "0.1.0"

@@ -184,6 +184,11 @@ int hs_backward(const hs_bwd_args* a, void* hip_stream) {
         set_error("hs_backward: pose gradients need dL_dviewmatrices, dL_dprojmatrices and dL_dcamposes together");
         return HS_EINVAL;
     }
+    const int ndens = (a->densify_grad_accum != nullptr) + (a->densify_denom != nullptr) + (a->densify_max_radii != nullptr);
+    if (ndens != 0 && ndens != 3) {
+        set_error("hs_backward: densification statistics need grad_accum, denom and max_radii together");
+        return HS_EINVAL;
+    }
     if (a->dims.P == 0) return HS_OK;
     if (a->stages & HS_BWD_RENDER) {
         rc = launch_render_bwd(*a, L, s);

@@ -329,6 +329,7 @@ struct PreBwd {
     float* d_means3D; float* d_means2D; float* d_opac; float* d_shs; float* d_colors; float* d_scales;
     float* d_rots; float* d_cov;
     float* d_view_colors;  // [N][P][3] or null: masked colour gradient per instance (hs_sh_backward_views input)
+    float* dens_grad; float* dens_denom; int* dens_radii;  // densification statistics, updated in place, or null
     float* pose_partials;  // [blocks][N][kPoseVals] or null
 };
 
@@ -376,9 +377,11 @@ __global__ void __launch_bounds__(kPreBwdBlock) preprocess_bwd_kernel(PreBwd p) 
 #pragma unroll
     for (int k = 0; k < 6; ++k) s6[k] = valid ? p.cov3D[6 * (int64_t)g + k] : 0.f;
 
+    int max_radius = 0;  // over poses
     for (int pose = 0; pose < p.N; ++pose) {
         const int64_t idx = (int64_t)pose * p.P + g;
         const bool on = valid && p.radii_inst[idx] > 0;
+        if (on) max_radius = max(max_radius, p.radii_inst[idx]);
         float pg[POSE ? kPoseVals : 1];
         if constexpr (POSE) {
 #pragma unroll
@@ -602,6 +605,11 @@ __global__ void __launch_bounds__(kPreBwdBlock) preprocess_bwd_kernel(PreBwd p) 
 #pragma unroll
         for (int k = 0; k < 6; ++k) p.d_cov[6 * (int64_t)g + k] = gcov[k];
     }
+    if (valid && p.dens_grad && max_radius > 0) {
+        p.dens_grad[g] += sqrtf(gm2d[0] * gm2d[0] + gm2d[1] * gm2d[1]);
+        p.dens_denom[g] += 1.f;
+        p.dens_radii[g] = max(p.dens_radii[g], max_radius);
+    }
     if (valid) {
         if (p.d_means3D) { p.d_means3D[3 * g] = gm[0]; p.d_means3D[3 * g + 1] = gm[1]; p.d_means3D[3 * g + 2] = gm[2]; }
         if (p.d_means2D) { p.d_means2D[3 * g] = gm2d[0]; p.d_means2D[3 * g + 1] = gm2d[1]; p.d_means2D[3 * g + 2] = 0.f; }
@@ -754,6 +762,7 @@ int launch_preprocess_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t 
     p.d_colors = a.dL_dcolors_precomp; p.d_scales = a.dL_dscales; p.d_rots = a.dL_drotations;
     p.d_cov = a.dL_dcov3D_precomp;
     p.d_view_colors = a.colors_precomp ? nullptr : a.dL_dview_colors;
+    p.dens_grad = a.densify_grad_accum; p.dens_denom = a.densify_denom; p.dens_radii = a.densify_max_radii;
     const bool shg = p.d_shs != nullptr;
     const int grid = ceil_div(d.P, kPreBwdBlock);
     const int deg = a.colors_precomp ? 0 : d.sh_degree;

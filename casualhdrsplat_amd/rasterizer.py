@@ -101,6 +101,23 @@ class _State:
                  "pending", "fwd_args", "keep")
 
 
+class DensifyStats:
+    """Per-Gaussian statistics a 3DGS trainer keeps between densification rounds, updated inside
+    the backward kernel of every GaussianRasterizer call that was given this object: `grad_accum` += |means2D.grad.xy|,
+    `denom` += 1 and `max_radii` = max(max_radii, radii), for the Gaussians rasterized in that call."""
+
+    def __init__(self, P: int, device="cuda"):
+        self.grad_accum = torch.zeros(P, dtype=torch.float32, device=device)
+        self.denom = torch.zeros(P, dtype=torch.float32, device=device)
+        self.max_radii = torch.zeros(P, dtype=torch.int32, device=device)
+
+    def mean_grad(self) -> torch.Tensor:
+        return self.grad_accum / self.denom.clamp_min(1.0)
+
+    def reset(self) -> None:
+        self.grad_accum.zero_(); self.denom.zero_(); self.max_radii.zero_()
+
+
 _PINNED_POOL: list = []  # recycled page-locked int32[2] buffers (hipHostMalloc per step is slow)
 
 
@@ -222,7 +239,7 @@ class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                 exposure, crf_table, viewmats, projmats, camposes, raster_settings, capacity, return_alpha=False,
-                deferred=None, return_invdepth=False):
+                deferred=None, return_invdepth=False, densify=None):
         dev = means3D.device
         m3 = _f32c(means3D, dev)
         op = _f32c(opacities, dev)
@@ -237,6 +254,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.st = st
         ctx.set_materialize_grads(False)  # an unused output (e.g. the radiance image) must not cost a zero image
         ctx.deferred = deferred if shs is not None else None
+        ctx.densify = densify
         ctx.exp_shape = None if exposure is None else tuple(exposure.shape)
         ctx.pose_shapes = (tuple(viewmats.shape), tuple(projmats.shape), tuple(camposes.shape))
         ctx.has = (shs is not None, cp is not None, sc is not None, cv is not None, exposure is not None,
@@ -274,7 +292,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         want_pose = any(ctx.needs_input_grad[10:13])
         with _on_device(dev):
             g = _launch_backward(st, saved, gcol, ghdr, L.HS_BWD_ALL, want_pose, galpha,
-                                 defer_sh=ctx.deferred is not None, ginvd=ginvd)
+                                 defer_sh=ctx.deferred is not None, ginvd=ginvd, densify=ctx.densify)
         if ctx.deferred is not None:
             # view-parallel exchange: hand the per-view colour gradients to distributed.exchange_view_gradients
             ctx.deferred.update(view_colors=g["view_colors"], camposes=st.camposes, means3D=saved[0],
@@ -292,11 +310,11 @@ class _RasterizeGaussians(torch.autograd.Function):
                 g["crf_table"] if has_crf else None,
                 g["viewmatrices"].reshape(ctx.pose_shapes[0]) if want_pose else None,
                 g["projmatrices"].reshape(ctx.pose_shapes[1]) if want_pose else None,
-                g["camposes"].reshape(ctx.pose_shapes[2]) if want_pose else None, None, None, None, None, None)
+                g["camposes"].reshape(ctx.pose_shapes[2]) if want_pose else None, None, None, None, None, None, None)
 
 
 def _launch_backward(st: "_State", saved, gcol, ghdr, stages: int, want_pose: bool = False, galpha=None,
-                     defer_sh: bool = False, ginvd=None) -> dict:
+                     defer_sh: bool = False, ginvd=None, densify=None) -> dict:
     """Enqueue hs_backward.  All per-Gaussian gradients are carved out of ONE flat fp32 buffer (the
     layout casualhdrsplat_amd.distributed all-reduces in a single RCCL call): [means3D | means2D |
     opacities | sh | colors | scales | rotations | cov3D | exposure | crf_table]."""
@@ -354,6 +372,11 @@ def _launch_backward(st: "_State", saved, gcol, ghdr, stages: int, want_pose: bo
                                                               _ptr(g["camposes"]))
     a.dL_dview_colors = _ptr(g["view_colors"])
     a.dL_dout_invdepth = _ptr(ginvd)
+    if densify is not None:
+        if densify.grad_accum.shape[0] != P or densify.grad_accum.device != dev:
+            raise ValueError("DensifyStats was created for a different number of Gaussians or another device")
+        a.densify_grad_accum, a.densify_denom = densify.grad_accum.data_ptr(), densify.denom.data_ptr()
+        a.densify_max_radii = densify.max_radii.data_ptr()
     if P > 0:
         L.check(lib.hs_backward(C.byref(a), _stream()), "hs_backward")
     else:
@@ -404,7 +427,8 @@ def sh_backward_views(means3D: torch.Tensor, camposes: torch.Tensor, view_colors
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                        raster_settings, capacity=None, return_alpha=False, deferred=None, return_invdepth=False):
+                        raster_settings, capacity=None, return_alpha=False, deferred=None, return_invdepth=False,
+                        densify=None):
     rs = raster_settings
     multi = rs.viewmatrices is not None
     # the camera tensors travel as autograd inputs so a trajectory model upstream receives pose gradients
@@ -413,7 +437,7 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
                                      rs.viewmatrices if multi else rs.viewmatrix,
                                      rs.projmatrices if multi else rs.projmatrix,
                                      rs.camposes if multi else rs.campos, rs, capacity, return_alpha, deferred,
-                                     return_invdepth)
+                                     return_invdepth, densify)
 
 
 class GaussianRasterizer(nn.Module):
@@ -425,8 +449,10 @@ class GaussianRasterizer(nn.Module):
     """
 
     def __init__(self, raster_settings: GaussianRasterizationSettings, capacity: Optional[int] = None,
-                 return_alpha: bool = False, defer_sh_grad: bool = False, return_invdepth: bool = False):
+                 return_alpha: bool = False, defer_sh_grad: bool = False, return_invdepth: bool = False,
+                 densify_stats: Optional[DensifyStats] = None):
         super().__init__()
+        self.densify_stats = densify_stats  # extension: updated in place by every backward (see DensifyStats)
         # extension (newer published rasterizers return (color, radii, invdepths)): append the expected inverse
         # depth image [H,W] = sum_i alpha_i T_i / z_i to the outputs, differentiable
         self.return_invdepth = return_invdepth
@@ -466,7 +492,7 @@ class GaussianRasterizer(nn.Module):
         self.deferred = {} if self.defer_sh_grad else None
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
                                    cov3D_precomp, rs, self.capacity, self.return_alpha, self.deferred,
-                                   self.return_invdepth)
+                                   self.return_invdepth, self.densify_stats)
 
 
 def inspect_state(out_tensor: torch.Tensor) -> dict:

@@ -166,6 +166,13 @@ typedef struct hs_bwd_args {
      * gradient is formed later from the views of ALL ranks by hs_sh_backward_views */
     float* dL_dview_colors;
     const float* dL_dout_invdepth; /* [H,W] or NULL: gradient w.r.t. the pose-averaged inverse-depth image */
+    /* densification statistics, all three or none; updated IN PLACE for every Gaussian that was
+     * rasterized in at least one pose: grad_accum += |dL/dmean2D.xy| (the NDC-scaled gradient returned in
+     * dL_dmeans2D), denom += 1, max_radii = max(max_radii, radius) -- what a 3DGS trainer keeps between
+     * densification rounds, without re-reading the gradient tensors */
+    float* densify_grad_accum;    /* [P] */
+    float* densify_denom;         /* [P] */
+    int32_t* densify_max_radii;   /* [P] */
 } hs_bwd_args;
 
 /* Byte offsets of the arrays carved out of the three state workspaces, for tests, profilers and

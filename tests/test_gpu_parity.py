@@ -569,3 +569,38 @@ def test_inverse_depth_output_and_antialiasing_vs_autograd(antialiasing, n_poses
     for name, g, w in (("viewmatrix", V.grad, Vr.grad), ("projmatrix", PV.grad, PVr.grad), ("campos", C.grad, Cr.grad)):
         g, w = g.cpu().double().numpy(), w.numpy()
         assert np.abs(g - w).max() <= 3e-4 * np.abs(w).max(), (name, float(np.abs(g - w).max() / np.abs(w).max()))
+
+
+def test_densification_statistics_in_kernel(tmp_path):
+    """grad_accum / denom / max_radii are updated inside the backward exactly as a trainer would
+    from means2D.grad and radii; the scene itself goes through the PLY exchange layout first."""
+    from casualhdrsplat_amd import DensifyStats, GaussianRasterizer
+    from casualhdrsplat_amd import scene_io as IO
+    P, W, H, deg = 4000, 160, 120, 2
+    sc = S.make_scene(P, W, H, deg, seed=8)
+    sc.means3D[:50, 2] = -5.0                                   # behind the camera: never rasterized
+    cloud = IO.GaussianCloud(sc.means3D, sc.shs, torch.logit(sc.opacities.clamp(1e-4, 1 - 1e-4)), torch.log(sc.scales),
+                             sc.rotations * 1.7)
+    IO.save_ply(str(tmp_path / "s.ply"), cloud)
+    act = IO.load_ply(str(tmp_path / "s.ply")).activated("cuda")
+    assert torch.allclose(act["scales"].cpu(), sc.scales, rtol=1e-6) and torch.allclose(act["rotations"].cpu(), sc.rotations, atol=1e-6)
+    stats = DensifyStats(P)
+    cams = [None, S.blur_poses(W, H, 3, step=0.05)]
+    want_g, want_n, want_r = torch.zeros(P), torch.zeros(P), torch.zeros(P, dtype=torch.int32)
+    for cameras in cams:
+        rs, _, _ = Hh.settings_from_scene(sc, "cuda", cameras)
+        m2 = torch.zeros(P, 3, device="cuda", requires_grad=True)
+        leaves = {k: v.clone().requires_grad_(True) for k, v in act.items()}
+        out = GaussianRasterizer(rs, densify_stats=stats)(leaves["means3D"], m2, leaves["opacities"], shs=leaves["shs"],
+                                                          scales=leaves["scales"], rotations=leaves["rotations"])
+        (out[0] * sc.dL_dimage.cuda()).sum().backward()
+        vis = (out[1] > 0).cpu()
+        want_g += torch.where(vis, m2.grad[:, :2].norm(dim=1).cpu(), torch.zeros(P))
+        want_n += vis.float()
+        want_r = torch.maximum(want_r, out[1].cpu())
+    assert torch.equal(stats.denom.cpu(), want_n) and torch.equal(stats.max_radii.cpu(), want_r)
+    assert torch.allclose(stats.grad_accum.cpu(), want_g, rtol=1e-5, atol=1e-12)
+    assert float(want_n[:50].sum()) == 0 and float(want_n.max()) == 2 and float(want_g.max()) > 0
+    assert torch.allclose(stats.mean_grad().cpu(), want_g / want_n.clamp_min(1), rtol=1e-5, atol=1e-12)
+    stats.reset()
+    assert float(stats.grad_accum.abs().sum()) == 0 and int(stats.max_radii.max()) == 0

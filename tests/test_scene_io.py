@@ -1,0 +1,145 @@
+"""Scene I/O: Gaussian-cloud PLY in the exchange layout, COLMAP sparse models, SfM initialisation.
+CPU only."""
+import math
+import struct
+
+import numpy as np
+import pytest
+import torch
+
+from casualhdrsplat_amd import scene_io as IO
+from casualhdrsplat_amd import synthetic as S
+
+
+def _cloud(P=37, deg=3, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    M = (deg + 1) ** 2
+    return IO.GaussianCloud(torch.randn(P, 3, generator=g), torch.randn(P, M, 3, generator=g),
+                            torch.randn(P, 1, generator=g), torch.randn(P, 3, generator=g), torch.randn(P, 4, generator=g))
+
+
+@pytest.mark.parametrize("deg", [0, 1, 3])
+def test_ply_round_trip_and_layout(tmp_path, deg):
+    c = _cloud(deg=deg)
+    path = str(tmp_path / "cloud.ply")
+    IO.save_ply(path, c)
+    raw = open(path, "rb").read()
+    header, body = raw.split(b"end_header\n", 1)
+    lines = header.decode().split("\n")
+    assert lines[0] == "ply" and lines[1] == "format binary_little_endian 1.0" and lines[2] == "element vertex 37"
+    props = [ln.split()[-1] for ln in lines if ln.startswith("property float")]
+    M = (deg + 1) ** 2
+    assert props[:9] == ["x", "y", "z", "nx", "ny", "nz", "f_dc_0", "f_dc_1", "f_dc_2"]
+    assert props[9:9 + 3 * (M - 1)] == [f"f_rest_{i}" for i in range(3 * (M - 1))]
+    assert props[-8:] == ["opacity", "scale_0", "scale_1", "scale_2", "rot_0", "rot_1", "rot_2", "rot_3"]
+    assert len(body) == 37 * 4 * len(props)
+    row0 = np.frombuffer(body, "<f4", count=len(props))
+    assert row0[6] == c.shs[0, 0, 0] and row0[7] == c.shs[0, 0, 1]          # f_dc_c = DC of channel c
+    if M > 1:                                                               # f_rest is channel-major
+        assert row0[9] == c.shs[0, 1, 0] and row0[9 + (M - 1)] == c.shs[0, 1, 1] and row0[10] == c.shs[0, 2, 0]
+    back = IO.load_ply(path)
+    for a, b in zip((c.means3D, c.shs, c.opacity_logit, c.log_scales, c.rotations),
+                    (back.means3D, back.shs, back.opacity_logit, back.log_scales, back.rotations)):
+        assert torch.equal(a, b)
+    assert back.sh_degree == deg
+    act = back.activated()
+    assert torch.allclose(act["rotations"].norm(dim=1), torch.ones(37)) and (act["opacities"] > 0).all()
+    assert torch.allclose(act["scales"], torch.exp(c.log_scales))
+
+
+def test_ply_ascii_and_errors(tmp_path):
+    c = _cloud(P=3, deg=0)
+    names = IO._property_names(1)
+    rows = torch.cat([c.means3D, torch.zeros(3, 3), c.shs[:, 0, :], c.opacity_logit, c.log_scales, c.rotations], dim=1)
+    p = tmp_path / "a.ply"
+    p.write_text("ply\nformat ascii 1.0\ncomment hello\nelement vertex 3\n" + "".join(f"property float {n}\n" for n in names) +
+                 "end_header\n" + "\n".join(" ".join(repr(float(v)) for v in r) for r in rows) + "\n")
+    back = IO.load_ply(str(p))
+    assert torch.allclose(back.means3D, c.means3D) and torch.allclose(back.rotations, c.rotations)
+    bad = tmp_path / "b.ply"
+    bad.write_text("ply\nformat ascii 1.0\nelement vertex 1\nproperty float x\nend_header\n0\n")
+    with pytest.raises(ValueError):
+        IO.load_ply(str(bad))
+    notply = tmp_path / "c.ply"
+    notply.write_text("hello\n")
+    with pytest.raises(ValueError):
+        IO.load_ply(str(notply))
+
+
+def _write_colmap_binary(d, pts, cams, ims):
+    with open(d / "points3D.bin", "wb") as f:
+        f.write(struct.pack("<Q", len(pts)))
+        for i, (xyz, rgb, err, track) in enumerate(pts):
+            f.write(struct.pack("<QdddBBBdQ", i + 1, *xyz, *rgb, err, len(track)))
+            for im, p2 in track:
+                f.write(struct.pack("<ii", im, p2))
+    with open(d / "cameras.bin", "wb") as f:
+        f.write(struct.pack("<Q", len(cams)))
+        for cid, model_id, w, h, params in cams:
+            f.write(struct.pack("<iiQQ", cid, model_id, w, h) + struct.pack("<" + "d" * len(params), *params))
+    with open(d / "images.bin", "wb") as f:
+        f.write(struct.pack("<Q", len(ims)))
+        for iid, q, t, cid, name, npts in ims:
+            f.write(struct.pack("<idddddddi", iid, *q, *t, cid) + name.encode() + b"\x00" + struct.pack("<Q", npts))
+            for k in range(npts):
+                f.write(struct.pack("<ddq", 1.0 * k, 2.0 * k, -1))
+
+
+def test_colmap_text_and_binary_agree(tmp_path):
+    pts = [((0.5, -1.0, 4.0), (255, 128, 0), 0.7, [(1, 5), (2, 9)]), ((1.5, 2.0, 6.0), (10, 20, 30), 1.2, [])]
+    cams = [(1, 1, 640, 480, (500.0, 510.0, 320.0, 240.0)), (2, 0, 320, 240, (250.0, 160.0, 120.0))]
+    q = np.array([0.9, 0.1, -0.2, 0.3]); q = q / np.linalg.norm(q)
+    ims = [(1, tuple(q), (0.1, -0.2, 0.3), 1, "frame 001.png", 2), (7, (1.0, 0.0, 0.0, 0.0), (0.0, 0.0, 0.0), 2, "b.jpg", 0)]
+    _write_colmap_binary(tmp_path, pts, cams, ims)
+    (tmp_path / "points3D.txt").write_text("# header\n" + "".join(
+        f"{i + 1} {x[0]} {x[1]} {x[2]} {c[0]} {c[1]} {c[2]} {e} " + " ".join(f"{a} {b}" for a, b in tr) + "\n"
+        for i, (x, c, e, tr) in enumerate(pts)))
+    (tmp_path / "cameras.txt").write_text("# cams\n1 PINHOLE 640 480 500.0 510.0 320.0 240.0\n2 SIMPLE_PINHOLE 320 240 250.0 160.0 120.0\n")
+    (tmp_path / "images.txt").write_text(
+        "# ims\n" + "1 " + " ".join(repr(float(v)) for v in q) + " 0.1 -0.2 0.3 1 frame 001.png\n0.0 0.0 -1 1.0 2.0 -1\n"
+        + "7 1.0 0.0 0.0 0.0 0.0 0.0 0.0 2 b.jpg\n\n")
+    for ext in (".bin", ".txt"):
+        xyz, rgb, err = IO.read_points3D(str(tmp_path / ("points3D" + ext)))
+        assert xyz.shape == (2, 3) and np.allclose(xyz[1], [1.5, 2.0, 6.0]) and rgb.dtype == np.uint8
+        assert list(rgb[0]) == [255, 128, 0] and np.allclose(err, [0.7, 1.2])
+        cs = IO.read_cameras(str(tmp_path / ("cameras" + ext)))
+        assert cs[1].model == "PINHOLE" and cs[1].focal() == (500.0, 510.0) and cs[2].focal() == (250.0, 250.0)
+        assert (cs[2].width, cs[2].height) == (320, 240)
+        im = IO.read_images(str(tmp_path / ("images" + ext)))
+        assert set(im) == {1, 7} and im[1].name == "frame 001.png" and im[7].camera_id == 2
+        assert np.allclose(im[1].qvec, q) and np.allclose(im[1].tvec, [0.1, -0.2, 0.3])
+
+
+def test_colmap_view_projects_like_the_synthetic_camera():
+    """The view built from a COLMAP pose puts a world point on the pixel the pinhole model predicts."""
+    q = np.array([0.95, 0.05, -0.1, 0.02]); q = q / np.linalg.norm(q)
+    im = IO.ColmapImage(1, q, np.array([0.2, -0.1, 0.5]), 1, "x")
+    cam = IO.ColmapCamera(1, "PINHOLE", 640, 480, np.array([520.0, 500.0, 320.0, 240.0]))
+    V, PV, campos, tx, ty = IO.colmap_view(im, cam)
+    R = IO.qvec_to_rotmat(q)
+    assert np.allclose(R @ R.T, np.eye(3), atol=1e-12)
+    X = np.array([0.3, 0.4, 5.0])
+    xc = R @ X + im.tvec
+    hom = np.append(X, 1.0) @ PV.double().numpy()          # row-vector convention
+    ndc = hom[:2] / hom[3]
+    px = ((ndc[0] + 1) * 640 - 1) * 0.5
+    py = ((ndc[1] + 1) * 480 - 1) * 0.5
+    assert abs(px - (520.0 * xc[0] / xc[2] + 319.5)) < 1e-3 and abs(py - (500.0 * xc[1] / xc[2] + 239.5)) < 1e-3
+    assert np.allclose((np.append(X, 1.0) @ V.double().numpy())[:3], xc, atol=1e-6)
+    assert np.allclose(R @ campos.double().numpy() + im.tvec, 0, atol=1e-6)
+    assert math.isclose(tx, 640 / (2 * 520.0)) and math.isclose(ty, 480 / (2 * 500.0))
+
+
+def test_init_from_points_matches_the_published_rule():
+    g = np.stack(np.meshgrid(np.arange(4.0), np.arange(4.0), np.arange(4.0), indexing="ij"), -1).reshape(-1, 3) * 0.5
+    rgb = np.full((64, 3), 255, np.uint8)
+    c = IO.init_from_points(g, rgb, sh_degree=2)
+    assert c.shs.shape == (64, 9, 3) and torch.count_nonzero(c.shs[:, 1:]) == 0
+    assert torch.allclose(c.shs[:, 0], torch.full((64, 3), 0.5 / IO.SH_C0))
+    # an interior point of a 0.5-spaced grid: three nearest neighbours at 0.5 -> scale exp(log 0.5)
+    interior = 1 * 16 + 1 * 4 + 1
+    assert torch.allclose(torch.exp(c.log_scales[interior]), torch.full((3,), 0.5), atol=1e-6)
+    assert torch.allclose(torch.sigmoid(c.opacity_logit), torch.full((64, 1), 0.1))
+    assert torch.equal(c.rotations[:, 0], torch.ones(64)) and torch.count_nonzero(c.rotations[:, 1:]) == 0
+    act = c.activated()
+    assert set(act) == {"means3D", "shs", "opacities", "scales", "rotations"}
