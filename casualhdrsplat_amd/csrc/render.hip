@@ -202,17 +202,22 @@ __device__ __forceinline__ float hs_exp2(float x) { return __builtin_amdgcn_exp2
 struct PixF {
     float T, C0, C1, C2, D;
     uint32_t last;
-    bool done;
 };
-// One compositing step (branch-free: predication keeps the scalar unit out of the inner loop).
+// LLVM floating-point predicates for __builtin_amdgcn_fcmpf (returns the 64-bit lane mask of the comparison)
+constexpr int kFcmpOGE = 3, kFcmpOLE = 5;
+// One compositing step.  The per-pixel "finished" flags of the wave live in one scalar register pair (`done`), the
+// skip / terminate decisions are three vector compares plus scalar mask algebra, and the selects take the mask
+// back through inverse_ballot: no vector instruction is spent on flag bookkeeping (the loop is VALU-issue bound).
 // DEPTH: also accumulate the expected inverse depth sum alpha T / z.
 template <bool DEPTH>
-__device__ __forceinline__ void blend_fwd(PixF& s, float pw, float alpha, float r, float g, float b, float invd,
-                                          uint32_t idx1) {
-    const bool valid = !s.done && pw <= 0.f && alpha >= kAlphaMin;
+__device__ __forceinline__ void blend_fwd(PixF& s, uint64_t& done, float pw, float alpha, float r, float g, float b,
+                                          float invd, uint32_t idx1) {
+    const uint64_t valid = ~done & __builtin_amdgcn_fcmpf(pw, 0.f, kFcmpOLE) &
+                           __builtin_amdgcn_fcmpf(alpha, kAlphaMin, kFcmpOGE);
     const float test_T = s.T * (1.f - alpha);
-    const bool upd = valid && !(test_T < kTmin);
-    s.done = s.done || (valid && test_T < kTmin);
+    const uint64_t cont = valid & __builtin_amdgcn_fcmpf(test_T, kTmin, kFcmpOGE);
+    done |= valid ^ cont;  // valid, but the transmittance would drop below 1e-4: the pixel terminates here
+    const bool upd = __builtin_amdgcn_inverse_ballot_w64(cont);
     const float w = upd ? alpha * s.T : 0.f;
     s.C0 += r * w; s.C1 += g * w; s.C2 += b * w;
     if constexpr (DEPTH) s.D += invd * w;
@@ -273,7 +278,8 @@ __global__ void __launch_bounds__(kBatch) render_fwd_kernel(RenderFwd p) {
     PixF s0, s1;
     s0.T = s1.T = 1.f; s0.C0 = s0.C1 = s0.C2 = s1.C0 = s1.C1 = s1.C2 = 0.f; s0.last = s1.last = 0;
     s0.D = s1.D = 0.f;
-    s0.done = !in0; s1.done = !in1;
+    // lane masks of finished pixels (all 64 lanes of both waves run the whole kernel: exec is full)
+    uint64_t done0 = __builtin_amdgcn_ballot_w64(!in0), done1 = __builtin_amdgcn_ballot_w64(!in1);
 
     // software pipeline of the staging gather: registers hold the NEXT batch while the current one is processed
     float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
@@ -286,7 +292,7 @@ __global__ void __launch_bounds__(kBatch) render_fwd_kernel(RenderFwd p) {
     }
     int it = 0;
     for (int base = 0; base < n; base += KB, ++it) {
-        const bool wave_alive = __ballot(!(s0.done && s1.done)) != 0ull;
+        const bool wave_alive = (done0 & done1) != ~0ull;
         if (lane == 0) s_alive[it & 1][wave] = wave_alive;
         __syncthreads();  // also: everyone finished reading the previous batch
         if (!(s_alive[it & 1][0] | s_alive[it & 1][1])) break;
@@ -327,9 +333,9 @@ __global__ void __launch_bounds__(kBatch) render_fwd_kernel(RenderFwd p) {
             const float al1 = fminf(kAlphaMax, b.y * hs_exp2(pw.y));
             const uint32_t idx1 = (uint32_t)(base + j + 1);
             const float invd = DEPTH ? s_id[j] : 0.f;
-            blend_fwd<DEPTH>(s0, pw.x, al0, b.z, b.w, cb, invd, idx1);
-            blend_fwd<DEPTH>(s1, pw.y, al1, b.z, b.w, cb, invd, idx1);
-            if (__ballot(!(s0.done && s1.done)) == 0ull) break;
+            blend_fwd<DEPTH>(s0, done0, pw.x, al0, b.z, b.w, cb, invd, idx1);
+            blend_fwd<DEPTH>(s1, done1, pw.y, al1, b.z, b.w, cb, invd, idx1);
+            if ((done0 & done1) == ~0ull) break;
         }
     }
     if (in0) write_pixel_fwd(p, s0, pose, px, py0);
@@ -458,7 +464,9 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
     __shared__ float4 s_a[KB];
     __shared__ float4 s_b[KB];
     __shared__ float4 s_c[KB];
-    __shared__ float s_acc[2][NV][KB];      // per-wave planes of reduced partials, summed in fixed order at write-out
+    // per-wave planes of reduced partials, summed in fixed order at write-out; the odd plane stride keeps the nine
+    // lanes that store one entry's totals on nine different LDS banks
+    __shared__ float s_acc[2][NV][KB + 1];
     __shared__ uint16_t s_list[2][KB];      // per-wave compacted list of touched staged entries
     __shared__ uint64_t s_wrote[2][KB / 64];
     __shared__ uint32_t s_max[2];
