@@ -196,6 +196,16 @@ struct RenderFwd {
 
 constexpr int kBatch = 128;  // staged entries per trip = threads per workgroup
 
+// Workgroups are dealt to the 8 XCDs round-robin by blockIdx, and each XCD has its own L2.  Mapping block b to
+// virtual tile  start(b % 8) + b / 8  gives every XCD one contiguous band of tiles, so the tiles an XCD works on at
+// the same time are neighbours on screen and the records of the Gaussians they share are gathered through one L2.
+__device__ __forceinline__ int xcd_band_tile(int b, int nb) {
+    constexpr int kXcd = 8;
+    const int x = b % kXcd, k = b / kXcd;
+    const int per = nb / kXcd, rem = nb % kXcd;
+    return x * per + min(x, rem) + k;
+}
+
 __device__ __forceinline__ float hs_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 // Per-pixel compositing state of the forward (two of these per lane).
@@ -260,7 +270,7 @@ __global__ void __launch_bounds__(kBatch) render_fwd_kernel(RenderFwd p) {
     __shared__ uint16_t s_list[2][KB];  // per-wave compacted list of staged entries that can touch its half tile
     __shared__ int s_alive[2][2];
 
-    const int vt = blockIdx.x;  // virtual tile = pose * ntiles + tile
+    const int vt = xcd_band_tile(blockIdx.x, gridDim.x);  // virtual tile = pose * ntiles + tile
     const int pose = vt / p.ntiles;
     const int tile = vt - pose * p.ntiles;
     const int tx = tile % p.gx, ty = tile / p.gx;
@@ -471,7 +481,7 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
     __shared__ uint64_t s_wrote[2][KB / 64];
     __shared__ uint32_t s_max[2];
 
-    const int vt = blockIdx.x;
+    const int vt = xcd_band_tile(blockIdx.x, gridDim.x);
     const int pose = vt / p.ntiles;
     const int tile = vt - pose * p.ntiles;
     const int tx = tile % p.gx, ty = tile / p.gx;
