@@ -71,7 +71,7 @@ static int plan(const hs_dims& d, hs_sizes* sz, hs_layout* L) {
     o = 0;
     l.pair_grads = carve(d.capacity * kPairFloats * 4);
     l.crf_partials = carve((int64_t)crf_partial_floats(4096) * 4);
-    l.inst_grads = carve(I * 12 * 4);
+    l.inst_grads = carve(I * kInstFloats * 4);
     l.pose_partials = carve(pose_partial_floats(d.P, d.n_poses) * 4);
     sz->bwd_bytes = o;
     if (L) *L = l;

@@ -350,7 +350,7 @@ __global__ void __launch_bounds__(256) emit_pairs_kernel(int64_t I, int P, int g
         rc = srect[i];
         beg = end - (rc.y & 0xFFFFu) * (rc.y >> 16);
         inst = inst_sorted[i];
-        if (end > beg) reinterpret_cast<float*>(rec + 3 * (int64_t)inst + 2)[3] = __uint_as_float(beg);
+        if (end > beg) reinterpret_cast<float*>(rec + kRecF4 * (int64_t)inst + 2)[3] = __uint_as_float(beg);
     }
     // lanes past the end of the array inherit the running end so the range stays monotone
     const uint32_t last_end = __shfl(end, 63 - __builtin_clzll(__ballot(i < I) | 1ull));

@@ -20,8 +20,14 @@ void set_error(const char* fmt, ...);
 #define HS_LAUNCH_CHECK() HS_HIP_CHECK(hipGetLastError())
 
 constexpr int kTile = HS_TILE;
-constexpr int kRecFloats = 12;   // per-instance render record: 3 x float4
-constexpr int kPairFloats = 12;  // per-(tile,instance) gradient record: 9 used, padded to 3 x float4
+// Gathered / scattered records occupy one aligned 64-byte memory sector each (kRecF4 float4): a 48-byte record at a
+// 48-byte stride straddles two sectors half of the time, which showed up as 2-3x the algorithmic HBM traffic.
+constexpr int kRecF4 = 4;                  // float4 per render-record slot (3 used)
+constexpr int kPairF4 = 4;                 // float4 per (tile,instance) gradient record slot (10 floats used)
+constexpr int kInstF4 = 4;                 // float4 per per-instance sum of the pair records
+constexpr int kRecFloats = 4 * kRecF4;
+constexpr int kPairFloats = 4 * kPairF4;
+constexpr int kInstFloats = 4 * kInstF4;
 constexpr int kSortItems = 16;   // keys per thread per radix block
 constexpr int kSortBlock = 256;
 constexpr int kSortTile = kSortItems * kSortBlock;  // 4096 keys per block

@@ -254,9 +254,10 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreFwd p) {
             }
         }
     }
-    p.rec[3 * idx + 0] = ra;
-    p.rec[3 * idx + 1] = rb;
-    p.rec[3 * idx + 2] = rc;
+    p.rec[kRecF4 * idx + 0] = ra;
+    p.rec[kRecF4 * idx + 1] = rb;
+    p.rec[kRecF4 * idx + 2] = rc;
+    p.rec[kRecF4 * idx + 3] = make_float4(0.f, 0.f, 0.f, 0.f);  // whole sector written: no partial-line write-back
     p.depth[idx] = depth;
     p.radii_inst[idx] = my_radius;
     p.tiles[idx] = ntiles;
@@ -296,10 +297,10 @@ __global__ void __launch_bounds__(256) pair_segsum_kernel(int64_t I, const uint3
     const uint32_t end = valid ? offs_sorted[i] : 0u;
     float r[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (uint32_t s = beg + q; s < end; s += 4) {
-        if (!pair_flags[s]) continue;  // never written this backward: skipping saves the 48-byte read (~55 % of pairs)
-        const float4 q0 = pair_grads[3 * (int64_t)s + 0];
-        const float4 q1 = pair_grads[3 * (int64_t)s + 1];
-        const float2 q2 = reinterpret_cast<const float2*>(pair_grads + 3 * (int64_t)s + 2)[0];
+        if (!pair_flags[s]) continue;  // never written this backward: skipping saves the record read (~55 % of pairs)
+        const float4 q0 = pair_grads[kPairF4 * (int64_t)s + 0];
+        const float4 q1 = pair_grads[kPairF4 * (int64_t)s + 1];
+        const float2 q2 = reinterpret_cast<const float2*>(pair_grads + kPairF4 * (int64_t)s + 2)[0];
         r[0] += q0.x; r[1] += q0.y; r[2] += q0.z; r[3] += q0.w;
         r[4] += q1.x; r[5] += q1.y; r[6] += q1.z; r[7] += q1.w;
         r[8] += q2.x; r[9] += q2.y;
@@ -310,10 +311,11 @@ __global__ void __launch_bounds__(256) pair_segsum_kernel(int64_t I, const uint3
         r[k] += __shfl_xor(r[k], 2);
     }
     if (i < I && q == 0) {
-        float4* o = inst_grads + 3 * (int64_t)inst_sorted[i];
+        float4* o = inst_grads + kInstF4 * (int64_t)inst_sorted[i];
         o[0] = make_float4(r[0], r[1], r[2], r[3]);
         o[1] = make_float4(r[4], r[5], r[6], r[7]);
         o[2] = make_float4(r[8], r[9], 0.f, 0.f);
+        if constexpr (kInstF4 == 4) o[3] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
 
@@ -394,12 +396,12 @@ __global__ void __launch_bounds__(kPreBwdBlock) preprocess_bwd_kernel(PreBwd p) 
         // ---- this instance's summed pair records (pair_segsum_kernel) ----
         float r[9];
         {
-            const float4 q0 = p.inst_grads[3 * idx + 0], q1 = p.inst_grads[3 * idx + 1];
+            const float4 q0 = p.inst_grads[kInstF4 * idx + 0], q1 = p.inst_grads[kInstF4 * idx + 1];
             r[0] = q0.x; r[1] = q0.y; r[2] = q0.z; r[3] = q0.w; r[4] = q1.x; r[5] = q1.y; r[6] = q1.z; r[7] = q1.w;
-            r[8] = reinterpret_cast<const float*>(p.inst_grads + 3 * idx + 2)[0];
+            r[8] = reinterpret_cast<const float*>(p.inst_grads + kInstF4 * idx + 2)[0];
         }
         // r = {dmean2D.x, dmean2D.y, dconic A, B, C, dopacity, dcolor r,g,b}; r9 = d(inverse depth)
-        const float r9 = reinterpret_cast<const float*>(p.inst_grads + 3 * idx + 2)[1];
+        const float r9 = reinterpret_cast<const float*>(p.inst_grads + kInstF4 * idx + 2)[1];
         gm2d[0] += r[0]; gm2d[1] += r[1];
         if (!p.antialias) gop += r[5];
 

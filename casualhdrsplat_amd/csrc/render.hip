@@ -7,7 +7,7 @@
 //  * one 128-thread workgroup (two wave64) per 16x16 binning tile; each wave owns a 16x8 half tile and each lane
 //    TWO vertically adjacent pixels, so dx and every per-Gaussian term is shared by the pair and the rest is
 //    packed fp32 (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32);
-//  * the tile's sorted instance list is staged 128 entries at a time into LDS (one gather of a 48-byte record
+//  * the tile's sorted instance list is staged 128 entries at a time into LDS (one gather of a 64-byte-aligned record
 //    per thread, the next batch prefetched into registers), the conic pre-scaled by -0.5*log2(e) so the inner
 //    loop is  dx, dy -> two FMAs -> v_exp_f32;
 //  * before touching a batch each wave tests the staged Gaussians against its own half tile, one Gaussian per
@@ -16,7 +16,7 @@
 //  * backward: no global atomics.  Per (wave, Gaussian) nine partial sums are formed in-lane over the pixel
 //    pair, reduced across the 64 lanes with v_permlane32_swap / v_permlane16_swap halving steps plus DPP row
 //    reductions (~29 instructions for all nine), parked in a per-wave LDS plane, combined over the two waves
-//    in fixed order and written as ONE 48-byte record per (tile, instance) pair at the pair's
+//    in fixed order and written as ONE record (a 64-byte sector) per (tile, instance) pair at the pair's
 //    duplicateWithKeys slot; preprocess-backward then sums each instance's contiguous slots.  Gradients are
 //    bitwise reproducible run to run.
 //
@@ -296,7 +296,7 @@ __global__ void __launch_bounds__(kBatch) render_fwd_kernel(RenderFwd p) {
     float rcb = 0.f, rdepth = 1.f;
     if ((int)threadIdx.x < n) {
         const uint32_t id = p.point_list[range.x + threadIdx.x];
-        const float4* r = p.rec + 3 * (int64_t)id;
+        const float4* r = p.rec + kRecF4 * (int64_t)id;
         ra = r[0]; rb = r[1]; rcb = reinterpret_cast<const float*>(r + 2)[0];
         if constexpr (DEPTH) rdepth = reinterpret_cast<const float*>(r + 2)[1];
     }
@@ -314,7 +314,7 @@ __global__ void __launch_bounds__(kBatch) render_fwd_kernel(RenderFwd p) {
         }
         if (base + KB + (int)threadIdx.x < n) {
             const uint32_t id = p.point_list[range.x + base + KB + threadIdx.x];
-            const float4* r = p.rec + 3 * (int64_t)id;
+            const float4* r = p.rec + kRecF4 * (int64_t)id;
             ra = r[0]; rb = r[1]; rcb = reinterpret_cast<const float*>(r + 2)[0];
             if constexpr (DEPTH) rdepth = reinterpret_cast<const float*>(r + 2)[1];
         }
@@ -513,7 +513,7 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
         else if (lane == 4) red_slot = 8;
     }
     const int nb = (n_proc + KB - 1) / KB;
-    // only the instance id of the NEXT batch is prefetched (one register); its 48-byte record is gathered at the
+    // only the instance id of the NEXT batch is prefetched (one register); its record is gathered at the
     // top of the batch -- keeping the three float4 in registers across the replay loop costs a wave of occupancy
     uint32_t id_next = 0;
     if (nb > 0) {
@@ -525,7 +525,7 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
         const int cnt = min(KB, n_proc - base);
         __syncthreads();  // previous batch's write-out finished
         if ((int)threadIdx.x < cnt) {
-            const float4* r = p.rec + 3 * (int64_t)id_next;
+            const float4* r = p.rec + kRecF4 * (int64_t)id_next;
             float4 ra = r[0], rb = r[1];
             float4 rc = r[2];
             if constexpr (DEPTH) rc.y = 1.f / rc.y;  // depth -> inverse depth
@@ -623,10 +623,11 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
             const int rmaxx = min(p.gx, max(0, (int)((a.x + (float)rad + (float)(kTile - 1)) / (float)kTile)));
             const int64_t slot = (int64_t)off + (int64_t)(ty - rminy) * (rmaxx - rminx) + (tx - rminx);
             p.pair_flags[slot] = 1;
-            float4* o = p.pair_grads + 3 * slot;
+            float4* o = p.pair_grads + kPairF4 * slot;
             o[0] = make_float4(gmx, gmy, -0.5f * v[2], -v[3]);
             o[1] = make_float4(-0.5f * v[4], v[5], v[6], v[7]);
             o[2] = make_float4(v[8], v[9], 0.f, 0.f);
+            if constexpr (kPairF4 == 4) o[3] = make_float4(0.f, 0.f, 0.f, 0.f);  // the record fills its 64-byte sector
         }
     }
 }

@@ -510,7 +510,7 @@ def inspect_state(out_tensor: torch.Tensor) -> dict:
         nbytes = count * torch.empty((), dtype=dtype).element_size()
         return buf[off:off + nbytes].view(dtype)
 
-    rec = view(st.geom, lay.rec, I * 12, torch.float32).reshape(I, 12)
+    rec = view(st.geom, lay.rec, I * 16, torch.float32).reshape(I, 16)
     depths = view(st.geom, lay.depth, I, torch.float32)
     tile_sorted = view(st.binning, lay.keys_sorted, R, torch.int32).to(torch.int64) & 0xFFFFFFFF
     pl = view(st.binning, lay.point_list, R, torch.int32)
