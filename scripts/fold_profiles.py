@@ -1,0 +1,58 @@
+"""Turns gpurun_out/prof_final/ (scripts/collect_profiles.sh) into the tracked files of profiles/ (development aid).
+usage: python scripts/fold_profiles.py pmc|bench <round-tag>"""
+import collections, csv, glob, json, os, shutil, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC, DST = os.path.join(ROOT, "gpurun_out", "prof_final"), os.path.join(ROOT, "profiles")
+what, tag = sys.argv[1], sys.argv[2]
+
+
+def counters(sub):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(os.path.join(SRC, sub, "*", "*counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            name = r["Kernel_Name"].replace("hs::(anonymous namespace)::", "").split("(")[0].replace("void ", "")
+            agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in agg.items()}
+
+
+if what == "pmc":
+    fetch, write = counters("pmc_FETCH_SIZE"), counters("pmc_WRITE_SIZE")
+    rows = []
+    for k in sorted(set(fetch) | set(write)):
+        if "at::" in k or "rocclr" in k:
+            continue
+        f, w = fetch.get(k, {}).get("FETCH_SIZE", 0.0), write.get(k, {}).get("WRITE_SIZE", 0.0)
+        rows.append((k, f, w, int((2 * f + w) * 1024)))
+    with open(os.path.join(DST, f"{tag}_pmc_traffic_c3.csv"), "w") as o:
+        o.write("kernel,FETCH_SIZE_KB_raw_avg,WRITE_SIZE_KB_avg,hbm_bytes_per_launch(2*FETCH+WRITE)\n")
+        for r in rows:
+            o.write(f"{r[0]},{r[1]:.1f},{r[2]:.1f},{r[3]}\n")
+    d = {r[0]: r[3] for r in rows}
+    pick = lambda s: next(v for k, v in d.items() if k.startswith(s))
+    json.dump({"c3": {"render_bwd_kernel_hbm_bytes": pick("render_bwd_kernel"), "render_fwd_kernel_hbm_bytes": pick("render_fwd_kernel"),
+                      "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (KB units); hbm = (2*FETCH_SIZE + WRITE_SIZE)*1024, "
+                                "the gfx950 FETCH_SIZE half-count correction; per-launch average; counted at the L2-fabric interface (Infinity-Cache hits included)",
+                      "source": f"profiles/{tag}_pmc_traffic_c3.csv"}}, open(os.path.join(DST, "pmc_traffic.json"), "w"), indent=1)
+    with open(os.path.join(DST, f"{tag}_pmc_sq_c3.csv"), "w") as o:
+        o.write("kernel,counter,avg_per_launch\n")
+        for i in range(1, 5):
+            for k, cs in sorted(counters(f"pmc_sq{i}").items()):
+                if k.startswith("render_"):
+                    for c, v in sorted(cs.items()):
+                        o.write(f"{k},{c},{v:.4e}\n")
+    print(open(os.path.join(DST, "pmc_traffic.json")).read())
+else:
+    for cfg in ("c3", "c4", "c2"):
+        line = open(os.path.join(SRC, f"bench_{cfg}.json")).read().strip().splitlines()[-1]
+        json.loads(line)
+        open(os.path.join(DST, f"{tag}_bench_{cfg}.json"), "w").write(line + "\n")
+    line = open(os.path.join(SRC, "bench_2rank_gloo_one_gpu.json")).read().strip().splitlines()[-1]
+    json.loads(line)
+    open(os.path.join(DST, f"{tag}_bench_2rank_gloo_one_gpu.json"), "w").write(line + "\n")
+    st = sorted(glob.glob(os.path.join(SRC, "stats", "*", "*_kernel_stats.csv")))[-1]
+    shutil.copy(st, os.path.join(DST, f"{tag}_bench_c3_kernel_stats.csv"))
+    if os.path.exists(os.path.join(SRC, "valu_rate.txt")):
+        shutil.copy(os.path.join(SRC, "valu_rate.txt"), os.path.join(DST, f"{tag}_valu_rate.txt"))
+    for cfg in ("c3", "c4", "c2"):
+        d = json.loads(open(os.path.join(DST, f"{tag}_bench_{cfg}.json")).read())
+        print(cfg, round(d["value"], 1), d["unit"], round(d["ms_per_step"], 4), "ms", {k: d.get("roofline", {}).get(k) for k in ("frac", "avg_ms", "traffic")})
