@@ -467,6 +467,46 @@ __device__ __forceinline__ void step_bwd(PixB& s, bool act, float G, float alpha
     sw = o * dop;
 }
 
+// The two pixels of a lane as one packed state: every update below is a two-wide (v_pk_*) instruction where the
+// hardware has one, which halves the FMA count of the replay (the loop is VALU-issue bound; v_pk_fma_f32 issues
+// at the rate of one v_fma_f32).
+struct PairB {
+    f2 T, T_final, R0, R1, R2, dL0, dL1, dL2, bg_dot, Rd, dLd;
+};
+__device__ __forceinline__ f2 splat(float v) { f2 r = {v, v}; return r; }
+__device__ __forceinline__ PairB pack_pair(const PixB& a, const PixB& b) {
+    PairB s;
+    s.T = f2{a.T, b.T}; s.T_final = f2{a.T_final, b.T_final};
+    s.R0 = f2{a.R0, b.R0}; s.R1 = f2{a.R1, b.R1}; s.R2 = f2{a.R2, b.R2};
+    s.dL0 = f2{a.dL0, b.dL0}; s.dL1 = f2{a.dL1, b.dL1}; s.dL2 = f2{a.dL2, b.dL2};
+    s.bg_dot = f2{a.bg_dot, b.bg_dot}; s.Rd = f2{a.Rd, b.Rd}; s.dLd = f2{a.dLd, b.dLd};
+    return s;
+}
+// One back-to-front step for the pixel pair (see step_bwd for the algebra).
+template <bool DEPTH>
+__device__ __forceinline__ void step_bwd_pair(PairB& s, bool act0, bool act1, f2 G, f2 alpha, float o, float r, float g,
+                                              float b, float invd, f2& sw, f2& dop, f2& dch) {
+    const f2 ae = {act0 ? alpha.x : 0.f, act1 ? alpha.y : 0.f};
+    const f2 one_m = splat(1.f) - ae;
+    const f2 rcp = {__builtin_amdgcn_rcpf(one_m.x), __builtin_amdgcn_rcpf(one_m.y)};
+    s.T *= rcp;
+    dch = ae * s.T;
+    const f2 d0 = splat(r) - s.R0, d1 = splat(g) - s.R1, d2 = splat(b) - s.R2;
+    f2 dLa = (d0 * s.dL0 + d1 * s.dL1) + d2 * s.dL2;
+    if constexpr (DEPTH) {
+        const f2 dd = splat(invd) - s.Rd;
+        dLa += dd * s.dLd;
+        s.Rd += ae * dd;
+    }
+    dLa = dLa * s.T - (s.T_final * rcp) * s.bg_dot;
+    s.R0 += ae * d0;
+    s.R1 += ae * d1;
+    s.R2 += ae * d2;
+    const f2 gd = G * dLa;
+    dop = f2{act0 ? gd.x : 0.f, act1 ? gd.y : 0.f};  // select AFTER the product (G may be inf at a skipped pixel)
+    sw = splat(o) * dop;
+}
+
 template <bool DEPTH>
 __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
     constexpr int KB = kBatch;
@@ -498,6 +538,7 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
     PixB s0, s1;
     load_pixel_bwd(p, s0, in0, pose, px, py0);
     load_pixel_bwd(p, s1, in1, pose, px, py1);
+    PairB ps = pack_pair(s0, s1);
 
     const uint32_t wave_max = wave_max_u32(max(s0.last, s1.last));
     if (lane == 0) s_max[wave] = wave_max;
@@ -567,26 +608,28 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
                 HS_STAT_ADD(0, 1);
                 HS_STAT_ADD(2, __popcll(__ballot(act0)) + __popcll(__ballot(act1)));
                 if (__ballot(act0 || act1) == 0ull) { HS_STAT_ADD(1, 1); continue; }
-                float w0, w1, dop0, dop1, dch0, dch1;
-                step_bwd<DEPTH>(s0, act0, G0, al0, b.y, b.z, b.w, cb, invd, w0, dop0, dch0);
-                step_bwd<DEPTH>(s1, act1, G1, al1, b.y, b.z, b.w, cb, invd, w1, dop1, dch1);
+                f2 sw, dop, dch;
+                step_bwd_pair<DEPTH>(ps, act0, act1, f2{G0, G1}, f2{al0, al1}, b.y, b.z, b.w, cb, invd, sw, dop, dch);
                 // in-lane sums over the pixel pair (dx is shared):  S1 = sum w dx, S2 = sum w dy, S3 = sum w dx^2,
                 // S4 = sum w dx dy, S5 = sum w dy^2 ; the conic factors are applied once per entry at write-out
-                const float m0 = w0 * dy.x, m1 = w1 * dy.y;
+                const f2 m = sw * dy;
+                const f2 m2 = m * dy;
+                const f2 c0 = dch * ps.dL0, c1 = dch * ps.dL1, c2 = dch * ps.dL2;
                 float g[9];
-                g[0] = (w0 + w1) * dx;
-                g[1] = m0 + m1;
+                g[0] = (sw.x + sw.y) * dx;
+                g[1] = m.x + m.y;
                 g[2] = g[0] * dx;
                 g[3] = g[1] * dx;
-                g[4] = m0 * dy.x + m1 * dy.y;
-                g[5] = dop0 + dop1;
-                g[6] = dch0 * s0.dL0 + dch1 * s1.dL0;
-                g[7] = dch0 * s0.dL1 + dch1 * s1.dL1;
-                g[8] = dch0 * s0.dL2 + dch1 * s1.dL2;
+                g[4] = m2.x + m2.y;
+                g[5] = dop.x + dop.y;
+                g[6] = c0.x + c0.y;
+                g[7] = c1.x + c1.y;
+                g[8] = c2.x + c2.y;
                 const float tot = wave_reduce9(g);
                 if (red_slot >= 0) s_acc[wave][red_slot][j] = tot;  // 9 lanes, one LDS store
                 if constexpr (DEPTH) {
-                    const float gd = wave_sum_hi(dch0 * s0.dLd + dch1 * s1.dLd);
+                    const f2 cd = dch * ps.dLd;
+                    const float gd = wave_sum_hi(cd.x + cd.y);
                     if (lane == 63) s_acc[wave][9][j] = gd;
                 }
                 wrote[j >> 6] |= 1ull << (j & 63);
