@@ -69,39 +69,52 @@ __device__ __forceinline__ float halve16(float x, float y) {  // lane bit 4 (x -
     auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
-// In-row halving step on DPP bank masks: returns a register whose lanes with (lane & SHIFT) == 0 hold
-// x[l] + x[l + SHIFT] and whose other lanes hold y[l] + y[l - SHIFT] (SHIFT = 8 or 4 inside each 16-lane row).
-template <int SHIFT>
-__device__ __forceinline__ float halve_row(float x, float y) {
-    constexpr int lo_banks = SHIFT == 8 ? 0x3 : 0x5;  // banks (4-lane groups) whose lanes have the bit clear
-    constexpr int hi_banks = SHIFT == 8 ? 0xC : 0xA;
-    const float u = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(y), __float_as_int(x), 0x100 + SHIFT,
-                                                               0xF, lo_banks, false));  // row_shl: lane l <- x[l+SHIFT]
-    const float v = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(y), 0x110 + SHIFT,
-                                                               0xF, hi_banks, false));  // row_shr: lane l <- y[l-SHIFT]
-    return u + v;
+// In-row halving steps on DPP bank masks, as two bank-masked v_add_f32_dpp each (the compiler's DPP combiner only
+// folds full-mask moves, leaving mov+mov+mov+add).  halve_row8(x, y): lanes with (lane & 8) == 0 get x[l] + x[l+8],
+// the others y[l] + y[l-8].  A VALU write followed by a DPP read of the same register needs two wait states,
+// hence the s_nop 1 in front of every dependent DPP instruction (hipcc pads nothing inside asm).
+__device__ __forceinline__ float halve_row8(float x, float y) {
+    float z;
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %0, %2, %2 row_shl:8 row_mask:0xf bank_mask:0x3"
+        : "=&v"(z) : "v"(y), "v"(x));
+    return z;
+}
+// halve_row4(x, y) (quads 0,2: x over lane bit 2; quads 1,3: y over bit 2) followed by the two quad steps: every
+// lane of a quad ends with the quad total of the halved register.
+__device__ __forceinline__ float halve_row4_quad(float x, float y) {
+    float w;
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %0, %2, %2 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+        : "=&v"(w) : "v"(y), "v"(x));
+    return w;
 }
 
-// Reduces g[0..8] over the wave in ~26 instructions.  Halving steps keep the register count shrinking
+// Reduces g[0..8] over the wave in ~24 instructions.  Halving steps keep the register count shrinking
 // (9 -> 5 -> 3 -> 2 -> 1); the result is ONE register in which, for DPP row r = lane >> 4 (0..3):
 //   lanes r*16 + 0..3   hold the wave total of g[{0,2,1,3}[r]],
 //   lanes r*16 + 8..11  hold the wave total of g[{4,6,5,7}[r]],
-//   lanes 4..7 (row 0)  hold the wave total of g[8].
-__device__ __forceinline__ float wave_reduce9(const float* g) {
+//   lanes 4..7 (row 0)  hold the wave total of g[8],
+//   lanes 36..39 (row 2) hold the wave total of the optional tenth value g9 (it rides in the half of a register
+//   the nine leave empty).
+__device__ __forceinline__ float wave_reduce9(const float* g, float g9 = 0.f) {
     const float r0 = halve32(g[0], g[1]);
     const float r1 = halve32(g[2], g[3]);
     const float r2 = halve32(g[4], g[5]);
     const float r3 = halve32(g[6], g[7]);
-    const float r4 = halve32(g[8], 0.f);
+    const float r4 = halve32(g[8], g9);
     const float h0 = halve16(r0, r1);   // rows: g0, g2, g1, g3
     const float h1 = halve16(r2, r3);   // rows: g4, g6, g5, g7
-    float h2 = halve16(r4, r4);         // rows: g8, g8, 0, 0
-    const float z = halve_row<8>(h0, h1);          // lanes 0-7: h0 over bit 3, lanes 8-15: h1 over bit 3
+    float h2 = halve16(r4, r4);         // rows: g8, g8, g9, g9
+    const float z = halve_row8(h0, h1);             // lanes 0-7: h0 over bit 3, lanes 8-15: h1 over bit 3
     h2 += dpp<0x128>(h2);                           // row_ror:8 -> h2 over bit 3 in every lane
-    float w = halve_row<4>(z, h2);                  // quads 0,2: z over bit 2 ; quads 1,3: h2 over bit 2
-    w += dpp<0xB1>(w);                              // quad_perm [1,0,3,2]
-    w += dpp<0x4E>(w);                              // quad_perm [2,3,0,1]
-    return w;
+    return halve_row4_quad(z, h2);                  // quads 0,2: z ; quads 1,3: h2 ; summed over bits 2,1,0
 }
 
 // number of set bits of a wave-uniform 64-bit mask below this lane
@@ -552,6 +565,7 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
         if (sub == 0) red_slot = v0;
         else if (sub == 8) red_slot = 4 + v0;
         else if (lane == 4) red_slot = 8;
+        else if (DEPTH && lane == 36) red_slot = 9;
     }
     const int nb = (n_proc + KB - 1) / KB;
     // only the instance id of the NEXT batch is prefetched (one register); its record is gathered at the
@@ -625,13 +639,13 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
                 g[6] = c0.x + c0.y;
                 g[7] = c1.x + c1.y;
                 g[8] = c2.x + c2.y;
-                const float tot = wave_reduce9(g);
-                if (red_slot >= 0) s_acc[wave][red_slot][j] = tot;  // 9 lanes, one LDS store
+                float g9 = 0.f;
                 if constexpr (DEPTH) {
                     const f2 cd = dch * ps.dLd;
-                    const float gd = wave_sum_hi(cd.x + cd.y);
-                    if (lane == 63) s_acc[wave][9][j] = gd;
+                    g9 = cd.x + cd.y;
                 }
+                const float tot = wave_reduce9(g, g9);
+                if (red_slot >= 0) s_acc[wave][red_slot][j] = tot;  // 9 (10) lanes, one LDS store
                 wrote[j >> 6] |= 1ull << (j & 63);
             }
         }
