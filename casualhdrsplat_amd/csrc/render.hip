@@ -228,24 +228,37 @@ struct PixF {
 };
 // LLVM floating-point predicates for __builtin_amdgcn_fcmpf (returns the 64-bit lane mask of the comparison)
 constexpr int kFcmpOGE = 3, kFcmpOLE = 5;
-// One compositing step.  The per-pixel "finished" flags of the wave live in one scalar register pair (`done`), the
-// skip / terminate decisions are three vector compares plus scalar mask algebra, and the selects take the mask
-// back through inverse_ballot: no vector instruction is spent on flag bookkeeping (the loop is VALU-issue bound).
+// One compositing step for the two pixels of a lane (packed state: two-wide instructions where they exist).  The
+// per-pixel "finished" flags of the wave live in scalar register pairs (`done0/1`), the skip / terminate decisions
+// are three vector compares per pixel plus scalar mask algebra, and the selects take the masks back through
+// inverse_ballot: no vector instruction is spent on flag bookkeeping (the loop is VALU-issue bound).
 // DEPTH: also accumulate the expected inverse depth sum alpha T / z.
+struct PairF {
+    f2 T, C0, C1, C2, D;
+    uint32_t last0, last1;
+};
 template <bool DEPTH>
-__device__ __forceinline__ void blend_fwd(PixF& s, uint64_t& done, float pw, float alpha, float r, float g, float b,
-                                          float invd, uint32_t idx1) {
-    const uint64_t valid = ~done & __builtin_amdgcn_fcmpf(pw, 0.f, kFcmpOLE) &
-                           __builtin_amdgcn_fcmpf(alpha, kAlphaMin, kFcmpOGE);
-    const float test_T = s.T * (1.f - alpha);
-    const uint64_t cont = valid & __builtin_amdgcn_fcmpf(test_T, kTmin, kFcmpOGE);
-    done |= valid ^ cont;  // valid, but the transmittance would drop below 1e-4: the pixel terminates here
-    const bool upd = __builtin_amdgcn_inverse_ballot_w64(cont);
-    const float w = upd ? alpha * s.T : 0.f;
-    s.C0 += r * w; s.C1 += g * w; s.C2 += b * w;
-    if constexpr (DEPTH) s.D += invd * w;
-    s.T = upd ? test_T : s.T;
-    s.last = upd ? idx1 : s.last;
+__device__ __forceinline__ void blend_fwd_pair(PairF& s, uint64_t& done0, uint64_t& done1, f2 pw, f2 alpha, float r,
+                                               float g, float b, float invd, uint32_t idx1) {
+    const uint64_t valid0 = ~done0 & __builtin_amdgcn_fcmpf(pw.x, 0.f, kFcmpOLE) &
+                            __builtin_amdgcn_fcmpf(alpha.x, kAlphaMin, kFcmpOGE);
+    const uint64_t valid1 = ~done1 & __builtin_amdgcn_fcmpf(pw.y, 0.f, kFcmpOLE) &
+                            __builtin_amdgcn_fcmpf(alpha.y, kAlphaMin, kFcmpOGE);
+    const f2 one = {1.f, 1.f};
+    const f2 test_T = s.T * (one - alpha);
+    const uint64_t cont0 = valid0 & __builtin_amdgcn_fcmpf(test_T.x, kTmin, kFcmpOGE);
+    const uint64_t cont1 = valid1 & __builtin_amdgcn_fcmpf(test_T.y, kTmin, kFcmpOGE);
+    done0 |= valid0 ^ cont0;  // valid, but the transmittance would drop below 1e-4: the pixel terminates here
+    done1 |= valid1 ^ cont1;
+    const bool upd0 = __builtin_amdgcn_inverse_ballot_w64(cont0), upd1 = __builtin_amdgcn_inverse_ballot_w64(cont1);
+    const f2 aT = alpha * s.T;
+    const f2 w = {upd0 ? aT.x : 0.f, upd1 ? aT.y : 0.f};
+    const f2 rr = {r, r}, gg = {g, g}, bb = {b, b};
+    s.C0 += rr * w; s.C1 += gg * w; s.C2 += bb * w;
+    if constexpr (DEPTH) { const f2 dd = {invd, invd}; s.D += dd * w; }
+    s.T = f2{upd0 ? test_T.x : s.T.x, upd1 ? test_T.y : s.T.y};
+    s.last0 = upd0 ? idx1 : s.last0;
+    s.last1 = upd1 ? idx1 : s.last1;
 }
 
 __device__ __forceinline__ void write_pixel_fwd(const RenderFwd& p, const PixF& st, int pose, int px, int py) {
@@ -298,9 +311,10 @@ __global__ void __launch_bounds__(kBatch) render_fwd_kernel(RenderFwd p) {
     const uint2 range = p.ranges[vt];
     const int n = (int)(range.y - range.x);
 
-    PixF s0, s1;
-    s0.T = s1.T = 1.f; s0.C0 = s0.C1 = s0.C2 = s1.C0 = s1.C1 = s1.C2 = 0.f; s0.last = s1.last = 0;
-    s0.D = s1.D = 0.f;
+    PairF ps;
+    ps.T = f2{1.f, 1.f};
+    ps.C0 = ps.C1 = ps.C2 = ps.D = f2{0.f, 0.f};
+    ps.last0 = ps.last1 = 0;
     // lane masks of finished pixels (all 64 lanes of both waves run the whole kernel: exec is full)
     uint64_t done0 = __builtin_amdgcn_ballot_w64(!in0), done1 = __builtin_amdgcn_ballot_w64(!in1);
 
@@ -356,17 +370,19 @@ __global__ void __launch_bounds__(kBatch) render_fwd_kernel(RenderFwd p) {
             const float al1 = fminf(kAlphaMax, b.y * hs_exp2(pw.y));
             const uint32_t idx1 = (uint32_t)(base + j + 1);
             const float invd = DEPTH ? s_id[j] : 0.f;
-            blend_fwd<DEPTH>(s0, done0, pw.x, al0, b.z, b.w, cb, invd, idx1);
-            blend_fwd<DEPTH>(s1, done1, pw.y, al1, b.z, b.w, cb, invd, idx1);
+            blend_fwd_pair<DEPTH>(ps, done0, done1, pw, f2{al0, al1}, b.z, b.w, cb, invd, idx1);
             if ((done0 & done1) == ~0ull) break;
         }
     }
+    PixF s0, s1;
+    s0.T = ps.T.x; s0.C0 = ps.C0.x; s0.C1 = ps.C1.x; s0.C2 = ps.C2.x; s0.last = ps.last0;
+    s1.T = ps.T.y; s1.C0 = ps.C0.y; s1.C1 = ps.C1.y; s1.C2 = ps.C2.y; s1.last = ps.last1;
     if (in0) write_pixel_fwd(p, s0, pose, px, py0);
     if (in1) write_pixel_fwd(p, s1, pose, px, py1);
     if constexpr (DEPTH) {
         const int64_t HW = (int64_t)p.H * p.W;
-        if (in0) p.out_invdepth[(int64_t)pose * HW + (int64_t)py0 * p.W + px] = s0.D;
-        if (in1) p.out_invdepth[(int64_t)pose * HW + (int64_t)py1 * p.W + px] = s1.D;
+        if (in0) p.out_invdepth[(int64_t)pose * HW + (int64_t)py0 * p.W + px] = ps.D.x;
+        if (in1) p.out_invdepth[(int64_t)pose * HW + (int64_t)py1 * p.W + px] = ps.D.y;
     }
 }
 
