@@ -291,7 +291,7 @@ def main():
             "kernel": "render_bwd_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
             "algorithmic_bytes": bytes_bwd, "avg_ms": bwd_ms, "median_ms": bwd_med,
-            "note": "stage = 7 MB pair-flag memset + render_bwd_kernel; the kernel is VALU-issue bound (DESIGN.md 4), not HBM bound",
+            "note": "the kernel is VALU-issue bound (DESIGN.md 4, profiles/README.md), not HBM bound; traffic = L2-fabric bytes from profiles/pmc_traffic.json",
             "fwd_bwd": {"kernels": "render_fwd_kernel + render_bwd_kernel", "algorithmic_bytes": bytes_fwd + bytes_bwd,
                         "avg_ms": fwd_ms + bwd_ms,
                         "achieved": (bytes_fwd + bytes_bwd) / ((fwd_ms + bwd_ms) * 1e-3) / 1e9,
