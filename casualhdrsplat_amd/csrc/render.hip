@@ -2,7 +2,7 @@
 // epilogue / prologue and N-pose resolve (a15).  Rules: SURVEY.md 8(a); no reference code exists.
 //
 // CDNA4 design (not a translation of the CUDA 16x16-thread tile).  Measured on MI355X the loops are bound by
-// VALU issue (~4 cycles per wave64 VALU instruction, profiles/r01_valu_rate.txt), so the design minimises vector
+// VALU issue (~4 cycles per wave64 VALU instruction, profiles/r01b_valu_rate.txt), so the design minimises vector
 // instructions per (pixel, Gaussian) pair:
 //  * one 128-thread workgroup (two wave64) per 16x16 binning tile; each wave owns a 16x8 half tile and each lane
 //    TWO vertically adjacent pixels, so dx and every per-Gaussian term is shared by the pair and the rest is
@@ -12,10 +12,12 @@
 //    loop is  dx, dy -> two FMAs -> v_exp_f32;
 //  * before touching a batch each wave tests the staged Gaussians against its own half tile, one Gaussian per
 //    lane, and compacts the survivors into a per-wave LDS index list (ballot + mbcnt); the compositing loop
-//    walks that list with the entry index in a VGPR (broadcast ds_read_b128), keeping the scalar unit idle;
+//    walks that list with the entry index in a VGPR (broadcast ds_read_b128);
+//  * workgroups map to tiles through an XCD-band permutation so that the tiles one XCD works on are neighbours and
+//    share its L2;
 //  * backward: no global atomics.  Per (wave, Gaussian) nine partial sums are formed in-lane over the pixel
-//    pair, reduced across the 64 lanes with v_permlane32_swap / v_permlane16_swap halving steps plus DPP row
-//    reductions (~29 instructions for all nine), parked in a per-wave LDS plane, combined over the two waves
+//    pair, reduced across the 64 lanes with v_permlane32_swap / v_permlane16_swap halving steps plus bank-masked
+//    DPP adds (~24 instructions for all nine), parked in a per-wave LDS plane, combined over the two waves
 //    in fixed order and written as ONE record (a 64-byte sector) per (tile, instance) pair at the pair's
 //    duplicateWithKeys slot; preprocess-backward then sums each instance's contiguous slots.  Gradients are
 //    bitwise reproducible run to run.
