@@ -672,6 +672,16 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
             for (int k = 0; k < KB / 64; ++k) s_wrote[wave][k] = wrote[k];
         }
         __syncthreads();
+#ifdef HS_STATS
+        if (threadIdx.x == 0) {
+            unsigned long long both = 0, one = 0;
+            for (int k = 0; k < KB / 64; ++k) {
+                both += __popcll(s_wrote[0][k] & s_wrote[1][k]);
+                one += __popcll(s_wrote[0][k] ^ s_wrote[1][k]);
+            }
+            atomicAdd(&g_stats[4], both); atomicAdd(&g_stats[5], one);
+        }
+#endif
         if ((int)threadIdx.x < cnt) {
             const int t = threadIdx.x;
             float v[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
