@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HS_LIB_PATH", os.path.join(_HERE, "libhdrsplat.so"))
 
 HS_OK, HS_EINVAL, HS_EHIP, HS_EOVERFLOW = 0, -1, -2, -3
-HS_STAGE_PREPROCESS, HS_STAGE_BIN, HS_STAGE_RENDER, HS_STAGE_ALL = 1, 2, 4, 7
+HS_STAGE_PREPROCESS, HS_STAGE_BIN, HS_STAGE_RENDER, HS_STAGE_ALL, HS_STAGE_OFFSETS = 1, 2, 4, 7, 8
 HS_FLAG_HDR, HS_FLAG_BLUR_HDR, HS_FLAG_DEBUG, HS_FLAG_ANTIALIAS = 1, 2, 4, 8
 HS_BWD_RENDER, HS_BWD_PREPROCESS, HS_BWD_CRF, HS_BWD_ALL = 1, 2, 4, 7
 HS_TILE = 16
@@ -71,7 +71,7 @@ class hs_bwd_args(C.Structure):
 
 class hs_layout(C.Structure):
     _fields_ = [(n, C.c_int64) for n in (
-        "counters", "rec", "depth", "radii", "tiles_touched", "offsets", "cov3D", "clamped", "scan_spine", "binfo",
+        "counters", "r_partials", "rec", "depth", "radii", "tiles_touched", "offsets", "cov3D", "clamped", "scan_spine", "binfo",
         "keys_sorted", "point_list", "keys_unsorted", "vals_unsorted", "ranges", "sort_tmp", "depth_keys", "depth_vals", "srect",
         "pair_flags",
         "final_T", "n_contrib", "pose_hdr",

@@ -38,6 +38,7 @@ static int plan(const hs_dims& d, hs_sizes* sz, hs_layout* L) {
     auto carve = [&o](int64_t bytes) { int64_t at = o; o = align_up(o + bytes, 256); return at; };
     // geometry
     l.counters = carve(sizeof(hs_counters));
+    l.r_partials = carve(kRPartials * 4);
     l.rec = carve(I * kRecFloats * 4);
     l.depth = carve(I * 4);
     l.radii = carve(I * 4);
@@ -141,8 +142,10 @@ int hs_forward(const hs_fwd_args* a, void* hip_stream) {
     if ((a->stages & HS_STAGE_PREPROCESS) && a->dims.P > 0) {
         rc = launch_preprocess_fwd(*a, L, s);
         if (rc) return rc;
-        rc = launch_scan(*a, L, s);
-        if (rc) return rc;
+        if (!(a->stages & HS_STAGE_BIN)) {  // upstream-style call: the host reads num_rendered before binning
+            rc = launch_fold_num_rendered(*a, L, s);
+            if (rc) return rc;
+        }
     }
     if (a->stages & HS_STAGE_BIN) {
         if (!a->binning) { set_error("hs_forward: null binning workspace"); return HS_EINVAL; }
@@ -153,6 +156,10 @@ int hs_forward(const hs_fwd_args* a, void* hip_stream) {
             const int64_t gx = (a->dims.W + kTile - 1) / kTile, gy = (a->dims.H + kTile - 1) / kTile;
             HS_HIP_CHECK(hipMemsetAsync((char*)a->binning + L.ranges, 0, (size_t)(gx * gy * a->dims.n_poses * 8), s));
         }
+    }
+    if ((a->stages & HS_STAGE_OFFSETS) && a->dims.P > 0) {
+        rc = launch_scan(*a, L, s);  // inspection only: a5 in instance order
+        if (rc) return rc;
     }
     if (a->stages & HS_STAGE_RENDER) {
         if (!a->binning || !a->image || !a->out_color) { set_error("hs_forward: null binning/image/out_color"); return HS_EINVAL; }

@@ -118,16 +118,26 @@ int scan_u32(const uint32_t* in, int64_t n, uint32_t* spine, uint32_t* out, uint
 // kernel of the forward reads n_sort, so an overflowing call degrades to an empty render instead of
 // writing out of bounds; the host sees counters.overflow and replays with a larger capacity.
 // The same launch clears the tile ranges (tiles without pairs must read (0,0)).
-__global__ void __launch_bounds__(256) bin_prepare_kernel(hs_counters* c, uint64_t capacity, uint32_t n_inst, uint2* ranges,
-                                                          int64_t ntiles) {
+__global__ void __launch_bounds__(256) bin_prepare_kernel(hs_counters* c, const uint32_t* r_partials, uint64_t capacity,
+                                                          uint32_t n_inst, uint2* ranges, int64_t ntiles) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < ntiles) ranges[i] = make_uint2(0u, 0u);
     if (i == 0) {
-        const bool ok = (uint64_t)c->num_rendered <= capacity;
-        c->reserved[0] = ok ? c->num_rendered : 0u;
+        uint32_t R = 0;
+        for (int k = 0; k < kRPartials; ++k) R += r_partials[k];
+        c->num_rendered = R;
+        const bool ok = (uint64_t)R <= capacity;
+        c->reserved[0] = ok ? R : 0u;
         c->reserved[1] = n_inst;
         c->overflow = ok ? 0u : 1u;
     }
+}
+
+// PREPROCESS-only calls (the upstream-style host read of num_rendered between the stages) fold the partial sums here.
+__global__ void fold_num_rendered_kernel(hs_counters* c, const uint32_t* r_partials) {
+    uint32_t R = 0;
+    for (int k = 0; k < kRPartials; ++k) R += r_partials[k];
+    c->num_rendered = R;
 }
 
 // ---------------------------------------------------------------- radix sort passes (a7)
@@ -408,15 +418,22 @@ int launch_radix_sort(uint64_t* k0, uint32_t* v0, uint64_t* k1, uint32_t* v1, co
     return radix_sort<uint64_t>(k0, v0, k1, v1, n_dev, n_launch, nbits, tmp, s);
 }
 
+// a5 in instance order, as the published pipeline lays it out: offsets[i] = sum_{j<=i} tiles_touched[j].  The
+// forward itself does not need it (preprocess accumulates R, the binning stage scans the depth-ordered counts);
+// HS_STAGE_OFFSETS fills it for inspection and parity tests.
 int launch_scan(const hs_fwd_args& a, const hs_layout& L, hipStream_t s) {
     const hs_dims& d = a.dims;
     char* geom = (char*)a.geom;
     const int64_t I = (int64_t)d.P * d.n_poses;
-    hs_counters* counters = (hs_counters*)(geom + L.counters);
-    // no clearing of the counters: num_rendered is written by the scan, the rest by bin_prepare_kernel
-    // offsets (instance order) are kept for inspection; their total is R
     return scan_u32((const uint32_t*)(geom + L.tiles_touched), I, (uint32_t*)(geom + L.scan_spine),
-                    (uint32_t*)(geom + L.offsets), &counters->num_rendered, s);
+                    (uint32_t*)(geom + L.offsets), nullptr, s);
+}
+
+int launch_fold_num_rendered(const hs_fwd_args& a, const hs_layout& L, hipStream_t s) {
+    char* geom = (char*)a.geom;
+    fold_num_rendered_kernel<<<1, 1, 0, s>>>((hs_counters*)(geom + L.counters), (const uint32_t*)(geom + L.r_partials));
+    HS_LAUNCH_CHECK();
+    return HS_OK;
 }
 
 int launch_binning(const hs_fwd_args& a, const hs_layout& L, hipStream_t s) {
@@ -430,7 +447,8 @@ int launch_binning(const hs_fwd_args& a, const hs_layout& L, hipStream_t s) {
     const uint32_t* n_sort = &counters->reserved[0];
     const uint32_t* n_inst = &counters->reserved[1];
     uint2* ranges = (uint2*)(bin + L.ranges);
-    bin_prepare_kernel<<<ceil_div(ntiles, 256), 256, 0, s>>>(counters, (uint64_t)d.capacity, (uint32_t)I, ranges, ntiles);
+    bin_prepare_kernel<<<ceil_div(ntiles, 256), 256, 0, s>>>(counters, (const uint32_t*)(geom + L.r_partials),
+                                                             (uint64_t)d.capacity, (uint32_t)I, ranges, ntiles);
 
     // 1. instances by depth (stable, 32-bit keys -> 4 passes: result back in the first buffer pair)
     uint32_t* dk0 = (uint32_t*)(bin + L.depth_keys);

@@ -510,6 +510,10 @@ def inspect_state(out_tensor: torch.Tensor) -> dict:
         nbytes = count * torch.empty((), dtype=dtype).element_size()
         return buf[off:off + nbytes].view(dtype)
 
+    if I > 0:  # instance-order offsets (a5 as published) are not part of the forward: fill them now
+        a = st.fwd_args
+        a.stages = L.HS_STAGE_OFFSETS
+        L.check(L.load().hs_forward(C.byref(a), _stream()), "hs_forward[offsets]")
     rec = view(st.geom, lay.rec, I * 16, torch.float32).reshape(I, 16)
     depths = view(st.geom, lay.depth, I, torch.float32)
     tile_sorted = view(st.binning, lay.keys_sorted, R, torch.int32).to(torch.int64) & 0xFFFFFFFF
