@@ -232,7 +232,7 @@ def main():
                 t = torch.tensor([dt_], dtype=torch.float64, device=dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 times[f"{mode}/{algo}"] = float(t.item()) / 3 * 1e3
-        best = min(times, key=times.get)
+        best = min(times, key=times.get) if times else "allreduce/rccl"
         state["exchange"] = tuple(best.split("/"))
         allreduce_info = {"choice": best, "step_ms": times}
 
