@@ -650,3 +650,49 @@ def test_randomized_configurations_vs_oracle(oracle):
             flips = check_image(g["color"], f["color"], u32(st["n_contrib"][0]), u32(f["n_contrib"]), what)
             if flips == 0:
                 Hh.assert_grads_close(g, b, frac_tol=2e-2, l2_tol=2e-4, what=what)
+
+
+def test_c_abi_from_a_plain_cpp_host(tmp_path, oracle):
+    """The boundary is a C ABI with plain device pointers: examples/abi_host (hipMalloc, no PyTorch) runs
+    plan / forward (with the upstream-style host read of num_rendered) / backward on a scene file and must give what
+    the Python layer gives through ctypes -- bit for bit, same kernels -- and agree with the oracle."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "abi_host")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.join(root, "casualhdrsplat_amd", "csrc")], check=True, capture_output=True)
+    P, W, H, deg = 2500, 200, 136, 2
+    sc = S.make_scene(P, W, H, deg, seed=31)
+    cam = sc.camera
+    M = sc.shs.shape[1]
+    with open(tmp_path / "scene.bin", "wb") as f:
+        f.write(np.array([P, M, deg, W, H], np.int32).tobytes())
+        f.write(np.array([cam.tanfovx, cam.tanfovy], np.float32).tobytes())
+        for t in (sc.bg, cam.viewmatrix, cam.projmatrix, cam.campos, sc.means3D, sc.opacities, sc.shs, sc.scales,
+                  sc.rotations, sc.dL_dimage):
+            f.write(t.contiguous().numpy().astype(np.float32).tobytes())
+    r = subprocess.run([exe, str(tmp_path / "scene.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    raw = open(tmp_path / "out.bin", "rb").read()
+    R = int(np.frombuffer(raw, np.uint32, 1)[0])
+    off = 4
+
+    def take(n, dt=np.float32):
+        nonlocal off
+        a = np.frombuffer(raw, dt, n, off)
+        off += 4 * n
+        return a
+
+    color = take(3 * H * W).reshape(3, H, W)
+    radii = take(P, np.int32)
+    got = {"d_means3D": take(P * 3).reshape(P, 3), "d_means2D": take(P * 3).reshape(P, 3), "d_opacities": take(P).reshape(P, 1),
+           "d_shs": take(P * M * 3).reshape(P, M, 3), "d_scales": take(P * 3).reshape(P, 3), "d_rotations": take(P * 4).reshape(P, 4)}
+    assert off == len(raw)
+    g = Hh.run_hip(sc)
+    assert R == g["state"]["num_rendered"] and np.array_equal(radii, g["radii"])
+    assert np.array_equal(Hh.bits(color), Hh.bits(g["color"]))
+    for k, v in got.items():
+        assert np.array_equal(Hh.bits(v), Hh.bits(g[k].reshape(v.shape))), k
+    f, b = Hh.run_oracle(oracle, sc)
+    assert R == f["R"]
+    check_image(color, f["color"], u32(g["state"]["n_contrib"][0]), u32(f["n_contrib"]), "abi_host")
