@@ -306,14 +306,30 @@ __global__ void __launch_bounds__(256) pair_segsum_kernel(int64_t I, const uint3
     const uint32_t beg = valid ? (i == 0 ? 0u : offs_sorted[i - 1]) : 0u;
     const uint32_t end = valid ? offs_sorted[i] : 0u;
     float r[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (uint32_t s = beg + q; s < end; s += 4) {
-        if (!pair_flags[s]) continue;  // never written this backward: skipping saves the record read (~55 % of pairs)
-        const float4 q0 = pair_grads[kPairF4 * (int64_t)s + 0];
-        const float4 q1 = pair_grads[kPairF4 * (int64_t)s + 1];
-        const float2 q2 = reinterpret_cast<const float2*>(pair_grads + kPairF4 * (int64_t)s + 2)[0];
-        r[0] += q0.x; r[1] += q0.y; r[2] += q0.z; r[3] += q0.w;
-        r[4] += q1.x; r[5] += q1.y; r[6] += q1.z; r[7] += q1.w;
-        r[8] += q2.x; r[9] += q2.y;
+    // two slots per trip: both flags first, then both records, so two record reads are in flight per lane; the
+    // sums keep the slot order (first slot added before the second)
+    for (uint32_t s = beg + q; s < end; s += 8) {
+        const bool two = s + 4 < end;
+        const bool f0 = pair_flags[s] != 0;  // unflagged: never written this backward (~55 % of pairs), not read
+        const bool f1 = two && pair_flags[s + 4] != 0;
+        float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, b0 = a0, b1 = a0;
+        float2 a2 = make_float2(0.f, 0.f), b2 = a2;
+        if (f0) {
+            a0 = pair_grads[kPairF4 * (int64_t)s + 0];
+            a1 = pair_grads[kPairF4 * (int64_t)s + 1];
+            a2 = reinterpret_cast<const float2*>(pair_grads + kPairF4 * (int64_t)s + 2)[0];
+        }
+        if (f1) {
+            b0 = pair_grads[kPairF4 * (int64_t)(s + 4) + 0];
+            b1 = pair_grads[kPairF4 * (int64_t)(s + 4) + 1];
+            b2 = reinterpret_cast<const float2*>(pair_grads + kPairF4 * (int64_t)(s + 4) + 2)[0];
+        }
+        r[0] += a0.x; r[1] += a0.y; r[2] += a0.z; r[3] += a0.w;
+        r[4] += a1.x; r[5] += a1.y; r[6] += a1.z; r[7] += a1.w;
+        r[8] += a2.x; r[9] += a2.y;
+        r[0] += b0.x; r[1] += b0.y; r[2] += b0.z; r[3] += b0.w;
+        r[4] += b1.x; r[5] += b1.y; r[6] += b1.z; r[7] += b1.w;
+        r[8] += b2.x; r[9] += b2.y;
     }
 #pragma unroll
     for (int k = 0; k < 10; ++k) {
