@@ -367,6 +367,38 @@ constexpr int kPoseVals = 28;
 
 constexpr int kPreBwdBlock = 128;
 
+// Block-cooperative copies between `rows` consecutive [M3]-float rows in HBM and LDS rows of stride `ld` (= M3 + 1,
+// conflict-free for one-row-per-thread access).  16-byte global accesses when a row is a multiple of four floats
+// (M = 4, 16: SH degree 1, 3) -- four times fewer memory instructions in flight per byte; rows start 16-byte
+// aligned because the block's first row index is a multiple of kPreBwdBlock.
+__device__ __forceinline__ void stage_rows_in(float* s_rows, const float* src, int rows, int M3, int ld) {
+    if ((M3 & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+        const int q = M3 >> 2;
+        const float4* src4 = reinterpret_cast<const float4*>(src);
+        for (int i = threadIdx.x; i < rows * q; i += kPreBwdBlock) {
+            const float4 v = src4[i];
+            const int r = i / q;
+            float* d = s_rows + r * ld + ((i - r * q) << 2);
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+    } else {
+        for (int i = threadIdx.x; i < rows * M3; i += kPreBwdBlock) s_rows[(i / M3) * ld + (i % M3)] = src[i];
+    }
+}
+__device__ __forceinline__ void stage_rows_out(float* dst, const float* s_rows, int rows, int M3, int ld) {
+    if ((M3 & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+        const int q = M3 >> 2;
+        float4* dst4 = reinterpret_cast<float4*>(dst);
+        for (int i = threadIdx.x; i < rows * q; i += kPreBwdBlock) {
+            const int r = i / q;
+            const float* sr = s_rows + r * ld + ((i - r * q) << 2);
+            dst4[i] = make_float4(sr[0], sr[1], sr[2], sr[3]);
+        }
+    } else {
+        for (int i = threadIdx.x; i < rows * M3; i += kPreBwdBlock) dst[i] = s_rows[(i / M3) * ld + (i % M3)];
+    }
+}
+
 // The [P, M, 3] SH tensors (input coefficients and their gradient) are the bulk of this kernel's bytes.  A thread
 // owns one Gaussian = one 12*M-byte row, so direct per-thread access would touch 64 different rows per wave
 // instruction; instead the block's rows are moved between HBM and LDS with fully coalesced accesses and each thread
@@ -383,8 +415,7 @@ __global__ void __launch_bounds__(kPreBwdBlock) preprocess_bwd_kernel(PreBwd p) 
     const int rows = min(kPreBwdBlock, p.P - g0);
     const bool stage_in = !p.has_colors_precomp && DEG >= 1;
     if (stage_in) {
-        const float* src = p.shs + (int64_t)g0 * M3;
-        for (int i = threadIdx.x; i < rows * M3; i += kPreBwdBlock) s_sh[(i / M3) * ld + (i % M3)] = src[i];
+        stage_rows_in(s_sh, p.shs + (int64_t)g0 * M3, rows, M3, ld);
         __syncthreads();
     }
     const bool valid = g < p.P;
@@ -655,7 +686,7 @@ __global__ void __launch_bounds__(kPreBwdBlock) preprocess_bwd_kernel(PreBwd p) 
             for (int k = NC * 3; k < M3; ++k) row[k] = 0.f;
             __syncthreads();
             float* dst = p.d_shs + (int64_t)g0 * M3;
-            for (int i = threadIdx.x; i < rows * M3; i += kPreBwdBlock) dst[i] = s_sh[(i / M3) * ld + (i % M3)];
+            stage_rows_out(dst, s_sh, rows, M3, ld);
         }
     }
 }
@@ -699,7 +730,7 @@ __global__ void __launch_bounds__(kPreBwdBlock) sh_views_kernel(int P, int M, in
     for (int k = NC * 3; k < M3; ++k) row[k] = 0.f;
     __syncthreads();
     float* dst = d_shs + (int64_t)g0 * M3;
-    for (int i = threadIdx.x; i < rows * M3; i += kPreBwdBlock) dst[i] = s_sh[(i / M3) * ld + (i % M3)];
+    stage_rows_out(dst, s_sh, rows, M3, ld);
 }
 
 // Pose-gradient partials [nblk][N*kPoseVals] -> column sums, two fixed-order stages (deterministic).
