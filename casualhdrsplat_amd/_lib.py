@@ -71,7 +71,7 @@ class hs_bwd_args(C.Structure):
 
 class hs_layout(C.Structure):
     _fields_ = [(n, C.c_int64) for n in (
-        "counters", "r_partials", "rec", "depth", "radii", "tiles_touched", "offsets", "cov3D", "clamped", "scan_spine", "binfo",
+        "counters", "rec", "depth", "radii", "tiles_touched", "offsets", "cov3D", "clamped", "scan_spine", "binfo",
         "keys_sorted", "point_list", "keys_unsorted", "vals_unsorted", "ranges", "sort_tmp", "depth_keys", "depth_vals", "srect",
         "pair_flags",
         "final_T", "n_contrib", "pose_hdr",

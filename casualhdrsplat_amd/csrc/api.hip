@@ -38,7 +38,6 @@ static int plan(const hs_dims& d, hs_sizes* sz, hs_layout* L) {
     auto carve = [&o](int64_t bytes) { int64_t at = o; o = align_up(o + bytes, 256); return at; };
     // geometry
     l.counters = carve(sizeof(hs_counters));
-    l.r_partials = carve(kRPartials * 4);
     l.rec = carve(I * kRecFloats * 4);
     l.depth = carve(I * 4);
     l.radii = carve(I * 4);
@@ -143,7 +142,7 @@ int hs_forward(const hs_fwd_args* a, void* hip_stream) {
         rc = launch_preprocess_fwd(*a, L, s);
         if (rc) return rc;
         if (!(a->stages & HS_STAGE_BIN)) {  // upstream-style call: the host reads num_rendered before binning
-            rc = launch_fold_num_rendered(*a, L, s);
+            rc = launch_scan(*a, L, s);
             if (rc) return rc;
         }
     }

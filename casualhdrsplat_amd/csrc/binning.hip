@@ -114,30 +114,12 @@ int scan_u32(const uint32_t* in, int64_t n, uint32_t* spine, uint32_t* out, uint
     return HS_OK;
 }
 
-// n_sort = R when it fits the binning capacity, else 0 (and the overflow flag is raised): every later
-// kernel of the forward reads n_sort, so an overflowing call degrades to an empty render instead of
-// writing out of bounds; the host sees counters.overflow and replays with a larger capacity.
-// The same launch clears the tile ranges (tiles without pairs must read (0,0)).
-__global__ void __launch_bounds__(256) bin_prepare_kernel(hs_counters* c, const uint32_t* r_partials, uint64_t capacity,
-                                                          uint32_t n_inst, uint2* ranges, int64_t ntiles) {
+// Start of the binning stage: the instance count for the depth sort, and cleared tile ranges (tiles without pairs
+// must read (0,0)).
+__global__ void __launch_bounds__(256) bin_prepare_kernel(hs_counters* c, uint32_t n_inst, uint2* ranges, int64_t ntiles) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < ntiles) ranges[i] = make_uint2(0u, 0u);
-    if (i == 0) {
-        uint32_t R = 0;
-        for (int k = 0; k < kRPartials; ++k) R += r_partials[k];
-        c->num_rendered = R;
-        const bool ok = (uint64_t)R <= capacity;
-        c->reserved[0] = ok ? R : 0u;
-        c->reserved[1] = n_inst;
-        c->overflow = ok ? 0u : 1u;
-    }
-}
-
-// PREPROCESS-only calls (the upstream-style host read of num_rendered between the stages) fold the partial sums here.
-__global__ void fold_num_rendered_kernel(hs_counters* c, const uint32_t* r_partials) {
-    uint32_t R = 0;
-    for (int k = 0; k < kRPartials; ++k) R += r_partials[k];
-    c->num_rendered = R;
+    if (i == 0) c->reserved[1] = n_inst;
 }
 
 // ---------------------------------------------------------------- radix sort passes (a7)
@@ -346,11 +328,19 @@ __global__ void __launch_bounds__(256) gather_binfo_kernel(int64_t I, const uint
 __global__ void __launch_bounds__(256) emit_pairs_kernel(int64_t I, int P, int gx, int gy, float4* rec,
                                                          const uint32_t* inst_sorted, const uint32_t* offs_sorted,
                                                          const uint2* srect, uint32_t* tile_keys, uint32_t* vals,
-                                                         uint8_t* pair_flags, const hs_counters* counters) {
+                                                         uint8_t* pair_flags, hs_counters* counters, uint64_t capacity) {
     __shared__ uint32_t s_beg[4][64];
     __shared__ uint2 s_rect[4][64];
     __shared__ uint32_t s_inst[4][64];
-    if (counters->overflow) return;
+    // num_rendered (total of the depth-ordered scan just before this launch) against the binning capacity: an
+    // overflowing call emits nothing, sorts nothing (n_sort = 0) and renders empty; the host sees counters.overflow
+    // and replays with a larger capacity.  One thread publishes the verdict for the later kernels.
+    const bool overflow = (uint64_t)counters->num_rendered > capacity;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        counters->overflow = overflow ? 1u : 0u;
+        counters->reserved[0] = overflow ? 0u : counters->num_rendered;
+    }
+    if (overflow) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     uint32_t beg = 0, end = 0, inst = 0;
@@ -418,22 +408,17 @@ int launch_radix_sort(uint64_t* k0, uint32_t* v0, uint64_t* k1, uint32_t* v1, co
     return radix_sort<uint64_t>(k0, v0, k1, v1, n_dev, n_launch, nbits, tmp, s);
 }
 
-// a5 in instance order, as the published pipeline lays it out: offsets[i] = sum_{j<=i} tiles_touched[j].  The
-// forward itself does not need it (preprocess accumulates R, the binning stage scans the depth-ordered counts);
-// HS_STAGE_OFFSETS fills it for inspection and parity tests.
+// a5 in instance order, as the published pipeline lays it out: offsets[i] = sum_{j<=i} tiles_touched[j], total =
+// num_rendered.  Run by PREPROCESS-only calls (the upstream-style host read of num_rendered before binning) and by
+// HS_STAGE_OFFSETS (inspection); a single-enqueue forward does not need it -- the binning stage scans the
+// depth-ordered counts, whose total is the same R.
 int launch_scan(const hs_fwd_args& a, const hs_layout& L, hipStream_t s) {
     const hs_dims& d = a.dims;
     char* geom = (char*)a.geom;
     const int64_t I = (int64_t)d.P * d.n_poses;
+    hs_counters* counters = (hs_counters*)(geom + L.counters);
     return scan_u32((const uint32_t*)(geom + L.tiles_touched), I, (uint32_t*)(geom + L.scan_spine),
-                    (uint32_t*)(geom + L.offsets), nullptr, s);
-}
-
-int launch_fold_num_rendered(const hs_fwd_args& a, const hs_layout& L, hipStream_t s) {
-    char* geom = (char*)a.geom;
-    fold_num_rendered_kernel<<<1, 1, 0, s>>>((hs_counters*)(geom + L.counters), (const uint32_t*)(geom + L.r_partials));
-    HS_LAUNCH_CHECK();
-    return HS_OK;
+                    (uint32_t*)(geom + L.offsets), &counters->num_rendered, s);
 }
 
 int launch_binning(const hs_fwd_args& a, const hs_layout& L, hipStream_t s) {
@@ -447,8 +432,7 @@ int launch_binning(const hs_fwd_args& a, const hs_layout& L, hipStream_t s) {
     const uint32_t* n_sort = &counters->reserved[0];
     const uint32_t* n_inst = &counters->reserved[1];
     uint2* ranges = (uint2*)(bin + L.ranges);
-    bin_prepare_kernel<<<ceil_div(ntiles, 256), 256, 0, s>>>(counters, (const uint32_t*)(geom + L.r_partials),
-                                                             (uint64_t)d.capacity, (uint32_t)I, ranges, ntiles);
+    bin_prepare_kernel<<<ceil_div(ntiles, 256), 256, 0, s>>>(counters, (uint32_t)I, ranges, ntiles);
 
     // 1. instances by depth (stable, 32-bit keys -> 4 passes: result back in the first buffer pair)
     uint32_t* dk0 = (uint32_t*)(bin + L.depth_keys);
@@ -466,7 +450,7 @@ int launch_binning(const hs_fwd_args& a, const hs_layout& L, hipStream_t s) {
     uint32_t* offs = dv1;    // inclusive scan of ts
     uint2* srect = (uint2*)(bin + L.srect);
     gather_binfo_kernel<<<ceil_div(I, 256), 256, 0, s>>>(I, inst_sorted, (const uint2*)(geom + L.binfo), srect, ts);
-    rc = scan_u32(ts, I, (uint32_t*)(geom + L.scan_spine), offs, nullptr, s);
+    rc = scan_u32(ts, I, (uint32_t*)(geom + L.scan_spine), offs, &counters->num_rendered, s);  // total = R
     if (rc != HS_OK) return rc;
     // the tile sort must end in (keys_sorted, point_list): start from A when the pass count is even
     const int tbits = tile_bits((uint32_t)ntiles);
@@ -480,7 +464,8 @@ int launch_binning(const hs_fwd_args& a, const hs_layout& L, hipStream_t s) {
     uint32_t* k1 = (passes % 2 == 0) ? kB : kA;
     uint32_t* v1 = (passes % 2 == 0) ? vB : vA;
     emit_pairs_kernel<<<ceil_div(I, 256), 256, 0, s>>>(I, d.P, gx, gy, (float4*)(geom + L.rec), inst_sorted, offs, srect,
-                                                       k0, v0, (uint8_t*)(bin + L.pair_flags), counters);
+                                                       k0, v0, (uint8_t*)(bin + L.pair_flags), counters,
+                                                       (uint64_t)d.capacity);
     HS_LAUNCH_CHECK();
     // 3. stable sort by tile id only
     rc = radix_sort<uint32_t>(k0, v0, k1, v1, n_sort, d.capacity, tbits, tmp, s);

@@ -28,7 +28,6 @@ constexpr int kInstF4 = 4;                 // float4 per per-instance sum of the
 constexpr int kRecFloats = 4 * kRecF4;
 constexpr int kPairFloats = 4 * kPairF4;
 constexpr int kInstFloats = 4 * kInstF4;
-constexpr int kRPartials = 64;   // words the preprocess kernel spreads its "sum of tiles_touched" atomics over
 constexpr int kSortItems = 16;   // keys per thread per radix block
 constexpr int kSortBlock = 256;
 constexpr int kSortTile = kSortItems * kSortBlock;  // 4096 keys per block
@@ -46,7 +45,6 @@ static inline int tile_bits(uint32_t n) {
 // ---- launchers (each enqueues on `s`, returns HS_OK / HS_EHIP) ----
 int launch_preprocess_fwd(const hs_fwd_args& a, const hs_layout& L, hipStream_t s);
 int launch_scan(const hs_fwd_args& a, const hs_layout& L, hipStream_t s);
-int launch_fold_num_rendered(const hs_fwd_args& a, const hs_layout& L, hipStream_t s);
 int launch_binning(const hs_fwd_args& a, const hs_layout& L, hipStream_t s);
 int launch_render_fwd(const hs_fwd_args& a, const hs_layout& L, hipStream_t s);
 int launch_render_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s);

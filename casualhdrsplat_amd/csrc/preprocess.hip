@@ -143,7 +143,6 @@ struct PreFwd {
     float4* rec; float* depth; int* radii_inst; uint32_t* tiles; float* cov3D; uint8_t* clamped;
     uint2* binfo;  // tile rectangle {min_x | min_y << 16, width | height << 16} for the pair emission
     int* radii_out;
-    uint32_t* r_partials;  // kRPartials zeroed words (see the end of the kernel)
     bool antialias;
 };
 
@@ -267,14 +266,6 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreFwd p) {
     if (p.N == 1) p.radii_out[g] = my_radius;
     else if (my_radius > 0) atomicMax(p.radii_out + g, my_radius);
     }  // idx < I
-    // R = sum of tiles_touched (a5's total): one integer atomic per wave, spread over kRPartials zeroed words (a
-    // single word would serialise ~16k atomics) -- exact and order independent, so the forward needs no scan of
-    // the instance-order counts (pairs are laid out in depth order, from a scan of the depth-ordered counts)
-    uint32_t wsum = ntiles;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) wsum += (uint32_t)__shfl_xor((int)wsum, d);
-    if ((threadIdx.x & 63) == 0 && wsum)
-        atomicAdd(p.r_partials + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & (kRPartials - 1)), wsum);
 }
 
 __global__ void mark_visible_kernel(int P, const float* means, const float* V, uint8_t* vis) {
@@ -779,8 +770,6 @@ int launch_preprocess_fwd(const hs_fwd_args& a, const hs_layout& L, hipStream_t 
     p.clamped = (uint8_t*)(geom + L.clamped); p.radii_out = a.radii;
     p.binfo = (uint2*)(geom + L.binfo);
     p.antialias = (a.flags & HS_FLAG_ANTIALIAS) != 0;
-    p.r_partials = (uint32_t*)(geom + L.r_partials);
-    HS_HIP_CHECK(hipMemsetAsync(geom + L.counters, 0, (size_t)(L.r_partials - L.counters) + kRPartials * 4, s));
     if (d.n_poses > 1) HS_HIP_CHECK(hipMemsetAsync(a.radii, 0, sizeof(int) * (size_t)d.P, s));
     const int64_t I = (int64_t)d.P * d.n_poses;
     const int grid = ceil_div(I, 256);

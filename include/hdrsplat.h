@@ -42,8 +42,10 @@ extern "C" {
 #define HS_TILE 16 /* binning tile edge in pixels (BLOCK_X = BLOCK_Y = 16 upstream) */
 
 /* hs_fwd_args.stages */
-#define HS_STAGE_PREPROCESS 1 /* preprocess; accumulates hs_counters.num_rendered = sum of tiles_touched */
-#define HS_STAGE_BIN 2        /* duplicateWithKeys + radix sort + tile ranges */
+#define HS_STAGE_PREPROCESS 1 /* preprocess; when run WITHOUT HS_STAGE_BIN (the upstream-style call, host reads
+                                 num_rendered before binning) also the instance-order scan of tiles_touched */
+#define HS_STAGE_BIN 2        /* depth sort, scan of the depth-ordered counts (writes num_rendered), duplicateWithKeys,
+                                 tile sort, tile ranges */
 #define HS_STAGE_RENDER 4     /* per-tile alpha blend (+ HDR epilogue, + N-pose resolve) */
 #define HS_STAGE_ALL 7
 #define HS_STAGE_OFFSETS 8    /* inspection only: inclusive scan of tiles_touched in instance order into the geom
@@ -181,9 +183,7 @@ typedef struct hs_bwd_args {
  * INTEGRATION.md-style bindings that want to inspect intermediates (keys, point_list, ranges...). */
 typedef struct hs_layout {
     /* geom workspace; arrays are indexed by instance = pose * P + gaussian */
-    /* r_partials: 64 u32 partial sums of tiles_touched right behind the counters (preprocess spreads its atomics
-     * over them; HS_STAGE_BIN, or the end of a PREPROCESS-only call, folds them into counters.num_rendered) */
-    int64_t counters, r_partials, rec, depth, radii, tiles_touched, offsets, cov3D, clamped, scan_spine, binfo;
+    int64_t counters, rec, depth, radii, tiles_touched, offsets, cov3D, clamped, scan_spine, binfo;
     /* binning workspace: keys_sorted = u32 tile id of each sorted pair, point_list = u32 instance of each sorted
      * pair (the sort key of the published algorithm is (tile << 32) | depth_bits[instance]); depth_keys/depth_vals
      * = the instances sorted by depth (2 x I u32 each, second halves are scratch) */
