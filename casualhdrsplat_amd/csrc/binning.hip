@@ -432,7 +432,9 @@ int launch_binning(const hs_fwd_args& a, const hs_layout& L, hipStream_t s) {
     const uint32_t* n_sort = &counters->reserved[0];
     const uint32_t* n_inst = &counters->reserved[1];
     uint2* ranges = (uint2*)(bin + L.ranges);
-    bin_prepare_kernel<<<ceil_div(ntiles, 256), 256, 0, s>>>(counters, (uint32_t)I, ranges, ntiles);
+    // when preprocess ran in this same call it already wrote the depth keys, the instance count and cleared ranges
+    const bool prepared = (a.stages & HS_STAGE_PREPROCESS) != 0;
+    if (!prepared) bin_prepare_kernel<<<ceil_div(ntiles, 256), 256, 0, s>>>(counters, (uint32_t)I, ranges, ntiles);
 
     // 1. instances by depth (stable, 32-bit keys -> 4 passes: result back in the first buffer pair)
     uint32_t* dk0 = (uint32_t*)(bin + L.depth_keys);
@@ -440,8 +442,9 @@ int launch_binning(const hs_fwd_args& a, const hs_layout& L, hipStream_t s) {
     uint32_t* dk1 = dk0 + I;
     uint32_t* dv1 = dv0 + I;
     void* tmp = bin + L.sort_tmp;
-    depth_keys_kernel<<<ceil_div(I, 256), 256, 0, s>>>(I, (const float*)(geom + L.depth), (const int*)(geom + L.radii),
-                                                       dk0, dv0);
+    if (!prepared)
+        depth_keys_kernel<<<ceil_div(I, 256), 256, 0, s>>>(I, (const float*)(geom + L.depth), (const int*)(geom + L.radii),
+                                                           dk0, dv0);
     int rc = radix_sort<uint32_t>(dk0, dv0, dk1, dv1, n_inst, I, 32, tmp, s);
     if (rc != HS_OK) return rc;
     const uint32_t* inst_sorted = dv0;

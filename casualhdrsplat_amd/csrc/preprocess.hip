@@ -143,6 +143,9 @@ struct PreFwd {
     float4* rec; float* depth; int* radii_inst; uint32_t* tiles; float* cov3D; uint8_t* clamped;
     uint2* binfo;  // tile rectangle {min_x | min_y << 16, width | height << 16} for the pair emission
     int* radii_out;
+    // single-enqueue forward (binning workspace already there): the start of the binning stage rides along --
+    // depth-sort keys/values of the instances, the instance count word, cleared tile ranges; else null
+    uint32_t* depth_keys; uint32_t* depth_vals; hs_counters* counters; uint2* ranges; int64_t n_vtiles;
     bool antialias;
 };
 
@@ -265,7 +268,15 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreFwd p) {
     p.clamped[idx] = clampbits;
     if (p.N == 1) p.radii_out[g] = my_radius;
     else if (my_radius > 0) atomicMax(p.radii_out + g, my_radius);
+    if (p.depth_keys) {  // culled instances get the largest key so they sort to the end
+        p.depth_keys[idx] = my_radius > 0 ? __float_as_uint(depth) : 0xFFFFFFFFu;
+        p.depth_vals[idx] = (uint32_t)idx;
+    }
     }  // idx < I
+    if (p.depth_keys) {
+        for (int64_t t = idx; t < p.n_vtiles; t += (int64_t)gridDim.x * 256) p.ranges[t] = make_uint2(0u, 0u);
+        if (idx == 0) p.counters->reserved[1] = (uint32_t)((int64_t)p.P * p.N);
+    }
 }
 
 __global__ void mark_visible_kernel(int P, const float* means, const float* V, uint8_t* vis) {
@@ -770,6 +781,13 @@ int launch_preprocess_fwd(const hs_fwd_args& a, const hs_layout& L, hipStream_t 
     p.clamped = (uint8_t*)(geom + L.clamped); p.radii_out = a.radii;
     p.binfo = (uint2*)(geom + L.binfo);
     p.antialias = (a.flags & HS_FLAG_ANTIALIAS) != 0;
+    p.depth_keys = nullptr; p.depth_vals = nullptr; p.counters = nullptr; p.ranges = nullptr; p.n_vtiles = 0;
+    if ((a.stages & HS_STAGE_BIN) && a.binning) {
+        char* bin = (char*)a.binning;
+        p.depth_keys = (uint32_t*)(bin + L.depth_keys); p.depth_vals = (uint32_t*)(bin + L.depth_vals);
+        p.counters = (hs_counters*)(geom + L.counters); p.ranges = (uint2*)(bin + L.ranges);
+        p.n_vtiles = (int64_t)((d.W + kTile - 1) / kTile) * ((d.H + kTile - 1) / kTile) * d.n_poses;
+    }
     if (d.n_poses > 1) HS_HIP_CHECK(hipMemsetAsync(a.radii, 0, sizeof(int) * (size_t)d.P, s));
     const int64_t I = (int64_t)d.P * d.n_poses;
     const int grid = ceil_div(I, 256);
