@@ -105,11 +105,9 @@ __global__ void __launch_bounds__(256) scan_apply_kernel(const uint32_t* in, int
     }
 }
 
-// reduce = false: the per-tile sums in `spine` were already produced (gather_binfo_kernel)
-int scan_u32(const uint32_t* in, int64_t n, uint32_t* spine, uint32_t* out, uint32_t* total_out, hipStream_t s,
-             bool reduce = true) {
+int scan_u32(const uint32_t* in, int64_t n, uint32_t* spine, uint32_t* out, uint32_t* total_out, hipStream_t s) {
     const int nblk = ceil_div(n, kScanTile);
-    if (reduce) scan_reduce_kernel<<<nblk, 256, 0, s>>>(in, n, spine);
+    scan_reduce_kernel<<<nblk, 256, 0, s>>>(in, n, spine);
     scan_spine_kernel<<<1, 256, 0, s>>>(spine, nblk, total_out);
     scan_apply_kernel<<<nblk, 256, 0, s>>>(in, n, spine, out);
     HS_LAUNCH_CHECK();
@@ -313,27 +311,13 @@ __global__ void __launch_bounds__(256) depth_keys_kernel(int64_t I, const float*
 
 // Tile rectangles and pair counts of the instances, gathered into depth order (one 8-byte gather per instance;
 // everything the emission needs afterwards is read coalesced).
-// The same pass is the first phase of the scan of the depth-ordered counts: one workgroup per scan tile, its total
-// goes to block_sums.
 __global__ void __launch_bounds__(256) gather_binfo_kernel(int64_t I, const uint32_t* inst_sorted, const uint2* binfo,
-                                                           uint2* srect, uint32_t* ts, uint32_t* block_sums) {
-    __shared__ uint32_t s_wave[4];
-    const int64_t base = (int64_t)blockIdx.x * kScanTile + threadIdx.x * kScanItems;
-    uint32_t v = 0;
-#pragma unroll
-    for (int k = 0; k < kScanItems; ++k) {
-        const int64_t i = base + k;
-        if (i < I) {
-            const uint2 b = binfo[inst_sorted[i]];
-            const uint32_t n = (b.y & 0xFFFFu) * (b.y >> 16);
-            srect[i] = b;
-            ts[i] = n;
-            v += n;
-        }
-    }
-    uint32_t total;
-    block_incl_scan(v, s_wave, &total);
-    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+                                                           uint2* srect, uint32_t* ts) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= I) return;
+    const uint2 b = binfo[inst_sorted[i]];
+    srect[i] = b;
+    ts[i] = (b.y & 0xFFFFu) * (b.y >> 16);
 }
 
 // duplicateWithKeys walking the instances in depth order.  A wave owns 64 consecutive instances, whose pair slots
@@ -468,9 +452,8 @@ int launch_binning(const hs_fwd_args& a, const hs_layout& L, hipStream_t s) {
     uint32_t* ts = dk1;      // tiles touched in depth order (reuses the depth-key scratch)
     uint32_t* offs = dv1;    // inclusive scan of ts
     uint2* srect = (uint2*)(bin + L.srect);
-    gather_binfo_kernel<<<ceil_div(I, kScanTile), 256, 0, s>>>(I, inst_sorted, (const uint2*)(geom + L.binfo), srect, ts,
-                                                               (uint32_t*)(geom + L.scan_spine));
-    rc = scan_u32(ts, I, (uint32_t*)(geom + L.scan_spine), offs, &counters->num_rendered, s, false);  // total = R
+    gather_binfo_kernel<<<ceil_div(I, 256), 256, 0, s>>>(I, inst_sorted, (const uint2*)(geom + L.binfo), srect, ts);
+    rc = scan_u32(ts, I, (uint32_t*)(geom + L.scan_spine), offs, &counters->num_rendered, s);  // total = R
     if (rc != HS_OK) return rc;
     // the tile sort must end in (keys_sorted, point_list): start from A when the pass count is even
     const int tbits = tile_bits((uint32_t)ntiles);
