@@ -4,6 +4,7 @@
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 O=$ROOT/gpurun_out/prof_final
+rm -rf $O   # counters are averaged over every file found: never mix runs
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 what=${1:-all}
