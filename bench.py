@@ -298,6 +298,14 @@ def main():
                         "frac": (bytes_fwd + bytes_bwd) / ((fwd_ms + bwd_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                         "pair_evals_per_s": 2 * E / ((fwd_ms + bwd_ms) * 1e-3)},
         }
+        # live per-stage times of the same frame (HIP events on the launch stream), for the reader of the line
+        stages = {"render_bwd": bwd_ms, "render_fwd": fwd_ms}
+        for name, fn in (("binning", lambda: replay_forward(out[0], L.HS_STAGE_BIN)),
+                         ("segsum_and_preprocess_bwd", lambda: replay_backward(out[0], dL, L.HS_BWD_PREPROCESS)),
+                         ("crf_gradient", (lambda: replay_backward(out[0], dL, L.HS_BWD_CRF)) if hdr else None)):
+            if fn is not None:
+                stages[name] = time_stage(fn, args.kernel_iters)[0]
+        line["stages_ms"] = {k: round(v, 4) for k, v in stages.items()}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(sc, cfg)
         print(json.dumps(line), flush=True)
