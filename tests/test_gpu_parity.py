@@ -696,3 +696,43 @@ def test_c_abi_from_a_plain_cpp_host(tmp_path, oracle):
     f, b = Hh.run_oracle(oracle, sc)
     assert R == f["R"]
     check_image(color, f["color"], u32(g["state"]["n_contrib"][0]), u32(f["n_contrib"]), "abi_host")
+
+
+def test_full_size_properties_c4_eight_poses():
+    """BASELINE c4 size (1M Gaussians, 1080p, 8 virtual poses per frame, HDR + CRF): oracle-free properties.  Pose 0
+    of the batched launch equals the single-pose launch bit for bit (same per-tile lists, same kernels), the tile
+    lists partition the pairs of all 8 poses, and the blur average of identical poses is the sharp image."""
+    from casualhdrsplat_amd import GaussianRasterizer, inspect_state
+    dev = "cuda"
+    P, W, H, N = 1_000_000, 1920, 1080, 8
+    sc = S.make_scene(P, W, H, 3, seed=0, hdr=True)
+    cams = S.blur_poses(W, H, N)
+    leaves = [t.to(dev) for t in (sc.means3D, torch.zeros(P, 3), sc.opacities, sc.shs, sc.scales, sc.rotations)]
+
+    def render(cameras):
+        rs, _, _ = Hh.settings_from_scene(sc, dev, cameras, hdr=True)
+        ls = [t.clone().requires_grad_(True) for t in leaves]
+        out = GaussianRasterizer(rs)(ls[0], ls[1], ls[2], shs=ls[3], scales=ls[4], rotations=ls[5])
+        return out, inspect_state(out[0]), ls
+
+    out8, st8, ls8 = render(cams)
+    R = st8["num_rendered"]
+    I = N * P
+    assert R == int(st8["tiles_touched"].to(torch.int64).sum()) and st8["tiles_touched"].numel() == I
+    keys = st8["keys_sorted"][:R]
+    assert bool((keys[1:] >= keys[:-1]).all()) and int((keys >> 32).max()) < N * 120 * 68
+    rng = st8["ranges"].to(torch.int64)
+    lens = rng[:, 1] - rng[:, 0]
+    assert int(lens.sum()) == R and rng.shape[0] == N * 120 * 68
+    pl = st8["point_list"][:R].to(torch.int64)
+    assert int(pl.max()) < I and int(torch.bincount(pl, minlength=I).sub(st8["tiles_touched"].to(torch.int64)).abs().max()) == 0
+    out1, st1, _ = render(None)                                    # single pose = the scene camera = cams[0]
+    assert torch.equal(st8["n_contrib"][0], st1["n_contrib"][0]) and torch.equal(st8["final_T"][0], st1["final_T"][0])
+    assert torch.equal(st8["radii"][:P], st1["radii"])
+    assert bool(torch.isfinite(out8[0]).all()) and bool(torch.isfinite(out8[2]).all())
+    (out8[0] * sc.dL_dimage.to(dev)).sum().backward()
+    assert all(bool(torch.isfinite(t.grad).all()) for t in ls8) and float(ls8[3].grad.abs().sum()) > 0
+    del out8, st8, ls8
+    torch.cuda.empty_cache()
+    same, _, _ = render([cams[0]] * N)
+    assert Hh.rel_err(same[0].detach().cpu().numpy(), out1[0].detach().cpu().numpy(), 1e-3)[0] <= 1e-5
