@@ -35,7 +35,7 @@ class _Camera(C.Structure):
         ("P", C.c_int), ("sh_degree", C.c_int), ("M", C.c_int), ("W", C.c_int), ("H", C.c_int),
         ("tanfovx", C.c_float), ("tanfovy", C.c_float), ("scale_modifier", C.c_float),
         ("bg", C.c_float * 3), ("viewmatrix", C.c_float * 16), ("projmatrix", C.c_float * 16),
-        ("campos", C.c_float * 3),
+        ("campos", C.c_float * 3), ("antialias", C.c_int),
     ]
 
 
@@ -70,6 +70,7 @@ class Camera:
     bg: np.ndarray
     scale_modifier: float = 1.0
     sh_degree: int = 0
+    antialias: bool = False
 
     def cstruct(self, P: int, M: int) -> _Camera:
         c = _Camera()
@@ -79,6 +80,7 @@ class Camera:
         c.viewmatrix[:] = [float(v) for v in np.asarray(self.viewmatrix, np.float32).reshape(16)]
         c.projmatrix[:] = [float(v) for v in np.asarray(self.projmatrix, np.float32).reshape(16)]
         c.campos[:] = [float(v) for v in np.asarray(self.campos, np.float32).reshape(3)]
+        c.antialias = int(bool(self.antialias))
         return c
 
     @property
@@ -130,14 +132,17 @@ def forward(cam: Camera, means3D, opacities, shs=None, colors_precomp=None, scal
     o["color"] = np.zeros((3, cam.H, cam.W), np.float32)
     o["final_T"] = np.zeros((cam.H, cam.W), np.float32)
     o["n_contrib"] = np.zeros((cam.H, cam.W), np.uint32)
+    o["invdepth"] = np.zeros((cam.H, cam.W), np.float32)  # expected inverse depth
     L.hso_render_fwd(C.byref(c), _p(o["ranges"]), _p(o["point_list"]), _p(o["xy"]), _p(o["conic_opacity"]),
-                     _p(o["rgb"]), _p(o["color"]), _p(o["final_T"]), _p(o["n_contrib"]))
+                     _p(o["rgb"]), _p(o["color"]), _p(o["final_T"]), _p(o["n_contrib"]), _p(o["depths"]),
+                     _p(o["invdepth"]))
+    o["opacities_in"] = opacities
     return o
 
 
 def backward(cam: Camera, fwd: dict, dL_dcolor_img, means3D, shs=None, colors_precomp=None,
-             scales=None, rotations=None, cov3D_precomp=None) -> dict:
-    """Runs a10..a12 given forward()'s intermediates and dL/d(out_color) [3,H,W]."""
+             scales=None, rotations=None, cov3D_precomp=None, dL_dinvdepth_img=None) -> dict:
+    """Runs a10..a12 given forward()'s intermediates and dL/d(out_color) [3,H,W] (+ optional dL/d(invdepth) [H,W])."""
     L = lib()
     means3D = _f32(means3D)
     P = means3D.shape[0]
@@ -151,10 +156,13 @@ def backward(cam: Camera, fwd: dict, dL_dcolor_img, means3D, shs=None, colors_pr
         dL_dopacity=np.zeros(P, np.float32), dL_dcolor=np.zeros((P, 3), np.float32),
         abs_scale=np.zeros(P, np.float32),
     )
+    gd = None if dL_dinvdepth_img is None else _f32(dL_dinvdepth_img).reshape(cam.H, cam.W)
+    o["dL_dinvdepth"] = None if gd is None else np.zeros(P, np.float32)
     rc = L.hso_render_bwd(C.byref(c), _p(fwd["ranges"]), _p(fwd["point_list"]), _p(fwd["xy"]),
                           _p(fwd["conic_opacity"]), _p(fwd["rgb"]), _p(fwd["final_T"]), _p(fwd["n_contrib"]),
                           _p(g), _p(o["dL_dmean2D"]), _p(o["dL_dconic"]), _p(o["dL_dopacity"]),
-                          _p(o["dL_dcolor"]), _p(o["abs_scale"]))
+                          _p(o["dL_dcolor"]), _p(o["abs_scale"]),
+                          _p(fwd["depths"]) if gd is not None else None, _p(gd), _p(o["dL_dinvdepth"]))
     assert rc == 0
     o["dL_dmeans3D"] = np.zeros((P, 3), np.float32)
     o["dL_dshs"] = np.zeros((P, M, 3), np.float32) if shs is not None else None
@@ -167,7 +175,8 @@ def backward(cam: Camera, fwd: dict, dL_dcolor_img, means3D, shs=None, colors_pr
                               _p(cov3D_precomp), _p(fwd["radii"]), _p(fwd["cov3D"]), _p(fwd["clamped"]),
                               _p(o["dL_dmean2D"]), _p(o["dL_dconic"]), _p(o["dL_dcolor"]),
                               _p(o["dL_dmeans3D"]), _p(o["dL_dshs"]), _p(o["dL_dcolors_precomp"]),
-                              _p(o["dL_dscales"]), _p(o["dL_drots"]), _p(o["dL_dcov3D"]))
+                              _p(o["dL_dscales"]), _p(o["dL_drots"]), _p(o["dL_dcov3D"]),
+                              _p(_f32(fwd["opacities_in"])), _p(o["dL_dopacity"]), _p(o["dL_dinvdepth"]))
     assert rc == 0
     o["dL_dmeans2D"] = np.concatenate([o["dL_dmean2D"], np.zeros((P, 1), np.float32)], axis=1)
     return o

@@ -14,7 +14,10 @@
  * *published* algorithm of that package as frozen in SURVEY.md section 8(a), rows
  * a4..a12 (each function below names its row).  It is pinned by closed-form
  * known-answer tests and by an independent float64 PyTorch-autograd implementation
- * (oracle/torch_rasterizer.py), see tests/test_oracle_*.py.
+ * (oracle/torch_rasterizer.py), see tests/test_oracle_*.py.  Also restated: the two extras of
+ * newer versions of that package that SURVEY.md 8(f) n3 lists -- the `antialiasing` opacity
+ * compensation (hso_camera.antialias) and the expected inverse-depth image with its gradient
+ * (the depths / invdepth arguments of hso_render_fwd / hso_render_bwd / hso_preprocess_bwd).
  *
  * Reference anchors (the only ones that exist): /root/reference/Readme.md:54
  * ("we train 3DGS to reconstruct an HDR scene ... jointly estimating camera motion,
@@ -47,6 +50,7 @@ typedef struct {
     float viewmatrix[16]; /* flat, "transposed": p_view.x = m[0]x+m[4]y+m[8]z+m[12] */
     float projmatrix[16]; /* full view*proj, same convention */
     float campos[3];
+    int antialias;        /* newer published rasterizer's flag: opacity *= sqrt(max(0.000025, det(cov2D)/det(cov2D + 0.3 I))) */
 } hso_camera;
 
 static const float SH_C0 = 0.28209479177387814f;
@@ -256,6 +260,10 @@ int hso_preprocess_fwd(const hso_camera* c, const float* means3D, const float* o
         xy[2 * i] = pix_x; xy[2 * i + 1] = pix_y;
         conic_opacity[4 * i + 0] = conA; conic_opacity[4 * i + 1] = conB;
         conic_opacity[4 * i + 2] = conC; conic_opacity[4 * i + 3] = opacities[i];
+        if (c->antialias) {
+            float det0 = (ca - 0.3f) * (cc - 0.3f) - cb * cb;
+            conic_opacity[4 * i + 3] = opacities[i] * sqrtf(fmaxf_(0.000025f, det0 / det));
+        }
         rect[4 * i + 0] = rminx; rect[4 * i + 1] = rminy; rect[4 * i + 2] = rmaxx; rect[4 * i + 3] = rmaxy;
         tiles_touched[i] = (uint32_t)((rmaxx - rminx) * (rmaxy - rminy));
     }
@@ -350,9 +358,12 @@ int hso_tile_ranges(const uint64_t* keys_sorted, int64_t R, int ntiles, uint32_t
 /* ------------------------------------------------------------------------------------------
  * a9  render forward.  out_color is [3,H,W]; final_T, n_contrib are [H,W].
  * ------------------------------------------------------------------------------------------ */
+/* depths / out_invdepth (both or neither, may be NULL): expected inverse depth image sum_i alpha_i T_i / depth_i
+ * (third output of newer published rasterizers). */
 int hso_render_fwd(const hso_camera* c, const uint32_t* ranges, const uint32_t* point_list,
                    const float* xy, const float* conic_opacity, const float* rgb,
-                   float* out_color, float* final_T, uint32_t* n_contrib) {
+                   float* out_color, float* final_T, uint32_t* n_contrib,
+                   const float* depths, float* out_invdepth) {
     const int W = c->W, H = c->H;
     const int gx = (W + HSO_TILE - 1) / HSO_TILE;
     for (int py = 0; py < H; ++py)
@@ -360,7 +371,7 @@ int hso_render_fwd(const hso_camera* c, const uint32_t* ranges, const uint32_t* 
             int tile = (py / HSO_TILE) * gx + (px / HSO_TILE);
             uint32_t beg = ranges[2 * tile], end = ranges[2 * tile + 1];
             float pxf = (float)px, pyf = (float)py;
-            float T = 1.0f, C[3] = {0.f, 0.f, 0.f};
+            float T = 1.0f, C[3] = {0.f, 0.f, 0.f}, D = 0.f;
             uint32_t contributor = 0, last = 0;
             for (uint32_t k = beg; k < end; ++k) {
                 ++contributor;
@@ -374,12 +385,14 @@ int hso_render_fwd(const hso_camera* c, const uint32_t* ranges, const uint32_t* 
                 float test_T = T * (1.f - alpha);
                 if (test_T < 0.0001f) break; /* pixel done */
                 for (int ch = 0; ch < 3; ++ch) C[ch] += rgb[3 * id + ch] * alpha * T;
+                if (out_invdepth) D += (1.f / depths[id]) * alpha * T;
                 T = test_T;
                 last = contributor;
             }
             size_t pix = (size_t)py * W + px;
             final_T[pix] = T;
             n_contrib[pix] = last;
+            if (out_invdepth) out_invdepth[pix] = D;
             for (int ch = 0; ch < 3; ++ch) out_color[(size_t)ch * H * W + pix] = C[ch] + T * c->bg[ch];
         }
     return 0;
@@ -396,10 +409,13 @@ int hso_render_bwd(const hso_camera* c, const uint32_t* ranges, const uint32_t* 
                    const float* xy, const float* conic_opacity, const float* rgb,
                    const float* final_T, const uint32_t* n_contrib, const float* dL_dpix,
                    float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
-                   float* abs_scale) {
+                   float* abs_scale,
+                   const float* depths, const float* dL_dinvdepth_pix, float* dL_dinvdepth) {
+    /* depths, dL_dinvdepth_pix [H*W], dL_dinvdepth [P] (all or none): the inverse-depth image is a fourth blended
+     * channel without a background term; dL_dinvdepth receives sum_pix alpha T dL/dD(pix) per Gaussian */
     const int W = c->W, H = c->H, P = c->P;
     const int gx = (W + HSO_TILE - 1) / HSO_TILE;
-    double* acc = (double*)calloc((size_t)P * 10, sizeof(double));
+    double* acc = (double*)calloc((size_t)P * 11, sizeof(double));
     if (!acc) return -1;
     const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
     for (int py = 0; py < H; ++py)
@@ -414,6 +430,8 @@ int hso_render_bwd(const hso_camera* c, const uint32_t* ranges, const uint32_t* 
             for (int ch = 0; ch < 3; ++ch) dLp[ch] = dL_dpix[(size_t)ch * H * W + pix];
             float bg_dot = (c->bg[0] * dLp[0] + c->bg[1] * dLp[1]) + c->bg[2] * dLp[2];
             float accum_rec[3] = {0.f, 0.f, 0.f}, last_color[3] = {0.f, 0.f, 0.f};
+            float accum_invd = 0.f, last_invd = 0.f;
+            const float dLd = dL_dinvdepth_pix ? dL_dinvdepth_pix[pix] : 0.f;
             float last_alpha = 0.f;
             float pxf = (float)px, pyf = (float)py;
             for (uint32_t kk = last; kk-- > 0;) {
@@ -428,7 +446,14 @@ int hso_render_bwd(const hso_camera* c, const uint32_t* ranges, const uint32_t* 
                 T = T / (1.f - alpha);
                 float dchannel_dcolor = alpha * T;
                 float dL_dalpha = 0.f;
-                double* a = acc + (size_t)id * 10;
+                double* a = acc + (size_t)id * 11;
+                if (dL_dinvdepth_pix) {
+                    float invd = 1.f / depths[id];
+                    accum_invd = last_alpha * last_invd + (1.f - last_alpha) * accum_invd;
+                    last_invd = invd;
+                    dL_dalpha += (invd - accum_invd) * dLd;
+                    a[10] += (double)(dchannel_dcolor * dLd);
+                }
                 for (int ch = 0; ch < 3; ++ch) {
                     float col = rgb[3 * id + ch];
                     accum_rec[ch] = last_alpha * last_color[ch] + (1.f - last_alpha) * accum_rec[ch];
@@ -454,7 +479,8 @@ int hso_render_bwd(const hso_camera* c, const uint32_t* ranges, const uint32_t* 
             }
         }
     for (int i = 0; i < P; ++i) {
-        const double* a = acc + (size_t)i * 10;
+        const double* a = acc + (size_t)i * 11;
+        if (dL_dinvdepth) dL_dinvdepth[i] = (float)a[10];
         dL_dmean2D[2 * i] = (float)a[0]; dL_dmean2D[2 * i + 1] = (float)a[1];
         dL_dconic[3 * i] = (float)a[2]; dL_dconic[3 * i + 1] = (float)a[3]; dL_dconic[3 * i + 2] = (float)a[4];
         dL_dopacity[i] = (float)a[5];
@@ -475,7 +501,10 @@ int hso_preprocess_bwd(const hso_camera* c, const float* means3D, const float* s
                        const uint8_t* clamped, const float* dL_dmean2D, const float* dL_dconic,
                        const float* dL_dcolor,
                        float* dL_dmeans3D, float* dL_dshs, float* dL_dcolors_precomp,
-                       float* dL_dscales, float* dL_drots, float* dL_dcov3D) {
+                       float* dL_dscales, float* dL_drots, float* dL_dcov3D,
+                       const float* opacities, float* dL_dopacity, const float* dL_dinvdepth) {
+    /* opacities + dL_dopacity (in: gradient w.r.t. the opacity the render used; out: w.r.t. the input opacity) are
+     * needed when c->antialias; dL_dinvdepth [P] (may be NULL) is the gradient w.r.t. 1/depth of each Gaussian */
     const int P = c->P;
     const int ncoef = (c->sh_degree + 1) * (c->sh_degree + 1);
     const float* V = c->viewmatrix;
@@ -506,10 +535,29 @@ int hso_preprocess_bwd(const hso_camera* c, const float* means3D, const float* s
         float denom = a * cc - b * b;
         float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
         float gA = dL_dconic[3 * i], gB = dL_dconic[3 * i + 1], gC = dL_dconic[3 * i + 2];
+        float aa_da = 0.f, aa_db = 0.f, aa_dc = 0.f;
+        if (c->antialias && opacities && dL_dopacity) {
+            /* opacity_eff = opacity * s, s = sqrt(max(eps, q)), q = det(cov - 0.3 I) / det(cov) */
+            float det0 = (a - 0.3f) * (cc - 0.3f) - b * b;
+            float q = det0 / denom;
+            float sfac = sqrtf(fmaxf_(0.000025f, q));
+            float g_eff = dL_dopacity[i];
+            dL_dopacity[i] = g_eff * sfac;
+            if (q > 0.000025f) {
+                float k = g_eff * opacities[i] * 0.5f / sfac / (denom * denom);
+                aa_da = k * ((cc - 0.3f) * denom - det0 * cc);
+                aa_dc = k * ((a - 0.3f) * denom - det0 * a);
+                aa_db = k * (2.f * b * (det0 - denom));
+            }
+        }
+        if (dL_dinvdepth && dL_dinvdepth[i] != 0.f) {
+            float dz = -dL_dinvdepth[i] / (pvz * pvz);
+            for (int j = 0; j < 3; ++j) gm[j] += V[4 * j + 2] * dz;
+        }
         if (denom2inv != 0.f) {
-            float dLda = denom2inv * (-cc * cc * gA + b * cc * gB + (denom - a * cc) * gC);
-            float dLdc = denom2inv * (-a * a * gC + a * b * gB + (denom - a * cc) * gA);
-            float dLdb = denom2inv * (2.f * b * cc * gA - (denom + 2.f * b * b) * gB + 2.f * a * b * gC);
+            float dLda = denom2inv * (-cc * cc * gA + b * cc * gB + (denom - a * cc) * gC) + aa_da;
+            float dLdc = denom2inv * (-a * a * gC + a * b * gB + (denom - a * cc) * gA) + aa_dc;
+            float dLdb = denom2inv * (2.f * b * cc * gA - (denom + 2.f * b * b) * gB + 2.f * a * b * gC) + aa_db;
             const float* p = e.a0; const float* q = e.a1;
             gcov[0] = p[0] * p[0] * dLda + p[0] * q[0] * dLdb + q[0] * q[0] * dLdc;
             gcov[3] = p[1] * p[1] * dLda + p[1] * q[1] * dLdb + q[1] * q[1] * dLdc;

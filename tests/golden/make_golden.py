@@ -29,6 +29,8 @@ CASES = [
     ("hdr_deg1_s3_n4_ldrblur", 400, 80, 64, 1, 3, True, 4, "ldr"),
     ("hdr_deg1_s3_n4_hdrblur", 400, 80, 64, 1, 3, True, 4, "hdr"),
 ]
+# antialiasing opacity compensation + expected inverse-depth output with its own upstream gradient
+EXTRA_CASES = [("ldr_deg2_s5_antialias_invdepth", 500, 88, 72, 2, 5)]
 
 
 def scene_inputs(sc, cams):
@@ -76,7 +78,31 @@ def make(name, P, W, H, deg, seed, hdr, n_poses, dom):
     print(name, {k: v.shape for k, v in out.items() if k.startswith("o_")})
 
 
+def make_extra(name, P, W, H, deg, seed):
+    import torch
+    sc = S.make_scene(P, W, H, deg, seed=seed)
+    out = scene_inputs(sc, [sc.camera])
+    out["meta"] = np.array([P, W, H, deg, seed, 0, 1, 0], np.int64)
+    out["antialias"] = np.array(1, np.int64)
+    gD = (torch.randn(H, W, generator=torch.Generator().manual_seed(seed + 100)) * 4).numpy()
+    out["dL_dinvdepth"] = gD
+    ocam = Hh.oracle_camera(O, sc)
+    ocam.antialias = True
+    kw = dict(shs=sc.shs.numpy(), scales=sc.scales.numpy(), rotations=sc.rotations.numpy())
+    f = O.forward(ocam, sc.means3D.numpy(), sc.opacities.numpy(), **kw)
+    b = O.backward(ocam, f, sc.dL_dimage.numpy(), sc.means3D.numpy(), dL_dinvdepth_img=gD, **kw)
+    for k in ("depths", "xy", "conic_opacity", "rgb", "radii", "tiles_touched", "offsets", "keys_sorted", "point_list",
+              "ranges", "color", "final_T", "n_contrib", "invdepth"):
+        out["o_" + k] = f[k]
+    for _, k in Hh.GRAD_KEYS:
+        out["o_" + k] = b[k]
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, {k: v.shape for k, v in out.items() if k.startswith("o_")})
+
+
 if __name__ == "__main__":
     O.build()
+    for case in EXTRA_CASES:
+        make_extra(*case)
     for c in CASES:
         make(*c)

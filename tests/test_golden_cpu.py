@@ -28,7 +28,7 @@ def scene_from_golden(z):
 
 
 def test_fixtures_present():
-    assert len(GOLDEN) >= 5
+    assert len(GOLDEN) >= 6
 
 
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
@@ -39,7 +39,17 @@ def test_oracle_reproduces_golden(oracle, path):
     P, W, H, deg, seed = [int(v) for v in z["meta"][:5]]
     again = S.make_scene(P, W, H, deg, seed=seed, hdr=hdr)
     assert torch.equal(again.means3D, sc.means3D) and torch.equal(again.shs, sc.shs)
-    if not hdr:
+    if "antialias" in z.files:  # SURVEY.md 8(f) n3 extras: antialiasing + inverse-depth output and gradient
+        ocam = Hh.oracle_camera(oracle, sc)
+        ocam.antialias = True
+        kw = dict(shs=sc.shs.numpy(), scales=sc.scales.numpy(), rotations=sc.rotations.numpy())
+        f = oracle.forward(ocam, sc.means3D.numpy(), sc.opacities.numpy(), **kw)
+        b = oracle.backward(ocam, f, sc.dL_dimage.numpy(), sc.means3D.numpy(), dL_dinvdepth_img=z["dL_dinvdepth"], **kw)
+        for k in ("conic_opacity", "point_list", "ranges", "color", "n_contrib", "invdepth"):
+            assert np.array_equal(f[k], z["o_" + k]), k
+        for _, k in Hh.GRAD_KEYS:
+            assert np.array_equal(b[k], z["o_" + k]), k
+    elif not hdr:
         f, b = Hh.run_oracle(oracle, sc)
         for k in ("depths", "xy", "conic_opacity", "rgb", "radii", "tiles_touched", "offsets", "keys_sorted",
                   "point_list", "ranges", "color", "final_T", "n_contrib"):

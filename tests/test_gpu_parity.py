@@ -83,11 +83,38 @@ def test_ldr_forward_backward_vs_oracle(oracle, P, W, H, deg, seed):
         Hh.assert_grads_close(g, b, frac_tol=2e-2, max_tol=1.0, l2_tol=5e-3, what=f"P={P} (flips={flips})")
 
 
+def _golden_antialias_invdepth(z, sc):
+    """HIP path with settings.antialiasing + return_invdepth against the committed oracle output."""
+    from casualhdrsplat_amd import GaussianRasterizationSettings, GaussianRasterizer, inspect_state
+    dev = "cuda"
+    rs, _, _ = Hh.settings_from_scene(sc, dev)
+    rs = rs._replace(antialiasing=True)
+    names = ("means3D", "opacities", "shs", "scales", "rotations")
+    leaf = {k: getattr(sc, k).to(dev).requires_grad_(True) for k in names}
+    m2 = torch.zeros(sc.means3D.shape[0], 3, device=dev, requires_grad=True)
+    out = GaussianRasterizer(rs, return_invdepth=True)(leaf["means3D"], m2, leaf["opacities"], shs=leaf["shs"],
+                                                       scales=leaf["scales"], rotations=leaf["rotations"])
+    st = inspect_state(out[0])
+    ((out[0] * sc.dL_dimage.to(dev)).sum() + (out[2] * torch.from_numpy(z["dL_dinvdepth"]).to(dev)).sum()).backward()
+    R = st["num_rendered"]
+    assert np.array_equal(Hh.bits(st["conic_opacity"].cpu().numpy()), Hh.bits(z["o_conic_opacity"]))  # incl. the AA opacity
+    assert np.array_equal(u32(st["point_list"][:R].cpu().numpy()), u32(z["o_point_list"]))
+    assert np.array_equal(u32(st["ranges"].cpu().numpy()), u32(z["o_ranges"]))
+    assert int((u32(st["n_contrib"][0].cpu().numpy()) != u32(z["o_n_contrib"])).sum()) == 0
+    assert Hh.rel_err(out[0].detach().cpu().numpy(), z["o_color"], 1e-2)[0] <= 1e-4
+    assert Hh.rel_err(out[2].detach().cpu().numpy(), z["o_invdepth"], 1e-3)[0] <= 1e-4
+    g = {"d_" + k: v.grad.cpu().numpy() for k, v in leaf.items()}
+    g["d_means2D"] = m2.grad.cpu().numpy()
+    Hh.assert_grads_close(g, {k: z["o_" + k] for _, k in Hh.GRAD_KEYS}, what="antialias+invdepth golden")
+
+
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
 def test_against_golden_fixtures(path):
     from test_golden_cpu import scene_from_golden
     z = np.load(path)
     sc, cams, hdr, dom = scene_from_golden(z)
+    if "antialias" in z.files:
+        return _golden_antialias_invdepth(z, sc)
     g = Hh.run_hip(sc, cameras=cams if len(cams) > 1 else None, hdr=hdr, blur_domain=dom)
     st = g["state"]
     assert np.array_equal(u32(st["point_list"][:st["num_rendered"]]), u32(z["o_point_list"]))

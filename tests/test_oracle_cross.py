@@ -113,3 +113,39 @@ def test_n_identical_poses_equal_single_pose():
         l1, h1 = TR.rasterize_hdr([v], *args, sc.exposure.to(dt), sc.crf_table.to(dt), sc.crf_range, blur_domain=dom, **kw)
         l4, h4 = TR.rasterize_hdr([v] * 4, *args, sc.exposure.to(dt), sc.crf_table.to(dt), sc.crf_range, blur_domain=dom, **kw)
         assert torch.allclose(l1, l4, rtol=1e-12, atol=1e-14) and torch.allclose(h1, h4, rtol=1e-12, atol=1e-14)
+
+
+@pytest.mark.parametrize("antialiasing", [False, True])
+def test_c_oracle_inverse_depth_and_antialiasing_match_fp64_autograd(oracle, antialiasing):
+    """The C restatement of the two n3 extras (expected inverse depth as a fourth blended channel; the antialiasing
+    opacity compensation with its covariance gradient) against float64 autograd of the pure-PyTorch rasterizer."""
+    P, W, H, deg = 400, 72, 56, 2
+    sc = S.make_scene(P, W, H, deg, seed=17)
+    cam = sc.camera
+    gen = torch.Generator().manual_seed(5)
+    gD = torch.randn(H, W, generator=gen) * 4
+    ocam = Hh.oracle_camera(oracle, sc)
+    ocam.antialias = antialiasing
+    kw = dict(shs=sc.shs.numpy(), scales=sc.scales.numpy(), rotations=sc.rotations.numpy())
+    f = oracle.forward(ocam, sc.means3D.numpy(), sc.opacities.numpy(), **kw)
+    b = oracle.backward(ocam, f, sc.dL_dimage.numpy(), sc.means3D.numpy(), dL_dinvdepth_img=gD.numpy(), **kw)
+
+    dt = torch.float64
+    leaves = {k: getattr(sc, k).to(dt).clone().requires_grad_(True) for k in ["means3D", "opacities", "shs", "scales", "rotations"]}
+    color, st = TR.rasterize(torch_view(cam, dt), leaves["means3D"], leaves["opacities"], deg, sc.bg, shs=leaves["shs"],
+                             scales=leaves["scales"], rotations=leaves["rotations"], return_state=True,
+                             antialiasing=antialiasing)
+    ((color * sc.dL_dimage.to(dt)).sum() + (st["invdepth"] * gD.to(dt)).sum()).backward()
+    assert (st["n_contrib"].numpy() != f["n_contrib"]).sum() == 0
+    assert Hh.rel_err(f["color"], color.detach().numpy(), 1e-2)[0] < 1e-5
+    assert Hh.rel_err(f["invdepth"], st["invdepth"].detach().numpy(), 1e-3)[0] < 1e-5
+    assert float(st["invdepth"].detach().max()) > 0.05
+    if antialiasing:  # the compensation is exercised: it changes the opacity the render sees
+        assert np.abs(f["conic_opacity"][:, 3] - sc.opacities.numpy().reshape(-1))[f["radii"] > 0].max() > 1e-3
+    for k, ok in [("means3D", "dL_dmeans3D"), ("opacities", "dL_dopacity"), ("shs", "dL_dshs"), ("scales", "dL_dscales"),
+                  ("rotations", "dL_drots")]:
+        ref = leaves[k].grad.numpy().reshape(b[ok].shape)
+        mx, frac = Hh.rel_err(b[ok], ref, Hh.grad_floor(ref))
+        assert frac < 2e-2 and mx < 3e-2, (k, mx, frac)
+        l2 = np.linalg.norm(b[ok].astype(np.float64) - ref) / max(np.linalg.norm(ref), 1e-30)
+        assert l2 < 5e-5, (k, l2)
