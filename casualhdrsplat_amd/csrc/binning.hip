@@ -282,11 +282,12 @@ int radix_sort(K* k0, uint32_t* v0, K* k1, uint32_t* v1, const uint32_t* n_dev, 
     const int passes = sort_passes(nbits);
     uint32_t* hist = (uint32_t*)tmp;
     uint32_t* totals = (uint32_t*)((char*)tmp + align_up(256 * (int64_t)nblk * 4, 256));  // [passes][256]
-    (void)passes;
     K* kin = k0; uint32_t* vin = v0; K* kout = k1; uint32_t* vout = v1;
+    // the passes share the key bits evenly (13 tile bits -> 7 + 6, not 8 + 5): fewer bins in the first pass mean
+    // longer digit runs per 4096-key block, i.e. wider contiguous stores
     int pass = 0;
-    for (int shift = 0; shift < nbits; shift += 8, ++pass) {
-        const int w = nbits - shift < 8 ? nbits - shift : 8;
+    for (int shift = 0, w = 0; shift < nbits; shift += w, ++pass) {
+        w = (nbits - shift + (passes - pass) - 1) / (passes - pass);
         const uint32_t mask = (1u << w) - 1u;
         uint32_t* tot = totals + 256 * pass;
         radix_hist_kernel<K><<<nblk, kHistThreads, 0, s>>>(kin, n_dev, shift, mask, hist, nblk);
