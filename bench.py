@@ -279,18 +279,21 @@ def main():
         fwd_ms, fwd_med = time_stage(lambda: replay_forward(out[0], L.HS_STAGE_RENDER), args.kernel_iters)
         bytes_bwd = 76 * Rp + 20 * WH
         bytes_fwd = 40 * Rp + 20 * WH + 8 * vtiles
-        traffic = None
+        traffic = valu_busy = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(args.config, {}).get("render_bwd_kernel_hbm_bytes")
+                pmc = json.load(open(tpath)).get(args.config, {})
+                traffic = pmc.get("render_bwd_kernel_hbm_bytes")
+                valu_busy = pmc.get("render_bwd_kernel_valu_busy_frac")
             except Exception:
-                traffic = None
+                traffic = valu_busy = None
         ach = bytes_bwd / (bwd_ms * 1e-3) / 1e9
         line["roofline"] = {
             "kernel": "render_bwd_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
             "algorithmic_bytes": bytes_bwd, "avg_ms": bwd_ms, "median_ms": bwd_med,
+            "valu_busy_frac": valu_busy,  # PMC (profiles/pmc_traffic.json): what actually bounds this kernel
             "note": "the kernel is VALU-issue bound (DESIGN.md 4, profiles/README.md), not HBM bound; traffic = L2-fabric bytes from profiles/pmc_traffic.json",
             "fwd_bwd": {"kernels": "render_fwd_kernel + render_bwd_kernel", "algorithmic_bytes": bytes_fwd + bytes_bwd,
                         "avg_ms": fwd_ms + bwd_ms,

@@ -13,8 +13,8 @@
 //  * before touching a batch each wave tests the staged Gaussians against its own half tile, one Gaussian per
 //    lane, and compacts the survivors into a per-wave LDS index list (ballot + mbcnt); the compositing loop
 //    walks that list with the entry index in a VGPR (broadcast ds_read_b128);
-//  * workgroups map to tiles through an XCD-band permutation so that the tiles one XCD works on are neighbours and
-//    share its L2;
+//  * workgroups map to tiles through an XCD strip permutation (two-tile-row strips dealt round-robin to the XCDs) so
+//    that the tiles one XCD works on are neighbours and share its L2;
 //  * backward: no global atomics.  Per (wave, Gaussian) nine partial sums are formed in-lane over the pixel
 //    pair, reduced across the 64 lanes with v_permlane32_swap / v_permlane16_swap halving steps plus bank-masked
 //    DPP adds (~24 instructions for all nine), parked in a per-wave LDS plane, combined over the two waves
@@ -211,14 +211,32 @@ struct RenderFwd {
 
 constexpr int kBatch = 128;  // staged entries per trip = threads per workgroup
 
-// Workgroups are dealt to the 8 XCDs round-robin by blockIdx, and each XCD has its own L2.  Mapping block b to
-// virtual tile  start(b % 8) + b / 8  gives every XCD one contiguous band of tiles, so the tiles an XCD works on at
-// the same time are neighbours on screen and the records of the Gaussians they share are gathered through one L2.
-__device__ __forceinline__ int xcd_band_tile(int b, int nb) {
-    constexpr int kXcd = 8;
+// Workgroups are dealt to the 8 XCDs round-robin by blockIdx, and each XCD has its own L2.  The block -> tile map
+// below gives XCD x the two-tile-row strips x, x + 8, x + 16, ... of the frame (all poses stacked): the tiles an XCD
+// works on at the same time are neighbours on screen, so the records of the Gaussians they share are gathered
+// through one L2, while every XCD still samples the whole image (a contiguous band per XCD would tie the launch
+// time to the densest band of a real scene).
+// Construction: list the strips class by class (class = strip % 8), tiles row-major inside a strip; XCD x takes the
+// x-th of 8 contiguous, equally long pieces of that list -- a bijection for any grid, piece boundaries fall within
+// a strip of the next class at worst.
+__device__ __forceinline__ int xcd_strip_tile(int b, int nb, int gx) {
+    constexpr int kXcd = 8, kRows = 2;
     const int x = b % kXcd, k = b / kXcd;
     const int per = nb / kXcd, rem = nb % kXcd;
-    return x * per + min(x, rem) + k;
+    int p = x * per + min(x, rem) + k;               // position in the class-ordered list
+    const int rows = nb / gx;                        // tile rows of all poses (nb = gx * gy * N)
+    const int nstrips = (rows + kRows - 1) / kRows;
+    const int strip_tiles = kRows * gx;
+    const int last_short = nstrips * strip_tiles - nb;  // tiles missing from the last strip
+    int c = 0;
+    for (; c < kXcd - 1; ++c) {
+        const int ns = (nstrips - c + kXcd - 1) / kXcd;  // strips of class c
+        const int nt = ns * strip_tiles - (((nstrips - 1) % kXcd) == c ? last_short : 0);
+        if (p < nt) break;
+        p -= nt;
+    }
+    const int s_local = p / strip_tiles, r = p - s_local * strip_tiles;
+    return (c + kXcd * s_local) * strip_tiles + r;   // strips are contiguous runs of kRows * gx tiles
 }
 
 __device__ __forceinline__ float hs_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
@@ -298,7 +316,7 @@ __global__ void __launch_bounds__(kBatch) render_fwd_kernel(RenderFwd p) {
     __shared__ uint16_t s_list[2][KB];  // per-wave compacted list of staged entries that can touch its half tile
     __shared__ int s_alive[2][2];
 
-    const int vt = xcd_band_tile(blockIdx.x, gridDim.x);  // virtual tile = pose * ntiles + tile
+    const int vt = xcd_strip_tile(blockIdx.x, gridDim.x, p.gx);  // virtual tile = pose * ntiles + tile
     const int pose = vt / p.ntiles;
     const int tile = vt - pose * p.ntiles;
     const int tx = tile % p.gx, ty = tile / p.gx;
@@ -552,7 +570,7 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
     __shared__ uint64_t s_wrote[2][KB / 64];
     __shared__ uint32_t s_max[2];
 
-    const int vt = xcd_band_tile(blockIdx.x, gridDim.x);
+    const int vt = xcd_strip_tile(blockIdx.x, gridDim.x, p.gx);
     const int pose = vt / p.ntiles;
     const int tile = vt - pose * p.ntiles;
     const int tx = tile % p.gx, ty = tile / p.gx;

@@ -40,6 +40,20 @@ if what == "pmc":
                 if k.startswith("render_"):
                     for c, v in sorted(cs.items()):
                         o.write(f"{k},{c},{v:.4e}\n")
+    # VALU-busy fraction of the render kernels: SQ_ACTIVE_INST_VALU counts quad-cycles summed over the 1024 SIMDs,
+    # GRBM_GUI_ACTIVE cycles summed over the 8 XCDs
+    sq = {}
+    for i in range(1, 5):
+        for k, cs in counters(f"pmc_sq{i}").items():
+            sq.setdefault(k, {}).update(cs)
+    tj = json.load(open(os.path.join(DST, "pmc_traffic.json")))
+    for k, cs in sq.items():
+        if k.startswith("render_") and "SQ_ACTIVE_INST_VALU" in cs and "GRBM_GUI_ACTIVE" in cs:
+            name = k.split("<")[0]
+            tj["c3"][name + "_valu_busy_frac"] = round(cs["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * cs["GRBM_GUI_ACTIVE"] / 8), 4)
+            tj["c3"][name + "_valu_insts_per_launch"] = cs.get("SQ_INSTS_VALU")
+    tj["c3"]["valu_method"] = "SQ_ACTIVE_INST_VALU * 4 / (1024 SIMDs * GRBM_GUI_ACTIVE / 8 XCDs), profiles/%s_pmc_sq_c3.csv" % tag
+    json.dump(tj, open(os.path.join(DST, "pmc_traffic.json"), "w"), indent=1)
     print(open(os.path.join(DST, "pmc_traffic.json")).read())
 else:
     for cfg in ("c3", "c4", "c2"):
