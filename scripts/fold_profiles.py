@@ -63,7 +63,9 @@ else:
     line = open(os.path.join(SRC, "bench_2rank_gloo_one_gpu.json")).read().strip().splitlines()[-1]
     json.loads(line)
     open(os.path.join(DST, f"{tag}_bench_2rank_gloo_one_gpu.json"), "w").write(line + "\n")
-    st = sorted(glob.glob(os.path.join(SRC, "stats", "*", "*_kernel_stats.csv")))[-1]
+    cands = glob.glob(os.path.join(SRC, "stats", "*", "*_kernel_stats.csv"))
+    assert len(cands) == 1, "gpurun_out/prof_final holds several runs: delete it locally before collecting"
+    st = cands[0]
     shutil.copy(st, os.path.join(DST, f"{tag}_bench_c3_kernel_stats.csv"))
     if os.path.exists(os.path.join(SRC, "valu_rate.txt")):
         shutil.copy(os.path.join(SRC, "valu_rate.txt"), os.path.join(DST, f"{tag}_valu_rate.txt"))
