@@ -19,7 +19,6 @@ Gradient conventions reproduced from the published rasterizer (they differ from 
 """
 from __future__ import annotations
 
-import math
 from dataclasses import dataclass
 
 import torch

@@ -2,7 +2,6 @@
 validation with the reference API's error messages, loud failure on CPU tensors, synthetic scenes."""
 import math
 
-import numpy as np
 import pytest
 import torch
 

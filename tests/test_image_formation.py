@@ -1,5 +1,4 @@
 """Image-formation module: host-side SE(3)/CRF math on CPU; the end-to-end step on the GPU."""
-import math
 
 import pytest
 import torch

@@ -6,7 +6,6 @@ import math
 
 import numpy as np
 import pytest
-import torch
 
 from casualhdrsplat_amd import synthetic as S
 

@@ -8,7 +8,6 @@ import pytest
 import torch
 
 from casualhdrsplat_amd import scene_io as IO
-from casualhdrsplat_amd import synthetic as S
 
 
 def _cloud(P=37, deg=3, seed=0):
