@@ -563,11 +563,12 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
     __shared__ float4 s_a[KB];
     __shared__ float4 s_b[KB];
     __shared__ float4 s_c[KB];
-    // per-wave planes of reduced partials, summed in fixed order at write-out; the odd plane stride keeps the nine
-    // lanes that store one entry's totals on nine different LDS banks
-    __shared__ float s_acc[2][NV][KB + 1];
+    // planes of reduced partials, one word per (value, staged entry): zeroed per batch, each wave ADDS its totals
+    // (ds_add_f32).  At most two adds reach a word and 0 + x + y does not depend on their order, so the result is
+    // still bitwise reproducible -- and one set of planes instead of one per wave is what lets six waves per SIMD
+    // fit in LDS.  The odd plane stride keeps the nine lanes of one entry on nine different banks.
+    __shared__ float s_acc[NV][KB + 1];
     __shared__ uint16_t s_list[2][KB];      // per-wave compacted list of touched staged entries
-    __shared__ uint64_t s_wrote[2][KB / 64];
     __shared__ uint32_t s_max[2];
 
     const int vt = xcd_strip_tile(blockIdx.x, gridDim.x, p.gx);
@@ -623,11 +624,10 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
             scale_entry(ra, rb);
             s_a[threadIdx.x] = ra; s_b[threadIdx.x] = rb; s_c[threadIdx.x] = rc;
         }
+#pragma unroll
+        for (int q = 0; q < NV; ++q) s_acc[q][threadIdx.x] = 0.f;
         if (bi > 0) id_next = p.point_list[range.x + base - KB + threadIdx.x];  // batches below the top are full
         __syncthreads();
-        uint64_t wrote[KB / 64];
-#pragma unroll
-        for (int k = 0; k < KB / 64; ++k) wrote[k] = 0ull;
         if (base < (int)wave_max) {
             int n_t = 0;
 #pragma unroll
@@ -681,35 +681,15 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
                     g9 = cd.x + cd.y;
                 }
                 const float tot = wave_reduce9(g, g9);
-                if (red_slot >= 0) s_acc[wave][red_slot][j] = tot;  // 9 (10) lanes, one LDS store
-                wrote[j >> 6] |= 1ull << (j & 63);
+                if (red_slot >= 0) atomicAdd(&s_acc[red_slot][j], tot);  // 9 (10) lanes, one LDS add
             }
-        }
-        if (lane == 0) {
-#pragma unroll
-            for (int k = 0; k < KB / 64; ++k) s_wrote[wave][k] = wrote[k];
         }
         __syncthreads();
-#ifdef HS_STATS
-        if (threadIdx.x == 0) {
-            unsigned long long both = 0, one = 0;
-            for (int k = 0; k < KB / 64; ++k) {
-                both += __popcll(s_wrote[0][k] & s_wrote[1][k]);
-                one += __popcll(s_wrote[0][k] ^ s_wrote[1][k]);
-            }
-            atomicAdd(&g_stats[4], both); atomicAdd(&g_stats[5], one);
-        }
-#endif
         if ((int)threadIdx.x < cnt) {
             const int t = threadIdx.x;
             float v[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int w = 0; w < 2; ++w) {
-                if ((s_wrote[w][t >> 6] >> (t & 63)) & 1ull) {
-#pragma unroll
-                    for (int q = 0; q < NV; ++q) v[q] += s_acc[w][q][t];
-                }
-            }
+            for (int q = 0; q < NV; ++q) v[q] = s_acc[q][t];
             const float4 a = s_a[t];
             const float4 c = s_c[t];
             // un-scale the conic: A = A2 * (-2/L), B = B2 * (-1/L), C = C2 * (-2/L)

@@ -11,4 +11,3 @@ assert lib.hs_debug_stats(out, 1) == 0
 nrun = 2  # step_c3 ran the step twice (warm + 1 timed)
 t, z, act, culled = out[0] / nrun, out[1] / nrun, out[2] / nrun, out[3] / nrun
 print(f"bwd trips={t:.0f} zero-active={z:.0f} ({100*z/max(t,1):.1f}%) mean active lanes/trip={act/max(t,1):.2f} (non-zero trips: {act/max(t-z,1):.2f}) culled={culled:.0f} cull frac={culled/max(culled+t,1):.3f}")
-print(f"entries reduced by both waves of a tile: {out[4]/nrun:.0f}, by exactly one: {out[5]/nrun:.0f}")
