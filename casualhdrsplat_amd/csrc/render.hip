@@ -520,15 +520,15 @@ __device__ __forceinline__ void step_bwd(PixB& s, bool act, float G, float alpha
 // hardware has one, which halves the FMA count of the replay (the loop is VALU-issue bound; v_pk_fma_f32 issues
 // at the rate of one v_fma_f32).
 struct PairB {
-    f2 T, T_final, R0, R1, R2, dL0, dL1, dL2, bg_dot, Rd, dLd;
+    f2 T, R0, R1, R2, dL0, dL1, dL2, Tf_bg, Rd, dLd;  // Tf_bg = final transmittance * (background . dL/dpixel)
 };
 __device__ __forceinline__ f2 splat(float v) { f2 r = {v, v}; return r; }
 __device__ __forceinline__ PairB pack_pair(const PixB& a, const PixB& b) {
     PairB s;
-    s.T = f2{a.T, b.T}; s.T_final = f2{a.T_final, b.T_final};
+    s.T = f2{a.T, b.T}; s.Tf_bg = f2{a.T_final * a.bg_dot, b.T_final * b.bg_dot};
     s.R0 = f2{a.R0, b.R0}; s.R1 = f2{a.R1, b.R1}; s.R2 = f2{a.R2, b.R2};
     s.dL0 = f2{a.dL0, b.dL0}; s.dL1 = f2{a.dL1, b.dL1}; s.dL2 = f2{a.dL2, b.dL2};
-    s.bg_dot = f2{a.bg_dot, b.bg_dot}; s.Rd = f2{a.Rd, b.Rd}; s.dLd = f2{a.dLd, b.dLd};
+    s.Rd = f2{a.Rd, b.Rd}; s.dLd = f2{a.dLd, b.dLd};
     return s;
 }
 // One back-to-front step for the pixel pair (see step_bwd for the algebra).
@@ -547,7 +547,7 @@ __device__ __forceinline__ void step_bwd_pair(PairB& s, bool act0, bool act1, f2
         dLa += dd * s.dLd;
         s.Rd += ae * dd;
     }
-    dLa = dLa * s.T - (s.T_final * rcp) * s.bg_dot;
+    dLa = dLa * s.T - s.Tf_bg * rcp;  // background term: -T_final / (1 - alpha) * (bg . dL/dpixel)
     s.R0 += ae * d0;
     s.R1 += ae * d1;
     s.R2 += ae * d2;
