@@ -428,11 +428,6 @@ __global__ void __launch_bounds__(kPreBwdBlock) preprocess_bwd_kernel(PreBwd p) 
     float gm2d[2] = {0.f, 0.f};
     float gop = 0.f;
     float gcol_pre[3] = {0.f, 0.f, 0.f};
-    float gsh[SHG ? NC * 3 : 1];
-    if constexpr (SHG) {
-#pragma unroll
-        for (int k = 0; k < NC * 3; ++k) gsh[k] = 0.f;
-    }
 
     float s6[6];
 #pragma unroll
@@ -568,22 +563,12 @@ __global__ void __launch_bounds__(kPreBwdBlock) preprocess_bwd_kernel(PreBwd p) 
             const float dx = x - cp[0], dy = y - cp[1], dz = z - cp[2];
             const float len = sqrtf((dx * dx + dy * dy) + dz * dz);
             const float ux = dx / len, uy = dy / len, uz = dz / len;
-            float bs[NC];
-            sh_basis<DEG>(ux, uy, uz, bs);
             const uint8_t cl = p.clamped[idx];
             float gc[3];
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) gc[ch] = ((cl >> ch) & 1) ? 0.f : r[6 + ch];
             if (p.d_view_colors) {
                 p.d_view_colors[3 * idx] = gc[0]; p.d_view_colors[3 * idx + 1] = gc[1]; p.d_view_colors[3 * idx + 2] = gc[2];
-            }
-            if constexpr (SHG) {
-#pragma unroll
-                for (int k = 0; k < NC; ++k) {
-                    gsh[3 * k + 0] += bs[k] * gc[0];
-                    gsh[3 * k + 1] += bs[k] * gc[1];
-                    gsh[3 * k + 2] += bs[k] * gc[2];
-                }
             }
             if constexpr (DEG >= 1) {
                 float gb[NC][3];
@@ -681,11 +666,33 @@ __global__ void __launch_bounds__(kPreBwdBlock) preprocess_bwd_kernel(PreBwd p) 
     }
     if constexpr (SHG) {
         if (!p.has_colors_precomp && p.d_shs) {
-            if (stage_in) __syncthreads();  // every thread has finished reading its input row
+            // dL/dsh = sum over poses of basis(dir) (x) masked colour gradient, accumulated in this thread's LDS row
+            // (the row held the SH input, which only this thread read and is done with): a second, cheap walk over
+            // the poses instead of 3*NC accumulator registers alive through the whole kernel -- those registers
+            // cost the kernel a wave of occupancy per SIMD, and it is bound by memory latency
             float* row = s_sh + threadIdx.x * ld;
+            for (int k = 0; k < M3; ++k) row[k] = 0.f;
+            if (valid) {
+                for (int pose = 0; pose < p.N; ++pose) {
+                    const int64_t idx = (int64_t)pose * p.P + g;
+                    if (p.radii_inst[idx] <= 0) continue;
+                    const float4 q1 = p.inst_grads[kInstF4 * idx + 1];
+                    const float q2 = reinterpret_cast<const float*>(p.inst_grads + kInstF4 * idx + 2)[0];
+                    const uint8_t cl = p.clamped[idx];
+                    const float gc[3] = {(cl & 1) ? 0.f : q1.z, (cl & 2) ? 0.f : q1.w, (cl & 4) ? 0.f : q2};
+                    const float* cp = p.campos + 3 * pose;
+                    const float dx = x - cp[0], dy = y - cp[1], dz = z - cp[2];
+                    const float len = sqrtf((dx * dx + dy * dy) + dz * dz);
+                    float bs[NC];
+                    sh_basis<DEG>(dx / len, dy / len, dz / len, bs);
 #pragma unroll
-            for (int k = 0; k < NC * 3; ++k) row[k] = gsh[k];
-            for (int k = NC * 3; k < M3; ++k) row[k] = 0.f;
+                    for (int k = 0; k < NC; ++k) {
+                        row[3 * k + 0] += bs[k] * gc[0];
+                        row[3 * k + 1] += bs[k] * gc[1];
+                        row[3 * k + 2] += bs[k] * gc[2];
+                    }
+                }
+            }
             __syncthreads();
             float* dst = p.d_shs + (int64_t)g0 * M3;
             stage_rows_out(dst, s_sh, rows, M3, ld);
