@@ -117,10 +117,13 @@ def autotune_all_reduce(flat: torch.Tensor, group=None, iters: int = 3) -> str:
     return _ALGO["choice"]
 
 
-def all_reduce_gradients(params: Iterable[torch.Tensor], group=None, average: bool = False, algo: str = "rccl") -> int:
+def all_reduce_gradients(params: Iterable[torch.Tensor], group=None, average: bool = False, algo: str = "rccl",
+                         pending: list | None = None) -> int:
     """Sum (or average) `.grad` of `params` over all ranks with one exchange.  Returns the number of fp32 elements
     exchanged (0 when not distributed).  algo: "rccl" = torch.distributed.all_reduce, "direct" = all_reduce_direct,
-    "auto" = whichever autotune_all_reduce measured faster."""
+    "auto" = whichever autotune_all_reduce measured faster.  `pending`: if a list is given and the exchange is a
+    single library all-reduce, it is issued asynchronously and a completion callable is appended instead of waiting
+    (the caller overlaps independent work and then calls it)."""
     grads = [p.grad for p in params if p is not None and p.grad is not None]
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return 0
@@ -131,6 +134,15 @@ def all_reduce_gradients(params: Iterable[torch.Tensor], group=None, average: bo
     if flat is not None:
         if algo == "direct" and flat.numel() % world == 0:
             all_reduce_direct(flat, group)
+        elif pending is not None:
+            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
+
+            def finish(work=work, flat=flat):
+                work.wait()
+                if average:
+                    flat.div_(world)
+            pending.append(finish)
+            return flat.numel()
         else:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
         if average:
@@ -163,8 +175,8 @@ def exchange_view_gradients(params: Iterable[torch.Tensor], shs: torch.Tensor, d
         raise RuntimeError("exchange_view_gradients: run backward through GaussianRasterizer(..., defer_sh_grad=True) first")
     vc, cams = deferred["view_colors"], deferred["camposes"].reshape(-1, 3)
     world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
-    reduced = all_reduce_gradients(params, group=group, average=average, algo=algo)
     gathered = 0
+    pending: list = []
     if world > 1:
         # rank-major concatenation along dim 0 (the layout every backend accepts)
         vc_all = torch.empty((world * vc.shape[0],) + tuple(vc.shape[1:]), dtype=vc.dtype, device=vc.device)
@@ -173,9 +185,14 @@ def exchange_view_gradients(params: Iterable[torch.Tensor], shs: torch.Tensor, d
         dist.all_gather_into_tensor(cams_all, cams.contiguous(), group=group)
         gathered = vc_all.numel() + cams_all.numel()
         vc, cams = vc_all, cams_all
+    # the all-reduce of the non-SH gradients is issued behind the all-gathers and left in flight while the SH rows
+    # are rebuilt (the kernel only needs the gathered colours)
+    reduced = all_reduce_gradients(params, group=group, average=average, algo=algo, pending=pending)
     if sh_backward is None:
         from .rasterizer import sh_backward_views as sh_backward
     g = sh_backward(deferred["means3D"], cams, vc, deferred["M"], deferred["sh_degree"])
+    for finish in pending:
+        finish()
     if average:
         g = g / world
     shs.grad = g if shs.grad is None else shs.grad + g
