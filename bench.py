@@ -87,7 +87,8 @@ def build_step(cfg, rank, world, dev):
     def make_rasterizer(capacity):
         # two front ends over the same kernels: plain, and with the SH gradient deferred to the view exchange
         return {"allreduce": GaussianRasterizer(rs, capacity=capacity),
-                "views": GaussianRasterizer(rs, capacity=capacity, defer_sh_grad=True)}
+                "views": GaussianRasterizer(rs, capacity=capacity, defer_sh_grad=True),
+                "views_overlap": GaussianRasterizer(rs, capacity=capacity, defer_sh_grad=True, gather_group=True)}
 
     # exchange = (what goes on the wire, all-reduce algorithm); chosen by measurement in main() when world > 1
     state = {"rast": make_rasterizer(None), "out": None, "exchange": ("allreduce", "rccl")}
@@ -101,7 +102,7 @@ def build_step(cfg, rank, world, dev):
                    scales=params["scales"], rotations=params["rotations"])
         torch.autograd.backward(out[0], grad_tensors=dL)
         if world > 1:
-            if mode == "views":
+            if mode != "allreduce":
                 exchange_view_gradients(non_sh, params["shs"], rast.deferred, algo=algo)
             else:
                 all_reduce_gradients(plist, algo=algo)
@@ -212,9 +213,10 @@ def main():
         # measure, don't guess: time a few whole steps with each gradient exchange on this node's links and keep the
         # fastest (max over ranks, so every rank takes the same decision).  "allreduce" = all-reduce of the flat
         # per-Gaussian gradient buffer; "views" = all-reduce of the non-SH part + all-gather of per-view colour
-        # gradients with the SH gradient rebuilt locally; "rccl" / "direct" = library ring vs 1-hop all-to-all form
+        # gradients with the SH gradient rebuilt locally; "views_overlap" = the same with the all-gather started
+        # inside the backward, under its per-Gaussian half; "rccl" / "direct" = library ring vs 1-hop all-to-all form
         times = {}
-        for mode in ("allreduce", "views"):
+        for mode in ("allreduce", "views", "views_overlap"):
             for algo in ("rccl", "direct"):
                 state["exchange"] = (mode, algo)
                 try:  # a backend that lacks a collective raises on every rank alike: skip that strategy

@@ -204,8 +204,9 @@ int hs_backward(const hs_bwd_args* a, void* hip_stream) {
         rc = launch_crf_bwd(*a, L, s);
         if (rc) return rc;
     }
-    if (a->stages & HS_BWD_PREPROCESS) {
-        rc = launch_preprocess_bwd(*a, L, s);
+    if (a->stages & (HS_BWD_PREPROCESS | HS_BWD_SEGSUM | HS_BWD_PROJECT)) {
+        const bool whole = (a->stages & HS_BWD_PREPROCESS) != 0;
+        rc = launch_preprocess_bwd(*a, L, s, whole || (a->stages & HS_BWD_SEGSUM), whole || (a->stages & HS_BWD_PROJECT));
         if (rc) return rc;
     }
     return HS_OK;

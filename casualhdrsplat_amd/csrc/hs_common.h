@@ -49,7 +49,7 @@ int launch_binning(const hs_fwd_args& a, const hs_layout& L, hipStream_t s);
 int launch_render_fwd(const hs_fwd_args& a, const hs_layout& L, hipStream_t s);
 int launch_render_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s);
 int launch_crf_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s);
-int launch_preprocess_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s);
+int launch_preprocess_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s, bool segsum, bool project);
 int launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* vis, hipStream_t s);
 int launch_sh_backward_views(int P, int M, int deg, int V, const float* means3D, const float* camposes,
                              const float* view_colors, float* d_shs, hipStream_t s);

@@ -296,7 +296,8 @@ __global__ void mark_visible_kernel(int P, const float* means, const float* V, u
 // Unflagged records were never written this backward (their tile's replay stopped before them): skipped by select.
 __global__ void __launch_bounds__(256) pair_segsum_kernel(int64_t I, const uint32_t* inst_sorted, const uint32_t* offs_sorted,
                                                           const float4* pair_grads, const uint8_t* pair_flags,
-                                                          float4* inst_grads, const hs_counters* counters) {
+                                                          float4* inst_grads, const hs_counters* counters,
+                                                          const int* radii_inst, const uint8_t* clamped, float* view_colors) {
     // four lanes (one DPP quad) per instance: lane q adds records beg+q, beg+q+4, ...; the four partial sums are
     // combined in a fixed butterfly, so the result does not depend on timing.  Quads shorten the longest run in a
     // wave fourfold (run lengths are heavy-tailed) and make neighbouring lanes read neighbouring records.
@@ -344,6 +345,14 @@ __global__ void __launch_bounds__(256) pair_segsum_kernel(int64_t I, const uint3
         o[1] = make_float4(r[4], r[5], r[6], r[7]);
         o[2] = make_float4(r[8], r[9], 0.f, 0.f);
         if constexpr (kInstF4 == 4) o[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (view_colors) {  // colour gradient of the instance after the SH clamp mask (hs_sh_backward_views input)
+            const int64_t inst = inst_sorted[i];
+            const uint8_t cl = clamped[inst];
+            const bool on = radii_inst[inst] > 0;
+            view_colors[3 * inst + 0] = (on && !(cl & 1)) ? r[6] : 0.f;
+            view_colors[3 * inst + 1] = (on && !(cl & 2)) ? r[7] : 0.f;
+            view_colors[3 * inst + 2] = (on && !(cl & 4)) ? r[8] : 0.f;
+        }
     }
 }
 
@@ -358,7 +367,6 @@ struct PreBwd {
     const float4* inst_grads;
     float* d_means3D; float* d_means2D; float* d_opac; float* d_shs; float* d_colors; float* d_scales;
     float* d_rots; float* d_cov;
-    float* d_view_colors;  // [N][P][3] or null: masked colour gradient per instance (hs_sh_backward_views input)
     float* dens_grad; float* dens_denom; int* dens_radii;  // densification statistics, updated in place, or null
     float* pose_partials;  // [blocks][N][kPoseVals] or null
 };
@@ -442,9 +450,6 @@ __global__ void __launch_bounds__(kPreBwdBlock) preprocess_bwd_kernel(PreBwd p) 
         if constexpr (POSE) {
 #pragma unroll
             for (int k = 0; k < kPoseVals; ++k) pg[k] = 0.f;
-        }
-        if (!on && valid && p.d_view_colors) {
-            p.d_view_colors[3 * idx] = 0.f; p.d_view_colors[3 * idx + 1] = 0.f; p.d_view_colors[3 * idx + 2] = 0.f;
         }
         if (on) {
         // ---- this instance's summed pair records (pair_segsum_kernel) ----
@@ -567,9 +572,6 @@ __global__ void __launch_bounds__(kPreBwdBlock) preprocess_bwd_kernel(PreBwd p) 
             float gc[3];
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) gc[ch] = ((cl >> ch) & 1) ? 0.f : r[6 + ch];
-            if (p.d_view_colors) {
-                p.d_view_colors[3 * idx] = gc[0]; p.d_view_colors[3 * idx + 1] = gc[1]; p.d_view_colors[3 * idx + 2] = gc[2];
-            }
             if constexpr (DEG >= 1) {
                 float gb[NC][3];
                 sh_basis_grad<DEG>(ux, uy, uz, gb);
@@ -809,7 +811,7 @@ int launch_preprocess_fwd(const hs_fwd_args& a, const hs_layout& L, hipStream_t 
     return HS_OK;
 }
 
-int launch_preprocess_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s) {
+int launch_preprocess_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s, bool segsum, bool project) {
     const hs_dims& d = a.dims;
     const char* geom = (const char*)a.geom;
     PreBwd p;
@@ -823,20 +825,21 @@ int launch_preprocess_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t 
     p.tiles = (const uint32_t*)(geom + L.tiles_touched); p.offsets = (const uint32_t*)(geom + L.offsets);
     p.cov3D = (const float*)(geom + L.cov3D); p.clamped = (const uint8_t*)(geom + L.clamped);
     p.inst_grads = (const float4*)((const char*)a.bwd + L.inst_grads);
-    {
+    if (segsum) {
         const int64_t I = (int64_t)d.P * d.n_poses;
         const char* bin = (const char*)a.binning;
         const uint32_t* dv0 = (const uint32_t*)(bin + L.depth_vals);
         pair_segsum_kernel<<<ceil_div(4 * I, 256), 256, 0, s>>>(I, dv0, dv0 + I, (const float4*)((const char*)a.bwd + L.pair_grads),
                                                            (const uint8_t*)bin + L.pair_flags,
                                                            (float4*)((char*)a.bwd + L.inst_grads),
-                                                           (const hs_counters*)(geom + L.counters));
+                                                           (const hs_counters*)(geom + L.counters), p.radii_inst, p.clamped,
+                                                           a.colors_precomp ? nullptr : a.dL_dview_colors);
         HS_LAUNCH_CHECK();
     }
+    if (!project) return HS_OK;
     p.d_means3D = a.dL_dmeans3D; p.d_means2D = a.dL_dmeans2D; p.d_opac = a.dL_dopacities; p.d_shs = a.dL_dshs;
     p.d_colors = a.dL_dcolors_precomp; p.d_scales = a.dL_dscales; p.d_rots = a.dL_drotations;
     p.d_cov = a.dL_dcov3D_precomp;
-    p.d_view_colors = a.colors_precomp ? nullptr : a.dL_dview_colors;
     p.dens_grad = a.densify_grad_accum; p.dens_denom = a.densify_denom; p.dens_radii = a.densify_max_radii;
     const bool shg = p.d_shs != nullptr;
     const int grid = ceil_div(d.P, kPreBwdBlock);

@@ -160,6 +160,24 @@ def all_reduce_gradients(params: Iterable[torch.Tensor], group=None, average: bo
     return packed.numel()
 
 
+def start_view_gather(view_colors: torch.Tensor, camposes: torch.Tensor, group=None):
+    """Issue the all-gathers of one view-parallel step asynchronously (called from the rasterizer's backward between
+    its two halves when GaussianRasterizer(..., gather_group=...) is used).  Returns None when not distributed, else
+    (works, colours of all ranks [world*N, P, 3], camera centres of all ranks [world*N, 3])."""
+    if group is True:
+        group = None
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return None
+    world = dist.get_world_size(group)
+    cams = camposes.reshape(-1, 3).contiguous()
+    vc = view_colors.contiguous()
+    vc_all = torch.empty((world * vc.shape[0],) + tuple(vc.shape[1:]), dtype=vc.dtype, device=vc.device)
+    cams_all = torch.empty((world * cams.shape[0], 3), dtype=cams.dtype, device=cams.device)
+    works = [dist.all_gather_into_tensor(vc_all, vc, group=group, async_op=True),
+             dist.all_gather_into_tensor(cams_all, cams, group=group, async_op=True)]
+    return works, vc_all, cams_all
+
+
 def exchange_view_gradients(params: Iterable[torch.Tensor], shs: torch.Tensor, deferred: dict, group=None,
                             average: bool = False, algo: str = "rccl", sh_backward=None) -> dict:
     """Gradient exchange of one view-parallel step when the rasterizer ran with `defer_sh_grad=True`.
@@ -177,7 +195,14 @@ def exchange_view_gradients(params: Iterable[torch.Tensor], shs: torch.Tensor, d
     world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
     gathered = 0
     pending: list = []
-    if world > 1:
+    started = deferred.get("gather")
+    if world > 1 and started is not None:  # the backward already issued the all-gathers: just wait for them
+        works, vc_all, cams_all = started
+        for w in works:
+            w.wait()
+        gathered = vc_all.numel() + cams_all.numel()
+        vc, cams = vc_all, cams_all
+    elif world > 1:
         # rank-major concatenation along dim 0 (the layout every backend accepts)
         vc_all = torch.empty((world * vc.shape[0],) + tuple(vc.shape[1:]), dtype=vc.dtype, device=vc.device)
         cams_all = torch.empty((world * cams.shape[0], 3), dtype=cams.dtype, device=cams.device)

@@ -292,11 +292,12 @@ class _RasterizeGaussians(torch.autograd.Function):
         want_pose = any(ctx.needs_input_grad[10:13])
         with _on_device(dev):
             g = _launch_backward(st, saved, gcol, ghdr, L.HS_BWD_ALL, want_pose, galpha,
-                                 defer_sh=ctx.deferred is not None, ginvd=ginvd, densify=ctx.densify)
+                                 defer_sh=ctx.deferred is not None, ginvd=ginvd, densify=ctx.densify,
+                                 gather_group=None if ctx.deferred is None else ctx.deferred.get("gather_group"))
         if ctx.deferred is not None:
             # view-parallel exchange: hand the per-view colour gradients to distributed.exchange_view_gradients
             ctx.deferred.update(view_colors=g["view_colors"], camposes=st.camposes, means3D=saved[0],
-                                M=st.dims.M, sh_degree=st.dims.sh_degree, flat=g["_flat"])
+                                M=st.dims.M, sh_degree=st.dims.sh_degree, flat=g["_flat"], gather=g.get("_gather"))
         if st.pending is not None:
             # sync-free mode: the kernels are already queued; only now look at the forward's counters
             st.num_rendered = st.pending.check()
@@ -314,7 +315,7 @@ class _RasterizeGaussians(torch.autograd.Function):
 
 
 def _launch_backward(st: "_State", saved, gcol, ghdr, stages: int, want_pose: bool = False, galpha=None,
-                     defer_sh: bool = False, ginvd=None, densify=None) -> dict:
+                     defer_sh: bool = False, ginvd=None, densify=None, gather_group=None) -> dict:
     """Enqueue hs_backward.  All per-Gaussian gradients are carved out of ONE flat fp32 buffer (the
     layout casualhdrsplat_amd.distributed all-reduces in a single RCCL call): [means3D | means2D |
     opacities | sh | colors | scales | rotations | cov3D | exposure | crf_table]."""
@@ -377,10 +378,20 @@ def _launch_backward(st: "_State", saved, gcol, ghdr, stages: int, want_pose: bo
             raise ValueError("DensifyStats was created for a different number of Gaussians or another device")
         a.densify_grad_accum, a.densify_denom = densify.grad_accum.data_ptr(), densify.denom.data_ptr()
         a.densify_max_radii = densify.max_radii.data_ptr()
-    if P > 0:
-        L.check(lib.hs_backward(C.byref(a), _stream()), "hs_backward")
-    else:
+    if P == 0:
         flat.zero_()
+    elif gather_group is not None and g["view_colors"] is not None and stages == L.HS_BWD_ALL:
+        # view-parallel step: the all-gather of this view's colour gradients starts as soon as the record sums
+        # exist and travels while the per-Gaussian backward runs (distributed.exchange_view_gradients waits for it)
+        from . import distributed as D
+        a.stages = L.HS_BWD_RENDER | L.HS_BWD_CRF | L.HS_BWD_SEGSUM
+        L.check(lib.hs_backward(C.byref(a), _stream()), "hs_backward[render+segsum]")
+        g["_gather"] = D.start_view_gather(g["view_colors"], st.camposes, gather_group)
+        a.stages = L.HS_BWD_PROJECT
+        L.check(lib.hs_backward(C.byref(a), _stream()), "hs_backward[project]")
+        a.stages = stages
+    else:
+        L.check(lib.hs_backward(C.byref(a), _stream()), "hs_backward")
     return g
 
 
@@ -450,8 +461,11 @@ class GaussianRasterizer(nn.Module):
 
     def __init__(self, raster_settings: GaussianRasterizationSettings, capacity: Optional[int] = None,
                  return_alpha: bool = False, defer_sh_grad: bool = False, return_invdepth: bool = False,
-                 densify_stats: Optional[DensifyStats] = None):
+                 densify_stats: Optional[DensifyStats] = None, gather_group=None):
         super().__init__()
+        # with defer_sh_grad: a torch.distributed process group (or True for the default group) makes the backward
+        # start the all-gather of the view colour gradients itself, overlapped with its per-Gaussian half
+        self.gather_group = gather_group
         self.densify_stats = densify_stats  # extension: updated in place by every backward (see DensifyStats)
         # extension (newer published rasterizers return (color, radii, invdepths)): append the expected inverse
         # depth image [H,W] = sum_i alpha_i T_i / z_i to the outputs, differentiable
@@ -490,6 +504,8 @@ class GaussianRasterizer(nn.Module):
         rotations = empty if rotations is None else rotations
         cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
         self.deferred = {} if self.defer_sh_grad else None
+        if self.deferred is not None and self.gather_group is not None:
+            self.deferred["gather_group"] = self.gather_group
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
                                    cov3D_precomp, rs, self.capacity, self.return_alpha, self.deferred,
                                    self.return_invdepth, self.densify_stats)

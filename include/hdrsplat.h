@@ -56,6 +56,10 @@ extern "C" {
 #define HS_BWD_PREPROCESS 2  /* per-instance record sum + computeCov2D/projection/SH/cov3D backward */
 #define HS_BWD_CRF 4         /* CRF-table and exposure gradients (HDR only) */
 #define HS_BWD_ALL 7
+/* the two halves of HS_BWD_PREPROCESS on their own (a caller that all-gathers dL_dview_colors over the ranks can
+ * start that exchange between them) */
+#define HS_BWD_SEGSUM 8      /* per-instance record sums (+ dL_dview_colors when given) */
+#define HS_BWD_PROJECT 16    /* computeCov2D/projection/SH/cov3D backward from the record sums */
 
 /* flags */
 #define HS_FLAG_HDR 1          /* exposure * CRF tone-map epilogue; out_color = LDR, out_hdr = radiance */
