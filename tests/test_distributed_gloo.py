@@ -45,12 +45,12 @@ def _view_deferred(rank, world):
     return sc, cam, vc, rest, b["dL_dshs"]
 
 
-def _worker_views(rank, world, port, q):
+def _worker_views(rank, world, port, q, early_gather=False):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
-    from casualhdrsplat_amd.distributed import exchange_view_gradients, init_from_env
+    from casualhdrsplat_amd.distributed import exchange_view_gradients, init_from_env, start_view_gather
     from oracle import torch_rasterizer as TR
     init_from_env("gloo")
     sc, cam, vc, rest, _ = _view_deferred(rank, world)
@@ -62,6 +62,9 @@ def _worker_views(rank, world, port, q):
     shs = torch.zeros(sc.shs.shape, requires_grad=True)
     deferred = dict(view_colors=torch.from_numpy(vc.copy())[None], camposes=cam.campos.reshape(1, 3).clone(),
                     means3D=sc.means3D, M=sc.shs.shape[1], sh_degree=sc.sh_degree)
+    if early_gather:  # what the rasterizer's backward does with gather_group set: the all-gathers are already in flight
+        deferred["gather"] = start_view_gather(deferred["view_colors"], deferred["camposes"])
+        assert deferred["gather"] is not None
     n = exchange_view_gradients(params, shs, deferred, sh_backward=TR.sh_backward_views)
     assert n["all_gathered"] == world * (vc.size + 3) and n["all_reduced"] >= sum(g.size for g in rest)
     if rank == 0:
@@ -70,13 +73,14 @@ def _worker_views(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_view_exchange_equals_sum_of_single_view_gradients(oracle):
+@pytest.mark.parametrize("early_gather", [False, True])
+def test_view_exchange_equals_sum_of_single_view_gradients(oracle, early_gather):
     """all-gather of per-view colour gradients + local SH outer product == all-reduce of the SH gradient rows."""
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_views, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker_views, args=(r, world, port, q, early_gather)) for r in range(world)]
     for p in procs:
         p.start()
     got = q.get(timeout=120)
