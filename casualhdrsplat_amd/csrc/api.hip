@@ -78,6 +78,18 @@ static int plan(const hs_dims& d, hs_sizes* sz, hs_layout* L) {
     return HS_OK;
 }
 
+// HS_FLAG_DEBUG (the `debug` field of the published settings): wait for each stage and report which one failed.  The
+// only situation in which the library synchronises.
+static int debug_sync(int flags, hipStream_t s, const char* stage) {
+    if (!(flags & HS_FLAG_DEBUG)) return HS_OK;
+    const hipError_t e = hipStreamSynchronize(s);
+    if (e != hipSuccess) {
+        set_error("debug: stage `%s` failed: %s", stage, hipGetErrorString(e));
+        return HS_EHIP;
+    }
+    return HS_OK;
+}
+
 static int check_common(const hs_dims& d, const float* means3D, const float* shs, const float* colors,
                         const float* scales, const float* rots, const float* cov, const float* view,
                         const float* proj, const float* campos, const float* bg, const char* who) {
@@ -141,6 +153,7 @@ int hs_forward(const hs_fwd_args* a, void* hip_stream) {
     if ((a->stages & HS_STAGE_PREPROCESS) && a->dims.P > 0) {
         rc = launch_preprocess_fwd(*a, L, s);
         if (rc) return rc;
+        if ((rc = debug_sync(a->flags, s, "preprocess"))) return rc;
         if (!(a->stages & HS_STAGE_BIN)) {  // upstream-style call: the host reads num_rendered before binning
             rc = launch_scan(*a, L, s);
             if (rc) return rc;
@@ -151,6 +164,7 @@ int hs_forward(const hs_fwd_args* a, void* hip_stream) {
         if (a->dims.P > 0) {
             rc = launch_binning(*a, L, s);
             if (rc) return rc;
+            if ((rc = debug_sync(a->flags, s, "binning"))) return rc;
         } else {
             const int64_t gx = (a->dims.W + kTile - 1) / kTile, gy = (a->dims.H + kTile - 1) / kTile;
             HS_HIP_CHECK(hipMemsetAsync((char*)a->binning + L.ranges, 0, (size_t)(gx * gy * a->dims.n_poses * 8), s));
@@ -164,6 +178,7 @@ int hs_forward(const hs_fwd_args* a, void* hip_stream) {
         if (!a->binning || !a->image || !a->out_color) { set_error("hs_forward: null binning/image/out_color"); return HS_EINVAL; }
         rc = launch_render_fwd(*a, L, s);
         if (rc) return rc;
+        if ((rc = debug_sync(a->flags, s, "render forward"))) return rc;
     }
     return HS_OK;
 }
@@ -199,15 +214,18 @@ int hs_backward(const hs_bwd_args* a, void* hip_stream) {
     if (a->stages & HS_BWD_RENDER) {
         rc = launch_render_bwd(*a, L, s);
         if (rc) return rc;
+        if ((rc = debug_sync(a->flags, s, "render backward"))) return rc;
     }
     if (a->stages & HS_BWD_CRF) {
         rc = launch_crf_bwd(*a, L, s);
         if (rc) return rc;
+        if ((rc = debug_sync(a->flags, s, "CRF gradient"))) return rc;
     }
     if (a->stages & (HS_BWD_PREPROCESS | HS_BWD_SEGSUM | HS_BWD_PROJECT)) {
         const bool whole = (a->stages & HS_BWD_PREPROCESS) != 0;
         rc = launch_preprocess_bwd(*a, L, s, whole || (a->stages & HS_BWD_SEGSUM), whole || (a->stages & HS_BWD_PROJECT));
         if (rc) return rc;
+        if ((rc = debug_sync(a->flags, s, "preprocess backward"))) return rc;
     }
     return HS_OK;
 }

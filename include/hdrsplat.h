@@ -64,7 +64,7 @@ extern "C" {
 /* flags */
 #define HS_FLAG_HDR 1          /* exposure * CRF tone-map epilogue; out_color = LDR, out_hdr = radiance */
 #define HS_FLAG_BLUR_HDR 2     /* N-pose average taken on radiance before the CRF (default: on LDR) */
-#define HS_FLAG_DEBUG 4
+#define HS_FLAG_DEBUG 4         /* wait for every stage and name the failing one (the only case of a sync) */
 #define HS_FLAG_ANTIALIAS 8    /* newer published rasterizer's `antialiasing`: opacity *= sqrt(max(0.000025,
                                   det(cov2D) / det(cov2D + 0.3 I))), with its gradient */
 

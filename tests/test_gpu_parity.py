@@ -763,3 +763,20 @@ def test_full_size_properties_c4_eight_poses():
     torch.cuda.empty_cache()
     same, _, _ = render([cams[0]] * N)
     assert Hh.rel_err(same[0].detach().cpu().numpy(), out1[0].detach().cpu().numpy(), 1e-3)[0] <= 1e-5
+
+
+def test_debug_flag_gives_identical_results():
+    """settings.debug=True (HS_FLAG_DEBUG: the library waits for every stage and names a failing one) changes nothing
+    but the synchronisation."""
+    sc = S.make_scene(3000, 160, 120, 2, seed=41, hdr=True)
+    a = Hh.run_hip(sc, hdr=True)
+    from casualhdrsplat_amd import GaussianRasterizer
+    rs, expo, crf = Hh.settings_from_scene(sc, "cuda", hdr=True, requires_grad=True)
+    rs = rs._replace(debug=True)
+    leaf = {k: getattr(sc, k).cuda().requires_grad_(True) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
+    out = GaussianRasterizer(rs)(leaf["means3D"], torch.zeros(3000, 3, device="cuda"), leaf["opacities"], shs=leaf["shs"],
+                                 scales=leaf["scales"], rotations=leaf["rotations"])
+    (out[0] * sc.dL_dimage.cuda()).sum().backward()
+    assert np.array_equal(out[0].detach().cpu().numpy(), a["color"])
+    for k in leaf:
+        assert np.array_equal(leaf[k].grad.cpu().numpy(), a["d_" + k]), k
