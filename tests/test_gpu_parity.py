@@ -780,3 +780,36 @@ def test_debug_flag_gives_identical_results():
     assert np.array_equal(out[0].detach().cpu().numpy(), a["color"])
     for k in leaf:
         assert np.array_equal(leaf[k].grad.cpu().numpy(), a["d_" + k]), k
+
+
+def test_all_optional_outputs_together_are_linear_in_their_gradients():
+    """(ldr, radii, hdr, alpha, invdepth) in one call: the backward with all four upstream gradients at once equals the
+    sum of four backwards with one gradient each (the replay is linear in them), so no output's gradient is dropped or
+    mis-ordered."""
+    from casualhdrsplat_amd import GaussianRasterizer
+    P, W, H = 2000, 144, 96
+    sc = S.make_scene(P, W, H, 2, seed=33, hdr=True)
+    rs, expo, crf = Hh.settings_from_scene(sc, "cuda", hdr=True, requires_grad=True)
+    gen = torch.Generator().manual_seed(9)
+    ups = [sc.dL_dimage.cuda(), torch.randn(3, H, W, generator=gen).cuda(), torch.randn(H, W, generator=gen).cuda(),
+           torch.randn(H, W, generator=gen).cuda() * 3]
+    names = ("means3D", "opacities", "shs", "scales", "rotations")
+
+    def run(weights):
+        leaf = {k: getattr(sc, k).cuda().requires_grad_(True) for k in names}
+        for t in (expo, crf):
+            t.grad = None
+        out = GaussianRasterizer(rs, return_alpha=True, return_invdepth=True)(
+            leaf["means3D"], torch.zeros(P, 3, device="cuda"), leaf["opacities"], shs=leaf["shs"], scales=leaf["scales"],
+            rotations=leaf["rotations"])
+        assert len(out) == 5 and out[2].shape == (3, H, W) and out[3].shape == (H, W) and out[4].shape == (H, W)
+        loss = sum(w * (o * u).sum() for w, o, u in zip(weights, (out[0], out[2], out[3], out[4]), ups) if w)
+        loss.backward()
+        return {k: v.grad.double() for k, v in leaf.items()} | {"crf": crf.grad.double().clone(), "exp": expo.grad.double().clone()}
+
+    total = run([1, 1, 1, 1])
+    parts = [run([1 if i == j else 0 for j in range(4)]) for i in range(4)]
+    for k in total:
+        s = sum(p[k] for p in parts)
+        assert torch.allclose(total[k], s, rtol=2e-4, atol=2e-5 * float(s.abs().max())), k
+    assert all(float(p["means3D"].abs().max()) > 0 for p in parts)
