@@ -661,9 +661,10 @@ def test_randomized_configurations_vs_oracle(oracle):
             pl = np.concatenate([f["point_list"].astype(np.int64) + k * P for k, f in enumerate(r["fwd"])])
             assert np.array_equal(u32(st["point_list"][:Rtot]), pl), what
             flips = sum(int((u32(st["n_contrib"][k]) != u32(f["n_contrib"])).sum()) for k, f in enumerate(r["fwd"]))
-            if flips == 0:
-                assert Hh.rel_err(g["color"], r["ldr"], 1e-2)[0] <= 1e-4, what
-                assert Hh.rel_err(g["hdr"], r["hdr"], 1e-2)[0] <= 1e-4, what
+            # a contributor within an ulp of the alpha >= 1/255 test can flip in the middle of a list without moving
+            # n_contrib: the image comparator counts such pixels, the gradient check is skipped when there are any
+            soft = assert_image_close(g["hdr"], r["hdr"], what) + assert_image_close(g["color"], r["ldr"], what)
+            if flips == 0 and soft == 0:
                 Hh.assert_grads_close(g, r, frac_tol=2e-2, l2_tol=2e-4, what=what)
         else:
             f, b = Hh.run_oracle(oracle, sc)
