@@ -100,15 +100,16 @@ def test_forward_backward_validate_before_touching_the_gpu(lib):
 
 def test_sh_backward_views_validates_before_touching_the_gpu(lib):
     """hs_sh_backward_views (the local half of the view-parallel exchange): argument errors come back as HS_EINVAL."""
-    f = lib.hs_sh_backward_views
-    one = C.c_void_p(256)  # non-null dummy pointers: validation must fail before any of them is dereferenced
-    assert f(10, 16, 3, 0, one, one, one, one, None) == L.HS_EINVAL          # V < 1
-    assert f(10, 4, 3, 2, one, one, one, one, None) == L.HS_EINVAL           # M too small for degree 3
-    assert f(10, 16, 4, 2, one, one, one, one, None) == L.HS_EINVAL          # degree out of range
-    assert f(10, 16, 3, 2, None, one, one, one, None) == L.HS_EINVAL         # null means3D
-    assert f(-1, 16, 3, 2, one, one, one, one, None) == L.HS_EINVAL
-    assert b"hs_sh_backward_views" in lib.hs_last_error()
-    assert f(0, 16, 3, 2, None, None, None, None, None) == L.HS_OK           # nothing to do
+    L = lib.load()
+    f = L.hs_sh_backward_views
+    one = 256  # non-null dummy pointers: validation must fail before any of them is dereferenced
+    assert f(10, 16, 3, 0, one, one, one, one, None) == lib.HS_EINVAL          # V < 1
+    assert f(10, 4, 3, 2, one, one, one, one, None) == lib.HS_EINVAL           # M too small for degree 3
+    assert f(10, 16, 4, 2, one, one, one, one, None) == lib.HS_EINVAL          # degree out of range
+    assert f(10, 16, 3, 2, None, one, one, one, None) == lib.HS_EINVAL         # null means3D
+    assert f(-1, 16, 3, 2, one, one, one, one, None) == lib.HS_EINVAL
+    assert b"hs_sh_backward_views" in L.hs_last_error()
+    assert f(0, 16, 3, 2, None, None, None, None, None) == lib.HS_OK           # nothing to do
 
 
 def test_missing_library_is_a_hard_error(lib, monkeypatch):
