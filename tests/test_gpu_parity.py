@@ -649,7 +649,12 @@ def test_randomized_configurations_vs_oracle(oracle):
         sc = S.make_scene(P, W, H, deg, seed=seed, hdr=hdr)
         cams = S.blur_poses(W, H, n_poses, step=0.03) if n_poses > 1 else None
         if hdr or n_poses > 1:
-            if not hdr:  # non-HDR multi-pose average: compare through the HDR oracle with an identity-free path
+            if not hdr:  # linear-radiance blur: the average of the per-pose oracle renders
+                fs = [Hh.run_oracle(oracle, sc, cam=c, backward=False)[0] for c in cams]
+                g = Hh.run_hip(sc, cameras=cams, backward=False)
+                ref = np.mean(np.stack([f["color"] for f in fs]), axis=0, dtype=np.float64)
+                assert_image_close(g["color"], ref, what)
+                assert np.array_equal(g["radii"], np.max(np.stack([f["radii"] for f in fs]), axis=0)), what
                 continue
             r = Hh.run_oracle_hdr(oracle, sc, cams, "ldr")
             Rtot = sum(f["R"] for f in r["fwd"])
