@@ -1,54 +1,98 @@
 #!/usr/bin/env python
 """bench.py -- train-step images/sec (fwd+bwd raster) @ 1M Gaussians 1080p on N MI355X.
 
-Contract: `python bench.py --gpus N --steps K --warmup W` (N>1 via torch.distributed.run, one
-rank per GPU over RCCL).  One "step" = one pass of the hot path on one synthetic view per rank:
-GaussianRasterizer forward (preprocess, scan, duplicateWithKeys, radix sort, ranges, per-tile
-alpha blend + exposure/CRF tone-map) and backward (per-pixel backward, preprocess backward),
-followed at N>1 by one RCCL all-reduce of the per-Gaussian gradients.  Inputs are resident in
-HBM before the timed region.  Rank 0 prints ONE JSON line.
+Contract: `python bench.py --gpus N --steps K --warmup W`.  One rank per GPU over RCCL; at N > 1 the ranks come
+either from the caller (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`: RANK / WORLD_SIZE
+are in the environment) or, when `python bench.py --gpus N` is run bare, from bench.py itself: before anything touches
+a GPU it starts `python -m torch.distributed.run` with N fresh child processes on a free port, forwards rank 0's JSON
+line and exits with the children's code.
 
-Workload = BASELINE.json configs[2] ("c3": 1M Gaussians, 1920x1080, SH degree 3, HDR linear
-radiance + learned CRF tone-map), the configuration the metric is quoted on; at N>1 each rank
-renders its own view of the same cloud (configs[4]).  Synthetic scene: SURVEY.md 8(d).
+One "step" = one pass of the hot path on one synthetic view per rank: GaussianRasterizer forward (preprocess, scan,
+duplicateWithKeys, radix sort, ranges, per-tile alpha blend + exposure/CRF tone-map) and backward (per-pixel backward,
+preprocess backward), followed at N>1 by the exchange that sums the per-Gaussian gradients over the views.  Inputs are
+resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
 
-Extra objects on the line:
-  roofline      -- the dominant kernel (render_bwd_kernel): algorithmic bytes per launch
-                   (76*R' + 20*W*H) / its average duration measured here with HIP events
-                   on the launch stream; peak = 8 TB/s HBM3E.  `fwd_bwd` repeats the figure for the
-                   per-tile alpha-blend forward+backward pair (116*R' + 40*W*H + 8*tiles), the
-                   quantity BASELINE.md's 40 % target is stated on.
-  cpu_baseline  -- the pure-PyTorch CPU autograd rasterizer (oracle/torch_rasterizer.py) timed on
-                   this box's host cores on a bounded sample of the same frame.
+Workload = BASELINE.json configs[2] ("c3": 1M Gaussians, 1920x1080, SH degree 3, HDR linear radiance + learned CRF
+tone-map), the configuration the metric is quoted on; at N>1 each rank renders its own view of the same cloud
+(configs[4]).  Synthetic scene: SURVEY.md 8(d), seed 0 for the headline, seeds {0,1,2} in `seeds_ms_per_step`.
+
+Extra objects on the line (all measured in this run unless marked `from_profiles`):
+  roofline      -- the dominant kernel (render_bwd_kernel): algorithmic bytes per launch (76*R' + 20*W*H) /
+                   its average duration measured here with HIP events on the launch stream; peak = 8 TB/s HBM3E.
+                   `fwd_bwd` repeats the figure for the per-tile alpha-blend forward+backward pair
+                   (116*R' + 40*W*H + 8*tiles), the quantity BASELINE.md's 40 % target is stated on.  `valu` is the
+                   roofline that actually binds these kernels: wave-level vector instructions per launch =
+                   (instructions per compositing-loop trip, read from the ISA by scripts/isa_loop_counts.py) x (trips,
+                   counted live by the diagnostic instantiation of the kernels), against the issue rate of the 1024
+                   SIMDs (one wave64 VALU instruction per 4 cycles per SIMD at 2.4 GHz); `lane_utilisation` = active
+                   pixels / (128 x trips).
+  cpu_baseline  -- the pure-PyTorch CPU autograd rasterizer (oracle/torch_rasterizer.py) timed on this box's host
+                   cores: BASELINE config c1 in full (median of 5), c2 in full when it fits the time budget, and a
+                   bounded sample of the c3 frame extrapolated to the whole frame (`value`).
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
+# VALU issue peak: 256 CUs x 4 SIMDs, one wave64 vector instruction per 4 cycles per SIMD (16 lanes/clk), 2.4 GHz
+N_SIMD, CLK_HZ, CYCLES_PER_VALU = 1024, 2.4e9, 4.0
+VALU_PEAK_WAVE_INSTR_PER_S = N_SIMD * CLK_HZ / CYCLES_PER_VALU
 
 CONFIGS = {
     # name: (P, W, H, sh_degree, hdr, n_poses)
+    "c1": (1_000, 128, 128, 0, False, 1),
     "c2": (100_000, 800, 800, 0, False, 1),
     "c3": (1_000_000, 1920, 1080, 3, True, 1),
     "c4": (1_000_000, 1920, 1080, 3, True, 8),
 }
 
 
-def build_step(cfg, rank, world, dev):
+def free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_command(argv: list[str], gpus: int, port: int) -> list[str]:
+    """The command a bare `python bench.py --gpus N` turns into: N fresh processes, one per GPU."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(argv: list[str], gpus: int) -> int:
+    """Parent of a bare multi-GPU run.  Nothing here imports torch or touches HIP: the ranks are started as ordinary
+    child processes (never an exec of a process that initialised the GPU) and this process only relays their output."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool (RCCL peer access)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(gpus, 1))))
+    cmd = launch_command(argv, gpus, free_port())
+    print(f"[bench] --gpus {gpus} without a torchrun environment: starting {' '.join(cmd)}", file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for ln in proc.stdout:  # rank 0's JSON line (and anything else the ranks print) goes straight through
+        sys.stdout.write(ln)
+        sys.stdout.flush()
+    return proc.wait()
+
+
+def build_step(cfg, rank, world, dev, seed=0):
+    import torch
     from casualhdrsplat_amd import GaussianRasterizationSettings, GaussianRasterizer, synthetic as S
     from casualhdrsplat_amd.distributed import all_reduce_gradients, exchange_view_gradients
     P, W, H, deg, hdr, n_poses = cfg
-    sc = S.make_scene(P, W, H, deg, seed=0, hdr=hdr)
+    sc = S.make_scene(P, W, H, deg, seed=seed, hdr=hdr)
     # one view per rank: yaw in [-5, +5] degrees about the cloud centre; rank 0 of a
     # single-GPU run uses the frontal camera the cloud was laid out for.
     if world > 1:
@@ -85,7 +129,7 @@ def build_step(cfg, rank, world, dev):
     non_sh = [p for k, p in params.items() if k != "shs"] + ([exposure, crf] if hdr else [])
 
     def make_rasterizer(capacity):
-        # two front ends over the same kernels: plain, and with the SH gradient deferred to the view exchange
+        # front ends over the same kernels: plain, and with the SH gradient deferred to the view exchange
         return {"allreduce": GaussianRasterizer(rs, capacity=capacity),
                 "views": GaussianRasterizer(rs, capacity=capacity, defer_sh_grad=True),
                 "views_overlap": GaussianRasterizer(rs, capacity=capacity, defer_sh_grad=True, gather_group=True)}
@@ -114,6 +158,7 @@ def build_step(cfg, rank, world, dev):
 
 def derived_counts(out, W, H, n_poses):
     """R, R' = sum over tiles of max n_contrib (entries a tile must fetch), E = sum n_contrib."""
+    import torch
     from casualhdrsplat_amd import inspect_state
     st = inspect_state(out[0])
     nc = st["n_contrib"].to(torch.int64)
@@ -126,6 +171,7 @@ def derived_counts(out, W, H, n_poses):
 
 def time_stage(fn, iters):
     """Average duration (ms) of fn() measured with HIP events on the current (= launch) stream."""
+    import torch
     fn()
     torch.cuda.synchronize()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
@@ -138,11 +184,33 @@ def time_stage(fn, iters):
     return sum(ts) / len(ts), ts[len(ts) // 2]
 
 
-def cpu_baseline(sc, cfg, n_tiles_sample=96):
-    """Pure-PyTorch CPU autograd rasterizer on a bounded sample: full preprocess + binning of the frame,
-    then forward+backward of every k-th tile; extrapolated to images/s of the whole frame."""
+def _cpu_full_frame(cfg, seed=0):
+    """One full fwd+bwd of a BASELINE config with the pure-PyTorch CPU rasterizer; returns seconds."""
+    from casualhdrsplat_amd import synthetic as S
     from oracle import torch_rasterizer as TR
     P, W, H, deg, hdr, n_poses = cfg
+    sc = S.make_scene(P, W, H, deg, seed=seed, hdr=hdr)
+    cam = sc.camera
+    view = TR.View(W, H, cam.tanfovx, cam.tanfovy, cam.viewmatrix, cam.projmatrix, cam.campos)
+    leaves = [t.clone().requires_grad_(True) for t in (sc.means3D, sc.opacities, sc.shs, sc.scales, sc.rotations)]
+    t0 = time.time()
+    color = TR.rasterize(view, leaves[0], leaves[1], deg, sc.bg, shs=leaves[2], scales=leaves[3], rotations=leaves[4])
+    (color * sc.dL_dimage).sum().backward()
+    return time.time() - t0
+
+
+def cpu_baseline(sc, cfg, n_tiles_sample=96, c2_budget_s=150.0):
+    """Pure-PyTorch CPU autograd rasterizer: c1 in full (median of 5), c2 in full when c1's
+    rate says it fits the budget, and -- `value` -- the c3 frame on a bounded sample: full preprocess + binning of
+    the frame, then forward+backward of every k-th tile, extrapolated to images/s of the whole frame."""
+    import torch
+    from oracle import torch_rasterizer as TR
+    P, W, H, deg, hdr, n_poses = cfg
+    t_start = time.time()
+    c1 = sorted(_cpu_full_frame(CONFIGS["c1"]) for _ in range(5))
+    c1_med = c1[2]
+    out = {"c1_full": {"images_per_s": 1.0 / c1_med, "seconds_median_of_5": c1_med,
+                       "workload": "1k Gaussians, 128x128, SH 0, fwd+bwd, whole frame"}}
     cam = sc.camera
     view = TR.View(W, H, cam.tanfovx, cam.tanfovy, cam.viewmatrix, cam.projmatrix, cam.campos)
     leaves = [t.clone().requires_grad_(True) for t in (sc.means3D, sc.opacities, sc.shs, sc.scales, sc.rotations)]
@@ -160,15 +228,90 @@ def cpu_baseline(sc, cfg, n_tiles_sample=96):
     (color * sc.dL_dimage).sum().backward()
     t2 = time.time()
     t_pre, t_tiles = t1 - t0, t2 - t1
-    t_full = t_pre + t_tiles * (ntiles / len(tiles))
-    return {
+    per_tile = t_tiles / len(tiles)
+    t_full = t_pre + per_tile * ntiles
+    # c2 in full if it fits: 2500 tiles at roughly c3's per-tile cost x (c2 list length / c3 list length ~ 0.25)
+    c2_est = 2500 * per_tile * 0.35 + 2.0
+    if c2_est <= c2_budget_s:
+        t = _cpu_full_frame(CONFIGS["c2"])
+        out["c2_full"] = {"images_per_s": 1.0 / t, "seconds": t, "workload": "100k Gaussians, 800x800, SH 0, LDR, fwd+bwd, whole frame"}
+    else:
+        out["c2_full"] = {"skipped": f"estimated {c2_est:.0f} s > budget {c2_budget_s:.0f} s"}
+    out.update({
         "value": 1.0 / t_full, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
         "host_cpus": os.cpu_count(),
         "sample": (f"pure-PyTorch fp32 autograd rasterizer (oracle/torch_rasterizer.py): full preprocess+binning of "
                    f"the {P}-Gaussian {W}x{H} frame ({t_pre:.1f} s) + fwd+bwd of {len(tiles)} of {ntiles} tiles "
                    f"({t_tiles:.1f} s, backward also covers preprocess); value extrapolates the tile part to all tiles"),
-        "measured_seconds": t2 - t0,
-    }
+        "measured_seconds": time.time() - t_start,
+    })
+    return out
+
+
+def isa_counts():
+    """Per-trip vector-instruction counts of the two compositing loops (scripts/isa_loop_counts.py reads them from
+    the compiler's ISA for gfx950 and commits them as profiles/isa_loop_counts.json).  They are a property of the
+    source, so the file records the hash of render.hip it was made from; `stale` says whether that still matches."""
+    path = os.path.join(ROOT, "profiles", "isa_loop_counts.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        d = json.load(open(path))
+        src = os.path.join(ROOT, "casualhdrsplat_amd", "csrc", "render.hip")
+        d["stale"] = hashlib.sha256(open(src, "rb").read()).hexdigest() != d.get("render_hip_sha256")
+        return d
+    except Exception:
+        return None
+
+
+def valu_roofline(stats, isa, fwd_ms, bwd_ms):
+    """The roofline that binds the render kernels (SURVEY.md 8d "which roofline"): wave-level vector instructions
+    issued per launch / launch time, against one wave64 VALU instruction per 4 cycles on each of the 1024 SIMDs."""
+    out = {"bound": "valu_issue", "peak": VALU_PEAK_WAVE_INSTR_PER_S, "unit": "wave64 VALU instr/s",
+           "peak_note": "1024 SIMDs x 2.4 GHz / 4 cycles per wave64 vector instruction (transcendentals and "
+                        "v_permlane*_swap take 8: `issue_cycles_frac` weights them)"}
+    for side, ms in (("bwd", bwd_ms), ("fwd", fwd_ms)):
+        trips, empty, pix = stats[f"{side}_trips"], stats[f"{side}_empty_trips"], stats[f"{side}_active_pixels"]
+        o = {"trips": trips, "empty_trips": empty,
+             "lane_utilisation": pix / (128.0 * trips) if trips else None,
+             "lane_utilisation_note": "active pixels / (128 pixels x trips), counted live (hs_render_stats)"}
+        if side == "bwd":
+            o["trips_by_active_lanes"] = {k[len("bwd_hist_"):]: stats[k] for k in stats if k.startswith("bwd_hist_")}
+        k = (isa or {}).get(f"render_{side}_kernel")
+        if k:
+            full, short = k["valu_per_trip"], k.get("valu_per_empty_trip", k["valu_per_trip"])
+            cyc_full, cyc_short = k["valu_cycles_per_trip"], k.get("valu_cycles_per_empty_trip", k["valu_cycles_per_trip"])
+            instr = full * (trips - empty) + short * empty
+            cycles = cyc_full * (trips - empty) + cyc_short * empty
+            o.update({"valu_instr_per_trip": full, "valu_instr_per_empty_trip": short,
+                      "valu_instr_per_launch_loop_only": instr, "achieved": instr / (ms * 1e-3),
+                      "frac": instr / (ms * 1e-3) / VALU_PEAK_WAVE_INSTR_PER_S,
+                      "issue_cycles_frac": cycles / (ms * 1e-3 * N_SIMD * CLK_HZ),
+                      "isa_from_profiles": True, "isa_source": (isa or {}).get("source"),
+                      "isa_stale": (isa or {}).get("stale")})
+        out[side] = o
+    return out
+
+
+def offline_profile(cfg_name):
+    """Counter-derived figures of an EARLIER rocprofv3 --pmc run (they cannot be collected inside a timed run): kept
+    apart from the live numbers and labelled with where they came from."""
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(tpath):
+        return None
+    try:
+        pmc = json.load(open(tpath)).get(cfg_name)
+        if not pmc:
+            return None
+        return {"from_profiles": True, "file": "profiles/pmc_traffic.json", "source": pmc.get("source"),
+                "source_commit": pmc.get("source_commit"),
+                "render_bwd_kernel_hbm_bytes": pmc.get("render_bwd_kernel_hbm_bytes"),
+                "render_fwd_kernel_hbm_bytes": pmc.get("render_fwd_kernel_hbm_bytes"),
+                "render_bwd_kernel_valu_busy_frac": pmc.get("render_bwd_kernel_valu_busy_frac"),
+                "render_fwd_kernel_valu_busy_frac": pmc.get("render_fwd_kernel_valu_busy_frac"),
+                "method": pmc.get("method")}
+    except Exception:
+        return None
 
 
 def main():
@@ -176,18 +319,27 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--config", default="c3", choices=sorted(c for c in CONFIGS if c != "c1"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the per-seed and per-stage legs (profiling runs)")
     ap.add_argument("--kernel-iters", type=int, default=10)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(sys.argv[1:], args.gpus))
+
+    import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback exists)")
     import torch.distributed as dist
     from casualhdrsplat_amd.distributed import init_from_env
     # HS_BENCH_BACKEND=gloo is a plumbing check for boxes with fewer GPUs than ranks (ranks then share devices);
     # measured runs use "nccl" (= RCCL over xGMI), one rank per GPU.
-    rank, world, local = init_from_env(os.environ.get("HS_BENCH_BACKEND", "nccl"))
+    backend = os.environ.get("HS_BENCH_BACKEND", "nccl")
+    if int(os.environ.get("WORLD_SIZE", "1")) > torch.cuda.device_count() and backend == "nccl":
+        raise SystemExit(f"--gpus {args.gpus}: only {torch.cuda.device_count()} GPU(s) visible (RCCL needs one per rank; "
+                         "HS_BENCH_BACKEND=gloo shares devices for a plumbing check)")
+    rank, world, local = init_from_env(backend)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     local = local % torch.cuda.device_count()
@@ -203,6 +355,7 @@ def main():
     torch.cuda.synchronize()
     R, Rp, E, vtiles = derived_counts(out, W, H, n_poses)
     state["rast"] = make_rasterizer(int(R * 1.25) + 4096)
+
     def barrier():
         if world > 1:
             dist.barrier()
@@ -216,10 +369,12 @@ def main():
         # gradients with the SH gradient rebuilt locally; "views_overlap" = the same with the all-gather started
         # inside the backward, under its per-Gaussian half; "rccl" / "direct" = library ring vs 1-hop all-to-all form
         times = {}
+        errors = {}
         for mode in ("allreduce", "views", "views_overlap"):
             for algo in ("rccl", "direct"):
                 state["exchange"] = (mode, algo)
-                try:  # a backend that lacks a collective raises on every rank alike: skip that strategy
+                ok, dt_ = 1.0, 0.0
+                try:  # a strategy the backend cannot run must not take the run down with it
                     step()
                     barrier()
                     t0 = time.perf_counter()
@@ -228,15 +383,20 @@ def main():
                     barrier()
                     dt_ = time.perf_counter() - t0
                 except RuntimeError as e:
-                    if rank == 0:
-                        print(f"[bench] exchange {mode}/{algo} unavailable: {e}", file=sys.stderr)
-                    continue
-                t = torch.tensor([dt_], dtype=torch.float64, device=dev)
+                    ok = 0.0
+                    errors[f"{mode}/{algo}"] = str(e)[:200]
+                # every rank learns whether ALL ranks finished the strategy (a one-sided failure must not leave the
+                # ranks with different choices), and the slowest rank's time
+                t = torch.tensor([dt_, -ok], dtype=torch.float64, device=dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                times[f"{mode}/{algo}"] = float(t.item()) / 3 * 1e3
+                if float(t[1].item()) == -1.0:
+                    times[f"{mode}/{algo}"] = float(t[0].item()) / 3 * 1e3
+                elif rank == 0:
+                    print(f"[bench] exchange {mode}/{algo} unavailable: {errors.get(f'{mode}/{algo}', 'failed on another rank')}",
+                          file=sys.stderr)
         best = min(times, key=times.get) if times else "allreduce/rccl"
         state["exchange"] = tuple(best.split("/"))
-        allreduce_info = {"choice": best, "step_ms": times}
+        allreduce_info = {"choice": best, "step_ms": times, "backend": backend}
 
     for _ in range(args.warmup):
         step()
@@ -261,7 +421,7 @@ def main():
         "config": {"workload": f"{args.config}: {P} Gaussians, {W}x{H}, SH degree {deg}, "
                                f"{'HDR radiance + CRF tone-map' if hdr else 'LDR'}, {n_poses} pose(s)/view, "
                                f"{world} view(s)/step (one per GPU)" + (", gradients summed over views (config.gradient_exchange)" if world > 1 else ""),
-                   "num_rendered_R": R, "R_prime": Rp, "pixel_pair_evals_E": E,
+                   "num_rendered_R": R, "R_prime": Rp, "pixel_pair_evals_E": E, "seed": 0,
                    "binning": "sync-free fixed capacity 1.25*R"},
         "mpix_per_s": world * args.steps * W * H * n_poses / elapsed / 1e6,
     }
@@ -270,47 +430,72 @@ def main():
 
     if rank == 0:
         from casualhdrsplat_amd import _lib as L
-        from casualhdrsplat_amd.rasterizer import replay_backward, replay_forward
+        from casualhdrsplat_amd.rasterizer import render_stats, replay_backward, replay_forward
         # a fresh forward whose autograd graph is kept (never .backward()-ed) so its stages can be replayed
         for p_ in plist:
             p_.grad = None
         out = state["rast"]["allreduce"](*[plist[i] for i in (0, 1, 2)], shs=plist[3], scales=plist[4], rotations=plist[5])
         R, Rp, E, vtiles = derived_counts(out, W, H, n_poses)
         WH = W * H * n_poses
-        bwd_ms, bwd_med = time_stage(lambda: replay_backward(out[0], dL, L.HS_BWD_RENDER), args.kernel_iters)
-        fwd_ms, fwd_med = time_stage(lambda: replay_forward(out[0], L.HS_STAGE_RENDER), args.kernel_iters)
+        it = args.kernel_iters
+        # order matters: the binning replay clears the pair flags the backward sets, so every backward stage is timed
+        # first, on the state a real step leaves behind (forward -> render bwd -> segmented sum + preprocess bwd)
+        bwd_ms, bwd_med = time_stage(lambda: replay_backward(out[0], dL, L.HS_BWD_RENDER), it)
+        stages = {"render_bwd": bwd_ms}
+        stages["segsum_and_preprocess_bwd"] = time_stage(lambda: replay_backward(out[0], dL, L.HS_BWD_PREPROCESS), it)[0]
+        if hdr:
+            stages["crf_gradient"] = time_stage(lambda: replay_backward(out[0], dL, L.HS_BWD_CRF), it)[0]
+        fwd_ms, fwd_med = time_stage(lambda: replay_forward(out[0], L.HS_STAGE_RENDER), it)
+        stages["render_fwd"] = fwd_ms
+        stats = render_stats(out[0], dL)
+        stages["binning"] = time_stage(lambda: replay_forward(out[0], L.HS_STAGE_BIN), it)[0]
+        stages["preprocess_fwd_and_binning"] = time_stage(
+            lambda: replay_forward(out[0], L.HS_STAGE_PREPROCESS | L.HS_STAGE_BIN), it)[0]
         bytes_bwd = 76 * Rp + 20 * WH
         bytes_fwd = 40 * Rp + 20 * WH + 8 * vtiles
-        traffic = valu_busy = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                pmc = json.load(open(tpath)).get(args.config, {})
-                traffic = pmc.get("render_bwd_kernel_hbm_bytes")
-                valu_busy = pmc.get("render_bwd_kernel_valu_busy_frac")
-            except Exception:
-                traffic = valu_busy = None
         ach = bytes_bwd / (bwd_ms * 1e-3) / 1e9
         line["roofline"] = {
             "kernel": "render_bwd_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+            "frac": ach / HBM_PEAK_GBS,
+            "traffic": None,  # PMC counters cannot be read inside a timed run: see `offline_profile`
             "algorithmic_bytes": bytes_bwd, "avg_ms": bwd_ms, "median_ms": bwd_med,
-            "valu_busy_frac": valu_busy,  # PMC (profiles/pmc_traffic.json): what actually bounds this kernel
-            "note": "the kernel is VALU-issue bound (DESIGN.md 4, profiles/README.md), not HBM bound; traffic = L2-fabric bytes from profiles/pmc_traffic.json",
+            "note": "the kernel is VALU-issue bound (roofline.valu; DESIGN.md 4), not HBM bound",
             "fwd_bwd": {"kernels": "render_fwd_kernel + render_bwd_kernel", "algorithmic_bytes": bytes_fwd + bytes_bwd,
                         "avg_ms": fwd_ms + bwd_ms,
                         "achieved": (bytes_fwd + bytes_bwd) / ((fwd_ms + bwd_ms) * 1e-3) / 1e9,
                         "frac": (bytes_fwd + bytes_bwd) / ((fwd_ms + bwd_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                         "pair_evals_per_s": 2 * E / ((fwd_ms + bwd_ms) * 1e-3)},
+            "valu": valu_roofline(stats, isa_counts(), fwd_ms, bwd_ms),
         }
-        # live per-stage times of the same frame (HIP events on the launch stream), for the reader of the line
-        stages = {"render_bwd": bwd_ms, "render_fwd": fwd_ms}
-        for name, fn in (("binning", lambda: replay_forward(out[0], L.HS_STAGE_BIN)),
-                         ("segsum_and_preprocess_bwd", lambda: replay_backward(out[0], dL, L.HS_BWD_PREPROCESS)),
-                         ("crf_gradient", (lambda: replay_backward(out[0], dL, L.HS_BWD_CRF)) if hdr else None)):
-            if fn is not None:
-                stages[name] = time_stage(fn, args.kernel_iters)[0]
+        off = offline_profile(args.config)
+        if off is not None:
+            line["roofline"]["offline_profile"] = off
         line["stages_ms"] = {k: round(v, 4) for k, v in stages.items()}
+        line["render_stats"] = stats
+        if world == 1 and not args.no_extras:
+            # the headline is seed 0; the other two seeds of SURVEY.md 8(d) are timed the same way (fewer steps)
+            per_seed = {"0": ms_per_step}
+            del out
+            for seed in (1, 2):
+                step_s, state_s, mk_s, _, _, _ = build_step(cfg, rank, world, dev, seed=seed)
+                o = step_s()
+                torch.cuda.synchronize()
+                Rs = derived_counts(o, W, H, n_poses)[0]
+                state_s["rast"] = mk_s(int(Rs * 1.25) + 4096)
+                del o
+                for _ in range(3):
+                    step_s()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                n_s = max(5, args.steps // 2)
+                for _ in range(n_s):
+                    step_s()
+                torch.cuda.synchronize()
+                per_seed[str(seed)] = (time.perf_counter() - t0) / n_s * 1e3
+                del step_s, state_s, mk_s
+                torch.cuda.empty_cache()
+            med = sorted(per_seed.values())[1]
+            line["seeds_ms_per_step"] = {**per_seed, "median": med, "median_images_per_s": 1e3 / med}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(sc, cfg)
         print(json.dumps(line), flush=True)

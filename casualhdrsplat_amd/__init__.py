@@ -6,8 +6,9 @@ casualhdrsplat_amd/libhdrsplat.so (hand-written HIP, gfx950) reached through the
 include/hdrsplat.h; importing the package does not load the library, calling it does, and a
 missing library is a hard error (no CPU fallback).
 """
-from .rasterizer import (DensifyStats, GaussianRasterizationSettings, GaussianRasterizer, inspect_state,
-                         rasterize_gaussians)
+from .rasterizer import (BinningOverflow, DensifyStats, GaussianRasterizationSettings, GaussianRasterizer,
+                         inspect_state, rasterize_gaussians)
 
-__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "DensifyStats", "rasterize_gaussians", "inspect_state"]
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "DensifyStats", "BinningOverflow",
+           "rasterize_gaussians", "inspect_state"]
 __version__ = "0.1.0"

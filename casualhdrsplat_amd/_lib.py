@@ -80,7 +80,8 @@ class hs_layout(C.Structure):
 
 
 EXPORTS = ("hs_version", "hs_last_error", "hs_plan", "hs_forward", "hs_backward", "hs_mark_visible",
-           "hs_sh_backward_views", "hs_sort_tmp_bytes", "hs_sort_pairs")
+           "hs_sh_backward_views", "hs_sort_tmp_bytes", "hs_sort_pairs", "hs_render_stats")
+HS_RENDER_STATS = 24
 
 _lib = None
 
@@ -112,6 +113,8 @@ def load() -> C.CDLL:
     lib.hs_sh_backward_views.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p]
     lib.hs_sh_backward_views.restype = C.c_int
+    lib.hs_render_stats.argtypes = [C.POINTER(hs_fwd_args), C.POINTER(hs_bwd_args), C.c_void_p, C.c_void_p]
+    lib.hs_render_stats.restype = C.c_int
     lib.hs_sort_tmp_bytes.argtypes = [C.c_int64]
     lib.hs_sort_tmp_bytes.restype = C.c_int64
     lib.hs_sort_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,

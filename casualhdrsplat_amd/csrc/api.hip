@@ -247,6 +247,31 @@ int hs_sh_backward_views(int32_t P, int32_t M, int32_t sh_degree, int32_t V, con
     return launch_sh_backward_views(P, M, sh_degree, V, means3D, camposes, dL_dview_colors, dL_dshs, (hipStream_t)hip_stream);
 }
 
+int hs_render_stats(const hs_fwd_args* fwd, const hs_bwd_args* bwd, uint64_t* stats, void* hip_stream) {
+    if ((!fwd && !bwd) || !stats) { set_error("hs_render_stats: null argument"); return HS_EINVAL; }
+    hipStream_t s = (hipStream_t)hip_stream;
+    hs_sizes sz; hs_layout L;
+    if (fwd) {
+        int rc = plan(fwd->dims, &sz, &L);
+        if (rc) return rc;
+        if (!fwd->geom || !fwd->binning || !fwd->image || !fwd->out_color || !fwd->bg) {
+            set_error("hs_render_stats: forward args need geom/binning/image/out_color/bg");
+            return HS_EINVAL;
+        }
+        if (fwd->dims.P > 0 && (rc = launch_render_fwd(*fwd, L, s, (unsigned long long*)stats))) return rc;
+    }
+    if (bwd) {
+        int rc = plan(bwd->dims, &sz, &L);
+        if (rc) return rc;
+        if (!bwd->geom || !bwd->binning || !bwd->image || !bwd->bwd || !bwd->dL_dout_color || !bwd->bg) {
+            set_error("hs_render_stats: backward args need geom/binning/image/bwd/dL_dout_color/bg");
+            return HS_EINVAL;
+        }
+        if (bwd->dims.P > 0 && (rc = launch_render_bwd(*bwd, L, s, (unsigned long long*)stats))) return rc;
+    }
+    return HS_OK;
+}
+
 int64_t hs_sort_tmp_bytes(int64_t n) { return sort_tmp_bytes(n) + 256 + 2 * align_up(n * 8, 256) + 2 * align_up(n * 4, 256); }
 
 int hs_sort_pairs(const uint64_t* keys_in, const uint32_t* vals_in, uint64_t* keys_out, uint32_t* vals_out,

@@ -36,14 +36,34 @@ constexpr float kTmin = 0.0001f;
 constexpr float kLogEps = 1e-8f;
 
 
-#ifdef HS_STATS
-// Development-only counters (never compiled into the shipped library): [0] (wave,entry) trips of the backward
-// loop, [1] trips with no active lane, [2] sum of active lanes, [3] culled by the sub-tile test, [4..7] same for fwd.
-__device__ unsigned long long g_stats[8];
-#define HS_STAT_ADD(i, v) do { const unsigned long long v_ = (unsigned long long)(v); if ((threadIdx.x & 63) == 0) atomicAdd(&g_stats[i], v_); } while (0)
-#else
-#define HS_STAT_ADD(i, v) do { } while (0)
-#endif
+// Diagnostic counters of the STATS instantiations (hs_render_stats: bench.py's lane-utilisation / VALU-roofline
+// leg and profiling; never part of a timed or differentiated call).  Each wave keeps its counts in registers and adds
+// them once at the end.
+enum {
+    kStBwdTrips = 0,      // (wave, entry) trips of the backward replay loop
+    kStBwdEmpty = 1,      // ... in which no lane had an active pixel
+    kStBwdActivePix = 2,  // sum over trips of active pixels (<= 128 per trip)
+    kStBwdCulled = 3,     // staged entries rejected by the half-tile test (per wave)
+    kStBwdHist = 4,       // [4..9] trips by active LANES: 0, 1-4, 5-8, 9-16, 17-32, 33-64
+    kStBwdStaged = 10,    // entries staged into LDS (per workgroup)
+    kStBwdBatches = 11,   // staging batches (per workgroup)
+    kStFwdTrips = 12, kStFwdEmpty = 13, kStFwdActivePix = 14, kStFwdCulled = 15, kStFwdStaged = 16, kStFwdBatches = 17,
+    kStCount = 24
+};
+struct WaveStats {
+    unsigned long long v[kStCount];
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int i = 0; i < kStCount; ++i) v[i] = 0;
+    }
+    __device__ __forceinline__ void flush(unsigned long long* dst) const {
+        if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+            for (int i = 0; i < kStCount; ++i)
+                if (v[i]) atomicAdd(dst + i, v[i]);
+        }
+    }
+};
 
 // ---- DPP cross-lane helpers (wave64) ----
 template <int CTRL, int ROW_MASK = 0xF>
@@ -207,6 +227,7 @@ struct RenderFwd {
     float* out_invdepth;  // [N,H,W] or null
     Crf crf;
     const float* exposure;
+    unsigned long long* stats;  // STATS instantiations only
 };
 
 constexpr int kBatch = 128;  // staged entries per trip = threads per workgroup
@@ -306,7 +327,7 @@ __device__ __forceinline__ void write_pixel_fwd(const RenderFwd& p, const PixF& 
     }
 }
 
-template <bool DEPTH>
+template <bool DEPTH, bool STATS>
 __global__ void __launch_bounds__(kBatch) render_fwd_kernel(RenderFwd p) {
     constexpr int KB = kBatch;
     __shared__ float4 s_a[KB];
@@ -347,6 +368,8 @@ __global__ void __launch_bounds__(kBatch) render_fwd_kernel(RenderFwd p) {
         ra = r[0]; rb = r[1]; rcb = reinterpret_cast<const float*>(r + 2)[0];
         if constexpr (DEPTH) rdepth = reinterpret_cast<const float*>(r + 2)[1];
     }
+    WaveStats ws;
+    if constexpr (STATS) ws.clear();
     int it = 0;
     for (int base = 0; base < n; base += KB, ++it) {
         const bool wave_alive = (done0 & done1) != ~0ull;
@@ -354,6 +377,7 @@ __global__ void __launch_bounds__(kBatch) render_fwd_kernel(RenderFwd p) {
         __syncthreads();  // also: everyone finished reading the previous batch
         if (!(s_alive[it & 1][0] | s_alive[it & 1][1])) break;
         const int cnt = min(KB, n - base);
+        if constexpr (STATS) { if (wave == 0) { ws.v[kStFwdStaged] += cnt; ws.v[kStFwdBatches] += 1; } }
         if ((int)threadIdx.x < cnt) {
             scale_entry(ra, rb);
             s_a[threadIdx.x] = ra; s_b[threadIdx.x] = rb; s_cb[threadIdx.x] = rcb;
@@ -375,6 +399,7 @@ __global__ void __launch_bounds__(kBatch) render_fwd_kernel(RenderFwd p) {
             bool touch = false;
             if (jj < cnt) touch = halftile_may_touch(s_a[jj], s_b[jj], sxf, syf);
             const uint64_t mask = __ballot(touch);
+            if constexpr (STATS) ws.v[kStFwdCulled] += __popcll(__ballot(jj < cnt && !touch));
             if (touch) s_list[wave][n_t + mask_prefix(mask)] = (uint16_t)jj;
             n_t += __popcll(mask);
         }
@@ -390,7 +415,14 @@ __global__ void __launch_bounds__(kBatch) render_fwd_kernel(RenderFwd p) {
             const float al1 = fminf(kAlphaMax, b.y * hs_exp2(pw.y));
             const uint32_t idx1 = (uint32_t)(base + j + 1);
             const float invd = DEPTH ? s_id[j] : 0.f;
-            blend_fwd_pair<DEPTH>(ps, done0, done1, pw, f2{al0, al1}, b.z, b.w, cb, invd, idx1);
+            if constexpr (STATS) {
+                const uint32_t l0 = ps.last0, l1 = ps.last1;
+                blend_fwd_pair<DEPTH>(ps, done0, done1, pw, f2{al0, al1}, b.z, b.w, cb, invd, idx1);
+                const int act = __popcll(__ballot(ps.last0 != l0)) + __popcll(__ballot(ps.last1 != l1));
+                ws.v[kStFwdTrips] += 1; ws.v[kStFwdActivePix] += act; ws.v[kStFwdEmpty] += act == 0;
+            } else {
+                blend_fwd_pair<DEPTH>(ps, done0, done1, pw, f2{al0, al1}, b.z, b.w, cb, invd, idx1);
+            }
             if ((done0 & done1) == ~0ull) break;
         }
     }
@@ -404,6 +436,7 @@ __global__ void __launch_bounds__(kBatch) render_fwd_kernel(RenderFwd p) {
         if (in0) p.out_invdepth[(int64_t)pose * HW + (int64_t)py0 * p.W + px] = ps.D.x;
         if (in1) p.out_invdepth[(int64_t)pose * HW + (int64_t)py1 * p.W + px] = ps.D.y;
     }
+    if constexpr (STATS) ws.flush(p.stats);
 }
 
 // N > 1: average the per-pose images.  LDR domain (default, follows assets/pipeline.png: the blur "+" is
@@ -441,6 +474,7 @@ struct RenderBwd {
     uint8_t* pair_flags;
     Crf crf;
     const float* exposure;
+    unsigned long long* stats;  // STATS instantiations only
 };
 
 // Upstream gradient w.r.t. this pose's radiance H_ch at one pixel (the HDR prologue).
@@ -556,7 +590,7 @@ __device__ __forceinline__ void step_bwd_pair(PairB& s, bool act0, bool act1, f2
     sw = splat(o) * dop;
 }
 
-template <bool DEPTH>
+template <bool DEPTH, bool STATS>
 __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
     constexpr int KB = kBatch;
     constexpr int NV = DEPTH ? 10 : 9;      // reduced values per (tile, entry): nine published sums (+ d inverse depth)
@@ -604,6 +638,8 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
         else if (lane == 4) red_slot = 8;
         else if (DEPTH && lane == 36) red_slot = 9;
     }
+    WaveStats ws;
+    if constexpr (STATS) ws.clear();
     const int nb = (n_proc + KB - 1) / KB;
     // only the instance id of the NEXT batch is prefetched (one register); its record is gathered at the
     // top of the batch -- keeping the three float4 in registers across the replay loop costs a wave of occupancy
@@ -615,6 +651,7 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
     for (int bi = nb - 1; bi >= 0; --bi) {
         const int base = bi * KB;
         const int cnt = min(KB, n_proc - base);
+        if constexpr (STATS) { if (wave == 0) { ws.v[kStBwdStaged] += cnt; ws.v[kStBwdBatches] += 1; } }
         __syncthreads();  // previous batch's write-out finished
         if ((int)threadIdx.x < cnt) {
             const float4* r = p.rec + kRecF4 * (int64_t)id_next;
@@ -636,7 +673,7 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
                 bool touch = false;
                 if (jj < cnt && base + jj < (int)wave_max) touch = halftile_may_touch(s_a[jj], s_b[jj], sxf, syf);
                 const uint64_t mask = __ballot(touch);
-                HS_STAT_ADD(3, __popcll(__ballot(jj < cnt && base + jj < (int)wave_max && !touch)));
+                if constexpr (STATS) ws.v[kStBwdCulled] += __popcll(__ballot(jj < cnt && base + jj < (int)wave_max && !touch));
                 if (touch) s_list[wave][n_t + mask_prefix(mask)] = (uint16_t)jj;
                 n_t += __popcll(mask);
             }
@@ -655,9 +692,15 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
                 const uint32_t idx = (uint32_t)(base + j);
                 const bool act0 = (idx < s0.last) && (pw.x <= 0.f) && (al0 >= kAlphaMin);
                 const bool act1 = (idx < s1.last) && (pw.y <= 0.f) && (al1 >= kAlphaMin);
-                HS_STAT_ADD(0, 1);
-                HS_STAT_ADD(2, __popcll(__ballot(act0)) + __popcll(__ballot(act1)));
-                if (__ballot(act0 || act1) == 0ull) { HS_STAT_ADD(1, 1); continue; }
+                if constexpr (STATS) {
+                    const int lanes = __popcll(__ballot(act0 || act1));
+                    ws.v[kStBwdTrips] += 1;
+                    ws.v[kStBwdEmpty] += lanes == 0;
+                    ws.v[kStBwdActivePix] += __popcll(__ballot(act0)) + __popcll(__ballot(act1));
+                    const int bin = lanes == 0 ? 0 : lanes <= 4 ? 1 : lanes <= 8 ? 2 : lanes <= 16 ? 3 : lanes <= 32 ? 4 : 5;
+                    ws.v[kStBwdHist + bin] += 1;
+                }
+                if (__ballot(act0 || act1) == 0ull) continue;
                 f2 sw, dop, dch;
                 step_bwd_pair<DEPTH>(ps, act0, act1, f2{G0, G1}, f2{al0, al1}, b.y, b.z, b.w, cb, invd, sw, dop, dch);
                 // in-lane sums over the pixel pair (dx is shared):  S1 = sum w dx, S2 = sum w dy, S3 = sum w dx^2,
@@ -713,6 +756,7 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
             if constexpr (kPairF4 == 4) o[3] = make_float4(0.f, 0.f, 0.f, 0.f);  // the record fills its 64-byte sector
         }
     }
+    if constexpr (STATS) ws.flush(p.stats);
 }
 
 // CRF-table and exposure gradients: fixed grid, LDS table per block, one partial row per block
@@ -809,16 +853,7 @@ __global__ void __launch_bounds__(256) crf_reduce_kernel(const float* partials, 
 
 }  // namespace
 
-#ifdef HS_STATS
-extern "C" int hs_debug_stats(unsigned long long* out8, int reset) {
-    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_stats), sizeof(unsigned long long) * 8) != hipSuccess) return -2;
-    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_stats), z, sizeof z) != hipSuccess) return -2; }
-    return 0;
-}
-#endif
-
-
-int launch_render_fwd(const hs_fwd_args& a, const hs_layout& L, hipStream_t s) {
+int launch_render_fwd(const hs_fwd_args& a, const hs_layout& L, hipStream_t s, unsigned long long* stats) {
     const hs_dims& d = a.dims;
     RenderFwd p;
     p.W = d.W; p.H = d.H; p.gx = (d.W + kTile - 1) / kTile;
@@ -834,8 +869,13 @@ int launch_render_fwd(const hs_fwd_args& a, const hs_layout& L, hipStream_t s) {
     p.crf.table = a.crf_table; p.crf.K = a.crf_K; p.crf.umin = a.crf_umin; p.crf.umax = a.crf_umax; p.crf.dt = 1.f;
     p.exposure = a.exposure;
     p.out_invdepth = a.out_invdepth;
-    if (a.out_invdepth) render_fwd_kernel<true><<<p.ntiles * d.n_poses, kBatch, 0, s>>>(p);
-    else render_fwd_kernel<false><<<p.ntiles * d.n_poses, kBatch, 0, s>>>(p);
+    p.stats = stats;
+    const int grid = p.ntiles * d.n_poses;
+    if (stats) {
+        if (a.out_invdepth) render_fwd_kernel<true, true><<<grid, kBatch, 0, s>>>(p);
+        else render_fwd_kernel<false, true><<<grid, kBatch, 0, s>>>(p);
+    } else if (a.out_invdepth) render_fwd_kernel<true, false><<<grid, kBatch, 0, s>>>(p);
+    else render_fwd_kernel<false, false><<<grid, kBatch, 0, s>>>(p);
     HS_LAUNCH_CHECK();
     if (d.n_poses > 1) {
         const int64_t HW = (int64_t)d.W * d.H;
@@ -867,7 +907,7 @@ int launch_crf_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s) {
     return HS_OK;
 }
 
-int launch_render_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s) {
+int launch_render_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s, unsigned long long* stats) {
     const hs_dims& d = a.dims;
     RenderBwd p;
     p.W = d.W; p.H = d.H; p.gx = (d.W + kTile - 1) / kTile; p.gy = (d.H + kTile - 1) / kTile;
@@ -886,11 +926,18 @@ int launch_render_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s) {
     // were cleared by the forward's pair emission; which records get written depends on the forward state alone,
     // so replays of this stage set the same flags again.
     p.pair_flags = (uint8_t*)a.binning + L.pair_flags;
-    if (a.dL_dout_invdepth) render_bwd_kernel<true><<<p.ntiles * d.n_poses, kBatch, 0, s>>>(p);
-    else render_bwd_kernel<false><<<p.ntiles * d.n_poses, kBatch, 0, s>>>(p);
+    p.stats = stats;
+    const int grid = p.ntiles * d.n_poses;
+    if (stats) {
+        if (a.dL_dout_invdepth) render_bwd_kernel<true, true><<<grid, kBatch, 0, s>>>(p);
+        else render_bwd_kernel<false, true><<<grid, kBatch, 0, s>>>(p);
+    } else if (a.dL_dout_invdepth) render_bwd_kernel<true, false><<<grid, kBatch, 0, s>>>(p);
+    else render_bwd_kernel<false, false><<<grid, kBatch, 0, s>>>(p);
     HS_LAUNCH_CHECK();
     return HS_OK;
 }
+
+int render_stats_count() { return kStCount; }
 
 int crf_partial_floats(int K) { return kCrfBlocks * (3 * K + 1); }
 

@@ -43,9 +43,10 @@ def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
     return rank, world, local
 
 
-def _shared_flat(grads: Sequence[torch.Tensor], multiple: int = 1) -> torch.Tensor | None:
-    """If all gradients are contiguous slices of one storage, return a 1-D tensor spanning them (its length
-    rounded up to `multiple` elements when the storage has the room: the rasterizer zero-pads its buffer)."""
+def _shared_flat(grads: Sequence[torch.Tensor]) -> torch.Tensor | None:
+    """If all gradients are contiguous slices of one storage, return a 1-D tensor spanning exactly the range from
+    the first to the last of them (never a byte more: whatever lies behind the last listed gradient -- another
+    slice of the rasterizer's flat buffer, or its uninitialised pad -- is not the caller's to reduce)."""
     if not grads:
         return None
     st = grads[0].untyped_storage()
@@ -59,12 +60,7 @@ def _shared_flat(grads: Sequence[torch.Tensor], multiple: int = 1) -> torch.Tens
         hi = o + g.numel() if hi is None else max(hi, o + g.numel())
     if sum(g.numel() for g in grads) < 0.9 * (hi - lo):
         return None  # sparse cover: packing is cheaper than reducing the gaps
-    n = hi - lo
-    if multiple > 1 and n % multiple:
-        n_up = (n + multiple - 1) // multiple * multiple
-        if (lo + n_up) * 4 <= st.nbytes():
-            n = n_up
-    return torch.empty(0, dtype=torch.float32, device=grads[0].device).set_(st, lo, (n,))
+    return torch.empty(0, dtype=torch.float32, device=grads[0].device).set_(st, lo, (hi - lo,))
 
 
 def all_reduce_direct(flat: torch.Tensor, group=None) -> None:
@@ -73,17 +69,27 @@ def all_reduce_direct(flat: torch.Tensor, group=None) -> None:
     xGMI on an 8 x MI355X node is a full mesh of point-to-point links (7 x ~153 GB/s per GPU), so a ring
     all-reduce is bound by ONE link (2*(n-1)/n * bytes / link) while sending shard j straight to rank j uses
     all seven links at once (~0.4 ms vs ~2.7 ms for 236 MB).  Every shard is summed by
-    exactly one rank in rank order and then broadcast, so all ranks end with bitwise identical results.
-    Requires flat.numel() % world == 0 (the rasterizer pads its gradient buffer accordingly)."""
+    exactly one rank in rank order and then sent to all, so all ranks end with bitwise identical results.
+    Any length works: the first world * (n // world) elements take the two all-to-alls, the (< world) elements
+    left over take one tiny library all-reduce.  One temporary of the buffer's size (the received shards); the
+    second exchange sends every peer the SAME reduced shard, so it needs no staging copy."""
     world = dist.get_world_size(group)
     n = flat.numel()
-    assert n % world == 0, (n, world)
     chunk = n // world
-    recv = torch.empty_like(flat)
-    dist.all_to_all_single(recv, flat, group=group)              # recv[j*chunk:(j+1)*chunk] = rank j's copy of MY shard
-    mine = recv.view(world, chunk).sum(dim=0)                    # fixed summation order
-    send = mine.unsqueeze(0).expand(world, chunk).contiguous().view(-1)
-    dist.all_to_all_single(flat, send, group=group)              # flat[j*chunk:...] = rank j's reduced shard
+    main = chunk * world
+    if chunk > 0:
+        body = flat[:main]
+        recv = torch.empty_like(body)
+        dist.all_to_all_single(recv, body, group=group)          # recv[j*chunk:(j+1)*chunk] = rank j's copy of MY shard
+        mine = recv.view(world, chunk).sum(dim=0)                # fixed summation order
+        # flat[j*chunk:(j+1)*chunk] = rank j's reduced shard.  RCCL: grouped point-to-point sends (1 hop, all links);
+        # backends without a list all-to-all (gloo, CPU tests) use the equivalent all-gather
+        if dist.get_backend(group) == "nccl":
+            dist.all_to_all(list(body.view(world, chunk).unbind(0)), [mine] * world, group=group)
+        else:
+            dist.all_gather_into_tensor(body, mine, group=group)
+    if main < n:
+        dist.all_reduce(flat[main:], op=dist.ReduceOp.SUM, group=group)
 
 
 _ALGO = {"choice": "rccl"}
@@ -94,10 +100,6 @@ def autotune_all_reduce(flat: torch.Tensor, group=None, iters: int = 3) -> str:
     for later all_reduce_gradients(..., algo="auto") calls.  The decision is taken on rank 0's maximum-over-ranks
     timings, so every rank chooses the same algorithm."""
     import time
-    world = dist.get_world_size(group)
-    if flat.numel() % world != 0:
-        _ALGO["choice"] = "rccl"
-        return "rccl"
     scratch = torch.zeros_like(flat)
     sync = torch.cuda.synchronize if flat.is_cuda else (lambda: None)
     times = {}
@@ -130,9 +132,9 @@ def all_reduce_gradients(params: Iterable[torch.Tensor], group=None, average: bo
     world = dist.get_world_size(group)
     if algo == "auto":
         algo = _ALGO["choice"]
-    flat = _shared_flat(grads, multiple=world)
+    flat = _shared_flat(grads)
     if flat is not None:
-        if algo == "direct" and flat.numel() % world == 0:
+        if algo == "direct":
             all_reduce_direct(flat, group)
         elif pending is not None:
             work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)

@@ -121,22 +121,42 @@ class DensifyStats:
 _PINNED_POOL: list = []  # recycled page-locked int32[2] buffers (hipHostMalloc per step is slow)
 
 
+class BinningOverflow(RuntimeError):
+    """Sync-free mode: the frame needed `num_rendered` (tile, Gaussian) pairs but the binning buffers held `capacity`;
+    the device rendered it empty (background only) instead of writing out of bounds."""
+    def __init__(self, num_rendered: int, capacity: int, where: str = ""):
+        self.num_rendered, self.capacity = num_rendered, capacity
+        super().__init__(
+            f"binning capacity {capacity} < num_rendered {num_rendered}: the frame was rendered empty{where}; "
+            "re-run with a larger `capacity` (or capacity=None for the synchronous mode)")
+
+
+def grown_capacity(num_rendered: int) -> int:
+    """Capacity to retry with after an overflow: 1.5 x the pair count the device reported."""
+    return int(num_rendered * 1.5) + 4096
+
+
 class _Pending:
-    """Deferred overflow check for the sync-free (fixed capacity) mode."""
+    """Deferred overflow check for the sync-free (fixed capacity) mode: the forward copies the device counters
+    {num_rendered, overflow} into a pinned buffer behind its kernels and records an event; nothing waits for it
+    until someone asks."""
     def __init__(self, host, event, capacity):
         self.host, self.event, self.capacity = host, event, capacity
 
-    def check(self):
+    def resolve(self):
+        """(num_rendered, overflowed) -- waits for the forward's counter copy on first use."""
         if self.host is not None:  # first call: wait for the copy, recycle the pinned buffer, remember the verdict
             self.event.synchronize()
-            self.n, self.overflow = int(self.host[0]), int(self.host[1])
+            self.n, self.overflow = int(self.host[0]) & 0xFFFFFFFF, int(self.host[1])
             _PINNED_POOL.append(self.host)
             self.host = None
-        if self.overflow != 0:
-            raise RuntimeError(
-                f"binning capacity {self.capacity} < num_rendered {self.n}: the frame was rendered "
-                "empty; re-run with a larger `capacity` (or capacity=None for the synchronous mode)")
-        return self.n
+        return self.n, self.overflow != 0
+
+    def check(self, where: str = ""):
+        n, over = self.resolve()
+        if over:
+            raise BinningOverflow(n, self.capacity, where)
+        return n
 
 
 def _run_forward(settings: GaussianRasterizationSettings, means3D, opacities, shs, colors_precomp, scales,
@@ -239,7 +259,7 @@ class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                 exposure, crf_table, viewmats, projmats, camposes, raster_settings, capacity, return_alpha=False,
-                deferred=None, return_invdepth=False, densify=None):
+                deferred=None, return_invdepth=False, densify=None, aux=None):
         dev = means3D.device
         m3 = _f32c(means3D, dev)
         op = _f32c(opacities, dev)
@@ -252,6 +272,11 @@ class _RasterizeGaussians(torch.autograd.Function):
             color, hdr, radii, st, exp_t, crf_t, invd = _run_forward(raster_settings, m3, op, shs, cp, sc, ro, cv,
                                                                      exposure, crf_table, capacity, return_invdepth)
         ctx.st = st
+        ctx.aux = aux
+        if aux is not None:  # what GaussianRasterizer keeps of the call (never the outputs: see st.keep)
+            aux["pending"], aux["num_rendered"] = st.pending, st.num_rendered
+            if aux.get("keep_state"):
+                aux["state"] = st
         ctx.set_materialize_grads(False)  # an unused output (e.g. the radiance image) must not cost a zero image
         ctx.deferred = deferred if shs is not None else None
         ctx.densify = densify
@@ -299,8 +324,16 @@ class _RasterizeGaussians(torch.autograd.Function):
             ctx.deferred.update(view_colors=g["view_colors"], camposes=st.camposes, means3D=saved[0],
                                 M=st.dims.M, sh_degree=st.dims.sh_degree, flat=g["_flat"], gather=g.get("_gather"))
         if st.pending is not None:
-            # sync-free mode: the kernels are already queued; only now look at the forward's counters
-            st.num_rendered = st.pending.check()
+            # sync-free mode: the kernels are already queued; only now look at the forward's counters.  An overflowed
+            # forward handed the caller an EMPTY frame, so the loss this gradient belongs to is already wrong: the
+            # step cannot be repaired here -- raise, and let the rasterizer grow its capacity for the next call
+            n, over = st.pending.resolve()
+            if over:
+                if ctx.aux is not None:
+                    ctx.aux["grow_to"] = grown_capacity(n)
+                raise BinningOverflow(n, st.pending.capacity, " and this backward belongs to that empty frame (the "
+                                      "rasterizer has grown its capacity for the following calls)")
+            st.num_rendered = n
             st.pending = None
         has_sh, has_cp, has_sc, has_cv, has_exp, has_crf = ctx.has
         hdr = bool(st.flags & L.HS_FLAG_HDR)
@@ -311,11 +344,12 @@ class _RasterizeGaussians(torch.autograd.Function):
                 g["crf_table"] if has_crf else None,
                 g["viewmatrices"].reshape(ctx.pose_shapes[0]) if want_pose else None,
                 g["projmatrices"].reshape(ctx.pose_shapes[1]) if want_pose else None,
-                g["camposes"].reshape(ctx.pose_shapes[2]) if want_pose else None, None, None, None, None, None, None)
+                g["camposes"].reshape(ctx.pose_shapes[2]) if want_pose else None, None, None, None, None, None, None,
+                None)
 
 
 def _launch_backward(st: "_State", saved, gcol, ghdr, stages: int, want_pose: bool = False, galpha=None,
-                     defer_sh: bool = False, ginvd=None, densify=None, gather_group=None) -> dict:
+                     defer_sh: bool = False, ginvd=None, densify=None, gather_group=None, stats=None) -> dict:
     """Enqueue hs_backward.  All per-Gaussian gradients are carved out of ONE flat fp32 buffer (the
     layout casualhdrsplat_amd.distributed all-reduces in a single RCCL call): [means3D | means2D |
     opacities | sh | colors | scales | rotations | cov3D | exposure | crf_table]."""
@@ -341,8 +375,7 @@ def _launch_backward(st: "_State", saved, gcol, ghdr, stages: int, want_pose: bo
                 n *= d
             offs[name] = (total, n, shape)
             total += (n + 3) // 4 * 4  # keep every slice 16-byte aligned
-    padded = (max(total, 4) + 1023) // 1024 * 1024  # room for the N-rank shard split of distributed.all_reduce_direct
-    flat = torch.empty(padded, dtype=torch.float32, device=dev)  # the pad is never read back: left uninitialised
+    flat = torch.empty(max(total, 4), dtype=torch.float32, device=dev)  # fully written by the kernels (16-byte slice pads aside)
     g = {name: None for name, _, _ in spec}
     for name, (o, n, shape) in offs.items():
         g[name] = flat[o:o + n].view(shape)
@@ -378,7 +411,9 @@ def _launch_backward(st: "_State", saved, gcol, ghdr, stages: int, want_pose: bo
             raise ValueError("DensifyStats was created for a different number of Gaussians or another device")
         a.densify_grad_accum, a.densify_denom = densify.grad_accum.data_ptr(), densify.denom.data_ptr()
         a.densify_max_radii = densify.max_radii.data_ptr()
-    if P == 0:
+    if stats is not None:  # diagnostic instantiation of the render backward only (render_stats)
+        L.check(lib.hs_render_stats(None, C.byref(a), stats.data_ptr(), _stream()), "hs_render_stats[bwd]")
+    elif P == 0:
         flat.zero_()
     elif gather_group is not None and g["view_colors"] is not None and stages == L.HS_BWD_ALL:
         # view-parallel step: the all-gather of this view's colour gradients starts as soon as the record sums
@@ -419,6 +454,32 @@ def replay_backward(out_tensor: torch.Tensor, grad_color: torch.Tensor, stages: 
                             None if grad_hdr is None else _f32c(grad_hdr, dev), stages)
 
 
+RENDER_STAT_NAMES = ("bwd_trips", "bwd_empty_trips", "bwd_active_pixels", "bwd_culled", "bwd_hist_0", "bwd_hist_1_4",
+                     "bwd_hist_5_8", "bwd_hist_9_16", "bwd_hist_17_32", "bwd_hist_33_64", "bwd_staged", "bwd_batches",
+                     "fwd_trips", "fwd_empty_trips", "fwd_active_pixels", "fwd_culled", "fwd_staged", "fwd_batches")
+
+
+def render_stats(out_tensor: torch.Tensor, grad_color: torch.Tensor, grad_hdr: Optional[torch.Tensor] = None) -> dict:
+    """Profiling helper (bench.py's lane-utilisation / VALU-roofline leg): replays the render forward and backward of
+    the call that produced `out_tensor` with the counting instantiation of the kernels (hs_render_stats) and returns
+    the counters by name: (wave, entry) trips of the two compositing loops, how many found no active lane, the sum
+    of active pixels (<= 128 per trip), entries removed by the half-tile test, staged entries and batches."""
+    fn = out_tensor.grad_fn
+    st: _State = fn.st
+    dev = out_tensor.device
+    stats = torch.zeros(L.HS_RENDER_STATS, dtype=torch.int64, device=dev)
+    a = st.fwd_args
+    a.stages = L.HS_STAGE_RENDER
+    a.out_color = out_tensor.data_ptr()
+    scratch_hdr = torch.empty_like(out_tensor) if (st.flags & L.HS_FLAG_HDR) else None
+    a.out_hdr, a.out_invdepth = _ptr(scratch_hdr), None
+    L.check(L.load().hs_render_stats(C.byref(a), None, stats.data_ptr(), _stream()), "hs_render_stats[fwd]")
+    _launch_backward(st, fn.saved_tensors, _f32c(grad_color, dev), None if grad_hdr is None else _f32c(grad_hdr, dev),
+                     L.HS_BWD_RENDER, stats=stats)
+    vals = stats.cpu().tolist()
+    return dict(zip(RENDER_STAT_NAMES, vals))
+
+
 def sh_backward_views(means3D: torch.Tensor, camposes: torch.Tensor, view_colors: torch.Tensor, M: int,
                       sh_degree: int) -> torch.Tensor:
     """dL/dsh [P,M,3] from per-view colour gradients [V,P,3] and the V camera centres [V,3] (hs_sh_backward_views):
@@ -439,7 +500,7 @@ def sh_backward_views(means3D: torch.Tensor, camposes: torch.Tensor, view_colors
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                         raster_settings, capacity=None, return_alpha=False, deferred=None, return_invdepth=False,
-                        densify=None):
+                        densify=None, aux=None):
     rs = raster_settings
     multi = rs.viewmatrices is not None
     # the camera tensors travel as autograd inputs so a trajectory model upstream receives pose gradients
@@ -448,20 +509,31 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
                                      rs.viewmatrices if multi else rs.viewmatrix,
                                      rs.projmatrices if multi else rs.projmatrix,
                                      rs.camposes if multi else rs.campos, rs, capacity, return_alpha, deferred,
-                                     return_invdepth, densify)
+                                     return_invdepth, densify, aux)
 
 
 class GaussianRasterizer(nn.Module):
     """Drop-in for diff_gaussian_rasterization.GaussianRasterizer.
 
-    `capacity` (extension): None = upstream behaviour (one host read of num_rendered per forward);
-    an int = sync-free mode with a fixed binning capacity in (tile, Gaussian) pairs, overflow is
-    detected lazily (at backward / `last_num_rendered`) and raises.
+    `capacity` (extension): None = upstream behaviour (one host read of num_rendered per forward); an int =
+    sync-free mode with a fixed binning capacity in (tile, Gaussian) pairs: the forward is a single enqueue and the
+    device itself turns a frame that does not fit into an empty (background) render plus an overflow flag.  Who
+    looks at the flag, and when (SURVEY.md 8b "grows capacity and replays on overflow"):
+      * a forward that cannot be followed by a backward (torch.no_grad(), or no input requires grad) checks it before
+        returning -- one event wait, evaluation can afford it -- and on overflow grows `self.capacity` to 1.5 x the
+        pair count the device reported and REPLAYS the forward, so the caller never sees the empty frame;
+      * a training forward returns without waiting; the backward checks the flag after enqueueing its kernels.  By then
+        the caller's loss was computed from the empty frame, so the step is lost: BinningOverflow is raised, and
+        `self.capacity` has been grown so that repeating the step succeeds;
+      * `last_num_rendered` / `check_overflow()` wait for the latest forward's counters on demand (e.g. right after
+        the forward of a step whose loss is expensive).
+    `keep_state=True` keeps the state buffers of the latest forward alive so `inspect_state(rasterizer)` also works
+    for forwards that recorded no autograd graph.
     """
 
     def __init__(self, raster_settings: GaussianRasterizationSettings, capacity: Optional[int] = None,
                  return_alpha: bool = False, defer_sh_grad: bool = False, return_invdepth: bool = False,
-                 densify_stats: Optional[DensifyStats] = None, gather_group=None):
+                 densify_stats: Optional[DensifyStats] = None, gather_group=None, keep_state: bool = False):
         super().__init__()
         # with defer_sh_grad: a torch.distributed process group (or True for the default group) makes the backward
         # start the all-gather of the view colour gradients itself, overlapped with its per-Gaussian half
@@ -478,6 +550,27 @@ class GaussianRasterizer(nn.Module):
         # (12 B per Gaussian and view instead of 12*M) and forms the summed SH gradient locally
         self.defer_sh_grad = defer_sh_grad
         self.deferred: Optional[dict] = None
+        self.keep_state = keep_state
+        self._last: dict = {}       # bookkeeping of the latest forward (pending counters, optional state)
+        self.overflow_replays = 0   # forwards that were replayed with a grown capacity
+
+    @property
+    def last_num_rendered(self) -> int:
+        """Number of (tile, Gaussian) pairs of the latest forward.  In sync-free mode this waits for that forward's
+        counters (one event) and raises BinningOverflow if it did not fit."""
+        return self.check_overflow()
+
+    def check_overflow(self) -> int:
+        """Wait for the latest forward's device counters; returns num_rendered, raises BinningOverflow (after growing
+        `self.capacity`) if the frame did not fit its binning capacity."""
+        pend = self._last.get("pending")
+        if pend is None:
+            return int(self._last.get("num_rendered", 0))
+        n, over = pend.resolve()
+        if over:
+            self.capacity = max(int(self.capacity or 0), grown_capacity(n))
+            raise BinningOverflow(n, pend.capacity)
+        return n
 
     def markVisible(self, positions: torch.Tensor) -> torch.Tensor:
         lib = L.load()
@@ -497,30 +590,65 @@ class GaussianRasterizer(nn.Module):
         if ((scales is None or rotations is None) and cov3D_precomp is None) or \
                 ((scales is not None or rotations is not None) and cov3D_precomp is not None):
             raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+        given = [t for t in (means3D, means2D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp,
+                             rs.exposure, rs.crf_table, rs.viewmatrix, rs.projmatrix, rs.campos, rs.viewmatrices,
+                             rs.projmatrices, rs.camposes) if isinstance(t, torch.Tensor)]
+        backward_possible = torch.is_grad_enabled() and any(t.requires_grad for t in given)
         empty = torch.Tensor([])
         shs = empty if shs is None else shs
         colors_precomp = empty if colors_precomp is None else colors_precomp
         scales = empty if scales is None else scales
         rotations = empty if rotations is None else rotations
         cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
-        self.deferred = {} if self.defer_sh_grad else None
-        if self.deferred is not None and self.gather_group is not None:
-            self.deferred["gather_group"] = self.gather_group
-        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
-                                   cov3D_precomp, rs, self.capacity, self.return_alpha, self.deferred,
-                                   self.return_invdepth, self.densify_stats)
+        grow = self._last.get("grow_to")  # an overflow found by the previous call's backward
+        if grow is not None and self.capacity is not None:
+            self.capacity = max(int(self.capacity), int(grow))
+        while True:
+            self.deferred = {} if self.defer_sh_grad else None
+            if self.deferred is not None and self.gather_group is not None:
+                self.deferred["gather_group"] = self.gather_group
+            aux = {"keep_state": self.keep_state}
+            outs = rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                                       cov3D_precomp, rs, self.capacity, self.return_alpha, self.deferred,
+                                       self.return_invdepth, self.densify_stats, aux)
+            self._last = aux
+            pend = aux.get("pending")
+            if pend is None or backward_possible:
+                return outs  # synchronous mode, or a training step (its backward looks at the counters)
+            n, over = pend.resolve()
+            if not over:
+                return outs
+            # nobody else would ever look: grow and render the frame again, transparently
+            self.capacity = max(int(self.capacity), grown_capacity(n))
+            self.overflow_replays += 1
 
 
-def inspect_state(out_tensor: torch.Tensor) -> dict:
-    """Test/profiling helper: the intermediates of the forward that produced `out_tensor` (a tensor
-    returned by GaussianRasterizer.forward with grad enabled), as views into the state workspaces."""
-    fn = out_tensor.grad_fn
-    st: _State = fn.st
+def _state_of(obj) -> "_State":
+    """The forward state behind an output tensor (through its autograd node) or behind a
+    GaussianRasterizer(..., keep_state=True)."""
+    if isinstance(obj, GaussianRasterizer):
+        st = obj._last.get("state")
+        if st is None:
+            raise RuntimeError("inspect_state(rasterizer): create it with keep_state=True and run a forward first")
+        return st
+    fn = getattr(obj, "grad_fn", None)
+    if fn is None or not hasattr(fn, "st"):
+        raise RuntimeError("inspect_state needs a tensor returned by GaussianRasterizer.forward with grad enabled; "
+                           "for torch.no_grad() forwards pass a GaussianRasterizer(..., keep_state=True) instead")
+    return fn.st
+
+
+def inspect_state(out_tensor) -> dict:
+    """Test/profiling helper: the intermediates of the forward that produced `out_tensor` (a tensor returned by
+    GaussianRasterizer.forward with grad enabled, or a GaussianRasterizer created with keep_state=True), as views
+    into the state workspaces."""
+    st: _State = _state_of(out_tensor)
     lay, d = st.layout, st.dims
     I = d.P * d.n_poses
     gx, gy = (d.W + L.HS_TILE - 1) // L.HS_TILE, (d.H + L.HS_TILE - 1) // L.HS_TILE
     vt = gx * gy * d.n_poses
     R = st.num_rendered if st.num_rendered >= 0 else st.pending.check()
+    R = min(R, int(d.capacity))
 
     def view(buf, off, count, dtype):
         nbytes = count * torch.empty((), dtype=dtype).element_size()

@@ -219,6 +219,17 @@ int hs_sh_backward_views(int32_t P, int32_t M, int32_t sh_degree, int32_t V, con
                          const float* camposes /* [V,3] */, const float* dL_dview_colors /* [V,P,3] */,
                          float* dL_dshs /* [P,M,3] */, void* hip_stream);
 
+/* Bench/profiling only: re-runs the render stage(s) of a finished hs_forward (and hs_backward) call -- same argument
+ * structs, same buffers, so the outputs are simply rewritten -- with the diagnostic instantiation of the kernels, which
+ * ADDS its counts to stats[0..HS_RENDER_STATS) (device memory, zeroed by the caller).  Either struct may be NULL.
+ *   [0] backward (wave, entry) trips  [1] ... with no active lane  [2] sum of active pixels over trips (<= 128 each)
+ *   [3] entries rejected by the half-tile test (per wave)  [4..9] trips by active lanes: 0, 1-4, 5-8, 9-16, 17-32, 33-64
+ *   [10] entries staged (per tile)  [11] staging batches  [12..17] forward: trips, empty, active pixels, culled,
+ *   staged, batches.  bench.py derives lane utilisation and the VALU roofline from them. */
+#define HS_RENDER_STATS 24
+int hs_render_stats(const hs_fwd_args* fwd /* or NULL */, const hs_bwd_args* bwd /* or NULL */, uint64_t* stats,
+                    void* hip_stream);
+
 /* Bench/test only: stable LSD radix sort of (u64 key, u32 value) pairs on bits [0, nbits), using the
  * same kernels as HS_STAGE_BIN.  tmp must hold hs_sort_tmp_bytes(n).  Result in keys_out/vals_out. */
 int64_t hs_sort_tmp_bytes(int64_t n);

@@ -19,9 +19,12 @@ def main():
     from casualhdrsplat_amd import GaussianRasterizer
     from casualhdrsplat_amd import synthetic as S
     from casualhdrsplat_amd.distributed import all_reduce_gradients, exchange_view_gradients, init_from_env
-    rank, world, _ = init_from_env("gloo")
-    torch.cuda.set_device(0)
-    dev = torch.device("cuda", 0)
+    # HS_DIST_BACKEND=nccl: one GPU per rank over RCCL (boxes with >= 2 GPUs); default gloo: both ranks share cuda:0
+    backend = os.environ.get("HS_DIST_BACKEND", "gloo")
+    rank, world, local = init_from_env(backend)
+    idx = local % torch.cuda.device_count() if backend == "nccl" else 0
+    torch.cuda.set_device(idx)
+    dev = torch.device("cuda", idx)
     W, Hh = 160, 120
     sc = S.make_scene(3000, W, Hh, 3, seed=7)
     names = ("means3D", "means2D", "opacities", "shs", "scales", "rotations")

@@ -150,3 +150,53 @@ def test_single_process_is_a_noop():
     p = torch.zeros(3, requires_grad=True)
     p.grad = torch.ones(3)
     assert all_reduce_gradients([p]) == 0 and torch.equal(p.grad, torch.ones(3))
+
+
+def _worker_subset(rank, world, port, q):
+    """The rasterizer's flat layout [per-Gaussian slices | exposure | crf_table] with an ODD Gaussian count; the
+    caller reduces only the per-Gaussian parameters.  Whatever follows them in the buffer must come back untouched
+    (the 1-hop form used to round its span up into the next slice)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from casualhdrsplat_amd.distributed import all_reduce_gradients, init_from_env
+    init_from_env("gloo")
+    P, K = 1001, 7
+    shapes = [(P, 3), (P, 3), (P, 1), (P, 4, 3), (P, 3), (P, 4)]          # odd total: 3003+3003+1001+12012+3003+4004
+    total = sum((int(np.prod(s)) + 3) // 4 * 4 for s in shapes)
+    flat = torch.full((total + 4 + 3 * K + 5,), float("nan"))             # NaN pads: reducing them would poison sums
+    params, o = [], 0
+    for i, sh in enumerate(shapes):
+        n = int(np.prod(sh))
+        flat[o:o + n] = float(rank + 1) * (i + 1)
+        flat[o + n:o + (n + 3) // 4 * 4] = 0.0 if i + 1 < len(shapes) else float("nan")  # inner pads are written, the tail is not
+        p = torch.zeros(sh, requires_grad=True)
+        p.grad = flat[o:o + n].view(sh)
+        params.append(p)
+        o += (n + 3) // 4 * 4
+    flat[o:o + 1] = 100.0 + rank                                            # exposure gradient of THIS rank
+    flat[o + 4:o + 4 + 3 * K] = 200.0 + rank                                # crf_table gradient of THIS rank
+    for algo in ("direct", "rccl"):
+        before = flat[o:].clone()
+        n = all_reduce_gradients(params, algo=algo)
+        assert n < total + 1, (n, total)
+        assert torch.equal(torch.nan_to_num(flat[o:], nan=-1.0), torch.nan_to_num(before, nan=-1.0)), algo
+    if rank == 0:
+        q.put([float(p.grad.reshape(-1)[0]) for p in params] + [float(p.grad.reshape(-1)[-1]) for p in params])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_reducing_a_subset_of_the_flat_buffer_leaves_its_neighbours_alone():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_subset, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    # two exchanges in a row (direct, then library): rank sums 1+2 = 3, then 3+3 = 6, times the slice's marker
+    assert got == [6.0 * (i + 1) for i in range(6)] * 2, got

@@ -267,6 +267,70 @@ def test_fixed_capacity_mode_and_overflow():
         Hh.run_hip(sc, capacity=R // 2)
 
 
+def _rasterizer_and_inputs(sc, capacity, requires_grad, **kw):
+    from casualhdrsplat_amd import GaussianRasterizer
+    rs, _, _ = Hh.settings_from_scene(sc, "cuda")
+    rast = GaussianRasterizer(rs, capacity=capacity, **kw)
+    leaf = {k: t.clone().cuda().requires_grad_(requires_grad) for k, t in
+            dict(means3D=sc.means3D, means2D=torch.zeros_like(sc.means3D), opacities=sc.opacities, shs=sc.shs,
+                 scales=sc.scales, rotations=sc.rotations).items()}
+    call = lambda: rast(leaf["means3D"], leaf["means2D"], leaf["opacities"], shs=leaf["shs"], scales=leaf["scales"],
+                        rotations=leaf["rotations"])
+    return rast, leaf, call
+
+
+def test_overflow_in_a_no_grad_forward_grows_capacity_and_replays():
+    """Sync-free mode, forward that no backward will follow: an overflowing frame is never handed
+    out empty -- the rasterizer grows its capacity to 1.5 x the device-reported pair count and replays; the result
+    equals the synchronous path bit for bit."""
+    from casualhdrsplat_amd import inspect_state
+    sc = S.make_scene(20000, 320, 200, 1, seed=5)
+    ref = Hh.run_hip(sc)
+    R = ref["state"]["num_rendered"]
+    for mode in ("no_grad", "no_leaf_requires_grad"):
+        rast, leaf, call = _rasterizer_and_inputs(sc, R // 3, requires_grad=False, keep_state=True)
+        if mode == "no_grad":
+            with torch.no_grad():
+                out = call()
+        else:
+            out = call()
+        assert rast.overflow_replays == 1 and rast.capacity >= R, (rast.overflow_replays, rast.capacity, R)
+        assert rast.last_num_rendered == R
+        assert np.array_equal(out[0].cpu().numpy(), ref["color"]), mode
+        assert np.array_equal(out[1].cpu().numpy(), ref["radii"])
+        st = inspect_state(rast)  # no autograd graph: the state comes from keep_state=True
+        assert st["num_rendered"] == R
+        assert np.array_equal(st["point_list"].cpu().numpy()[:R], ref["state"]["point_list"][:R])
+        out2 = call()  # the grown capacity stays: no second replay
+        assert rast.overflow_replays == 1 and np.array_equal(out2[0].cpu().numpy(), ref["color"])
+
+
+def test_overflow_in_a_training_step_raises_then_the_repeated_step_succeeds():
+    """A training forward does not wait for its counters; its backward finds the overflow, raises (the loss was
+    computed from an empty frame) and leaves the rasterizer with a capacity that fits, so repeating the step works
+    and matches the synchronous path."""
+    from casualhdrsplat_amd import BinningOverflow
+    sc = S.make_scene(20000, 320, 200, 1, seed=5)
+    ref = Hh.run_hip(sc)
+    R = ref["state"]["num_rendered"]
+    rast, leaf, call = _rasterizer_and_inputs(sc, R // 2, requires_grad=True)
+    out = call()
+    with pytest.raises(BinningOverflow, match="binning capacity"):
+        rast.check_overflow()          # explicit early check: one event wait
+    assert rast.capacity >= R
+    rast.capacity = R // 2             # undo, to exercise the lazy path through the backward
+    out = call()
+    assert float(out[0].abs().max()) == 0.0   # the device rendered the frame empty (background 0), nothing out of bounds
+    with pytest.raises(BinningOverflow, match="empty frame"):
+        (out[0] * sc.dL_dimage.cuda()).sum().backward()
+    out = call()                       # capacity was grown by the failed backward's verdict
+    assert rast.capacity >= R and rast.last_num_rendered == R
+    (out[0] * sc.dL_dimage.cuda()).sum().backward()
+    assert np.array_equal(out[0].detach().cpu().numpy(), ref["color"])
+    for k in ("means3D", "shs", "scales"):
+        assert np.array_equal(leaf[k].grad.cpu().numpy(), ref["d_" + k]), k
+
+
 def test_run_to_run_bitwise_determinism():
     sc = S.make_scene(50000, 640, 360, 3, seed=9, hdr=True)
     a = Hh.run_hip(sc, hdr=True)
@@ -525,6 +589,50 @@ def test_view_parallel_step_two_ranks_on_one_gpu():
                        capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert r.stdout.count("VIEW-EXCHANGE-OK") == 2, r.stdout[-2000:]
+
+
+def test_view_parallel_step_two_ranks_over_rccl():
+    """The same check over backend "nccl" (= RCCL), one GPU per rank -- runs wherever the box has two GPUs."""
+    import socket
+    import subprocess
+    import sys
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (the driver's 8-GPU node); single-GPU boxes run the gloo variant above")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dist_gpu_worker.py")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", HS_DIST_BACKEND="nccl")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), worker],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert r.stdout.count("VIEW-EXCHANGE-OK") == 2, r.stdout[-2000:]
+
+
+def test_bench_bare_multi_gpu_invocation_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no torchrun environment (the shape the driver may use): bench.py starts its
+    own ranks and rank 0's JSON line comes back through the parent.  RCCL when the box has two GPUs, else both ranks
+    share the GPU over gloo (plumbing only)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    if torch.cuda.device_count() < 2:
+        env["HS_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", "c2", "--steps", "2",
+                        "--warmup", "1", "--no-cpu-baseline", "--kernel-iters", "2"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
+    ex = d["config"]["gradient_exchange"]
+    assert ex["choice"] in ex["step_ms"] and len(ex["step_ms"]) >= 2, ex
 
 
 def test_steps_do_not_leak_device_memory():

@@ -94,3 +94,38 @@ def test_yaw_camera_keeps_cloud_centre_fixed():
     R = w2c[:3, :3]
     assert torch.allclose(R @ R.t(), torch.eye(3, dtype=torch.float64), atol=1e-6)
     assert math.degrees(math.acos(float(R[0, 0]))) == pytest.approx(5.0, abs=1e-4)
+
+
+def test_bench_launch_command_shape():
+    """`python bench.py --gpus N` without a torchrun environment re-launches itself as N ranks (VERDICT r1 #1)."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    cmd = bench.launch_command(["--gpus", "8", "--steps", "5"], 8, 12345)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node=8" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "12345"
+    assert cmd[-5:] == [os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "5"]
+    p1, p2 = bench.free_port(), bench.free_port()
+    assert 1024 < p1 < 65536 and 1024 < p2 < 65536
+
+
+def test_bench_self_launches_ranks_and_forwards_their_exit_code():
+    """End to end on a box without GPUs: the parent starts two child ranks through torch.distributed.run, every rank
+    stops with the loud no-GPU message (there is no CPU fallback), and the parent exits non-zero instead of hanging
+    or printing a fake line."""
+    import os
+    import subprocess
+    import sys
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0
+    assert "torch.distributed.run" in r.stderr and "--nproc-per-node=2" in r.stderr
+    assert "bench.py needs an MI355X" in r.stderr
+    assert not r.stdout.strip().startswith("{")
