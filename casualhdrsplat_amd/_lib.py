@@ -24,7 +24,7 @@ _fp = C.c_void_p  # device pointers travel as plain addresses
 
 class hs_dims(C.Structure):
     _fields_ = [("P", C.c_int32), ("M", C.c_int32), ("sh_degree", C.c_int32), ("W", C.c_int32), ("H", C.c_int32),
-                ("n_poses", C.c_int32), ("capacity", C.c_int64)]
+                ("n_poses", C.c_int32), ("capacity", C.c_int64), ("crf_K", C.c_int32), ("reserved", C.c_int32)]
 
 
 class hs_sizes(C.Structure):
@@ -130,8 +130,8 @@ def check(rc: int, what: str) -> None:
         raise RuntimeError(f"{what} failed (code {rc}): {msg}")
 
 
-def plan(P: int, M: int, sh_degree: int, W: int, H: int, n_poses: int, capacity: int):
-    d = hs_dims(P, M, sh_degree, W, H, n_poses, capacity)
+def plan(P: int, M: int, sh_degree: int, W: int, H: int, n_poses: int, capacity: int, crf_K: int = 0):
+    d = hs_dims(P, M, sh_degree, W, H, n_poses, capacity, crf_K, 0)
     sz, lay = hs_sizes(), hs_layout()
     check(load().hs_plan(C.byref(d), C.byref(sz), C.byref(lay)), "hs_plan")
     return d, sz, lay

@@ -17,11 +17,12 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-int crf_partial_floats(int K);
+int64_t crf_partial_floats(int K, int64_t HW, int n_poses);
 int64_t pose_partial_floats(int P, int N);
 
 static int plan(const hs_dims& d, hs_sizes* sz, hs_layout* L) {
-    if (d.P < 0 || d.W <= 0 || d.H <= 0 || d.n_poses < 1 || d.capacity < 0 || d.M < 0) {
+    if (d.P < 0 || d.W <= 0 || d.H <= 0 || d.n_poses < 1 || d.capacity < 0 || d.M < 0 || d.crf_K < 0 || d.crf_K > 4096 ||
+        d.crf_K == 1 || d.n_poses > 21845) {
         set_error("hs_plan: bad dims P=%d W=%d H=%d N=%d capacity=%lld", d.P, d.W, d.H, d.n_poses, (long long)d.capacity);
         return HS_EINVAL;
     }
@@ -70,7 +71,7 @@ static int plan(const hs_dims& d, hs_sizes* sz, hs_layout* L) {
     // backward scratch
     o = 0;
     l.pair_grads = carve(d.capacity * kPairFloats * 4);
-    l.crf_partials = carve((int64_t)crf_partial_floats(4096) * 4);
+    l.crf_partials = carve(crf_partial_floats(d.crf_K, HW, d.n_poses) * 4);
     l.inst_grads = carve(I * kInstFloats * 4);
     l.pose_partials = carve(pose_partial_floats(d.P, d.n_poses) * 4);
     sz->bwd_bytes = o;
@@ -101,6 +102,10 @@ static int check_common(const hs_dims& d, const float* means3D, const float* shs
         return HS_EINVAL;
     }
     if (shs) {
+        if (d.M > 32) {  // preprocess-backward stages 128 rows of 3M + 1 floats in LDS (64 KB at M = 42)
+            set_error("%s: M=%d SH coefficients per channel; at most 32 are supported", who, d.M);
+            return HS_EINVAL;
+        }
         if (d.sh_degree < 0 || d.sh_degree > 3 || (d.sh_degree + 1) * (d.sh_degree + 1) > d.M) {
             set_error("%s: sh_degree %d needs %d coefficients, M=%d", who, d.sh_degree, (d.sh_degree + 1) * (d.sh_degree + 1), d.M);
             return HS_EINVAL;
@@ -140,6 +145,10 @@ int hs_forward(const hs_fwd_args* a, void* hip_stream) {
     if (!a->geom || !a->bg) { set_error("hs_forward: null geom/bg"); return HS_EINVAL; }
     if ((a->flags & HS_FLAG_HDR) && (!a->exposure || !a->crf_table || a->crf_K < 2 || a->crf_K > 4096 || !(a->crf_umax > a->crf_umin))) {
         set_error("hs_forward: HDR needs exposure, crf_table, 2 <= crf_K <= 4096 and umax > umin");
+        return HS_EINVAL;
+    }
+    if ((a->flags & HS_FLAG_HDR) && a->dims.crf_K != a->crf_K) {
+        set_error("hs_forward: dims.crf_K (%d, sizes the workspaces) differs from crf_K (%d)", a->dims.crf_K, a->crf_K);
         return HS_EINVAL;
     }
     if (((uintptr_t)a->geom & 255) || ((uintptr_t)a->binning & 255) || ((uintptr_t)a->image & 255)) {
@@ -196,8 +205,8 @@ int hs_backward(const hs_bwd_args* a, void* hip_stream) {
         set_error("hs_backward: null workspace or dL_dout_color");
         return HS_EINVAL;
     }
-    if ((a->flags & HS_FLAG_HDR) && (!a->exposure || !a->crf_table || a->crf_K < 2 || a->crf_K > 4096)) {
-        set_error("hs_backward: HDR needs exposure and crf_table");
+    if ((a->flags & HS_FLAG_HDR) && (!a->exposure || !a->crf_table || a->crf_K < 2 || a->crf_K > 4096 || a->dims.crf_K != a->crf_K)) {
+        set_error("hs_backward: HDR needs exposure, crf_table and dims.crf_K == crf_K");
         return HS_EINVAL;
     }
     const int npose_out = (a->dL_dviewmatrices != nullptr) + (a->dL_dprojmatrices != nullptr) + (a->dL_dcamposes != nullptr);

@@ -759,94 +759,141 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
     if constexpr (STATS) ws.flush(p.stats);
 }
 
-// CRF-table and exposure gradients: fixed grid, LDS table per block, one partial row per block
-// ([3K] table + [1] exposure), reduced by crf_reduce_kernel.
-// grid = (blocks_x, 3 * npose): blockIdx.y selects the (pose, channel) image plane, x-blocks grid-stride over its
-// pixels in float4 quads -- no 64-bit integer division in the loop.
+// CRF-table and exposure gradients (a15 backward), bitwise reproducible.
+// grid = (ceil(HW / 4096), planes): blockIdx.y selects the (pose, channel) image plane, each block owns 4096 consecutive
+// pixels of it, 16 per thread, all held in registers.  A pixel whose log-exposure falls between knots i and i+1 adds
+// (1 - f) g to dL/dtable[i] and f g to dL/dtable[i+1].  Both weights travel in ONE 64-bit LDS atomic per run of pixels
+// that share an interval (neighbouring pixels of a natural image mostly do): they are converted to fixed point with a
+// power-of-two scale derived from the block's own max |g| (19 bits below 2^31, so 4096 addends cannot overflow a 32-bit
+// field) and packed as  (q1 << 32) + q0  with q0 sign-extended -- integer adds commute, so the block's table does not
+// depend on the order in which lanes reach the LDS, unlike the float atomics this replaces; the fields are split
+// again, turned back into floats and written as the block's partial row.  Quantisation step = 2^-19 of the block's
+// largest |g|, unbiased.  Exposure gradient and the clamped ends of the table: per-thread float sums in pixel order,
+// fixed DPP tree over the wave, the four waves added in wave order.  crf_reduce_kernel adds the blocks in a fixed order.
+constexpr int kCrfPixPerBlock = 4096;
+
 __global__ void __launch_bounds__(256) crf_grad_kernel(int64_t HW, int N, int flags, const float* pose_hdr, Crf crf,
                                                        const float* exposure, const float* dL_dcolor, float* partials) {
-    extern __shared__ float s_tab[];  // 3K + 4
-    const int K3 = 3 * crf.K;
-    for (int i = threadIdx.x; i < K3 + 4; i += 256) s_tab[i] = 0.f;
-    __syncthreads();
+    extern __shared__ unsigned long long s_tab64[];  // K - 1 intervals
+    __shared__ float s_wave[4][4];
+    __shared__ float s_max[4];
+    const int K = crf.K;
+    for (int i = threadIdx.x; i < K - 1; i += 256) s_tab64[i] = 0ull;
     crf.dt = exposure[0];
     const bool blur_hdr = (flags & HS_FLAG_BLUR_HDR) && N > 1;
     const float gs = blur_hdr ? 1.f : 1.f / (float)N;
-    const float scale = (float)(crf.K - 1) / (crf.umax - crf.umin);
+    const float scale = (float)(K - 1) / (crf.umax - crf.umin);
     const int plane = blockIdx.y;            // pose * 3 + ch
     const int pose = plane / 3, ch = plane - 3 * pose;
     const float* Hp = pose_hdr + ((int64_t)(blur_hdr ? N : pose) * 3 + ch) * HW;
     const float* gp = dL_dcolor + (int64_t)ch * HW;
-    const float* t = crf.table + ch * crf.K;
-    float* tab = s_tab + ch * crf.K;
-    float gexp = 0.f, g_lo = 0.f, g_hi = 0.f;
-    // Each thread walks 16 consecutive pixels (four float4 loads per array in flight) and merges the run of pixels
-    // that fall between the same two knots in registers: neighbouring pixels of a natural image mostly share a
-    // knot interval, and same-address LDS atomics of one wave serialise, so merging runs removes most of them.
-    for (int64_t i16 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 16; i16 < HW; i16 += (int64_t)gridDim.x * 4096) {
-        float Hv[16], g[16];
-        if (i16 + 16 <= HW && (HW & 3) == 0) {
+    const float* t = crf.table + ch * K;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+    const int64_t i16 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 16;
+    float Hv[16], g[16];
+    if (i16 + 16 <= HW && (HW & 3) == 0) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 h4 = reinterpret_cast<const float4*>(Hp + i16)[q];
-                const float4 g4 = reinterpret_cast<const float4*>(gp + i16)[q];
-                Hv[4 * q] = h4.x; Hv[4 * q + 1] = h4.y; Hv[4 * q + 2] = h4.z; Hv[4 * q + 3] = h4.w;
-                g[4 * q] = g4.x * gs; g[4 * q + 1] = g4.y * gs; g[4 * q + 2] = g4.z * gs; g[4 * q + 3] = g4.w * gs;
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const bool ok = i16 + e < HW;
-                Hv[e] = ok ? Hp[i16 + e] : 0.f;
-                g[e] = ok ? gp[i16 + e] * gs : 0.f;
-            }
+        for (int q = 0; q < 4; ++q) {
+            const float4 h4 = reinterpret_cast<const float4*>(Hp + i16)[q];
+            const float4 g4 = reinterpret_cast<const float4*>(gp + i16)[q];
+            Hv[4 * q] = h4.x; Hv[4 * q + 1] = h4.y; Hv[4 * q + 2] = h4.z; Hv[4 * q + 3] = h4.w;
+            g[4 * q] = g4.x * gs; g[4 * q + 1] = g4.y * gs; g[4 * q + 2] = g4.z * gs; g[4 * q + 3] = g4.w * gs;
         }
-        int run = -1;            // knot interval of the pending run (-1: none)
-        float r0 = 0.f, r1 = 0.f;  // pending contributions to tab[run], tab[run + 1]
+    } else {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            int idx; float f, xv; bool in;
-            crf_locate(crf, Hv[e], idx, f, xv, in);
-            // pixels clamped to an end of the table (black / saturated regions) are summed per thread
-            const bool lo = idx == 0 && f == 0.f, hi = idx == crf.K - 2 && f == 1.f;
-            g_lo += lo ? g[e] : 0.f;
-            g_hi += hi ? g[e] : 0.f;
-            if (!lo && !hi) {
-                if (idx != run) {
-                    if (run >= 0) { atomicAdd(&tab[run], r0); atomicAdd(&tab[run + 1], r1); }
-                    run = idx; r0 = 0.f; r1 = 0.f;
-                }
-                r0 += (1.f - f) * g[e];
-                r1 += f * g[e];
-            }
-            if (in) gexp += g[e] * (t[idx + 1] - t[idx]) * scale * __builtin_amdgcn_rcpf(xv) * Hv[e];
+            const bool ok = i16 + e < HW;
+            Hv[e] = ok ? Hp[i16 + e] : 0.f;
+            g[e] = ok ? gp[i16 + e] * gs : 0.f;
         }
-        if (run >= 0) { atomicAdd(&tab[run], r0); atomicAdd(&tab[run + 1], r1); }
     }
+    // block maximum of |g| -> fixed-point scale (max is order independent)
+    float mx = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) mx = fmaxf(mx, fabsf(g[e]));
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
+    if (lane == 0) s_max[wave] = mx;
+    __syncthreads();  // also: the table is cleared
+    mx = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+    // mx = m * 2^x with m in [0.5, 1)  ->  |g| * 2^(19 - x) < 2^19 ; non-finite or zero gradients: scale 1 (sums are
+    // zero or garbage-in-garbage-out, as with float adds)
+    int xexp = 0;
+    if (mx > 0.f && mx < 3.0e38f) (void)frexpf(mx, &xexp);
+    const float to_fix = ldexpf(1.f, 19 - xexp), from_fix = ldexpf(1.f, xexp - 19);
+
+    float gexp = 0.f, g_lo = 0.f, g_hi = 0.f;
+    int run = -1;              // knot interval of the pending run (-1: none)
+    float r0 = 0.f, r1 = 0.f;  // pending contributions to table[run], table[run + 1]
+    auto flush = [&]() {
+        const long long q0 = (long long)__float2int_rn(r0 * to_fix), q1 = (long long)__float2int_rn(r1 * to_fix);
+        atomicAdd(&s_tab64[run], (unsigned long long)((q1 << 32) + q0));
+    };
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        int idx; float f, xv; bool in;
+        crf_locate(crf, Hv[e], idx, f, xv, in);
+        // pixels clamped to an end of the table (black / saturated regions) are summed per thread
+        const bool lo = idx == 0 && f == 0.f, hi = idx == K - 2 && f == 1.f;
+        g_lo += lo ? g[e] : 0.f;
+        g_hi += hi ? g[e] : 0.f;
+        if (!lo && !hi) {
+            if (idx != run) {
+                if (run >= 0) flush();
+                run = idx; r0 = 0.f; r1 = 0.f;
+            }
+            r0 += (1.f - f) * g[e];
+            r1 += f * g[e];
+        }
+        if (in) gexp += g[e] * (t[idx + 1] - t[idx]) * scale * __builtin_amdgcn_rcpf(xv) * Hv[e];
+    }
+    if (run >= 0) flush();
     gexp = wave_sum_hi(gexp);
     g_lo = wave_sum_hi(g_lo);
     g_hi = wave_sum_hi(g_hi);
-    if ((threadIdx.x & 63) == 63) {
-        atomicAdd(&s_tab[K3], gexp);
-        atomicAdd(&tab[0], g_lo);
-        atomicAdd(&tab[crf.K - 1], g_hi);
-    }
+    if (lane == 63) { s_wave[wave][0] = gexp; s_wave[wave][1] = g_lo; s_wave[wave][2] = g_hi; }
     __syncthreads();
-    float* dst = partials + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (K3 + 1);
-    for (int i = threadIdx.x; i < K3 + 1; i += 256) dst[i] = s_tab[i];
+    // partial row of this block: K knots of its channel + its exposure term
+    float* dst = partials + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (K + 1);
+    for (int k = threadIdx.x; k <= K; k += 256) {
+        float v;
+        if (k == K) {
+            v = ((s_wave[0][0] + s_wave[1][0]) + s_wave[2][0]) + s_wave[3][0];
+        } else {
+            long long acc = 0;  // field 0 of interval k + field 1 of interval k - 1
+            if (k < K - 1) acc += (long long)(int)(uint32_t)(s_tab64[k] & 0xFFFFFFFFull);
+            if (k > 0) {
+                const long long w = (long long)s_tab64[k - 1];
+                acc += (w - (long long)(int)(uint32_t)((unsigned long long)w & 0xFFFFFFFFull)) >> 32;
+            }
+            v = (float)acc * from_fix;
+            if (k == 0) v += ((s_wave[0][1] + s_wave[1][1]) + s_wave[2][1]) + s_wave[3][1];
+            if (k == K - 1) v += ((s_wave[0][2] + s_wave[1][2]) + s_wave[2][2]) + s_wave[3][2];
+        }
+        dst[k] = v;
+    }
 }
 
-// One wave per output element: lanes stride over the per-block partial rows (fixed order -> reproducible).
-__global__ void __launch_bounds__(256) crf_reduce_kernel(const float* partials, int nblk, int K3, float* d_table,
+// One wave per output element (3K table entries + the exposure): lanes stride over the partial rows of the blocks that
+// worked on that channel -- every pose, every pixel block -- in a fixed order, then a fixed DPP tree: reproducible.
+__global__ void __launch_bounds__(256) crf_reduce_kernel(const float* partials, int bx, int planes, int K, float* d_table,
                                                          float* d_exposure) {
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);  // 0 .. 3K: table entry ch * K + k, or 3K = exposure
     const int lane = threadIdx.x & 63;
-    if (i > K3) return;
+    if (i > 3 * K) return;
+    const bool expo = i == 3 * K;
+    const int ch = expo ? 0 : i / K, k = expo ? K : i - ch * K;
     float acc = 0.f;
-    for (int b = lane; b < nblk; b += 64) acc += partials[(int64_t)b * (K3 + 1) + i];
+    // rows of plane p = [p * bx, (p + 1) * bx); plane p carries channel p % 3
+    const int nrows = expo ? planes * bx : (planes / 3) * bx;
+    for (int r = lane; r < nrows; r += 64) {
+        const int row = expo ? r : ((r / bx) * 3 + ch) * bx + (r % bx);
+        acc += partials[(int64_t)row * (K + 1) + k];
+    }
     acc = wave_sum_hi(acc);
     if (lane == 63) {
-        if (i < K3) { if (d_table) d_table[i] = acc; }
+        if (!expo) { if (d_table) d_table[i] = acc; }
         else if (d_exposure) d_exposure[0] = acc;
     }
 }
@@ -886,8 +933,6 @@ int launch_render_fwd(const hs_fwd_args& a, const hs_layout& L, hipStream_t s, u
     return HS_OK;
 }
 
-constexpr int kCrfBlocks = 1024;
-
 int launch_crf_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s) {
     const hs_dims& d = a.dims;
     if (!((a.flags & HS_FLAG_HDR) && (a.dL_dcrf_table || a.dL_dexposure))) return HS_OK;
@@ -896,13 +941,13 @@ int launch_crf_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s) {
     const int64_t HW = (int64_t)d.W * d.H;
     float* partials = (float*)((char*)a.bwd + L.crf_partials);
     const float* pose_hdr = (const float*)((const char*)a.image + L.pose_hdr);
-    const int K3 = 3 * a.crf_K;
     const bool blur_hdr = (a.flags & HS_FLAG_BLUR_HDR) && d.n_poses > 1;
     const int planes = 3 * (blur_hdr ? 1 : d.n_poses);
-    const int bx = max(1, kCrfBlocks / planes);
-    crf_grad_kernel<<<dim3(bx, planes), 256, (K3 + 4) * sizeof(float), s>>>(HW, d.n_poses, a.flags, pose_hdr, crf,
-                                                                           a.exposure, a.dL_dout_color, partials);
-    crf_reduce_kernel<<<ceil_div(K3 + 1, 4), 256, 0, s>>>(partials, bx * planes, K3, a.dL_dcrf_table, a.dL_dexposure);
+    const int bx = ceil_div(HW, kCrfPixPerBlock);
+    crf_grad_kernel<<<dim3(bx, planes), 256, (size_t)(a.crf_K - 1) * sizeof(unsigned long long), s>>>(
+        HW, d.n_poses, a.flags, pose_hdr, crf, a.exposure, a.dL_dout_color, partials);
+    crf_reduce_kernel<<<ceil_div(3 * a.crf_K + 1, 4), 256, 0, s>>>(partials, bx, planes, a.crf_K, a.dL_dcrf_table,
+                                                                 a.dL_dexposure);
     HS_LAUNCH_CHECK();
     return HS_OK;
 }
@@ -939,6 +984,9 @@ int launch_render_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s, u
 
 int render_stats_count() { return kStCount; }
 
-int crf_partial_floats(int K) { return kCrfBlocks * (3 * K + 1); }
+// scratch of the CRF-gradient stage: one row of K + 1 floats per (pixel block, pose, channel)
+int64_t crf_partial_floats(int K, int64_t HW, int n_poses) {
+    return K > 0 ? (int64_t)ceil_div(HW, kCrfPixPerBlock) * 3 * n_poses * (K + 1) : 0;
+}
 
 }  // namespace hs

@@ -199,7 +199,7 @@ def _run_forward(settings: GaussianRasterizationSettings, means3D, opacities, sh
     crf_K = int(crf_table.shape[1]) if hdr else 0
 
     sync_mode = capacity is None
-    dims, sizes, layout = L.plan(P, M, int(settings.sh_degree), W, H, N, 0 if sync_mode else int(capacity))
+    dims, sizes, layout = L.plan(P, M, int(settings.sh_degree), W, H, N, 0 if sync_mode else int(capacity), crf_K)
     geom = torch.empty(max(int(sizes.geom_bytes), 256), dtype=torch.uint8, device=dev)
     out_color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
     out_hdr = torch.empty(3, H, W, dtype=torch.float32, device=dev) if hdr else None
@@ -227,7 +227,7 @@ def _run_forward(settings: GaussianRasterizationSettings, means3D, opacities, sh
         a.stages = L.HS_STAGE_PREPROCESS
         L.check(lib.hs_forward(C.byref(a), stream), "hs_forward[preprocess]")
         R = int(geom[:4].view(torch.int32).item()) & 0xFFFFFFFF if P > 0 else 0
-        dims, sizes, layout = L.plan(P, M, int(settings.sh_degree), W, H, N, R)
+        dims, sizes, layout = L.plan(P, M, int(settings.sh_degree), W, H, N, R, crf_K)
         a.dims = dims
         a.stages = L.HS_STAGE_BIN | L.HS_STAGE_RENDER
     else:
@@ -357,7 +357,7 @@ def _launch_backward(st: "_State", saved, gcol, ghdr, stages: int, want_pose: bo
     m3, op, shs, cp, sc, ro, cv, exp_t, crf_t = saved
     dev = m3.device
     P, M = st.dims.P, st.dims.M
-    _, sizes, _ = L.plan(P, M, st.dims.sh_degree, st.W, st.H, st.dims.n_poses, st.dims.capacity)
+    _, sizes, _ = L.plan(P, M, st.dims.sh_degree, st.W, st.H, st.dims.n_poses, st.dims.capacity, st.dims.crf_K)
     bwd = torch.empty(max(int(sizes.bwd_bytes), 256), dtype=torch.uint8, device=dev)
     hdr = bool(st.flags & L.HS_FLAG_HDR)
     spec = [("means3D", (P, 3), True), ("means2D", (P, 3), True), ("opacities", (P, 1), True),

@@ -64,7 +64,7 @@ int main(int argc, char** argv) {
     hipStream_t stream;
     CK(hipStreamCreate(&stream));
     hs_fwd_args f = {};
-    f.dims = hs_dims{P, M, deg, W, H, 1, 0};
+    f.dims = hs_dims{P, M, deg, W, H, 1, 0, 0, 0};
     f.tanfovx = tf[0]; f.tanfovy = tf[1]; f.scale_modifier = 1.f;
     f.bg = to_device(bg); f.viewmatrices = to_device(view); f.projmatrices = to_device(proj); f.camposes = to_device(campos);
     f.means3D = to_device(means); f.opacities = to_device(opac); f.shs = to_device(shs);

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define HS_VERSION 100
+#define HS_VERSION 200
 
 #define HS_OK 0
 #define HS_EINVAL (-1)    /* bad argument (null pointer, bad shape, unsupported degree ...) */
@@ -75,6 +75,9 @@ typedef struct hs_dims {
     int32_t W, H;
     int32_t n_poses;   /* N >= 1 */
     int64_t capacity;  /* binning capacity in (tile, instance) pairs */
+    int32_t crf_K;     /* knots per channel of the CRF table, 0 when the call has no HDR tone-map: sizes the scratch of
+                          the CRF-gradient stage (must equal hs_fwd_args.crf_K / hs_bwd_args.crf_K under HS_FLAG_HDR) */
+    int32_t reserved;  /* 0 */
 } hs_dims;
 
 typedef struct hs_sizes {

@@ -334,10 +334,29 @@ def test_overflow_in_a_training_step_raises_then_the_repeated_step_succeeds():
 def test_run_to_run_bitwise_determinism():
     sc = S.make_scene(50000, 640, 360, 3, seed=9, hdr=True)
     a = Hh.run_hip(sc, hdr=True)
-    b = Hh.run_hip(sc, hdr=True)
-    assert np.array_equal(a["color"], b["color"]) and np.array_equal(a["hdr"], b["hdr"])
-    for k in ("means3D", "means2D", "opacities", "shs", "scales", "rotations"):
-        assert np.array_equal(a["d_" + k], b["d_" + k]), k
+    for rep in range(3):
+        b = Hh.run_hip(sc, hdr=True)
+        assert np.array_equal(a["color"], b["color"]) and np.array_equal(a["hdr"], b["hdr"])
+        # every output, the CRF-table and exposure gradients included (fixed-point LDS accumulation, fixed-order sums)
+        for k in ("means3D", "means2D", "opacities", "shs", "scales", "rotations", "crf_table", "exposure"):
+            assert np.array_equal(a["d_" + k], b["d_" + k]), (k, rep)
+    assert np.abs(a["d_crf_table"]).max() > 0 and float(np.abs(a["d_exposure"]).max()) > 0
+
+
+def test_crf_gradient_blur_domains_run_to_run_and_tiny_gradients():
+    """The fixed-point CRF-gradient accumulation scales itself to each block's largest |dL/dLDR|: a loss gradient
+    eight orders of magnitude smaller gives the same table gradient up to that factor (no underflow to zero), for
+    both averaging domains of the N-pose blur."""
+    sc = S.make_scene(6000, 200, 120, 1, seed=4, hdr=True)
+    cams = S.blur_poses(200, 120, 3, step=0.02)
+    for dom in ("ldr", "hdr"):
+        a = Hh.run_hip(sc, cameras=cams, hdr=True, blur_domain=dom)
+        b = Hh.run_hip(sc, cameras=cams, hdr=True, blur_domain=dom)
+        assert np.array_equal(a["d_crf_table"], b["d_crf_table"]) and np.array_equal(a["d_exposure"], b["d_exposure"])
+        small = S.make_scene(6000, 200, 120, 1, seed=4, hdr=True)
+        small.dL_dimage = sc.dL_dimage * 2.0 ** -27   # power of two: every float product scales exactly
+        c = Hh.run_hip(small, cameras=cams, hdr=True, blur_domain=dom)
+        assert np.array_equal(c["d_crf_table"] * 2.0 ** 27, a["d_crf_table"]), dom
 
 
 def test_device_radix_sort_matches_stable_reference():
