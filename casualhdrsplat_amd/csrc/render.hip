@@ -495,18 +495,27 @@ __device__ __forceinline__ float pixel_grad(const RenderBwd& p, const Crf& c, in
 }
 
 // Per-pixel state of the backward replay (two per lane).
+//
+// The published recurrence keeps the colour accumulated behind the current entry per channel ("accum_rec") and forms
+// dL/dalpha_i = T_i * sum_ch (c_i,ch - accum_rec_ch) dL_ch  -  T_final / (1 - alpha_i) * (bg . dL).  Only the dot product
+// with this pixel's dL ever leaves that state, and the recurrence is linear, so the replay tracks the ONE number
+//     q_i = accum_rec_i . dL  +  (T_final / T_{i+1}) * (bg . dL)
+// (the background is the opaque layer behind the last contributor: q starts at bg . dL and is multiplied by
+// (1 - alpha) at every step like the colour behind it), and dL/dalpha_i = T_i * (c_i . dL - q_i),
+// q_{i-1} = q_i + alpha_i * (c_i . dL - q_i).  Same algebra, five vector instructions and six registers fewer per
+// trip than the per-channel form; the inverse-depth channel (DEPTH) just adds invd * dLd to c . dL.
 struct PixB {
-    float T, T_final, R0, R1, R2, dL0, dL1, dL2, bg_dot;
-    float Rd, dLd;  // inverse-depth channel (DEPTH kernels only): value accumulated behind, upstream gradient
+    float T, dL0, dL1, dL2, q;
+    float dLd;  // inverse-depth channel (DEPTH kernels only): upstream gradient
     uint32_t last;
 };
 
 __device__ __forceinline__ void load_pixel_bwd(const RenderBwd& p, PixB& s, bool inside, int pose, int px, int py) {
     const int64_t HW = (int64_t)p.H * p.W;
     const int64_t pix = (int64_t)py * p.W + px;
-    s.T_final = 0.f; s.dL0 = s.dL1 = s.dL2 = 0.f; s.last = 0;
+    s.T = 0.f; s.dL0 = s.dL1 = s.dL2 = 0.f; s.last = 0;
     if (inside) {
-        s.T_final = p.final_T[(int64_t)pose * HW + pix];
+        s.T = p.final_T[(int64_t)pose * HW + pix];
         s.last = p.n_contrib[(int64_t)pose * HW + pix];
         Crf c = p.crf;
         if (p.flags & HS_FLAG_HDR) c.dt = p.exposure[0];
@@ -514,78 +523,43 @@ __device__ __forceinline__ void load_pixel_bwd(const RenderBwd& p, PixB& s, bool
         s.dL1 = pixel_grad(p, c, pose, 1, pix, HW);
         s.dL2 = pixel_grad(p, c, pose, 2, pix, HW);
     }
-    s.bg_dot = (p.bg[0] * s.dL0 + p.bg[1] * s.dL1) + p.bg[2] * s.dL2;
+    float bg_dot = (p.bg[0] * s.dL0 + p.bg[1] * s.dL1) + p.bg[2] * s.dL2;
     // accumulated opacity A = 1 - T_final: dA/dalpha_i = T_final / (1 - alpha_i), the background term with sign flipped
-    if (p.dL_dalpha && inside) s.bg_dot -= p.dL_dalpha[pix] / (float)p.N;
-    s.T = s.T_final;
-    s.R0 = s.R1 = s.R2 = 0.f;  // colour accumulated behind the current entry ("accum_rec")
-    s.Rd = 0.f;
+    if (p.dL_dalpha && inside) bg_dot -= p.dL_dalpha[pix] / (float)p.N;
+    s.q = bg_dot;
     s.dLd = (p.dL_dinvdepth && inside) ? p.dL_dinvdepth[pix] / (float)p.N : 0.f;
-}
-
-// One back-to-front step for one pixel.  Outputs s_ = dL/dG * G (weight of the geometric sums), the opacity
-// term G * dL/dalpha and dch = alpha * T (colour weight); inactive pixels give exact zeros and keep their state
-// (alpha_eff = 0 makes every update an identity), so no per-field selects are needed.
-template <bool DEPTH>
-__device__ __forceinline__ void step_bwd(PixB& s, bool act, float G, float alpha, float o, float r, float g, float b,
-                                         float invd, float& sw, float& dop, float& dch) {
-    const float ae = act ? alpha : 0.f;
-    const float one_m = 1.f - ae;
-    const float rcp = __builtin_amdgcn_rcpf(one_m);
-    s.T *= rcp;
-    dch = ae * s.T;
-    const float d0 = r - s.R0, d1 = g - s.R1, d2 = b - s.R2;
-    float dLa = (d0 * s.dL0 + d1 * s.dL1) + d2 * s.dL2;
-    if constexpr (DEPTH) {  // the inverse-depth image is a fourth blended channel without background
-        const float dd = invd - s.Rd;
-        dLa += dd * s.dLd;
-        s.Rd += ae * dd;
-    }
-    dLa = dLa * s.T - (s.T_final * rcp) * s.bg_dot;
-    // accum_rec <- alpha*c + (1-alpha)*accum_rec, written as one FMA per channel on the difference already formed
-    s.R0 += ae * d0;
-    s.R1 += ae * d1;
-    s.R2 += ae * d2;
-    dop = act ? G * dLa : 0.f;  // select AFTER the product: an indefinite conic can give G = inf at a skipped pixel
-    sw = o * dop;
 }
 
 // The two pixels of a lane as one packed state: every update below is a two-wide (v_pk_*) instruction where the
 // hardware has one, which halves the FMA count of the replay (the loop is VALU-issue bound; v_pk_fma_f32 issues
 // at the rate of one v_fma_f32).
 struct PairB {
-    f2 T, R0, R1, R2, dL0, dL1, dL2, Tf_bg, Rd, dLd;  // Tf_bg = final transmittance * (background . dL/dpixel)
+    f2 T, q, dL0, dL1, dL2, dLd;
 };
 __device__ __forceinline__ f2 splat(float v) { f2 r = {v, v}; return r; }
 __device__ __forceinline__ PairB pack_pair(const PixB& a, const PixB& b) {
     PairB s;
-    s.T = f2{a.T, b.T}; s.Tf_bg = f2{a.T_final * a.bg_dot, b.T_final * b.bg_dot};
-    s.R0 = f2{a.R0, b.R0}; s.R1 = f2{a.R1, b.R1}; s.R2 = f2{a.R2, b.R2};
+    s.T = f2{a.T, b.T}; s.q = f2{a.q, b.q};
     s.dL0 = f2{a.dL0, b.dL0}; s.dL1 = f2{a.dL1, b.dL1}; s.dL2 = f2{a.dL2, b.dL2};
-    s.Rd = f2{a.Rd, b.Rd}; s.dLd = f2{a.dLd, b.dLd};
+    s.dLd = f2{a.dLd, b.dLd};
     return s;
 }
-// One back-to-front step for the pixel pair (see step_bwd for the algebra).
+// One back-to-front step for the pixel pair.  Outputs dop = G * dL/dalpha (the opacity term), sw = o * dop (weight of
+// the geometric sums) and dch = alpha * T (colour weight); inactive pixels give exact zeros and keep their state
+// (alpha_eff = 0 makes every update an identity), so no per-field selects are needed.
 template <bool DEPTH>
 __device__ __forceinline__ void step_bwd_pair(PairB& s, bool act0, bool act1, f2 G, f2 alpha, float o, float r, float g,
                                               float b, float invd, f2& sw, f2& dop, f2& dch) {
     const f2 ae = {act0 ? alpha.x : 0.f, act1 ? alpha.y : 0.f};
     const f2 one_m = splat(1.f) - ae;
     const f2 rcp = {__builtin_amdgcn_rcpf(one_m.x), __builtin_amdgcn_rcpf(one_m.y)};
-    s.T *= rcp;
+    s.T *= rcp;  // T_i = T_{i+1} / (1 - alpha_i)
     dch = ae * s.T;
-    const f2 d0 = splat(r) - s.R0, d1 = splat(g) - s.R1, d2 = splat(b) - s.R2;
-    f2 dLa = (d0 * s.dL0 + d1 * s.dL1) + d2 * s.dL2;
-    if constexpr (DEPTH) {
-        const f2 dd = splat(invd) - s.Rd;
-        dLa += dd * s.dLd;
-        s.Rd += ae * dd;
-    }
-    dLa = dLa * s.T - s.Tf_bg * rcp;  // background term: -T_final / (1 - alpha) * (bg . dL/dpixel)
-    s.R0 += ae * d0;
-    s.R1 += ae * d1;
-    s.R2 += ae * d2;
-    const f2 gd = G * dLa;
+    f2 cd = (splat(r) * s.dL0 + splat(g) * s.dL1) + splat(b) * s.dL2;  // c_i . dL
+    if constexpr (DEPTH) cd += splat(invd) * s.dLd;                     // the inverse-depth image: a fourth channel
+    const f2 diff = cd - s.q;
+    const f2 gd = G * (diff * s.T);
+    s.q += ae * diff;
     dop = f2{act0 ? gd.x : 0.f, act1 ? gd.y : 0.f};  // select AFTER the product (G may be inf at a skipped pixel)
     sw = splat(o) * dop;
 }
