@@ -80,9 +80,13 @@ __device__ __forceinline__ float wave_sum_hi(float v) {
     v += dpp<0x143, 0xC>(v);  // row_bcast:31 -> rows 2,3
     return v;
 }
-// Halving steps of the 9-value wave reduction (gfx950 v_permlane{32,16}_swap): the sum of TWO registers over
-// one lane bit costs one swap + one add, and the result holds x's partial sums in the lanes whose bit is 0 and
-// y's in the lanes whose bit is 1.
+// ---- the 9 (10) value wave reduction of the backward replay ----
+// Every halving step sums TWO registers over one lane bit into ONE register (x's partial sums land in the lanes
+// whose bit is 0, y's in the lanes whose bit is 1), so the register count shrinks 10 -> 5 -> 3 -> 2 -> 1.  The steps
+// differ in price -- a bank-masked v_add_f32_dpp issues in 4 cycles, a v_permlane{32,16}_swap in 8 (plus its add) -- so
+// the cheap in-row steps (lane bits 3 and 2) run FIRST, while there are many registers, and the swaps (bits 5 and 4)
+// last, on the few that remain: 21 vector instructions / 92 issue cycles for all ten values (the earlier order, swaps
+// first, cost 27 / 130).
 __device__ __forceinline__ float halve32(float x, float y) {  // lane bit 5
     auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
@@ -91,52 +95,83 @@ __device__ __forceinline__ float halve16(float x, float y) {  // lane bit 4 (x -
     auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
-// In-row halving steps on DPP bank masks, as two bank-masked v_add_f32_dpp each (the compiler's DPP combiner only
-// folds full-mask moves, leaving mov+mov+mov+add).  halve_row8(x, y): lanes with (lane & 8) == 0 get x[l] + x[l+8],
-// the others y[l] + y[l-8].  A VALU write followed by a DPP read of the same register needs two wait states,
-// hence the s_nop 1 in front of every dependent DPP instruction (hipcc pads nothing inside asm).
-__device__ __forceinline__ float halve_row8(float x, float y) {
-    float z;
-    asm("s_nop 1\n\t"
-        "v_add_f32_dpp %0, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
-        "v_add_f32_dpp %0, %2, %2 row_shl:8 row_mask:0xf bank_mask:0x3"
-        : "=&v"(z) : "v"(y), "v"(x));
-    return z;
+// In-row steps as bank-masked DPP adds (the compiler's DPP combiner only folds full-mask moves, so these are written
+// out).  pair8(x, y): lanes with (lane & 8) == 0 get x[l] + x[l+8], the others y[l] + y[l-8]; pair4 likewise on lane
+// bit 2.  A VALU write followed by a DPP read of the same register needs two wait states (hipcc pads nothing inside
+// asm): the ten inputs are written by ordinary code just before, hence the leading s_nop; inside the block every
+// register is read at least two instructions after it was written.  The trailing s_nop covers the v_permlane32_swap
+// the compiler places behind the block.
+// Out: w0 = {g0, g2, g1, g3} by quad, w1 = {g4, g6, g5, g7} by quad, w2 = {g8, g8, g9, g9} by quad -- each the sum over
+// lane bits 3 and 2, i.e. over the four quads of the row.
+template <bool TEN>
+__device__ __forceinline__ void reduce_in_rows(const float* g, float g9, float& w0, float& w1, float& w2) {
+    float z0, z1, z2, z3, z4;
+    if constexpr (TEN) {
+        asm("s_nop 1\n\t"
+            "v_add_f32_dpp %3, %9, %9 row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_add_f32_dpp %3, %8, %8 row_shl:8 row_mask:0xf bank_mask:0x3\n\t"
+            "v_add_f32_dpp %4, %11, %11 row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_add_f32_dpp %4, %10, %10 row_shl:8 row_mask:0xf bank_mask:0x3\n\t"
+            "v_add_f32_dpp %5, %13, %13 row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_add_f32_dpp %5, %12, %12 row_shl:8 row_mask:0xf bank_mask:0x3\n\t"
+            "v_add_f32_dpp %6, %15, %15 row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_add_f32_dpp %6, %14, %14 row_shl:8 row_mask:0xf bank_mask:0x3\n\t"
+            "v_add_f32_dpp %7, %17, %17 row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_add_f32_dpp %7, %16, %16 row_shl:8 row_mask:0xf bank_mask:0x3\n\t"
+            "v_add_f32_dpp %0, %4, %4 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+            "v_add_f32_dpp %0, %3, %3 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_f32_dpp %1, %6, %6 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+            "v_add_f32_dpp %1, %5, %5 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_f32_dpp %2, %7, %7 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+            "v_add_f32_dpp %2, %7, %7 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+            "s_nop 1"
+            : "=&v"(w0), "=&v"(w1), "=&v"(w2), "=&v"(z0), "=&v"(z1), "=&v"(z2), "=&v"(z3), "=&v"(z4)
+            : "v"(g[0]), "v"(g[1]), "v"(g[2]), "v"(g[3]), "v"(g[4]), "v"(g[5]), "v"(g[6]), "v"(g[7]), "v"(g[8]), "v"(g9));
+    } else {
+        // nine values: the odd one is summed over bits 3 and 2 by two full-row rotations (every lane gets the total)
+        asm("s_nop 1\n\t"
+            "v_add_f32_dpp %3, %9, %9 row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_add_f32_dpp %3, %8, %8 row_shl:8 row_mask:0xf bank_mask:0x3\n\t"
+            "v_add_f32_dpp %4, %11, %11 row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_add_f32_dpp %4, %10, %10 row_shl:8 row_mask:0xf bank_mask:0x3\n\t"
+            "v_add_f32_dpp %5, %13, %13 row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_add_f32_dpp %5, %12, %12 row_shl:8 row_mask:0xf bank_mask:0x3\n\t"
+            "v_add_f32_dpp %6, %15, %15 row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_add_f32_dpp %6, %14, %14 row_shl:8 row_mask:0xf bank_mask:0x3\n\t"
+            "v_add_f32_dpp %7, %16, %16 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, %4, %4 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+            "v_add_f32_dpp %0, %3, %3 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_f32_dpp %1, %6, %6 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+            "v_add_f32_dpp %1, %5, %5 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_f32_dpp %2, %7, %7 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 1"
+            : "=&v"(w0), "=&v"(w1), "=&v"(w2), "=&v"(z0), "=&v"(z1), "=&v"(z2), "=&v"(z3), "=&v"(z4)
+            : "v"(g[0]), "v"(g[1]), "v"(g[2]), "v"(g[3]), "v"(g[4]), "v"(g[5]), "v"(g[6]), "v"(g[7]), "v"(g[8]));
+    }
 }
-// halve_row4(x, y) (quads 0,2: x over lane bit 2; quads 1,3: y over bit 2) followed by the two quad steps: every
-// lane of a quad ends with the quad total of the halved register.
-__device__ __forceinline__ float halve_row4_quad(float x, float y) {
-    float w;
+// The two quad steps (lane bits 1 and 0): every lane of a quad ends with the quad's total.
+__device__ __forceinline__ float reduce_in_quads(float t) {
     asm("s_nop 1\n\t"
-        "v_add_f32_dpp %0, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
-        "v_add_f32_dpp %0, %2, %2 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
-        "s_nop 1\n\t"
         "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
         "s_nop 1\n\t"
         "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
-        : "=&v"(w) : "v"(y), "v"(x));
-    return w;
+        : "+v"(t));
+    return t;
 }
 
-// Reduces g[0..8] over the wave in ~24 instructions.  Halving steps keep the register count shrinking
-// (9 -> 5 -> 3 -> 2 -> 1); the result is ONE register in which, for DPP row r = lane >> 4 (0..3):
-//   lanes r*16 + 0..3   hold the wave total of g[{0,2,1,3}[r]],
-//   lanes r*16 + 8..11  hold the wave total of g[{4,6,5,7}[r]],
-//   lanes 4..7 (row 0)  hold the wave total of g[8],
-//   lanes 36..39 (row 2) hold the wave total of the optional tenth value g9 (it rides in the half of a register
-//   the nine leave empty).
-__device__ __forceinline__ float wave_reduce9(const float* g, float g9 = 0.f) {
-    const float r0 = halve32(g[0], g[1]);
-    const float r1 = halve32(g[2], g[3]);
-    const float r2 = halve32(g[4], g[5]);
-    const float r3 = halve32(g[6], g[7]);
-    const float r4 = halve32(g[8], g9);
-    const float h0 = halve16(r0, r1);   // rows: g0, g2, g1, g3
-    const float h1 = halve16(r2, r3);   // rows: g4, g6, g5, g7
-    float h2 = halve16(r4, r4);         // rows: g8, g8, g9, g9
-    const float z = halve_row8(h0, h1);             // lanes 0-7: h0 over bit 3, lanes 8-15: h1 over bit 3
-    h2 += dpp<0x128>(h2);                           // row_ror:8 -> h2 over bit 3 in every lane
-    return halve_row4_quad(z, h2);                  // quads 0,2: z ; quads 1,3: h2 ; summed over bits 2,1,0
+// Reduces g[0..8] (and g9 when TEN) over the wave.  `xor32_addr` = ((lane ^ 32) << 2), the ds_bpermute address of the
+// lane's partner in the other half: the odd register of the bit-5 step is summed through the LDS crossbar (an LDS-pipe
+// instruction plus ONE vector add) instead of a copy + swap + add -- the loop is bound by vector issue, the LDS pipe
+// is not.  Result: ONE register in which lane 16*r + 4*k (all four lanes of that quad) holds the wave total of
+//     r = 0: g0, g2, g1, g3 (k = 0..3)     r = 2: g4, g6, g5, g7     r = 1 (and 3): g8, g8, g9, g9.
+template <bool TEN>
+__device__ __forceinline__ float wave_reduce(const float* g, float g9, int xor32_addr) {
+    float w0, w1, w2;
+    reduce_in_rows<TEN>(g, g9, w0, w1, w2);
+    const float u0 = halve32(w0, w1);  // lanes 0-31: w0 over bit 5, lanes 32-63: w1 over bit 5
+    const float u1 = w2 + __int_as_float(__builtin_amdgcn_ds_bpermute(xor32_addr, __float_as_int(w2)));
+    const float t = halve16(u0, u1);   // rows 0, 2: u0 over bit 4 ; rows 1, 3: u1 over bit 4
+    return reduce_in_quads(t);
 }
 
 // number of set bits of a wave-uniform 64-bit mask below this lane
@@ -564,19 +599,23 @@ __device__ __forceinline__ void step_bwd_pair(PairB& s, bool act0, bool act1, f2
     sw = splat(o) * dop;
 }
 
+// LDS record of one staged entry in the backward: the twelve floats of its render record followed by the planes of
+// reduced partial sums, so ONE per-entry byte offset (what the per-wave lists store) addresses both.
+//   [0..3] x, y, A2, B2   [4..7] C2, opacity, r, g   [8..11] b, 1/depth (DEPTH) or depth, radius, pair-slot start
+//   [12..21] the nine (ten) sums of the entry: zeroed per batch, each wave ADDS its totals (ds_add_f32).  At most two
+//   adds reach a word and 0 + x + y does not depend on their order, so the result is still bitwise reproducible -- and
+//   one set of sums instead of one per wave is what keeps the kernel at 11.6 KB of LDS.
+constexpr int kEntF = 22;             // floats per LDS entry record
+constexpr int kEntB = kEntF * 4;      // 88 bytes: not a multiple of 128, so the ten lanes adding one entry's sums and
+                                      // the per-thread staging writes spread over the banks
+constexpr int kAccF = 12;             // first float of the sums
+
 template <bool DEPTH, bool STATS>
 __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
     constexpr int KB = kBatch;
     constexpr int NV = DEPTH ? 10 : 9;      // reduced values per (tile, entry): nine published sums (+ d inverse depth)
-    __shared__ float4 s_a[KB];
-    __shared__ float4 s_b[KB];
-    __shared__ float4 s_c[KB];
-    // planes of reduced partials, one word per (value, staged entry): zeroed per batch, each wave ADDS its totals
-    // (ds_add_f32).  At most two adds reach a word and 0 + x + y does not depend on their order, so the result is
-    // still bitwise reproducible -- and one set of planes instead of one per wave is what lets six waves per SIMD
-    // fit in LDS.  The odd plane stride keeps the nine lanes of one entry on nine different banks.
-    __shared__ float s_acc[NV][KB + 1];
-    __shared__ uint16_t s_list[2][KB];      // per-wave compacted list of touched staged entries
+    __shared__ __attribute__((aligned(16))) float s_ent[KB * kEntF];
+    __shared__ uint16_t s_list[2][KB];      // per-wave compacted list of touched staged entries (byte offsets into s_ent)
     __shared__ uint32_t s_max[2];
 
     const int vt = xcd_strip_tile(blockIdx.x, gridDim.x, p.gx);
@@ -603,15 +642,22 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
     __syncthreads();
     const int n_proc = (int)max(s_max[0], s_max[1]);
 
-    // which of the nine wave totals this lane holds after wave_reduce9 (-1: none)
-    int red_slot = -1;
+    // which of the wave totals this lane holds after wave_reduce (see there), as a byte offset inside the entry record
+    int red_off = -1;
     {
-        const int row = lane >> 4, sub = lane & 15, v0 = ((row & 1) << 1) | (row >> 1);
-        if (sub == 0) red_slot = v0;
-        else if (sub == 8) red_slot = 4 + v0;
-        else if (lane == 4) red_slot = 8;
-        else if (DEPTH && lane == 36) red_slot = 9;
+        const int row = lane >> 4, k = (lane & 15) >> 2;
+        constexpr int kOrd[4] = {0, 2, 1, 3};
+        if ((lane & 3) == 0) {
+            if (row == 0) red_off = kOrd[k];
+            else if (row == 2) red_off = 4 + kOrd[k];
+            else if (row == 1 && k == 0) red_off = 8;
+            else if (DEPTH && row == 1 && k == 2) red_off = 9;
+        }
+        if (red_off >= 0) red_off = (kAccF + red_off) * 4;
     }
+    const int xor32_addr = (lane ^ 32) << 2;
+    char* const ent = reinterpret_cast<char*>(s_ent);
+    float* const my_ent = s_ent + threadIdx.x * kEntF;
     WaveStats ws;
     if constexpr (STATS) ws.clear();
     const int nb = (n_proc + KB - 1) / KB;
@@ -633,10 +679,12 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
             float4 rc = r[2];
             if constexpr (DEPTH) rc.y = 1.f / rc.y;  // depth -> inverse depth
             scale_entry(ra, rb);
-            s_a[threadIdx.x] = ra; s_b[threadIdx.x] = rb; s_c[threadIdx.x] = rc;
+            reinterpret_cast<float4*>(my_ent)[0] = ra;   // 88-byte records: 8-byte aligned, written as float2 pairs
+            reinterpret_cast<float4*>(my_ent)[1] = rb;
+            reinterpret_cast<float4*>(my_ent)[2] = rc;
         }
 #pragma unroll
-        for (int q = 0; q < NV; ++q) s_acc[q][threadIdx.x] = 0.f;
+        for (int q = 0; q < 10; q += 2) reinterpret_cast<float2*>(my_ent + kAccF)[q >> 1] = make_float2(0.f, 0.f);
         if (bi > 0) id_next = p.point_list[range.x + base - KB + threadIdx.x];  // batches below the top are full
         __syncthreads();
         if (base < (int)wave_max) {
@@ -645,27 +693,33 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
             for (int k = 0; k < KB / 64; ++k) {
                 const int jj = k * 64 + lane;
                 bool touch = false;
-                if (jj < cnt && base + jj < (int)wave_max) touch = halftile_may_touch(s_a[jj], s_b[jj], sxf, syf);
+                if (jj < cnt && base + jj < (int)wave_max) {
+                    const float4 a = reinterpret_cast<const float4*>(s_ent + jj * kEntF)[0];
+                    const float4 b = reinterpret_cast<const float4*>(s_ent + jj * kEntF)[1];
+                    touch = halftile_may_touch(a, b, sxf, syf);
+                }
                 const uint64_t mask = __ballot(touch);
                 if constexpr (STATS) ws.v[kStBwdCulled] += __popcll(__ballot(jj < cnt && base + jj < (int)wave_max && !touch));
-                if (touch) s_list[wave][n_t + mask_prefix(mask)] = (uint16_t)jj;
+                if (touch) s_list[wave][n_t + mask_prefix(mask)] = (uint16_t)(jj * kEntB);
                 n_t += __popcll(mask);
             }
+            // a pixel takes part in entry j of this batch iff base + j < last, i.e. iff j * 88 < (last - base) * 88
+            const int lim0 = ((int)s0.last - base) * kEntB, lim1 = ((int)s1.last - base) * kEntB;
             for (int i = n_t - 1; i >= 0; --i) {  // back to front
-                const int j = (int)s_list[wave][i];
-                const float4 a = s_a[j];
-                const float4 b = s_b[j];
-                const float cb = s_c[j].x;
-                const float invd = DEPTH ? s_c[j].y : 0.f;  // staged as 1 / depth in DEPTH kernels
+                const int jb = (int)s_list[wave][i];  // uniform across lanes -> broadcast LDS reads below
+                const float4 a = *reinterpret_cast<const float4*>(ent + jb);
+                const float4 b = *reinterpret_cast<const float4*>(ent + jb + 16);
+                const float2 c = *reinterpret_cast<const float2*>(ent + jb + 32);
+                const float cb = c.x;
+                const float invd = DEPTH ? c.y : 0.f;  // staged as 1 / depth in DEPTH kernels
                 const float dx = a.x - pxf;
                 const f2 dy = a.y - pyf;
                 const float t = a.z * dx * dx, u = a.w * dx;
                 const f2 pw = dy * (b.x * dy + u) + t;
                 const float G0 = hs_exp2(pw.x), G1 = hs_exp2(pw.y);
                 const float al0 = fminf(kAlphaMax, b.y * G0), al1 = fminf(kAlphaMax, b.y * G1);
-                const uint32_t idx = (uint32_t)(base + j);
-                const bool act0 = (idx < s0.last) && (pw.x <= 0.f) && (al0 >= kAlphaMin);
-                const bool act1 = (idx < s1.last) && (pw.y <= 0.f) && (al1 >= kAlphaMin);
+                const bool act0 = (jb < lim0) && (pw.x <= 0.f) && (al0 >= kAlphaMin);
+                const bool act1 = (jb < lim1) && (pw.y <= 0.f) && (al1 >= kAlphaMin);
                 if constexpr (STATS) {
                     const int lanes = __popcll(__ballot(act0 || act1));
                     ws.v[kStBwdTrips] += 1;
@@ -697,20 +751,19 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
                     const f2 cd = dch * ps.dLd;
                     g9 = cd.x + cd.y;
                 }
-                const float tot = wave_reduce9(g, g9);
-                if (red_slot >= 0) atomicAdd(&s_acc[red_slot][j], tot);  // 9 (10) lanes, one LDS add
+                const float tot = wave_reduce<DEPTH>(g, g9, xor32_addr);
+                if (red_off >= 0) atomicAdd(reinterpret_cast<float*>(ent + jb + red_off), tot);  // 9 (10) lanes, one LDS add
             }
         }
         __syncthreads();
         if ((int)threadIdx.x < cnt) {
-            const int t = threadIdx.x;
             float v[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int q = 0; q < NV; ++q) v[q] = s_acc[q][t];
-            const float4 a = s_a[t];
-            const float4 c = s_c[t];
+            for (int q = 0; q < NV; ++q) v[q] = my_ent[kAccF + q];
+            const float4 a = reinterpret_cast<const float4*>(my_ent)[0];
+            const float4 c = reinterpret_cast<const float4*>(my_ent)[2];
             // un-scale the conic: A = A2 * (-2/L), B = B2 * (-1/L), C = C2 * (-2/L)
-            const float A = a.z * (-2.f / kLog2e), B = a.w * (-1.f / kLog2e), C = s_b[t].x * (-2.f / kLog2e);
+            const float A = a.z * (-2.f / kLog2e), B = a.w * (-1.f / kLog2e), C = my_ent[4] * (-2.f / kLog2e);
             const float ddelx_dx = 0.5f * (float)p.W, ddely_dy = 0.5f * (float)p.H;
             // dL/dmean2D = -(A S1 + B S2, C S2 + B S1) (NDC-scaled); dL/dconic = (-0.5 S3, -S4, -0.5 S5)
             const float gmx = -(A * v[0] + B * v[1]) * ddelx_dx;
