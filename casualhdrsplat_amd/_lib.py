@@ -113,7 +113,7 @@ def load() -> C.CDLL:
     lib.hs_sh_backward_views.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p]
     lib.hs_sh_backward_views.restype = C.c_int
-    lib.hs_render_stats.argtypes = [C.POINTER(hs_fwd_args), C.POINTER(hs_bwd_args), C.c_void_p, C.c_void_p]
+    lib.hs_render_stats.argtypes = [C.POINTER(hs_fwd_args), C.POINTER(hs_bwd_args), C.c_void_p, C.c_void_p, C.c_void_p]
     lib.hs_render_stats.restype = C.c_int
     lib.hs_sort_tmp_bytes.argtypes = [C.c_int64]
     lib.hs_sort_tmp_bytes.restype = C.c_int64

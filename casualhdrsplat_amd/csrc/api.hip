@@ -256,7 +256,7 @@ int hs_sh_backward_views(int32_t P, int32_t M, int32_t sh_degree, int32_t V, con
     return launch_sh_backward_views(P, M, sh_degree, V, means3D, camposes, dL_dview_colors, dL_dshs, (hipStream_t)hip_stream);
 }
 
-int hs_render_stats(const hs_fwd_args* fwd, const hs_bwd_args* bwd, uint64_t* stats, void* hip_stream) {
+int hs_render_stats(const hs_fwd_args* fwd, const hs_bwd_args* bwd, uint64_t* stats, uint64_t* bwd_timeline, void* hip_stream) {
     if ((!fwd && !bwd) || !stats) { set_error("hs_render_stats: null argument"); return HS_EINVAL; }
     hipStream_t s = (hipStream_t)hip_stream;
     hs_sizes sz; hs_layout L;
@@ -276,7 +276,7 @@ int hs_render_stats(const hs_fwd_args* fwd, const hs_bwd_args* bwd, uint64_t* st
             set_error("hs_render_stats: backward args need geom/binning/image/bwd/dL_dout_color/bg");
             return HS_EINVAL;
         }
-        if (bwd->dims.P > 0 && (rc = launch_render_bwd(*bwd, L, s, (unsigned long long*)stats))) return rc;
+        if (bwd->dims.P > 0 && (rc = launch_render_bwd(*bwd, L, s, (unsigned long long*)stats, (unsigned long long*)bwd_timeline))) return rc;
     }
     return HS_OK;
 }

@@ -48,7 +48,8 @@ int launch_scan(const hs_fwd_args& a, const hs_layout& L, hipStream_t s);
 int launch_binning(const hs_fwd_args& a, const hs_layout& L, hipStream_t s);
 // `stats` (device, render_stats_count() u64 counters, or null) selects the diagnostic instantiation of the kernel
 int launch_render_fwd(const hs_fwd_args& a, const hs_layout& L, hipStream_t s, unsigned long long* stats = nullptr);
-int launch_render_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s, unsigned long long* stats = nullptr);
+int launch_render_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s, unsigned long long* stats = nullptr,
+                      unsigned long long* timeline = nullptr);
 int render_stats_count();
 int launch_crf_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s);
 int launch_preprocess_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s, bool segsum, bool project);

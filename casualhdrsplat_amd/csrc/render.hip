@@ -169,7 +169,11 @@ __device__ __forceinline__ float wave_reduce(const float* g, float g9, int xor32
     float w0, w1, w2;
     reduce_in_rows<TEN>(g, g9, w0, w1, w2);
     const float u0 = halve32(w0, w1);  // lanes 0-31: w0 over bit 5, lanes 32-63: w1 over bit 5
+#ifdef HS_EXP_SWAP_SINGLE
+    const float u1 = halve32(w2, w2);
+#else
     const float u1 = w2 + __int_as_float(__builtin_amdgcn_ds_bpermute(xor32_addr, __float_as_int(w2)));
+#endif
     const float t = halve16(u0, u1);   // rows 0, 2: u0 over bit 4 ; rows 1, 3: u1 over bit 4
     return reduce_in_quads(t);
 }
@@ -263,6 +267,7 @@ struct RenderFwd {
     Crf crf;
     const float* exposure;
     unsigned long long* stats;  // STATS instantiations only
+    unsigned long long* timeline;
 };
 
 constexpr int kBatch = 128;  // staged entries per trip = threads per workgroup
@@ -509,7 +514,9 @@ struct RenderBwd {
     uint8_t* pair_flags;
     Crf crf;
     const float* exposure;
-    unsigned long long* stats;  // STATS instantiations only
+    unsigned long long* stats;     // STATS instantiations only
+    unsigned long long* timeline;  // STATS instantiations only, may be null: {start, end (100 MHz clock), XCC | CU ids}
+                                   // per workgroup
 };
 
 // Upstream gradient w.r.t. this pose's radiance H_ch at one pixel (the HDR prologue).
@@ -604,18 +611,27 @@ __device__ __forceinline__ void step_bwd_pair(PairB& s, bool act0, bool act1, f2
 //   [0..3] x, y, A2, B2   [4..7] C2, opacity, r, g   [8..11] b, 1/depth (DEPTH) or depth, radius, pair-slot start
 //   [12..21] the nine (ten) sums of the entry: zeroed per batch, each wave ADDS its totals (ds_add_f32).  At most two
 //   adds reach a word and 0 + x + y does not depend on their order, so the result is still bitwise reproducible -- and
-//   one set of sums instead of one per wave is what keeps the kernel at 11.6 KB of LDS.
-constexpr int kEntF = 22;             // floats per LDS entry record
-constexpr int kEntB = kEntF * 4;      // 88 bytes: not a multiple of 128, so the ten lanes adding one entry's sums and
-                                      // the per-thread staging writes spread over the banks
+//   one set of sums instead of one per wave is what keeps the kernel at 12.8 KB of LDS (six waves per SIMD).
+#ifndef HS_EXP_ENTF
+#define HS_EXP_ENTF 24
+#endif
+constexpr int kEntF = HS_EXP_ENTF;    // floats per LDS entry record (22 used): 96 bytes keeps every record 16-byte
+constexpr int kEntB = kEntF * 4;      // aligned (measured on one box: 88-byte records, i.e. split ds_read_b128, +5 %)
 constexpr int kAccF = 12;             // first float of the sums
+#ifdef HS_EXP_LIST8
+typedef uint8_t list_t;               // the per-wave lists hold the entry index, the loop multiplies
+constexpr int kListMul = 1;
+#else
+typedef uint16_t list_t;              // the per-wave lists hold the entry's byte offset
+constexpr int kListMul = kEntB;
+#endif
 
 template <bool DEPTH, bool STATS>
 __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
     constexpr int KB = kBatch;
     constexpr int NV = DEPTH ? 10 : 9;      // reduced values per (tile, entry): nine published sums (+ d inverse depth)
     __shared__ __attribute__((aligned(16))) float s_ent[KB * kEntF];
-    __shared__ uint16_t s_list[2][KB];      // per-wave compacted list of touched staged entries (byte offsets into s_ent)
+    __shared__ list_t s_list[2][KB];        // per-wave compacted list of touched staged entries (byte offsets into s_ent)
     __shared__ uint32_t s_max[2];
 
     const int vt = xcd_strip_tile(blockIdx.x, gridDim.x, p.gx);
@@ -630,6 +646,8 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
     const f2 pyf = {(float)py0, (float)py1};
     const float sxf = (float)sx, syf = (float)sy;
 
+    unsigned long long t_start = 0;
+    if constexpr (STATS) t_start = wall_clock64();
     const uint2 range = p.ranges[vt];
 
     PixB s0, s1;
@@ -679,12 +697,12 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
             float4 rc = r[2];
             if constexpr (DEPTH) rc.y = 1.f / rc.y;  // depth -> inverse depth
             scale_entry(ra, rb);
-            reinterpret_cast<float4*>(my_ent)[0] = ra;   // 88-byte records: 8-byte aligned, written as float2 pairs
+            reinterpret_cast<float4*>(my_ent)[0] = ra;
             reinterpret_cast<float4*>(my_ent)[1] = rb;
             reinterpret_cast<float4*>(my_ent)[2] = rc;
         }
 #pragma unroll
-        for (int q = 0; q < 10; q += 2) reinterpret_cast<float2*>(my_ent + kAccF)[q >> 1] = make_float2(0.f, 0.f);
+        for (int q = 0; q < 10; q += 2) reinterpret_cast<float2*>(my_ent + kAccF)[q >> 1] = make_float2(0.f, 0.f);  // 8-byte aligned
         if (bi > 0) id_next = p.point_list[range.x + base - KB + threadIdx.x];  // batches below the top are full
         __syncthreads();
         if (base < (int)wave_max) {
@@ -700,13 +718,13 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
                 }
                 const uint64_t mask = __ballot(touch);
                 if constexpr (STATS) ws.v[kStBwdCulled] += __popcll(__ballot(jj < cnt && base + jj < (int)wave_max && !touch));
-                if (touch) s_list[wave][n_t + mask_prefix(mask)] = (uint16_t)(jj * kEntB);
+                if (touch) s_list[wave][n_t + mask_prefix(mask)] = (list_t)(jj * kListMul);
                 n_t += __popcll(mask);
             }
-            // a pixel takes part in entry j of this batch iff base + j < last, i.e. iff j * 88 < (last - base) * 88
+            // a pixel takes part in entry j of this batch iff base + j < last, i.e. iff j * 96 < (last - base) * 96
             const int lim0 = ((int)s0.last - base) * kEntB, lim1 = ((int)s1.last - base) * kEntB;
             for (int i = n_t - 1; i >= 0; --i) {  // back to front
-                const int jb = (int)s_list[wave][i];  // uniform across lanes -> broadcast LDS reads below
+                const int jb = (int)s_list[wave][i] * (kEntB / kListMul);  // uniform across lanes -> broadcast LDS reads below
                 const float4 a = *reinterpret_cast<const float4*>(ent + jb);
                 const float4 b = *reinterpret_cast<const float4*>(ent + jb + 16);
                 const float2 c = *reinterpret_cast<const float2*>(ent + jb + 32);
@@ -783,7 +801,17 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
             if constexpr (kPairF4 == 4) o[3] = make_float4(0.f, 0.f, 0.f, 0.f);  // the record fills its 64-byte sector
         }
     }
-    if constexpr (STATS) ws.flush(p.stats);
+    if constexpr (STATS) {
+        ws.flush(p.stats);
+        if (p.timeline && threadIdx.x == 0) {
+            p.timeline[3 * blockIdx.x + 0] = t_start;
+            p.timeline[3 * blockIdx.x + 1] = wall_clock64();
+            // HW_REG_XCC_ID (20): bits 3:0 ; HW_REG_HW_ID (4): cu_id bits 11:8, sh_id 12, se_id 15:13
+            const uint32_t xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);
+            const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
+            p.timeline[3 * blockIdx.x + 2] = ((unsigned long long)xcc << 32) | hw;
+        }
+    }
 }
 
 // CRF-table and exposure gradients (a15 backward), bitwise reproducible.
@@ -928,6 +956,7 @@ __global__ void __launch_bounds__(256) crf_reduce_kernel(const float* partials, 
 }  // namespace
 
 int launch_render_fwd(const hs_fwd_args& a, const hs_layout& L, hipStream_t s, unsigned long long* stats) {
+    // (the forward records no timeline)
     const hs_dims& d = a.dims;
     RenderFwd p;
     p.W = d.W; p.H = d.H; p.gx = (d.W + kTile - 1) / kTile;
@@ -943,7 +972,7 @@ int launch_render_fwd(const hs_fwd_args& a, const hs_layout& L, hipStream_t s, u
     p.crf.table = a.crf_table; p.crf.K = a.crf_K; p.crf.umin = a.crf_umin; p.crf.umax = a.crf_umax; p.crf.dt = 1.f;
     p.exposure = a.exposure;
     p.out_invdepth = a.out_invdepth;
-    p.stats = stats;
+    p.stats = stats; p.timeline = nullptr;
     const int grid = p.ntiles * d.n_poses;
     if (stats) {
         if (a.out_invdepth) render_fwd_kernel<true, true><<<grid, kBatch, 0, s>>>(p);
@@ -979,7 +1008,8 @@ int launch_crf_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s) {
     return HS_OK;
 }
 
-int launch_render_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s, unsigned long long* stats) {
+int launch_render_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s, unsigned long long* stats,
+                      unsigned long long* timeline) {
     const hs_dims& d = a.dims;
     RenderBwd p;
     p.W = d.W; p.H = d.H; p.gx = (d.W + kTile - 1) / kTile; p.gy = (d.H + kTile - 1) / kTile;
@@ -998,7 +1028,7 @@ int launch_render_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s, u
     // were cleared by the forward's pair emission; which records get written depends on the forward state alone,
     // so replays of this stage set the same flags again.
     p.pair_flags = (uint8_t*)a.binning + L.pair_flags;
-    p.stats = stats;
+    p.stats = stats; p.timeline = timeline;
     const int grid = p.ntiles * d.n_poses;
     if (stats) {
         if (a.dL_dout_invdepth) render_bwd_kernel<true, true><<<grid, kBatch, 0, s>>>(p);

@@ -349,7 +349,8 @@ class _RasterizeGaussians(torch.autograd.Function):
 
 
 def _launch_backward(st: "_State", saved, gcol, ghdr, stages: int, want_pose: bool = False, galpha=None,
-                     defer_sh: bool = False, ginvd=None, densify=None, gather_group=None, stats=None) -> dict:
+                     defer_sh: bool = False, ginvd=None, densify=None, gather_group=None, stats=None,
+                     timeline=None) -> dict:
     """Enqueue hs_backward.  All per-Gaussian gradients are carved out of ONE flat fp32 buffer (the
     layout casualhdrsplat_amd.distributed all-reduces in a single RCCL call): [means3D | means2D |
     opacities | sh | colors | scales | rotations | cov3D | exposure | crf_table]."""
@@ -412,7 +413,7 @@ def _launch_backward(st: "_State", saved, gcol, ghdr, stages: int, want_pose: bo
         a.densify_grad_accum, a.densify_denom = densify.grad_accum.data_ptr(), densify.denom.data_ptr()
         a.densify_max_radii = densify.max_radii.data_ptr()
     if stats is not None:  # diagnostic instantiation of the render backward only (render_stats)
-        L.check(lib.hs_render_stats(None, C.byref(a), stats.data_ptr(), _stream()), "hs_render_stats[bwd]")
+        L.check(lib.hs_render_stats(None, C.byref(a), stats.data_ptr(), _ptr(timeline), _stream()), "hs_render_stats[bwd]")
     elif P == 0:
         flat.zero_()
     elif gather_group is not None and g["view_colors"] is not None and stages == L.HS_BWD_ALL:
@@ -459,7 +460,8 @@ RENDER_STAT_NAMES = ("bwd_trips", "bwd_empty_trips", "bwd_active_pixels", "bwd_c
                      "fwd_trips", "fwd_empty_trips", "fwd_active_pixels", "fwd_culled", "fwd_staged", "fwd_batches")
 
 
-def render_stats(out_tensor: torch.Tensor, grad_color: torch.Tensor, grad_hdr: Optional[torch.Tensor] = None) -> dict:
+def render_stats(out_tensor: torch.Tensor, grad_color: torch.Tensor, grad_hdr: Optional[torch.Tensor] = None,
+                 timeline: bool = False) -> dict:
     """Profiling helper (bench.py's lane-utilisation / VALU-roofline leg): replays the render forward and backward of
     the call that produced `out_tensor` with the counting instantiation of the kernels (hs_render_stats) and returns
     the counters by name: (wave, entry) trips of the two compositing loops, how many found no active lane, the sum
@@ -473,11 +475,18 @@ def render_stats(out_tensor: torch.Tensor, grad_color: torch.Tensor, grad_hdr: O
     a.out_color = out_tensor.data_ptr()
     scratch_hdr = torch.empty_like(out_tensor) if (st.flags & L.HS_FLAG_HDR) else None
     a.out_hdr, a.out_invdepth = _ptr(scratch_hdr), None
-    L.check(L.load().hs_render_stats(C.byref(a), None, stats.data_ptr(), _stream()), "hs_render_stats[fwd]")
+    L.check(L.load().hs_render_stats(C.byref(a), None, stats.data_ptr(), None, _stream()), "hs_render_stats[fwd]")
+    d = st.dims
+    n_wg = ((d.W + L.HS_TILE - 1) // L.HS_TILE) * ((d.H + L.HS_TILE - 1) // L.HS_TILE) * d.n_poses
+    tl = torch.zeros(n_wg, 3, dtype=torch.int64, device=dev) if timeline else None
     _launch_backward(st, fn.saved_tensors, _f32c(grad_color, dev), None if grad_hdr is None else _f32c(grad_hdr, dev),
-                     L.HS_BWD_RENDER, stats=stats)
+                     L.HS_BWD_RENDER, stats=stats, timeline=tl)
     vals = stats.cpu().tolist()
-    return dict(zip(RENDER_STAT_NAMES, vals))
+    res = dict(zip(RENDER_STAT_NAMES, vals))
+    if timeline:  # [workgroup] -> (start, end) on the 100 MHz device clock, (XCC id << 32 | HW_ID); padding blocks dropped
+        tl = tl.cpu()
+        res["bwd_timeline"] = tl[tl[:, 1] > 0]
+    return res
 
 
 def sh_backward_views(means3D: torch.Tensor, camposes: torch.Tensor, view_colors: torch.Tensor, M: int,

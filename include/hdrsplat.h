@@ -231,6 +231,8 @@ int hs_sh_backward_views(int32_t P, int32_t M, int32_t sh_degree, int32_t V, con
  *   staged, batches.  bench.py derives lane utilisation and the VALU roofline from them. */
 #define HS_RENDER_STATS 24
 int hs_render_stats(const hs_fwd_args* fwd /* or NULL */, const hs_bwd_args* bwd /* or NULL */, uint64_t* stats,
+                    uint64_t* bwd_timeline /* or NULL: per workgroup of the backward launch (tiles x poses of them)
+                                              {start, end} on the 100 MHz device clock and (XCC id << 32 | HW_ID) */,
                     void* hip_stream);
 
 /* Bench/test only: stable LSD radix sort of (u64 key, u32 value) pairs on bits [0, nbits), using the
