@@ -115,6 +115,14 @@ static int check_common(const hs_dims& d, const float* means3D, const float* shs
     return HS_OK;
 }
 
+static int check_flags(int flags, const char* who) {
+    if ((flags & HS_FLAG_RADIANCE_EXP) && (flags & HS_FLAG_RADIANCE_SOFTPLUS)) {
+        set_error("%s: HS_FLAG_RADIANCE_EXP and HS_FLAG_RADIANCE_SOFTPLUS are mutually exclusive", who);
+        return HS_EINVAL;
+    }
+    return HS_OK;
+}
+
 }  // namespace hs
 
 using namespace hs;
@@ -136,6 +144,7 @@ int hs_forward(const hs_fwd_args* a, void* hip_stream) {
     hs_sizes sz; hs_layout L;
     int rc = plan(a->dims, &sz, &L);
     if (rc) return rc;
+    if ((rc = check_flags(a->flags, "hs_forward"))) return rc;
     if (a->dims.P > 0) {  // an empty cloud has no arrays to validate: it renders the background
         rc = check_common(a->dims, a->means3D, a->shs, a->colors_precomp, a->scales, a->rotations, a->cov3D_precomp,
                           a->viewmatrices, a->projmatrices, a->camposes, a->bg, "hs_forward");
@@ -198,6 +207,7 @@ int hs_backward(const hs_bwd_args* a, void* hip_stream) {
     hs_sizes sz; hs_layout L;
     int rc = plan(a->dims, &sz, &L);
     if (rc) return rc;
+    if ((rc = check_flags(a->flags, "hs_backward"))) return rc;
     rc = check_common(a->dims, a->means3D, a->shs, a->colors_precomp, a->scales, a->rotations, a->cov3D_precomp,
                       a->viewmatrices, a->projmatrices, a->camposes, a->bg, "hs_backward");
     if (rc) return rc;

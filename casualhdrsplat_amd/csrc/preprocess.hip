@@ -147,7 +147,15 @@ struct PreFwd {
     // depth-sort keys/values of the instances, the instance count word, cleared tile ranges; else null
     uint32_t* depth_keys; uint32_t* depth_vals; hs_counters* counters; uint2* ranges; int64_t n_vtiles;
     bool antialias;
+    int act;  // radiance activation: 0 relu_shift, 1 exp, 2 softplus
 };
+
+// d colour / d s of the radiance activation, from the stored colour (and the clamp bit for relu_shift)
+__device__ __forceinline__ float radiance_dact(int act, float col, bool was_clamped) {
+    if (act == 1) return col;
+    if (act == 2) return 1.0f - expf(-col);
+    return was_clamped ? 0.f : 1.f;
+}
 
 // a4.  instance = pose * P + g.
 template <int DEG>
@@ -236,9 +244,15 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreFwd p) {
                     }
 #pragma unroll
                     for (int ch = 0; ch < 3; ++ch) {
-                        float v = acc[ch] + 0.5f;
-                        if (v < 0.f) clampbits |= (uint8_t)(1u << ch);
-                        col[ch] = fmaxf(v, 0.f);
+                        if (p.act == 1) {
+                            col[ch] = expf(acc[ch]);
+                        } else if (p.act == 2) {
+                            col[ch] = acc[ch] > 20.f ? acc[ch] : log1pf(expf(acc[ch]));
+                        } else {
+                            float v = acc[ch] + 0.5f;
+                            if (v < 0.f) clampbits |= (uint8_t)(1u << ch);
+                            col[ch] = fmaxf(v, 0.f);
+                        }
                     }
                 }
                 my_radius = rad;
@@ -297,7 +311,8 @@ __global__ void mark_visible_kernel(int P, const float* means, const float* V, u
 __global__ void __launch_bounds__(256) pair_segsum_kernel(int64_t I, const uint32_t* inst_sorted, const uint32_t* offs_sorted,
                                                           const float4* pair_grads, const uint8_t* pair_flags,
                                                           float4* inst_grads, const hs_counters* counters,
-                                                          const int* radii_inst, const uint8_t* clamped, float* view_colors) {
+                                                          const int* radii_inst, const uint8_t* clamped, float* view_colors,
+                                                          const float4* rec, int act) {
     // four lanes (one DPP quad) per instance: lane q adds records beg+q, beg+q+4, ...; the four partial sums are
     // combined in a fixed butterfly, so the result does not depend on timing.  Quads shorten the longest run in a
     // wave fourfold (run lengths are heavy-tailed) and make neighbouring lanes read neighbouring records.
@@ -349,9 +364,14 @@ __global__ void __launch_bounds__(256) pair_segsum_kernel(int64_t I, const uint3
             const int64_t inst = inst_sorted[i];
             const uint8_t cl = clamped[inst];
             const bool on = radii_inst[inst] > 0;
-            view_colors[3 * inst + 0] = (on && !(cl & 1)) ? r[6] : 0.f;
-            view_colors[3 * inst + 1] = (on && !(cl & 2)) ? r[7] : 0.f;
-            view_colors[3 * inst + 2] = (on && !(cl & 4)) ? r[8] : 0.f;
+            float col[3] = {0.f, 0.f, 0.f};
+            if (act != 0 && on) {  // exp / softplus: the factor comes from the stored colour
+                const float4 rb = rec[kRecF4 * inst + 1];
+                col[0] = rb.z; col[1] = rb.w; col[2] = reinterpret_cast<const float*>(rec + kRecF4 * inst + 2)[0];
+            }
+            view_colors[3 * inst + 0] = on ? radiance_dact(act, col[0], cl & 1) * r[6] : 0.f;
+            view_colors[3 * inst + 1] = on ? radiance_dact(act, col[1], cl & 2) * r[7] : 0.f;
+            view_colors[3 * inst + 2] = on ? radiance_dact(act, col[2], cl & 4) * r[8] : 0.f;
         }
     }
 }
@@ -362,6 +382,7 @@ struct PreBwd {
     const float* view; const float* proj; const float* campos;
     const float* means; const float* shs; const float* scales; const float* rots; const float* opac;
     bool has_colors_precomp, has_cov_pre, antialias;
+    int act;  // radiance activation: 0 relu_shift, 1 exp, 2 softplus
     const float4* rec; const int* radii_inst; const uint32_t* tiles; const uint32_t* offsets; const float* cov3D;
     const uint8_t* clamped;
     const float4* inst_grads;
@@ -570,8 +591,15 @@ __global__ void __launch_bounds__(kPreBwdBlock) preprocess_bwd_kernel(PreBwd p) 
             const float ux = dx / len, uy = dy / len, uz = dz / len;
             const uint8_t cl = p.clamped[idx];
             float gc[3];
+            {
+                float col[3] = {0.f, 0.f, 0.f};
+                if (p.act != 0) {
+                    const float4 rb = p.rec[kRecF4 * idx + 1];
+                    col[0] = rb.z; col[1] = rb.w; col[2] = reinterpret_cast<const float*>(p.rec + kRecF4 * idx + 2)[0];
+                }
 #pragma unroll
-            for (int ch = 0; ch < 3; ++ch) gc[ch] = ((cl >> ch) & 1) ? 0.f : r[6 + ch];
+                for (int ch = 0; ch < 3; ++ch) gc[ch] = radiance_dact(p.act, col[ch], (cl >> ch) & 1) * r[6 + ch];
+            }
             if constexpr (DEG >= 1) {
                 float gb[NC][3];
                 sh_basis_grad<DEG>(ux, uy, uz, gb);
@@ -681,7 +709,13 @@ __global__ void __launch_bounds__(kPreBwdBlock) preprocess_bwd_kernel(PreBwd p) 
                     const float4 q1 = p.inst_grads[kInstF4 * idx + 1];
                     const float q2 = reinterpret_cast<const float*>(p.inst_grads + kInstF4 * idx + 2)[0];
                     const uint8_t cl = p.clamped[idx];
-                    const float gc[3] = {(cl & 1) ? 0.f : q1.z, (cl & 2) ? 0.f : q1.w, (cl & 4) ? 0.f : q2};
+                    float col[3] = {0.f, 0.f, 0.f};
+                    if (p.act != 0) {
+                        const float4 rb = p.rec[kRecF4 * idx + 1];
+                        col[0] = rb.z; col[1] = rb.w; col[2] = reinterpret_cast<const float*>(p.rec + kRecF4 * idx + 2)[0];
+                    }
+                    const float gc[3] = {radiance_dact(p.act, col[0], cl & 1) * q1.z, radiance_dact(p.act, col[1], cl & 2) * q1.w,
+                                         radiance_dact(p.act, col[2], cl & 4) * q2};
                     const float* cp = p.campos + 3 * pose;
                     const float dx = x - cp[0], dy = y - cp[1], dz = z - cp[2];
                     const float len = sqrtf((dx * dx + dy * dy) + dz * dz);
@@ -790,6 +824,7 @@ int launch_preprocess_fwd(const hs_fwd_args& a, const hs_layout& L, hipStream_t 
     p.clamped = (uint8_t*)(geom + L.clamped); p.radii_out = a.radii;
     p.binfo = (uint2*)(geom + L.binfo);
     p.antialias = (a.flags & HS_FLAG_ANTIALIAS) != 0;
+    p.act = (a.flags & HS_FLAG_RADIANCE_EXP) ? 1 : (a.flags & HS_FLAG_RADIANCE_SOFTPLUS) ? 2 : 0;
     p.depth_keys = nullptr; p.depth_vals = nullptr; p.counters = nullptr; p.ranges = nullptr; p.n_vtiles = 0;
     if ((a.stages & HS_STAGE_BIN) && a.binning) {
         char* bin = (char*)a.binning;
@@ -820,6 +855,7 @@ int launch_preprocess_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t 
     p.view = a.viewmatrices; p.proj = a.projmatrices; p.campos = a.camposes;
     p.means = a.means3D; p.shs = a.shs; p.scales = a.scales; p.rots = a.rotations; p.opac = a.opacities;
     p.antialias = (a.flags & HS_FLAG_ANTIALIAS) != 0;
+    p.act = (a.flags & HS_FLAG_RADIANCE_EXP) ? 1 : (a.flags & HS_FLAG_RADIANCE_SOFTPLUS) ? 2 : 0;
     p.has_colors_precomp = a.colors_precomp != nullptr; p.has_cov_pre = a.cov3D_precomp != nullptr;
     p.rec = (const float4*)(geom + L.rec); p.radii_inst = (const int*)(geom + L.radii);
     p.tiles = (const uint32_t*)(geom + L.tiles_touched); p.offsets = (const uint32_t*)(geom + L.offsets);
@@ -833,7 +869,7 @@ int launch_preprocess_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t 
                                                            (const uint8_t*)bin + L.pair_flags,
                                                            (float4*)((char*)a.bwd + L.inst_grads),
                                                            (const hs_counters*)(geom + L.counters), p.radii_inst, p.clamped,
-                                                           a.colors_precomp ? nullptr : a.dL_dview_colors);
+                                                           a.colors_precomp ? nullptr : a.dL_dview_colors, p.rec, p.act);
         HS_LAUNCH_CHECK();
     }
     if (!project) return HS_OK;

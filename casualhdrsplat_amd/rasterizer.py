@@ -56,6 +56,9 @@ class GaussianRasterizationSettings(NamedTuple):
     projmatrices: Optional[torch.Tensor] = None   # [N,4,4]
     camposes: Optional[torch.Tensor] = None       # [N,3]
     blur_domain: str = "ldr"                      # "ldr" (figure) or "hdr"
+    # how the SH sum s becomes the Gaussian's linear radiance: "relu_shift" = max(s + 0.5, 0) (the published rule),
+    # "exp" = e^s, "softplus" = ln(1 + e^s) (an HDR scene wants an unbounded, positive radiance)
+    radiance_activation: str = "relu_shift"
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -194,6 +197,13 @@ def _run_forward(settings: GaussianRasterizationSettings, means3D, opacities, sh
         flags |= L.HS_FLAG_DEBUG
     if settings.antialiasing:
         flags |= L.HS_FLAG_ANTIALIAS
+    act = getattr(settings, "radiance_activation", "relu_shift")
+    if act == "exp":
+        flags |= L.HS_FLAG_RADIANCE_EXP
+    elif act == "softplus":
+        flags |= L.HS_FLAG_RADIANCE_SOFTPLUS
+    elif act != "relu_shift":
+        raise ValueError("radiance_activation must be 'relu_shift', 'exp' or 'softplus'")
     exposure = None if exposure is None else _f32c(exposure, dev).reshape(1)
     crf_table = _f32c(crf_table, dev)
     crf_K = int(crf_table.shape[1]) if hdr else 0

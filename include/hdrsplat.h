@@ -67,6 +67,12 @@ extern "C" {
 #define HS_FLAG_DEBUG 4         /* wait for every stage and name the failing one (the only case of a sync) */
 #define HS_FLAG_ANTIALIAS 8    /* newer published rasterizer's `antialiasing`: opacity *= sqrt(max(0.000025,
                                   det(cov2D) / det(cov2D + 0.3 I))), with its gradient */
+/* radiance activation (SURVEY.md 7.3 / 8a a1 `radiance_activation`; the reference reconstructs an HDR scene,
+ * /root/reference/Readme.md:54): how the SH sum s of a Gaussian becomes its linear-radiance colour.  Neither bit:
+ * relu_shift = max(s + 0.5, 0), the published rule (unbounded above, clamped below with the clamp mask zeroing the
+ * gradient).  Precomputed colours pass through unchanged. */
+#define HS_FLAG_RADIANCE_EXP 16       /* colour = e^s            (always positive; d colour / d s = colour) */
+#define HS_FLAG_RADIANCE_SOFTPLUS 32  /* colour = ln(1 + e^s)    (d colour / d s = sigmoid(s) = 1 - e^-colour) */
 
 typedef struct hs_dims {
     int32_t P;         /* Gaussians */

@@ -35,8 +35,11 @@ class _Camera(C.Structure):
         ("P", C.c_int), ("sh_degree", C.c_int), ("M", C.c_int), ("W", C.c_int), ("H", C.c_int),
         ("tanfovx", C.c_float), ("tanfovy", C.c_float), ("scale_modifier", C.c_float),
         ("bg", C.c_float * 3), ("viewmatrix", C.c_float * 16), ("projmatrix", C.c_float * 16),
-        ("campos", C.c_float * 3), ("antialias", C.c_int),
+        ("campos", C.c_float * 3), ("antialias", C.c_int), ("radiance_activation", C.c_int),
     ]
+
+
+RADIANCE_ACTIVATIONS = {"relu_shift": 0, "exp": 1, "softplus": 2}
 
 
 _lib = None
@@ -47,6 +50,7 @@ def lib():
     if _lib is None:
         _lib = C.CDLL(build())
         _lib.hso_scan.restype = C.c_int64
+        _lib.hso_threshold_risk.restype = C.c_int64
     return _lib
 
 
@@ -71,6 +75,7 @@ class Camera:
     scale_modifier: float = 1.0
     sh_degree: int = 0
     antialias: bool = False
+    radiance_activation: str = "relu_shift"
 
     def cstruct(self, P: int, M: int) -> _Camera:
         c = _Camera()
@@ -81,6 +86,7 @@ class Camera:
         c.projmatrix[:] = [float(v) for v in np.asarray(self.projmatrix, np.float32).reshape(16)]
         c.campos[:] = [float(v) for v in np.asarray(self.campos, np.float32).reshape(3)]
         c.antialias = int(bool(self.antialias))
+        c.radiance_activation = RADIANCE_ACTIVATIONS[self.radiance_activation]
         return c
 
     @property
@@ -140,6 +146,23 @@ def forward(cam: Camera, means3D, opacities, shs=None, colors_precomp=None, scal
     return o
 
 
+def threshold_risk(cam: Camera, fwd: dict, guard_alpha: float = 2e-5, guard_T: float = 1e-4) -> dict:
+    """Guard band of the frame `fwd` (forward()'s dict) around the three piecewise-constant decisions of the
+    compositing loop (hso_threshold_risk): pixels / Gaussians on which another fp32 implementation may legitimately
+    decide differently, and the smallest margins seen.  guard_alpha is relative to 1/255, guard_T relative to 1e-4."""
+    L = lib()
+    P = fwd["radii"].shape[0]
+    c = cam.cstruct(P, 0)
+    pix = np.zeros((cam.H, cam.W), np.uint8)
+    gs = np.zeros(P, np.uint8)
+    mm = np.zeros(3, np.float64)
+    n = int(L.hso_threshold_risk(C.byref(c), _p(fwd["ranges"]), _p(fwd["point_list"]), _p(fwd["xy"]),
+                                 _p(fwd["conic_opacity"]), C.c_float(guard_alpha), C.c_float(guard_T), _p(pix), _p(gs),
+                                 _p(mm)))
+    return dict(n_risky_pixels=n, pix_risk=pix.astype(bool), gauss_risk=gs.astype(bool),
+                min_margin_alpha=float(mm[0]), min_margin_T=float(mm[1]), min_abs_power=float(mm[2]))
+
+
 def backward(cam: Camera, fwd: dict, dL_dcolor_img, means3D, shs=None, colors_precomp=None,
              scales=None, rotations=None, cov3D_precomp=None, dL_dinvdepth_img=None) -> dict:
     """Runs a10..a12 given forward()'s intermediates and dL/d(out_color) [3,H,W] (+ optional dL/d(invdepth) [H,W])."""
@@ -173,7 +196,7 @@ def backward(cam: Camera, fwd: dict, dL_dcolor_img, means3D, shs=None, colors_pr
     o["dL_dcov3D"] = np.zeros((P, 6), np.float32) if not has_sr else None
     rc = L.hso_preprocess_bwd(C.byref(c), _p(means3D), _p(shs), _p(colors_precomp), _p(scales), _p(rotations),
                               _p(cov3D_precomp), _p(fwd["radii"]), _p(fwd["cov3D"]), _p(fwd["clamped"]),
-                              _p(o["dL_dmean2D"]), _p(o["dL_dconic"]), _p(o["dL_dcolor"]),
+                              _p(fwd["rgb"]), _p(o["dL_dmean2D"]), _p(o["dL_dconic"]), _p(o["dL_dcolor"]),
                               _p(o["dL_dmeans3D"]), _p(o["dL_dshs"]), _p(o["dL_dcolors_precomp"]),
                               _p(o["dL_dscales"]), _p(o["dL_drots"]), _p(o["dL_dcov3D"]),
                               _p(_f32(fwd["opacities_in"])), _p(o["dL_dopacity"]), _p(o["dL_dinvdepth"]))

@@ -51,7 +51,17 @@ typedef struct {
     float projmatrix[16]; /* full view*proj, same convention */
     float campos[3];
     int antialias;        /* newer published rasterizer's flag: opacity *= sqrt(max(0.000025, det(cov2D)/det(cov2D + 0.3 I))) */
+    int radiance_activation; /* how the SH sum s becomes the (linear, HDR) colour -- SURVEY.md 7.3 / 8a a1:
+                                0 relu_shift: max(s + 0.5, 0) (the published rule, unbounded above),
+                                1 exp: e^s,  2 softplus: ln(1 + e^s).  Precomputed colours pass through unchanged. */
 } hso_camera;
+
+/* d colour / d s of the radiance activation, from the stored colour (and the clamp bit for relu_shift) */
+static inline float radiance_dact(int act, float col, int was_clamped) {
+    if (act == 1) return col;                       /* d e^s = e^s */
+    if (act == 2) return 1.0f - expf(-col);         /* sigmoid(s) = 1 - e^{-softplus(s)} */
+    return was_clamped ? 0.f : 1.f;
+}
 
 static const float SH_C0 = 0.28209479177387814f;
 static const float SH_C1 = 0.4886025119029199f;
@@ -250,9 +260,15 @@ int hso_preprocess_fwd(const hso_camera* c, const float* means3D, const float* o
             for (int ch = 0; ch < 3; ++ch) {
                 float acc = b[0] * sh[ch];
                 for (int k = 1; k < ncoef; ++k) acc = acc + b[k] * sh[3 * k + ch];
-                acc = acc + 0.5f;
-                clamped[3 * i + ch] = acc < 0.f;
-                rgb[3 * i + ch] = fmaxf_(acc, 0.f);
+                if (c->radiance_activation == 1) {
+                    rgb[3 * i + ch] = expf(acc);
+                } else if (c->radiance_activation == 2) {
+                    rgb[3 * i + ch] = acc > 20.f ? acc : log1pf(expf(acc));
+                } else {
+                    acc = acc + 0.5f;
+                    clamped[3 * i + ch] = acc < 0.f;
+                    rgb[3 * i + ch] = fmaxf_(acc, 0.f);
+                }
             }
         }
         depths[i] = pvz;
@@ -399,6 +415,79 @@ int hso_render_fwd(const hso_camera* c, const uint32_t* ranges, const uint32_t* 
 }
 
 /* ------------------------------------------------------------------------------------------
+ * Threshold guard band of a rendered frame (test infrastructure for SURVEY.md 7.4-3).  The forward takes three
+ * piecewise-constant decisions per (pixel, entry): `power > 0`, `alpha < 1/255` and `T (1 - alpha) < 1e-4`.  Any other
+ * fp32 implementation (a GPU's exp2-based falloff, a different multiplication order of T) may land on the other side
+ * of a threshold when the value sits within rounding distance of it, which changes a whole contribution and not the
+ * last bit.  This walks the frame exactly like hso_render_fwd and reports
+ *   pix_risk[H*W]   1 where some decision of that pixel had |alpha * 255 - 1| < guard_alpha, |test_T * 1e4 - 1| < guard_T
+ *                   or 0 < |power| < 1e-6,
+ *   gauss_risk[P]   1 for every Gaussian visited by such a pixel (a flipped contributor changes T for all of them),
+ *   min_margin[3]   the smallest |alpha * 255 - 1|, |test_T * 1e4 - 1| and non-zero |power| seen.
+ * Fixtures are reject-sampled until no pixel is at risk; comparators of larger scenes require every difference in the
+ * decisions to sit on a pixel at risk and apply the strict gradient tolerance to the Gaussians that are not.
+ * ------------------------------------------------------------------------------------------ */
+int64_t hso_threshold_risk(const hso_camera* c, const uint32_t* ranges, const uint32_t* point_list, const float* xy,
+                           const float* conic_opacity, float guard_alpha, float guard_T, uint8_t* pix_risk,
+                           uint8_t* gauss_risk, double* min_margin) {
+    const int W = c->W, H = c->H;
+    const int gx = (W + HSO_TILE - 1) / HSO_TILE;
+    int64_t n_risky = 0;
+    min_margin[0] = min_margin[1] = min_margin[2] = 1e30;
+    if (gauss_risk) memset(gauss_risk, 0, (size_t)c->P);
+    for (int py = 0; py < H; ++py)
+        for (int px = 0; px < W; ++px) {
+            int tile = (py / HSO_TILE) * gx + (px / HSO_TILE);
+            uint32_t beg = ranges[2 * tile], end = ranges[2 * tile + 1];
+            float pxf = (float)px, pyf = (float)py;
+            float T = 1.0f;
+            int risky = 0, risky_T = 0;
+            uint32_t k_end = end;
+            for (uint32_t k = beg; k < end; ++k) {
+                uint32_t id = point_list[k];
+                float dx = xy[2 * id] - pxf, dy = xy[2 * id + 1] - pyf;
+                const float* co = conic_opacity + 4 * id;
+                float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                double ap = fabs((double)power);
+                if (ap > 0.0 && ap < min_margin[2]) min_margin[2] = ap;
+                if (ap > 0.0 && ap < 1e-6) risky = 1;
+                if (power > 0.0f) continue;
+                float alpha = fminf_(0.99f, co[3] * expf(power));
+                double ma = fabs((double)alpha * 255.0 - 1.0);
+                if (ma < min_margin[0]) min_margin[0] = ma;
+                if (ma < guard_alpha) risky = 1;
+                if (alpha < 1.0f / 255.0f) continue;
+                float test_T = T * (1.f - alpha);
+                double mt = fabs((double)test_T * 1e4 - 1.0);
+                if (mt < min_margin[1]) min_margin[1] = mt;
+                if (mt < guard_T) risky = risky_T = 1;
+                if (test_T < 0.0001f) { k_end = k + 1; break; }
+                T = test_T;
+            }
+            pix_risk[(size_t)py * W + px] = (uint8_t)risky;
+            if (risky) {
+                ++n_risky;
+                /* the Gaussians whose gradient a flipped decision of this pixel reaches: every entry that contributes
+                 * (or is within the guard band of contributing) up to the entry that ends the pixel -- up to the end
+                 * of the list when it is the terminating decision that may flip */
+                if (gauss_risk) {
+                    const uint32_t stop = risky_T ? end : k_end;
+                    for (uint32_t k = beg; k < stop; ++k) {
+                        uint32_t id = point_list[k];
+                        float dx = xy[2 * id] - pxf, dy = xy[2 * id + 1] - pyf;
+                        const float* co = conic_opacity + 4 * id;
+                        float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                        if (power > 1e-6f) continue;
+                        float alpha = fminf_(0.99f, co[3] * expf(power));
+                        if ((double)alpha * 255.0 >= 1.0 - guard_alpha) gauss_risk[id] = 1;
+                    }
+                }
+            }
+        }
+    return n_risky;
+}
+
+/* ------------------------------------------------------------------------------------------
  * a10  render backward (per pixel, back to front).  Outputs per Gaussian:
  *   dL_dmean2D [P,2]  in NDC-scaled units (pixel gradient * 0.5*W, 0.5*H),
  *   dL_dconic  [P,3]  true partials w.r.t. (A,B,C) of power = -0.5(A dx^2 + C dy^2) - B dx dy,
@@ -498,7 +587,7 @@ int hso_render_bwd(const hso_camera* c, const uint32_t* ranges, const uint32_t* 
 int hso_preprocess_bwd(const hso_camera* c, const float* means3D, const float* shs,
                        const float* colors_precomp, const float* scales, const float* rotations,
                        const float* cov3D_precomp, const int* radii, const float* cov3D,
-                       const uint8_t* clamped, const float* dL_dmean2D, const float* dL_dconic,
+                       const uint8_t* clamped, const float* rgb, const float* dL_dmean2D, const float* dL_dconic,
                        const float* dL_dcolor,
                        float* dL_dmeans3D, float* dL_dshs, float* dL_dcolors_precomp,
                        float* dL_dscales, float* dL_drots, float* dL_dcov3D,
@@ -607,7 +696,7 @@ int hso_preprocess_bwd(const hso_camera* c, const float* means3D, const float* s
             const float* sh = shs + (size_t)i * c->M * 3;
             float gdir[3] = {0.f, 0.f, 0.f};
             for (int ch = 0; ch < 3; ++ch) {
-                float g = clamped[3 * i + ch] ? 0.f : dL_dcolor[3 * i + ch];
+                float g = radiance_dact(c->radiance_activation, rgb[3 * i + ch], clamped[3 * i + ch]) * dL_dcolor[3 * i + ch];
                 for (int k = 0; k < ncoef; ++k) {
                     if (dL_dshs) dL_dshs[((size_t)i * c->M + k) * 3 + ch] = bs[k] * g;
                     for (int d = 0; d < 3; ++d) gdir[d] += gb[k][d] * sh[3 * k + ch] * g;

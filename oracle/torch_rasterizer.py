@@ -85,7 +85,8 @@ def quat_to_R(q):
 
 
 def preprocess(view: View, means3D, opacities, sh_degree, shs=None, colors_precomp=None, scales=None,
-               rotations=None, cov3D_precomp=None, scale_modifier=1.0, means2D=None, antialiasing=False):
+               rotations=None, cov3D_precomp=None, scale_modifier=1.0, means2D=None, antialiasing=False,
+               radiance_activation="relu_shift"):
     """a4.  Returns a dict; differentiable w.r.t. every float input.  Culled Gaussians have radii == 0.
     antialiasing (newer published rasterizer): opacity is scaled by sqrt(max(0.000025, det(cov2D) / det(cov2D +
     0.3 I))), compensating the energy the 0.3-pixel dilation adds to small splats."""
@@ -149,9 +150,17 @@ def preprocess(view: View, means3D, opacities, sh_degree, shs=None, colors_preco
         d = means3D - view.campos.to(dt)[None, :]
         d = d / d.norm(dim=1, keepdim=True)
         B = sh_basis(sh_degree, d)
-        raw = (B[:, :, None] * shs[:, :B.shape[1], :]).sum(dim=1) + 0.5
-        clamped = raw < 0
-        rgb = torch.clamp_min(raw, 0.0)
+        raw = (B[:, :, None] * shs[:, :B.shape[1], :]).sum(dim=1)
+        if radiance_activation == "exp":           # linear radiance through a positive activation
+            rgb, clamped = torch.exp(raw), torch.zeros_like(raw, dtype=torch.bool)
+        elif radiance_activation == "softplus":
+            rgb, clamped = torch.nn.functional.softplus(raw), torch.zeros_like(raw, dtype=torch.bool)
+        elif radiance_activation == "relu_shift":  # the published rule: + 0.5, clamped below only
+            raw = raw + 0.5
+            clamped = raw < 0
+            rgb = torch.clamp_min(raw, 0.0)
+        else:
+            raise ValueError(radiance_activation)
     radii = torch.where(ok, radius, torch.zeros_like(radius)).to(torch.int32)
     opac = opacities.reshape(-1)
     if antialiasing:
@@ -261,9 +270,9 @@ def tonemap(hdr, exposure, table, u_range, eps=1e-8):
 
 def rasterize(view: View, means3D, opacities, sh_degree, bg, shs=None, colors_precomp=None, scales=None,
               rotations=None, cov3D_precomp=None, scale_modifier=1.0, means2D=None, tiles=None, return_state=False,
-              antialiasing=False):
+              antialiasing=False, radiance_activation="relu_shift"):
     pre = preprocess(view, means3D, opacities, sh_degree, shs, colors_precomp, scales, rotations, cov3D_precomp,
-                     scale_modifier, means2D, antialiasing)
+                     scale_modifier, means2D, antialiasing, radiance_activation)
     point_list, ranges, keys_sorted = bin_tiles(view, pre)
     if return_state:
         color, final_T, n_contrib, invdepth = render(view, pre, point_list, ranges, bg, tiles, want_invdepth=True)

@@ -21,16 +21,41 @@ import helpers as Hh  # noqa: E402
 from casualhdrsplat_amd import synthetic as S  # noqa: E402
 from oracle import c_oracle as O  # noqa: E402
 
+# Every fixture is GUARD-BANDED: the seed is the first one >= `seed` for which no (pixel, entry)
+# decision of any pose lies within the guard band of a threshold (alpha = 1/255 within 2e-5 relative, T = 1e-4 within
+# 1e-4 relative, power = 0 within 1e-6) -- oracle.threshold_risk -- so any correct fp32 implementation takes exactly the
+# decisions stored here and the GPU tests can demand zero flips and the strict gradient bar on every Gaussian.
 CASES = [
-    # name, P, W, H, deg, seed, hdr, n_poses, blur_domain
-    ("ldr_deg0_s0", 600, 96, 96, 0, 0, False, 1, "ldr"),
-    ("ldr_deg3_s1", 600, 96, 80, 3, 1, False, 1, "ldr"),
-    ("hdr_deg3_s2", 600, 96, 96, 3, 2, True, 1, "ldr"),
-    ("hdr_deg1_s3_n4_ldrblur", 400, 80, 64, 1, 3, True, 4, "ldr"),
-    ("hdr_deg1_s3_n4_hdrblur", 400, 80, 64, 1, 3, True, 4, "hdr"),
+    # name, P, W, H, deg, first seed to try, hdr, n_poses, blur_domain, radiance_activation
+    ("ldr_deg0", 600, 96, 96, 0, 0, False, 1, "ldr", "relu_shift"),
+    ("ldr_deg3", 600, 96, 80, 3, 1, False, 1, "ldr", "relu_shift"),
+    ("hdr_deg3", 600, 96, 96, 3, 2, True, 1, "ldr", "relu_shift"),
+    ("hdr_deg1_n4_ldrblur", 400, 80, 64, 1, 3, True, 4, "ldr", "relu_shift"),
+    ("hdr_deg1_n4_hdrblur", 400, 80, 64, 1, 3, True, 4, "hdr", "relu_shift"),
+    # linear radiance through a positive activation of the SH sum
+    ("hdr_deg2_radiance_exp", 500, 88, 80, 2, 6, True, 1, "ldr", "exp"),
+    ("ldr_deg1_radiance_softplus", 500, 80, 88, 1, 7, False, 1, "ldr", "softplus"),
 ]
 # antialiasing opacity compensation + expected inverse-depth output with its own upstream gradient
-EXTRA_CASES = [("ldr_deg2_s5_antialias_invdepth", 500, 88, 72, 2, 5)]
+EXTRA_CASES = [("ldr_deg2_antialias_invdepth", 500, 88, 72, 2, 5)]
+
+
+def guarded(P, W, H, deg, seed, hdr, n_poses, act="relu_shift", antialias=False):
+    for s_ in range(seed, seed + 5000):
+        sc = S.make_scene(P, W, H, deg, seed=s_, hdr=hdr)
+        cams = S.blur_poses(W, H, n_poses, step=0.02) if n_poses > 1 else [sc.camera]
+        clean = True
+        for cam in cams:
+            ocam = Hh.oracle_camera(O, sc, cam, act)
+            ocam.antialias = antialias
+            f = O.forward(ocam, sc.means3D.numpy(), sc.opacities.numpy(), shs=sc.shs.numpy(), scales=sc.scales.numpy(),
+                          rotations=sc.rotations.numpy())
+            if O.threshold_risk(ocam, f, 2e-5, 1e-4)["n_risky_pixels"]:
+                clean = False
+                break
+        if clean:
+            return sc, cams, s_
+    raise RuntimeError("no guard-banded seed")
 
 
 def scene_inputs(sc, cams):
@@ -46,20 +71,21 @@ def scene_inputs(sc, cams):
     return d
 
 
-def make(name, P, W, H, deg, seed, hdr, n_poses, dom):
-    sc = S.make_scene(P, W, H, deg, seed=seed, hdr=hdr)
-    cams = S.blur_poses(W, H, n_poses, step=0.02) if n_poses > 1 else [sc.camera]
+def make(name, P, W, H, deg, seed, hdr, n_poses, dom, act):
+    sc, cams, seed = guarded(P, W, H, deg, seed, hdr, n_poses, act)
     out = scene_inputs(sc, cams)
     out["meta"] = np.array([P, W, H, deg, seed, int(hdr), n_poses, int(dom == "hdr")], np.int64)
+    out["radiance_activation"] = np.array(act)
+    out["guard_banded"] = np.array(1, np.int64)
     if not hdr:
-        f, b = Hh.run_oracle(O, sc)
+        f, b = Hh.run_oracle(O, sc, radiance_activation=act)
         for k in ("depths", "xy", "conic_opacity", "rgb", "radii", "tiles_touched", "offsets", "keys_sorted",
                   "point_list", "ranges", "color", "final_T", "n_contrib"):
             out["o_" + k] = f[k]
         for _, k in Hh.GRAD_KEYS:
             out["o_" + k] = b[k]
     else:
-        r = Hh.run_oracle_hdr(O, sc, cams, dom)
+        r = Hh.run_oracle_hdr(O, sc, cams, dom, radiance_activation=act)
         out["o_color"], out["o_hdr"] = r["ldr"], r["hdr"]
         out["o_point_list"] = np.concatenate([f["point_list"] + k * P for k, f in enumerate(r["fwd"])])
         base, rr = 0, []
@@ -75,15 +101,16 @@ def make(name, P, W, H, deg, seed, hdr, n_poses, dom):
             out["o_" + k] = r[k]
         out["o_dL_dcrf_table"], out["o_dL_dexposure"] = r["dL_dcrf_table"], np.array(r["dL_dexposure"], np.float64)
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
-    print(name, {k: v.shape for k, v in out.items() if k.startswith("o_")})
+    print(name, "seed", seed, {k: v.shape for k, v in out.items() if k.startswith("o_")})
 
 
 def make_extra(name, P, W, H, deg, seed):
     import torch
-    sc = S.make_scene(P, W, H, deg, seed=seed)
+    sc, _, seed = guarded(P, W, H, deg, seed, False, 1, antialias=True)
     out = scene_inputs(sc, [sc.camera])
     out["meta"] = np.array([P, W, H, deg, seed, 0, 1, 0], np.int64)
     out["antialias"] = np.array(1, np.int64)
+    out["guard_banded"] = np.array(1, np.int64)
     gD = (torch.randn(H, W, generator=torch.Generator().manual_seed(seed + 100)) * 4).numpy()
     out["dL_dinvdepth"] = gD
     ocam = Hh.oracle_camera(O, sc)
@@ -97,11 +124,14 @@ def make_extra(name, P, W, H, deg, seed):
     for _, k in Hh.GRAD_KEYS:
         out["o_" + k] = b[k]
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
-    print(name, {k: v.shape for k, v in out.items() if k.startswith("o_")})
+    print(name, "seed", seed, {k: v.shape for k, v in out.items() if k.startswith("o_")})
 
 
 if __name__ == "__main__":
+    import glob
     O.build()
+    for old in glob.glob(os.path.join(HERE, "*.npz")):
+        os.remove(old)
     for case in EXTRA_CASES:
         make_extra(*case)
     for c in CASES:

@@ -10,7 +10,8 @@ import torch
 from casualhdrsplat_amd import synthetic as S
 
 
-def settings_from_scene(sc: S.Scene, device, cameras=None, hdr=False, blur_domain="ldr", requires_grad=False):
+def settings_from_scene(sc: S.Scene, device, cameras=None, hdr=False, blur_domain="ldr", requires_grad=False,
+                        radiance_activation="relu_shift"):
     from casualhdrsplat_amd import GaussianRasterizationSettings
     cam = sc.camera
     kw = {}
@@ -26,15 +27,17 @@ def settings_from_scene(sc: S.Scene, device, cameras=None, hdr=False, blur_domai
     rs = GaussianRasterizationSettings(
         image_height=cam.H, image_width=cam.W, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=sc.bg.to(device),
         scale_modifier=1.0, viewmatrix=cam.viewmatrix.to(device), projmatrix=cam.projmatrix.to(device),
-        sh_degree=sc.sh_degree, campos=cam.campos.to(device), prefiltered=False, debug=False, **kw)
+        sh_degree=sc.sh_degree, campos=cam.campos.to(device), prefiltered=False, debug=False,
+        radiance_activation=radiance_activation, **kw)
     return rs, exposure, crf
 
 
 def run_hip(sc: S.Scene, device="cuda", cameras=None, hdr=False, blur_domain="ldr", backward=True, capacity=None,
-            use_cov_precomp=None, use_colors_precomp=None, grad_hdr=None):
+            use_cov_precomp=None, use_colors_precomp=None, grad_hdr=None, radiance_activation="relu_shift"):
     """Forward (+ backward with sc.dL_dimage) through GaussianRasterizer on the GPU."""
     from casualhdrsplat_amd import GaussianRasterizer, inspect_state
-    rs, exposure, crf = settings_from_scene(sc, device, cameras, hdr, blur_domain, requires_grad=backward)
+    rs, exposure, crf = settings_from_scene(sc, device, cameras, hdr, blur_domain, requires_grad=backward,
+                                            radiance_activation=radiance_activation)
     leaf = {}
 
     def mk(name, t):
@@ -75,15 +78,16 @@ def run_hip(sc: S.Scene, device="cuda", cameras=None, hdr=False, blur_domain="ld
     return res
 
 
-def oracle_camera(O, sc: S.Scene, cam=None):
+def oracle_camera(O, sc: S.Scene, cam=None, radiance_activation="relu_shift"):
     cam = cam or sc.camera
     return O.Camera(cam.W, cam.H, cam.tanfovx, cam.tanfovy, cam.viewmatrix.numpy(), cam.projmatrix.numpy(),
-                    cam.campos.numpy(), sc.bg.numpy(), 1.0, sc.sh_degree)
+                    cam.campos.numpy(), sc.bg.numpy(), 1.0, sc.sh_degree, radiance_activation=radiance_activation)
 
 
-def run_oracle(O, sc: S.Scene, cam=None, dL=None, backward=True, use_cov_precomp=None, use_colors_precomp=None):
+def run_oracle(O, sc: S.Scene, cam=None, dL=None, backward=True, use_cov_precomp=None, use_colors_precomp=None,
+               radiance_activation="relu_shift"):
     """Single-pose LDR/linear render through the C oracle (a4..a12)."""
-    ocam = oracle_camera(O, sc, cam)
+    ocam = oracle_camera(O, sc, cam, radiance_activation)
     kw = {}
     if use_colors_precomp is not None:
         kw["colors_precomp"] = use_colors_precomp.numpy()
@@ -124,7 +128,8 @@ def grad_floor(ref):
     return max(1e-3 * rms, 1e-30)
 
 
-def run_oracle_hdr(O, sc: S.Scene, cameras=None, blur_domain="ldr", dL_ldr=None, dL_hdr=None):
+def run_oracle_hdr(O, sc: S.Scene, cameras=None, blur_domain="ldr", dL_ldr=None, dL_hdr=None,
+                   radiance_activation="relu_shift"):
     """HDR image formation with the C oracle: per pose H_k (a4..a9), tone-map (a15), average over poses;
     backward chains tonemap_bwd into the rasterizer backward per pose and sums.  Returns dict of outputs
     and gradients (numpy)."""
@@ -134,7 +139,7 @@ def run_oracle_hdr(O, sc: S.Scene, cameras=None, blur_domain="ldr", dL_ldr=None,
     dt = float(sc.exposure)
     tab = sc.crf_table.numpy()
     umin, umax = sc.crf_range
-    fs = [run_oracle(O, sc, cam=c, backward=False)[0] for c in cams]
+    fs = [run_oracle(O, sc, cam=c, backward=False, radiance_activation=radiance_activation)[0] for c in cams]
     Hs = [f["color"] for f in fs]
     Hm = np.mean(np.stack(Hs), axis=0, dtype=np.float64).astype(np.float32)
     if blur_domain == "ldr":
@@ -156,7 +161,7 @@ def run_oracle_hdr(O, sc: S.Scene, cameras=None, blur_domain="ldr", dL_ldr=None,
             dH = dHm / N
         if dL_hdr is not None:
             dH = dH + dL_hdr / N
-        ocam = oracle_camera(O, sc, c)
+        ocam = oracle_camera(O, sc, c, radiance_activation)
         b = O.backward(ocam, fs[k], dH.astype(np.float32), sc.means3D.numpy(), shs=sc.shs.numpy(),
                        scales=sc.scales.numpy(), rotations=sc.rotations.numpy())
         keys = ["dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dshs", "dL_dscales", "dL_drots"]
@@ -175,15 +180,68 @@ GRAD_KEYS = [("means3D", "dL_dmeans3D"), ("means2D", "dL_dmeans2D"), ("opacities
              ("shs", "dL_dshs"), ("scales", "dL_dscales"), ("rotations", "dL_drots")]
 
 
-def assert_grads_close(got: dict, ref: dict, keys=GRAD_KEYS, frac_tol=1e-2, max_tol=5e-2, l2_tol=5e-5, what=""):
-    """Gradient parity: >= (1-frac_tol) of the elements within 1e-4 relative (floor 1e-3 * tensor RMS), the
-    fp32-ill-conditioned tail bounded by max_tol, and the whole tensor within l2_tol in relative L2."""
+# The gradient contract (profiles/r02_parity_table.json, scripts/parity_table.py): on identical decisions the HIP path
+# and the fp32 C oracle are equally far from the float64 autograd truth (relative L2 2-5e-6, 99.9th percentile 2-7e-4,
+# worst element up to 1e-2 of max(|x|, 1e-3 RMS) -- the fp32 conditioning of the T / (1 - alpha) recurrences), and
+# within a few 1e-4 of each other.  Bars below = those measurements with headroom, not round numbers.
+STRICT = dict(frac_tol=5e-3, max_tol=1e-2, l2_tol=1e-5)
+# Gaussians a pixel inside the threshold guard band reaches (oracle.threshold_risk): one of their contributions may
+# legitimately exist in one fp32 implementation and not in the other
+AT_RISK = dict(frac_tol=5e-2, max_tol=1.0, l2_tol=5e-3)
+
+
+def assert_grads_close(got: dict, ref: dict, keys=GRAD_KEYS, frac_tol=None, max_tol=None, l2_tol=None, what="",
+                       at_risk=None):
+    """Gradient parity against the oracle.  Per tensor: the fraction of elements beyond 1e-4 relative (floor 1e-3 *
+    tensor RMS) <= frac_tol, the worst element <= max_tol, relative L2 <= l2_tol (defaults: STRICT).  `at_risk`: bool
+    [P] from oracle.threshold_risk -- those Gaussians (rows) are held to AT_RISK instead, all others to the strict
+    bar; without it every row is strict."""
+    bar = dict(STRICT)
+    for k, v in (("frac_tol", frac_tol), ("max_tol", max_tol), ("l2_tol", l2_tol)):
+        if v is not None:
+            bar[k] = v
     report = {}
     for gk, rk in keys:
         r = np.asarray(ref[rk])
         g = np.asarray(got["d_" + gk]).reshape(r.shape)
-        mx, frac = rel_err(g, r, grad_floor(r))
-        l2 = float(np.linalg.norm(g.astype(np.float64) - r) / max(np.linalg.norm(r.astype(np.float64)), 1e-30))
-        report[gk] = (mx, frac, l2)
-        assert frac <= frac_tol and mx <= max_tol and l2 <= l2_tol, (what, gk, mx, frac, l2)
+        floor = grad_floor(r)
+        parts = [("", slice(None), bar)]
+        if at_risk is not None and at_risk.any() and r.shape[0] == at_risk.shape[0]:
+            parts = [("[clear]", ~at_risk, bar), ("[at risk]", at_risk, AT_RISK)]
+        for tag, rows, b in parts:
+            rr, gg = r[rows], g[rows]
+            if rr.size == 0:
+                continue
+            mx, frac = rel_err(gg, rr, floor)
+            l2 = float(np.linalg.norm(gg.astype(np.float64) - rr) / max(np.linalg.norm(r.astype(np.float64)), 1e-30))
+            report[gk + tag] = (mx, frac, l2)
+            assert frac <= b["frac_tol"] and mx <= b["max_tol"] and l2 <= b["l2_tol"], (what, gk + tag, mx, frac, l2)
     return report
+
+
+def oracle_risk(O, sc: S.Scene, fwds, cams=None, guard_alpha=1e-5, guard_T=5e-5):
+    """Union over the poses of oracle.threshold_risk: (pix_risk [N,H,W], gauss_risk [P])."""
+    cams = cams or [sc.camera]
+    pix, gs = [], None
+    for cam, f in zip(cams, fwds):
+        r = O.threshold_risk(oracle_camera(O, sc, cam), f, guard_alpha, guard_T)
+        pix.append(r["pix_risk"])
+        gs = r["gauss_risk"] if gs is None else (gs | r["gauss_risk"])
+    return np.stack(pix), gs
+
+
+def guarded_scene(O, P, W, H, deg, seed=0, hdr=False, cams_fn=None, tries=2000, **kw):
+    """First scene with seed >= `seed` whose frame(s) have NO pixel inside the threshold guard band (SURVEY.md 7.4-3:
+    fixtures are reject-sampled so that every fp32 implementation takes identical skip / termination decisions)."""
+    for s_ in range(seed, seed + tries):
+        sc = S.make_scene(P, W, H, deg, seed=s_, hdr=hdr, **kw)
+        cams = cams_fn(W, H) if cams_fn else [sc.camera]
+        ok = True
+        for cam in cams:
+            f, _ = run_oracle(O, sc, cam=cam, backward=False)
+            if O.threshold_risk(oracle_camera(O, sc, cam), f, 2e-5, 1e-4)["n_risky_pixels"]:
+                ok = False
+                break
+        if ok:
+            return sc, s_
+    raise RuntimeError("no guard-banded seed found")

@@ -27,8 +27,30 @@ def scene_from_golden(z):
     return sc, cams, bool(hdr), ("hdr" if dom else "ldr")
 
 
+def activation_of(z):
+    return str(z["radiance_activation"]) if "radiance_activation" in z.files else "relu_shift"
+
+
 def test_fixtures_present():
-    assert len(GOLDEN) >= 6
+    assert len(GOLDEN) >= 8
+    acts = {activation_of(np.load(p)) for p in GOLDEN}
+    assert acts == {"relu_shift", "exp", "softplus"}
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
+def test_fixtures_are_guard_banded(oracle, path):
+    """no (pixel, entry) decision of a fixture lies within the guard band of a threshold, so every
+    correct fp32 implementation must reproduce its decisions exactly (the GPU leg asserts zero flips)."""
+    z = np.load(path)
+    sc, cams, hdr, dom = scene_from_golden(z)
+    for cam in cams:
+        ocam = Hh.oracle_camera(oracle, sc, cam, activation_of(z))
+        ocam.antialias = "antialias" in z.files
+        f = oracle.forward(ocam, sc.means3D.numpy(), sc.opacities.numpy(), shs=sc.shs.numpy(), scales=sc.scales.numpy(),
+                           rotations=sc.rotations.numpy())
+        r = oracle.threshold_risk(ocam, f, 2e-5, 1e-4)
+        assert r["n_risky_pixels"] == 0 and not r["gauss_risk"].any()
+        assert r["min_margin_alpha"] >= 2e-5 and r["min_margin_T"] >= 1e-4
 
 
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
@@ -50,14 +72,14 @@ def test_oracle_reproduces_golden(oracle, path):
         for _, k in Hh.GRAD_KEYS:
             assert np.array_equal(b[k], z["o_" + k]), k
     elif not hdr:
-        f, b = Hh.run_oracle(oracle, sc)
+        f, b = Hh.run_oracle(oracle, sc, radiance_activation=activation_of(z))
         for k in ("depths", "xy", "conic_opacity", "rgb", "radii", "tiles_touched", "offsets", "keys_sorted",
                   "point_list", "ranges", "color", "final_T", "n_contrib"):
             assert np.array_equal(f[k], z["o_" + k]), k
         for _, k in Hh.GRAD_KEYS:
             assert np.array_equal(b[k], z["o_" + k]), k
     else:
-        r = Hh.run_oracle_hdr(oracle, sc, cams, dom)
+        r = Hh.run_oracle_hdr(oracle, sc, cams, dom, radiance_activation=activation_of(z))
         assert np.array_equal(r["ldr"], z["o_color"]) and np.array_equal(r["hdr"], z["o_hdr"])
         for _, k in Hh.GRAD_KEYS:
             assert np.array_equal(r[k], z["o_" + k]), k

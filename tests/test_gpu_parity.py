@@ -6,9 +6,13 @@ Bars (BASELINE.json north_star): tile assignment / indexing bit-exact; pixel and
   * images: |got-ref| <= 1e-4 * max(|ref|, 1e-2) on every pixel, except that a pixel whose
     alpha / transmittance sits within an ulp of a threshold (1/255, 1e-4) may flip a contributor between
     the GPU's exp and glibc's expf -- such pixels are counted and bounded (<= 2e-5 of the pixels);
-  * gradients: helpers.assert_grads_close (>= 99 % of elements within 1e-4 relative with a floor of
-    1e-3 * RMS, relative L2 error <= 5e-5; the tail is the fp32 conditioning of the T/(1-alpha)
-    recurrences that tests/test_oracle_cross.py shows for the fp32 oracle itself against float64).
+  * decisions: where HIP and oracle disagree on a pixel's contributors, that pixel must lie inside the oracle's
+    threshold guard band (oracle.threshold_risk); the golden fixtures are reject-sampled to have NO such pixel, so
+    on them zero flips are demanded;
+  * gradients: helpers.assert_grads_close with the STRICT bar (>= 99.5 % of elements within 1e-4 relative with a floor
+    of 1e-3 * RMS, worst element <= 1e-2, relative L2 <= 1e-5) on every Gaussian no at-risk pixel reaches; the bar is
+    what profiles/r02_parity_table.json measures: HIP and the fp32 C oracle are equally far from float64 autograd
+    (test_hip_is_as_close_to_fp64_truth_as_the_fp32_oracle asserts that triangle directly).
 """
 import glob
 import os
@@ -53,9 +57,17 @@ def assert_image_close(got, ref, what):
     return nbad
 
 
-def check_image(got, ref, nc_got, nc_ref, what):
-    flips = int((nc_got != nc_ref).sum())
+def check_image(got, ref, nc_got, nc_ref, what, pix_risk=None):
+    """`pix_risk` (bool [H,W], oracle.threshold_risk): a pixel whose contributor count differs from the oracle's, or
+    whose value is off by more than 1e-4, must be one the oracle flagged as sitting inside the threshold guard band."""
+    flipped = np.asarray(nc_got) != np.asarray(nc_ref)
+    flips = int(flipped.sum())
     assert flips <= max(2, int(2e-5 * nc_got.size)), (what, "n_contrib flips", flips)
+    if pix_risk is not None:
+        assert not (flipped & ~pix_risk).any(), (what, "a contributor count differs OUTSIDE the guard band")
+        e = np.abs(np.asarray(got, np.float64) - ref) / np.maximum(np.abs(ref), 1e-2)
+        bad = (e > 1e-4).any(axis=0) if e.ndim == 3 else (e > 1e-4)
+        assert not (bad & ~pix_risk).any(), (what, "a pixel beyond 1e-4 OUTSIDE the guard band", float(e.max()))
     return flips + assert_image_close(got, ref, what)
 
 
@@ -75,12 +87,16 @@ def test_ldr_forward_backward_vs_oracle(oracle, P, W, H, deg, seed):
     assert np.array_equal(u32(st["ranges"]), u32(f["ranges"]))
     assert np.array_equal(g["radii"], f["radii"])
     nc = u32(st["n_contrib"][0])
-    flips = check_image(g["color"], f["color"], nc, u32(f["n_contrib"]), "color")
-    check_image(st["final_T"][0], f["final_T"], nc, u32(f["n_contrib"]), "final_T")
-    if flips == 0:
-        Hh.assert_grads_close(g, b, what=f"P={P}")
-    else:  # a flipped contributor perturbs the gradients of the Gaussians on that pixel
-        Hh.assert_grads_close(g, b, frac_tol=2e-2, max_tol=1.0, l2_tol=5e-3, what=f"P={P} (flips={flips})")
+    pix_risk, gauss_risk = Hh.oracle_risk(oracle, sc, [f])
+    check_image(g["color"], f["color"], nc, u32(f["n_contrib"]), "color", pix_risk[0])
+    check_image(st["final_T"][0], f["final_T"], nc, u32(f["n_contrib"]), "final_T", pix_risk[0])
+    # strict bar on every Gaussian no at-risk pixel reaches; a flipped contributor may perturb the others
+    Hh.assert_grads_close(g, b, what=f"P={P}", at_risk=gauss_risk)
+    assert gauss_risk.mean() < 0.5
+
+
+def _act(z):
+    return str(z["radiance_activation"]) if "radiance_activation" in z.files else "relu_shift"
 
 
 def _golden_antialias_invdepth(z, sc):
@@ -115,15 +131,17 @@ def test_against_golden_fixtures(path):
     sc, cams, hdr, dom = scene_from_golden(z)
     if "antialias" in z.files:
         return _golden_antialias_invdepth(z, sc)
-    g = Hh.run_hip(sc, cameras=cams if len(cams) > 1 else None, hdr=hdr, blur_domain=dom)
+    g = Hh.run_hip(sc, cameras=cams if len(cams) > 1 else None, hdr=hdr, blur_domain=dom, radiance_activation=_act(z))
     st = g["state"]
     assert np.array_equal(u32(st["point_list"][:st["num_rendered"]]), u32(z["o_point_list"]))
     assert np.array_equal(u32(st["ranges"]), u32(z["o_ranges"]))
     assert Hh.rel_err(g["color"], z["o_color"], 1e-2)[0] <= 1e-4
     ref = {k: z["o_" + k] for _, k in Hh.GRAD_KEYS}
+    # guard-banded fixture: every fp32 implementation takes the stored decisions -- zero flips, on every pose
+    nc_ref = u32(z["o_n_contrib"]).reshape(u32(st["n_contrib"]).shape)
+    assert int((u32(st["n_contrib"]) != nc_ref).sum()) == 0
     if hdr:
         assert Hh.rel_err(g["hdr"], z["o_hdr"], 1e-2)[0] <= 1e-4
-        assert int((u32(st["n_contrib"]) != u32(z["o_n_contrib"])).sum()) == 0
         tab = z["o_dL_dcrf_table"]
         assert Hh.rel_err(g["d_crf_table"], tab, 1e3 * Hh.grad_floor(tab))[0] <= 2e-4
         assert float(g["d_exposure"]) == pytest.approx(float(z["o_dL_dexposure"]), rel=2e-4, abs=1e-3)
@@ -131,6 +149,63 @@ def test_against_golden_fixtures(path):
         assert np.array_equal(st["keys_sorted"].view(np.uint64)[:st["num_rendered"]], z["o_keys_sorted"])
         assert np.array_equal(Hh.bits(st["depths"]), Hh.bits(z["o_depths"]))
     Hh.assert_grads_close(g, ref, what=os.path.basename(path))
+
+
+def test_hip_is_as_close_to_fp64_truth_as_the_fp32_oracle(oracle):
+    """The testable form of "as accurate as the reference precision" (VERDICT r1 #2b): on guard-banded scenes (all
+    three implementations take identical decisions) the error of the HIP gradients against float64 autograd of the
+    pure-PyTorch rasterizer is no larger than that of the fp32 C oracle against the same truth -- in relative L2 within
+    10 %, in the 99.9th percentile and the worst element within a factor of two (order statistics of ~1e3-1e4 elements
+    fluctuate by that much between two equally accurate fp32 evaluation orders; profiles/r02_parity_table.json)."""
+    from test_oracle_cross import torch_run
+    for P, W, H, deg, seed0 in ((1000, 128, 128, 3, 0), (600, 96, 96, 1, 0)):
+        sc, seed = Hh.guarded_scene(oracle, P, W, H, deg, seed=seed0)
+        f, b = Hh.run_oracle(oracle, sc)
+        g = Hh.run_hip(sc)
+        _, st64, g64 = torch_run(sc, torch.float64)
+        assert int((st64["n_contrib"].numpy() != f["n_contrib"]).sum()) == 0
+        assert int((u32(g["state"]["n_contrib"][0]) != u32(f["n_contrib"])).sum()) == 0
+        for k, ok in Hh.GRAD_KEYS:
+            truth = g64[k].reshape(b[ok].shape).astype(np.float64)
+            floor = Hh.grad_floor(truth)
+
+            def err(x):
+                e = np.abs(np.asarray(x, np.float64).reshape(truth.shape) - truth) / np.maximum(np.abs(truth), floor)
+                l2 = np.linalg.norm(np.asarray(x, np.float64).reshape(truth.shape) - truth) / np.linalg.norm(truth)
+                return float(e.max()), float(np.percentile(e, 99.9)), float(l2)
+
+            (mh, ph, lh), (mo, po, lo) = err(g["d_" + k]), err(b[ok])
+            assert lh <= 1.1 * lo + 1e-8 and ph <= 2.0 * po + 1e-6 and mh <= 2.0 * mo + 1e-5, (P, seed, k, (mh, ph, lh), (mo, po, lo))
+            assert lh <= 1e-5 and ph <= 2e-3, (k, lh, ph)
+
+
+@pytest.mark.parametrize("act", ["exp", "softplus"])
+def test_radiance_activations_vs_oracle(oracle, act):
+    """colour = e^s / ln(1 + e^s) of the SH sum.  HIP against the C oracle: a single view, and
+    the N-pose HDR image formation (tone-map, blur average, CRF / exposure gradients) on top of it."""
+    sc = S.make_scene(6000, 224, 144, 2, seed=12)
+    g = Hh.run_hip(sc, radiance_activation=act)
+    f, b = Hh.run_oracle(oracle, sc, radiance_activation=act)
+    st = g["state"]
+    check_structure(st, f)
+    assert np.array_equal(u32(st["point_list"][:f["R"]]), u32(f["point_list"]))
+    assert f["rgb"][f["radii"] > 0].min() > 0 and not st["clamped"].any()
+    pix_risk, gauss_risk = Hh.oracle_risk(oracle, sc, [f])
+    check_image(g["color"], f["color"], u32(st["n_contrib"][0]), u32(f["n_contrib"]), act, pix_risk[0])
+    Hh.assert_grads_close(g, b, what=act, at_risk=gauss_risk)
+    # N poses + exposure / CRF epilogue
+    sch = S.make_scene(2500, 160, 96, 1, seed=13, hdr=True)
+    sch.shs[:, 0] *= 0.25   # keep e^s inside the CRF table's range for most Gaussians
+    cams = S.blur_poses(160, 96, 3, step=0.02)
+    g = Hh.run_hip(sch, cameras=cams, hdr=True, radiance_activation=act)
+    r = Hh.run_oracle_hdr(oracle, sch, cams, "ldr", radiance_activation=act)
+    assert_image_close(g["color"], r["ldr"], act)
+    assert_image_close(g["hdr"], r["hdr"], act)
+    pix_risk, gauss_risk = Hh.oracle_risk(oracle, sch, r["fwd"], cams)
+    Hh.assert_grads_close(g, r, what=act + " hdr", at_risk=gauss_risk)
+    tab = r["dL_dcrf_table"]
+    assert Hh.rel_err(g["d_crf_table"], tab, 1e3 * Hh.grad_floor(tab))[0] <= 2e-4
+    assert float(g["d_exposure"]) == pytest.approx(r["dL_dexposure"], rel=1e-3)
 
 
 def test_precomputed_colors_and_covariance(oracle):
@@ -155,11 +230,12 @@ def test_hdr_with_direct_radiance_gradient(oracle):
     gh = torch.randn(3, 128, 192, generator=torch.Generator().manual_seed(5))
     g = Hh.run_hip(sc, hdr=True, grad_hdr=gh)
     r = Hh.run_oracle_hdr(oracle, sc, dL_hdr=gh.numpy())
-    flips = assert_image_close(g["color"], r["ldr"], "ldr") + assert_image_close(g["hdr"], r["hdr"], "hdr")
-    if flips == 0:
-        Hh.assert_grads_close(g, r)
-    else:
-        Hh.assert_grads_close(g, r, frac_tol=2e-2, max_tol=1.0, l2_tol=5e-3)
+    assert_image_close(g["color"], r["ldr"], "ldr")
+    assert_image_close(g["hdr"], r["hdr"], "hdr")
+    pix_risk, gauss_risk = Hh.oracle_risk(oracle, sc, r["fwd"])
+    flipped = u32(g["state"]["n_contrib"][0]) != u32(r["fwd"][0]["n_contrib"])
+    assert not (flipped & ~pix_risk[0]).any()
+    Hh.assert_grads_close(g, r, at_risk=gauss_risk)
     assert float(g["d_exposure"]) == pytest.approx(r["dL_dexposure"], rel=1e-3)
 
 
@@ -174,11 +250,12 @@ def test_motion_blur_n_poses(oracle, dom):
         check_structure(st, f, pose=k, P=3000)
     assert st["num_rendered"] == sum(f["R"] for f in r["fwd"])
     assert np.array_equal(g["radii"], np.max(np.stack([f["radii"] for f in r["fwd"]]), axis=0))
-    flips = assert_image_close(g["color"], r["ldr"], "ldr") + assert_image_close(g["hdr"], r["hdr"], "hdr")
-    if flips == 0:
-        Hh.assert_grads_close(g, r)
-    else:
-        Hh.assert_grads_close(g, r, frac_tol=2e-2, max_tol=1.0, l2_tol=5e-3)
+    assert_image_close(g["color"], r["ldr"], "ldr")
+    assert_image_close(g["hdr"], r["hdr"], "hdr")
+    pix_risk, gauss_risk = Hh.oracle_risk(oracle, sc, r["fwd"], cams)
+    for k, f in enumerate(r["fwd"]):
+        assert not ((u32(st["n_contrib"][k]) != u32(f["n_contrib"])) & ~pix_risk[k]).any(), k
+    Hh.assert_grads_close(g, r, at_risk=gauss_risk)
     tab = r["dL_dcrf_table"]
     assert Hh.rel_err(g["d_crf_table"], tab, 1e3 * Hh.grad_floor(tab))[0] <= 2e-4
 
@@ -725,7 +802,7 @@ def test_inverse_depth_output_and_antialiasing_vs_autograd(antialiasing, n_poses
         assert np.abs(g - w).max() <= 3e-4 * np.abs(w).max(), (name, float(np.abs(g - w).max() / np.abs(w).max()))
 
 
-def test_densification_statistics_in_kernel(tmp_path):
+def test_densification_statistics_in_kernel(tmp_path, oracle):
     """grad_accum / denom / max_radii are updated inside the backward exactly as a trainer would
     from means2D.grad and radii; the scene itself goes through the PLY exchange layout first."""
     from casualhdrsplat_amd import DensifyStats, GaussianRasterizer
@@ -741,6 +818,19 @@ def test_densification_statistics_in_kernel(tmp_path):
     stats = DensifyStats(P)
     cams = [None, S.blur_poses(W, H, 3, step=0.05)]
     want_g, want_n, want_r = torch.zeros(P), torch.zeros(P), torch.zeros(P, dtype=torch.int32)
+    # the same statistics from the ORACLE's screen-space gradient and radii (not from the HIP path's own outputs)
+    orc_g, orc_n, orc_r = np.zeros(P), np.zeros(P), np.zeros(P, np.int32)
+    for cameras in cams:
+        ocs = cameras or [sc.camera]
+        g2d, rad = np.zeros((P, 2)), np.zeros(P, np.int32)
+        for cam in ocs:
+            f_o, b_o = Hh.run_oracle(oracle, sc, cam=cam, dL=sc.dL_dimage.numpy() / len(ocs))
+            g2d += b_o["dL_dmeans2D"][:, :2]
+            rad = np.maximum(rad, f_o["radii"])
+        seen = rad > 0
+        orc_g += np.where(seen, np.linalg.norm(g2d, axis=1), 0.0)
+        orc_n += seen
+        orc_r = np.maximum(orc_r, rad)
     for cameras in cams:
         rs, _, _ = Hh.settings_from_scene(sc, "cuda", cameras)
         m2 = torch.zeros(P, 3, device="cuda", requires_grad=True)
@@ -756,8 +846,18 @@ def test_densification_statistics_in_kernel(tmp_path):
     assert torch.allclose(stats.grad_accum.cpu(), want_g, rtol=1e-5, atol=1e-12)
     assert float(want_n[:50].sum()) == 0 and float(want_n.max()) == 2 and float(want_g.max()) > 0
     assert torch.allclose(stats.mean_grad().cpu(), want_g / want_n.clamp_min(1), rtol=1e-5, atol=1e-12)
+    # against the oracle: counts and radii exactly, the gradient norms within the gradient contract
+    assert np.array_equal(stats.denom.cpu().numpy(), orc_n) and np.array_equal(stats.max_radii.cpu().numpy(), orc_r)
+    e = np.abs(stats.grad_accum.cpu().numpy() - orc_g) / np.maximum(orc_g, 1e-3 * np.sqrt((orc_g ** 2).mean()))
+    assert np.percentile(e, 99.5) <= 1e-4 and e.max() <= 1e-2, (float(np.percentile(e, 99.5)), float(e.max()))
     stats.reset()
     assert float(stats.grad_accum.abs().sum()) == 0 and int(stats.max_radii.max()) == 0
+
+
+# tiny clouds (P down to 1) put a handful of elements in a tensor: one fp32-ill-conditioned element is then a large
+# fraction of it, so the sweep bounds the fraction more loosely than the fixed-size tests; the worst element and the
+# L2 bar stay strict
+SWEEP_BAR = dict(frac_tol=2e-2, l2_tol=2e-5)
 
 
 def test_randomized_configurations_vs_oracle(oracle):
@@ -792,12 +892,14 @@ def test_randomized_configurations_vs_oracle(oracle):
                 check_structure(st, f, pose=k, P=P)
             pl = np.concatenate([f["point_list"].astype(np.int64) + k * P for k, f in enumerate(r["fwd"])])
             assert np.array_equal(u32(st["point_list"][:Rtot]), pl), what
-            flips = sum(int((u32(st["n_contrib"][k]) != u32(f["n_contrib"])).sum()) for k, f in enumerate(r["fwd"]))
-            # a contributor within an ulp of the alpha >= 1/255 test can flip in the middle of a list without moving
-            # n_contrib: the image comparator counts such pixels, the gradient check is skipped when there are any
-            soft = assert_image_close(g["hdr"], r["hdr"], what) + assert_image_close(g["color"], r["ldr"], what)
-            if flips == 0 and soft == 0:
-                Hh.assert_grads_close(g, r, frac_tol=2e-2, l2_tol=2e-4, what=what)
+            # decisions may differ from the oracle's only on pixels inside its threshold guard band; the gradients of
+            # every Gaussian such a pixel does not reach are held to the strict bar -- nothing is skipped
+            pix_risk, gauss_risk = Hh.oracle_risk(oracle, sc, r["fwd"], cams)
+            for k, f in enumerate(r["fwd"]):
+                assert not ((u32(st["n_contrib"][k]) != u32(f["n_contrib"])) & ~pix_risk[k]).any(), what
+            assert_image_close(g["hdr"], r["hdr"], what)
+            assert_image_close(g["color"], r["ldr"], what)
+            Hh.assert_grads_close(g, r, what=what, at_risk=gauss_risk, **SWEEP_BAR)
         else:
             f, b = Hh.run_oracle(oracle, sc)
             g = Hh.run_hip(sc, capacity=None if case % 2 else f["R"] + 1)
@@ -807,9 +909,9 @@ def test_randomized_configurations_vs_oracle(oracle):
             assert np.array_equal(u32(st["offsets"]), u32(f["offsets"])), what
             assert np.array_equal(u32(st["point_list"][:f["R"]]), u32(f["point_list"])), what
             assert np.array_equal(u32(st["ranges"]), u32(f["ranges"])), what
-            flips = check_image(g["color"], f["color"], u32(st["n_contrib"][0]), u32(f["n_contrib"]), what)
-            if flips == 0:
-                Hh.assert_grads_close(g, b, frac_tol=2e-2, l2_tol=2e-4, what=what)
+            pix_risk, gauss_risk = Hh.oracle_risk(oracle, sc, [f])
+            check_image(g["color"], f["color"], u32(st["n_contrib"][0]), u32(f["n_contrib"]), what, pix_risk[0])
+            Hh.assert_grads_close(g, b, what=what, at_risk=gauss_risk, **SWEEP_BAR)
 
 
 def test_c_abi_from_a_plain_cpp_host(tmp_path, oracle):

@@ -149,3 +149,34 @@ def test_c_oracle_inverse_depth_and_antialiasing_match_fp64_autograd(oracle, ant
         assert frac < 2e-2 and mx < 3e-2, (k, mx, frac)
         l2 = np.linalg.norm(b[ok].astype(np.float64) - ref) / max(np.linalg.norm(ref), 1e-30)
         assert l2 < 5e-5, (k, l2)
+
+
+@pytest.mark.parametrize("act", ["exp", "softplus"])
+def test_c_oracle_radiance_activations_match_fp64_autograd(oracle, act):
+    """SURVEY.md 7.3 / 8a a1 `radiance_activation`: colour = e^s or ln(1 + e^s) of the SH sum instead of the published
+    max(s + 0.5, 0).  The C restatement (forward and the hand-derived factor d colour / d s in the SH backward)
+    against float64 autograd of the pure-PyTorch rasterizer."""
+    P, W, H, deg = 400, 72, 56, 2
+    sc = S.make_scene(P, W, H, deg, seed=21)
+    f, b = Hh.run_oracle(oracle, sc, radiance_activation=act)
+    dt = torch.float64
+    leaves = {k: getattr(sc, k).to(dt).clone().requires_grad_(True) for k in ["means3D", "opacities", "shs", "scales", "rotations"]}
+    color, st = TR.rasterize(torch_view(sc.camera, dt), leaves["means3D"], leaves["opacities"], deg, sc.bg, shs=leaves["shs"],
+                             scales=leaves["scales"], rotations=leaves["rotations"], return_state=True,
+                             radiance_activation=act)
+    (color * sc.dL_dimage.to(dt)).sum().backward()
+    vis = f["radii"] > 0
+    want = st["pre"]["rgb"].detach().numpy()[vis]
+    assert np.allclose(f["rgb"][vis], want, rtol=2e-6, atol=1e-7)
+    assert f["rgb"][vis].min() > 0 and not f["clamped"].any()      # positive radiance, no clamp mask
+    raw = np.log(np.expm1(want)) if act == "softplus" else np.log(want)
+    assert raw.min() < -0.6                                        # relu_shift would have clamped some of these
+    assert (st["n_contrib"].numpy() != f["n_contrib"]).sum() == 0
+    assert Hh.rel_err(f["color"], color.detach().numpy(), 1e-2)[0] < 1e-5
+    for k, ok in [("means3D", "dL_dmeans3D"), ("opacities", "dL_dopacity"), ("shs", "dL_dshs"), ("scales", "dL_dscales"),
+                  ("rotations", "dL_drots")]:
+        ref = leaves[k].grad.numpy().reshape(b[ok].shape)
+        mx, frac = Hh.rel_err(b[ok], ref, Hh.grad_floor(ref))
+        assert frac < 2e-2 and mx < 3e-2, (k, mx, frac)
+        l2 = np.linalg.norm(b[ok].astype(np.float64) - ref) / max(np.linalg.norm(ref), 1e-30)
+        assert l2 < 5e-5, (k, l2)
