@@ -24,6 +24,6 @@ if [ "$what" = bench ] || [ "$what" = all ]; then
   python3 $ROOT/bench.py --config c2 --steps 50 --warmup 5 --no-cpu-baseline > $O/bench_c2.json 2> $O/bench_c2.err
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/stats.log 2>&1
   HS_BENCH_BACKEND=gloo timeout 600 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 $ROOT/bench.py --gpus 2 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_2rank_gloo_one_gpu.json 2> $O/bench_2rank.err
-  $ROOT/scripts/ubench/valu_rate > $O/valu_rate.txt 2>&1 || true
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 $ROOT/scripts/ubench/valu_rate.hip -o /tmp/valu_rate && /tmp/valu_rate > $O/valu_rate.txt 2>&1 || true
 fi
 ls $O

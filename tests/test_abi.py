@@ -117,3 +117,13 @@ def test_missing_library_is_a_hard_error(lib, monkeypatch):
     monkeypatch.setattr(lib, "LIB_PATH", "/nonexistent/libhdrsplat.so")
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         lib.load()
+
+
+def test_host_code_is_clean_under_address_and_ub_sanitizers():
+    """the host side of the library (hs_plan's carving arithmetic, every entry point's argument
+    validation, the thread-local error text, two threads at once) built with -fsanitize=address,undefined and driven
+    by tests/native/asan_host.cpp -- no GPU involved (sanitizers for device code are not available on this pool)."""
+    r = subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "casualhdrsplat_amd", "csrc"), "asan"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "asan_host: clean" in r.stdout and "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr
