@@ -46,7 +46,7 @@ static int plan(const hs_dims& d, hs_sizes* sz, hs_layout* L) {
     l.offsets = carve(I * 4);
     l.cov3D = carve((int64_t)d.P * 6 * 4);
     l.clamped = carve(I);
-    l.scan_spine = carve(((I + 1023) / 1024 + 1) * 4);
+    l.scan_spine = carve(((I + 255) / 256 + 1) * 4);
     l.binfo = carve(I * 8);
     sz->geom_bytes = o;
     // binning

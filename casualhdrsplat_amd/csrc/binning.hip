@@ -105,6 +105,16 @@ __global__ void __launch_bounds__(256) scan_apply_kernel(const uint32_t* in, int
     }
 }
 
+// Sums of 256 consecutive values (the pair emission's block size): with scan_spine_kernel, the first two thirds of the
+// scan whose last third runs inside emit_pairs_kernel.
+__global__ void __launch_bounds__(256) scan_reduce256_kernel(const uint32_t* in, int64_t n, uint32_t* block_sums) {
+    __shared__ uint32_t s_wave[4];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    uint32_t total;
+    block_incl_scan(i < n ? in[i] : 0u, s_wave, &total);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
 int scan_u32(const uint32_t* in, int64_t n, uint32_t* spine, uint32_t* out, uint32_t* total_out, hipStream_t s) {
     const int nblk = ceil_div(n, kScanTile);
     scan_reduce_kernel<<<nblk, 256, 0, s>>>(in, n, spine);
@@ -326,13 +336,18 @@ __global__ void __launch_bounds__(256) gather_binfo_kernel(int64_t I, const uint
 // owner by binary search over the 64 slot starts in LDS and its tile from the owner's rectangle (row-major, the
 // published emission order).  Also records where each instance's slots start (render-backward addresses its
 // gradient records with it; the segmented sum walks them).
+// The inclusive scan of the depth-ordered pair counts (a5 on the order the pairs are laid out in) is finished HERE: the
+// two small kernels before this one leave the exclusive sum of every 256-instance block in `block_excl`, the block adds
+// its own running counts and writes `offs_sorted` (the segmented sum of the backward walks it again).
 __global__ void __launch_bounds__(256) emit_pairs_kernel(int64_t I, int P, int gx, int gy, float4* rec,
-                                                         const uint32_t* inst_sorted, const uint32_t* offs_sorted,
+                                                         const uint32_t* inst_sorted, const uint32_t* block_excl,
+                                                         uint32_t* offs_sorted,
                                                          const uint2* srect, uint32_t* tile_keys, uint32_t* vals,
                                                          uint8_t* pair_flags, hs_counters* counters, uint64_t capacity) {
     __shared__ uint32_t s_beg[4][64];
     __shared__ uint2 s_rect[4][64];
     __shared__ uint32_t s_inst[4][64];
+    __shared__ uint32_t s_wsum[4];
     // num_rendered (total of the depth-ordered scan just before this launch) against the binning capacity: an
     // overflowing call emits nothing, sorts nothing (n_sort = 0) and renders empty; the host sees counters.overflow
     // and replays with a larger capacity.  One thread publishes the verdict for the later kernels.
@@ -341,15 +356,20 @@ __global__ void __launch_bounds__(256) emit_pairs_kernel(int64_t I, int P, int g
         counters->overflow = overflow ? 1u : 0u;
         counters->reserved[0] = overflow ? 0u : counters->num_rendered;
     }
-    if (overflow) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     uint32_t beg = 0, end = 0, inst = 0;
     uint2 rc = make_uint2(0u, 0u);
+    if (i < I) rc = srect[i];
+    {   // inclusive scan of the block's pair counts on top of the block's exclusive sum
+        const uint32_t cnt = (rc.y & 0xFFFFu) * (rc.y >> 16);
+        uint32_t total;
+        end = block_excl[blockIdx.x] + block_incl_scan(cnt, s_wsum, &total);
+        beg = end - cnt;
+        if (i < I) offs_sorted[i] = end;   // written even on overflow: the segmented sum then finds nothing flagged
+    }
+    if (overflow) return;
     if (i < I) {
-        end = offs_sorted[i];
-        rc = srect[i];
-        beg = end - (rc.y & 0xFFFFu) * (rc.y >> 16);
         inst = inst_sorted[i];
         if (end > beg) reinterpret_cast<float*>(rec + kRecF4 * (int64_t)inst + 2)[3] = __uint_as_float(beg);
     }
@@ -454,8 +474,11 @@ int launch_binning(const hs_fwd_args& a, const hs_layout& L, hipStream_t s) {
     uint32_t* offs = dv1;    // inclusive scan of ts
     uint2* srect = (uint2*)(bin + L.srect);
     gather_binfo_kernel<<<ceil_div(I, 256), 256, 0, s>>>(I, inst_sorted, (const uint2*)(geom + L.binfo), srect, ts);
-    rc = scan_u32(ts, I, (uint32_t*)(geom + L.scan_spine), offs, &counters->num_rendered, s);  // total = R
-    if (rc != HS_OK) return rc;
+    // pair offsets in depth order: block sums + their exclusive scan here, the rest inside the emission
+    uint32_t* spine = (uint32_t*)(geom + L.scan_spine);
+    const int eblk = ceil_div(I, 256);
+    scan_reduce256_kernel<<<eblk, 256, 0, s>>>(ts, I, spine);
+    scan_spine_kernel<<<1, 256, 0, s>>>(spine, eblk, &counters->num_rendered);  // total = R
     // the tile sort must end in (keys_sorted, point_list): start from A when the pass count is even
     const int tbits = tile_bits((uint32_t)ntiles);
     const int passes = sort_passes(tbits);
@@ -467,9 +490,8 @@ int launch_binning(const hs_fwd_args& a, const hs_layout& L, hipStream_t s) {
     uint32_t* v0 = (passes % 2 == 0) ? vA : vB;
     uint32_t* k1 = (passes % 2 == 0) ? kB : kA;
     uint32_t* v1 = (passes % 2 == 0) ? vB : vA;
-    emit_pairs_kernel<<<ceil_div(I, 256), 256, 0, s>>>(I, d.P, gx, gy, (float4*)(geom + L.rec), inst_sorted, offs, srect,
-                                                       k0, v0, (uint8_t*)(bin + L.pair_flags), counters,
-                                                       (uint64_t)d.capacity);
+    emit_pairs_kernel<<<eblk, 256, 0, s>>>(I, d.P, gx, gy, (float4*)(geom + L.rec), inst_sorted, spine, offs, srect,
+                                           k0, v0, (uint8_t*)(bin + L.pair_flags), counters, (uint64_t)d.capacity);
     HS_LAUNCH_CHECK();
     // 3. stable sort by tile id only
     rc = radix_sort<uint32_t>(k0, v0, k1, v1, n_sort, d.capacity, tbits, tmp, s);

@@ -1,3 +1,3 @@
-for v in "" _l8 _e24; do
-  HS_LIB_PATH=$PWD/casualhdrsplat_amd/libhdrsplat$v.so python scripts/ab_render.py --iters 30 2>/dev/null | tail -1
+for v in "" _h256 _h512 "" _h256 _h512; do
+  HS_LIB_PATH=$PWD/casualhdrsplat_amd/libhdrsplat$v.so python scripts/ab_render.py --iters 30 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['lib'], d['binning_ms'], d['step_med'])"
 done
