@@ -61,6 +61,7 @@ static int plan(const hs_dims& d, hs_sizes* sz, hs_layout* L) {
     l.depth_vals = carve(2 * I * 4);
     l.srect = carve(I * 8);
     l.pair_flags = carve(d.capacity);  // cleared by the pair emission, set by the render backward
+    l.pair_act = carve(d.capacity);    // written by the render forward, read by the render backward
     sz->binning_bytes = o;
     // image
     o = 0;

@@ -268,6 +268,7 @@ struct RenderFwd {
     const float* exposure;
     unsigned long long* stats;  // STATS instantiations only
     unsigned long long* timeline;
+    uint8_t* pair_act;          // out: per sorted pair, bit w = some pixel of wave w's half tile took the entry
 };
 
 constexpr int kBatch = 128;  // staged entries per trip = threads per workgroup
@@ -318,9 +319,10 @@ struct PairF {
     f2 T, C0, C1, C2, D;
     uint32_t last0, last1;
 };
+// Returns the lane mask of the lanes in which at least one of the two pixels took the entry.
 template <bool DEPTH>
-__device__ __forceinline__ void blend_fwd_pair(PairF& s, uint64_t& done0, uint64_t& done1, f2 pw, f2 alpha, float r,
-                                               float g, float b, float invd, uint32_t idx1) {
+__device__ __forceinline__ uint64_t blend_fwd_pair(PairF& s, uint64_t& done0, uint64_t& done1, f2 pw, f2 alpha, float r,
+                                                   float g, float b, float invd, uint32_t idx1) {
     const uint64_t valid0 = ~done0 & __builtin_amdgcn_fcmpf(pw.x, 0.f, kFcmpOLE) &
                             __builtin_amdgcn_fcmpf(alpha.x, kAlphaMin, kFcmpOGE);
     const uint64_t valid1 = ~done1 & __builtin_amdgcn_fcmpf(pw.y, 0.f, kFcmpOLE) &
@@ -340,6 +342,7 @@ __device__ __forceinline__ void blend_fwd_pair(PairF& s, uint64_t& done0, uint64
     s.T = f2{upd0 ? test_T.x : s.T.x, upd1 ? test_T.y : s.T.y};
     s.last0 = upd0 ? idx1 : s.last0;
     s.last1 = upd1 ? idx1 : s.last1;
+    return cont0 | cont1;
 }
 
 __device__ __forceinline__ void write_pixel_fwd(const RenderFwd& p, const PixF& st, int pose, int px, int py) {
@@ -367,15 +370,17 @@ __device__ __forceinline__ void write_pixel_fwd(const RenderFwd& p, const PixF& 
     }
 }
 
+// LDS record of one staged entry in the forward: {x, y, A2, B2 | C2, opacity, r, g | b, 1/depth, -, -} -- 48 bytes, so
+// one (scalar-computed) byte offset addresses all of it.
+constexpr int kFwdEntF = 12;
+
 template <bool DEPTH, bool STATS>
 __global__ void __launch_bounds__(kBatch) render_fwd_kernel(RenderFwd p) {
     constexpr int KB = kBatch;
-    __shared__ float4 s_a[KB];
-    __shared__ float4 s_b[KB];
-    __shared__ float s_cb[KB];
-    __shared__ float s_id[DEPTH ? KB : 1];  // 1 / depth of the staged entries
-    __shared__ uint16_t s_list[2][KB];  // per-wave compacted list of staged entries that can touch its half tile
+    __shared__ __attribute__((aligned(16))) float s_ent[KB * kFwdEntF];
     __shared__ int s_alive[2][2];
+    __shared__ uint16_t s_list[2][KB];  // per-wave compacted list of staged entries that can touch its half tile (byte offsets)
+    __shared__ uint8_t s_taken[2][KB];  // [wave][entry]: some pixel of the wave took the entry
 
     const int vt = xcd_strip_tile(blockIdx.x, gridDim.x, p.gx);  // virtual tile = pose * ntiles + tile
     const int pose = vt / p.ntiles;
@@ -410,18 +415,64 @@ __global__ void __launch_bounds__(kBatch) render_fwd_kernel(RenderFwd p) {
     }
     WaveStats ws;
     if constexpr (STATS) ws.clear();
-    int it = 0;
-    for (int base = 0; base < n; base += KB, ++it) {
+    const char* const ent = reinterpret_cast<const char*>(s_ent);
+    float* const my_ent = s_ent + threadIdx.x * kFwdEntF;
+    // The activity bits of a batch -- which of its entries found a taker in which wave -- go to `pair_act`, one byte per
+    // sorted pair (bit w = wave w): the backward walks exactly those entries, per wave, instead of testing every staged
+    // entry against the half tile again, and neither gathers nor writes a record for an entry nobody took.
+    auto flush_activity = [&](int base_prev, int cnt_prev) {
+        const int t = threadIdx.x;
+        if (t < cnt_prev) p.pair_act[(int64_t)range.x + base_prev + t] = (uint8_t)(s_taken[0][t] | (s_taken[1][t] << 1));
+        s_taken[0][t] = 0; s_taken[1][t] = 0;  // cleared for the batch about to be staged (written after the next barrier)
+    };
+    // Walks list positions [i0, i1) of this wave's compacted list (entries that can touch its half tile), front to
+    // back; returns the mask (bit i - i0) of positions whose entry some pixel of the wave took.  The list holds the
+    // entry's LDS byte offset, so the loop spends no vector instruction on address arithmetic; the contributor number
+    // is kept scaled the same way (`last` = (index + 1) * 48, divided once at the end).
+    auto walk = [&](int i0, int i1, int base48) -> uint64_t {
+        uint64_t act = 0ull;
+        for (int i = i0; i < i1; ++i) {
+            const int jb = (int)s_list[wave][i];            // uniform -> broadcast LDS reads below
+            const char* e = ent + jb;
+            const float4 a = *reinterpret_cast<const float4*>(e);
+            const float4 b = *reinterpret_cast<const float4*>(e + 16);
+            const float2 c = *reinterpret_cast<const float2*>(e + 32);
+            const float dx = a.x - pxf;
+            const f2 dy = a.y - pyf;
+            const float t = a.z * dx * dx, u = a.w * dx;
+            const f2 pw = dy * (b.x * dy + u) + t;          // log2 of the Gaussian falloff at the two pixels
+            const float al0 = fminf(kAlphaMax, b.y * hs_exp2(pw.x));
+            const float al1 = fminf(kAlphaMax, b.y * hs_exp2(pw.y));
+            const uint32_t idx48 = (uint32_t)(base48 + jb + kFwdEntF * 4);
+            uint64_t took = blend_fwd_pair<DEPTH>(ps, done0, done1, pw, f2{al0, al1}, b.z, b.w, c.x, DEPTH ? c.y : 0.f, idx48);
+            const int bit = i - i0;
+            // act |= (took != 0) << bit, kept in scalar registers (the compiler turns the plain expression into five
+            // vector instructions: it materialises the uniform condition through a VGPR)
+            asm("s_cmp_lg_u64 %1, 0\n\t"
+                "s_cselect_b64 %1, 1, 0\n\t"
+                "s_lshl_b64 %1, %1, %2\n\t"
+                "s_or_b64 %0, %0, %1"
+                : "+s"(act), "+s"(took) : "s"(bit) : "scc");
+            if constexpr (STATS) { ws.v[kStFwdTrips] += 1; ws.v[kStFwdEmpty] += took == 0ull; }  // took: now 0 or 1 << bit
+            if ((done0 & done1) == ~0ull) break;
+        }
+        return act;
+    };
+    s_taken[0][threadIdx.x] = 0; s_taken[1][threadIdx.x] = 0;
+    int it = 0, base = 0;
+    for (; base < n; base += KB, ++it) {
         const bool wave_alive = (done0 & done1) != ~0ull;
         if (lane == 0) s_alive[it & 1][wave] = wave_alive;
-        __syncthreads();  // also: everyone finished reading the previous batch
+        __syncthreads();  // also: everyone finished reading the previous batch, and its activity masks are in LDS
+        if (it > 0) flush_activity(base - KB, KB);
         if (!(s_alive[it & 1][0] | s_alive[it & 1][1])) break;
         const int cnt = min(KB, n - base);
         if constexpr (STATS) { if (wave == 0) { ws.v[kStFwdStaged] += cnt; ws.v[kStFwdBatches] += 1; } }
         if ((int)threadIdx.x < cnt) {
             scale_entry(ra, rb);
-            s_a[threadIdx.x] = ra; s_b[threadIdx.x] = rb; s_cb[threadIdx.x] = rcb;
-            if constexpr (DEPTH) s_id[threadIdx.x] = 1.f / rdepth;
+            reinterpret_cast<float4*>(my_ent)[0] = ra;
+            reinterpret_cast<float4*>(my_ent)[1] = rb;
+            reinterpret_cast<float2*>(my_ent)[4] = make_float2(rcb, DEPTH ? 1.f / rdepth : 0.f);
         }
         if (base + KB + (int)threadIdx.x < n) {
             const uint32_t id = p.point_list[range.x + base + KB + threadIdx.x];
@@ -429,46 +480,39 @@ __global__ void __launch_bounds__(kBatch) render_fwd_kernel(RenderFwd p) {
             ra = r[0]; rb = r[1]; rcb = reinterpret_cast<const float*>(r + 2)[0];
             if constexpr (DEPTH) rdepth = reinterpret_cast<const float*>(r + 2)[1];
         }
-        __syncthreads();
-        if (!wave_alive) continue;
-        // compaction: one staged Gaussian per lane against this wave's half tile, survivors appended in order
-        int n_t = 0;
+        __syncthreads();  // staged; every thread has read the previous batch's activity masks
+        if (wave_alive) {
+            // compaction: one staged Gaussian per lane against this wave's half tile, survivors appended in order
+            int n_t = 0;
 #pragma unroll
-        for (int k = 0; k < KB / 64; ++k) {
-            const int jj = k * 64 + lane;
-            bool touch = false;
-            if (jj < cnt) touch = halftile_may_touch(s_a[jj], s_b[jj], sxf, syf);
-            const uint64_t mask = __ballot(touch);
-            if constexpr (STATS) ws.v[kStFwdCulled] += __popcll(__ballot(jj < cnt && !touch));
-            if (touch) s_list[wave][n_t + mask_prefix(mask)] = (uint16_t)jj;
-            n_t += __popcll(mask);
-        }
-        for (int i = 0; i < n_t; ++i) {
-            const int j = (int)s_list[wave][i];  // uniform across lanes -> broadcast LDS reads below
-            const float4 a = s_a[j], b = s_b[j];
-            const float cb = s_cb[j];
-            const float dx = a.x - pxf;
-            const f2 dy = a.y - pyf;
-            const float t = a.z * dx * dx, u = a.w * dx;
-            const f2 pw = dy * (b.x * dy + u) + t;  // log2 of the Gaussian falloff at the two pixels
-            const float al0 = fminf(kAlphaMax, b.y * hs_exp2(pw.x));
-            const float al1 = fminf(kAlphaMax, b.y * hs_exp2(pw.y));
-            const uint32_t idx1 = (uint32_t)(base + j + 1);
-            const float invd = DEPTH ? s_id[j] : 0.f;
-            if constexpr (STATS) {
-                const uint32_t l0 = ps.last0, l1 = ps.last1;
-                blend_fwd_pair<DEPTH>(ps, done0, done1, pw, f2{al0, al1}, b.z, b.w, cb, invd, idx1);
-                const int act = __popcll(__ballot(ps.last0 != l0)) + __popcll(__ballot(ps.last1 != l1));
-                ws.v[kStFwdTrips] += 1; ws.v[kStFwdActivePix] += act; ws.v[kStFwdEmpty] += act == 0;
-            } else {
-                blend_fwd_pair<DEPTH>(ps, done0, done1, pw, f2{al0, al1}, b.z, b.w, cb, invd, idx1);
+            for (int k = 0; k < KB / 64; ++k) {
+                const int jj = k * 64 + lane;
+                bool touch = false;
+                if (jj < cnt) {
+                    const float4 a = reinterpret_cast<const float4*>(s_ent + jj * kFwdEntF)[0];
+                    const float4 b = reinterpret_cast<const float4*>(s_ent + jj * kFwdEntF)[1];
+                    touch = halftile_may_touch(a, b, sxf, syf);
+                }
+                const uint64_t mask = __ballot(touch);
+                if constexpr (STATS) ws.v[kStFwdCulled] += __popcll(__ballot(jj < cnt && !touch));
+                if (touch) s_list[wave][n_t + mask_prefix(mask)] = (uint16_t)(jj * kFwdEntF * 4);
+                n_t += __popcll(mask);
             }
-            if ((done0 & done1) == ~0ull) break;
+            // takers by LIST position (two scalar masks), then one lane per position marks its entry
+            const uint64_t t0 = walk(0, min(n_t, 64), base * kFwdEntF * 4);
+            const uint64_t t1 = ((done0 & done1) != ~0ull && n_t > 64) ? walk(64, n_t, base * kFwdEntF * 4) : 0ull;
+            if ((t0 >> lane) & 1ull) s_taken[wave][s_list[wave][lane] / (kFwdEntF * 4)] = 1;
+            if ((t1 >> lane) & 1ull) s_taken[wave][s_list[wave][64 + lane] / (kFwdEntF * 4)] = 1;
         }
     }
+    if (it > 0 && base >= n) {  // the loop ran out of entries: the last batch's activity is still in LDS
+        __syncthreads();
+        flush_activity(base - KB, n - (base - KB));
+    }
     PixF s0, s1;
-    s0.T = ps.T.x; s0.C0 = ps.C0.x; s0.C1 = ps.C1.x; s0.C2 = ps.C2.x; s0.last = ps.last0;
-    s1.T = ps.T.y; s1.C0 = ps.C0.y; s1.C1 = ps.C1.y; s1.C2 = ps.C2.y; s1.last = ps.last1;
+    // `last` was kept as (contributor number) * 48
+    s0.T = ps.T.x; s0.C0 = ps.C0.x; s0.C1 = ps.C1.x; s0.C2 = ps.C2.x; s0.last = ps.last0 / (kFwdEntF * 4);
+    s1.T = ps.T.y; s1.C0 = ps.C0.y; s1.C1 = ps.C1.y; s1.C2 = ps.C2.y; s1.last = ps.last1 / (kFwdEntF * 4);
     if (in0) write_pixel_fwd(p, s0, pose, px, py0);
     if (in1) write_pixel_fwd(p, s1, pose, px, py1);
     if constexpr (DEPTH) {
@@ -512,6 +556,7 @@ struct RenderBwd {
     const float* dL_dcolor; const float* dL_dhdr; const float* dL_dalpha; const float* dL_dinvdepth;
     float4* pair_grads;
     uint8_t* pair_flags;
+    const uint8_t* pair_act;   // per sorted pair: bit w = wave w's half tile took the entry (written by the forward)
     Crf crf;
     const float* exposure;
     unsigned long long* stats;     // STATS instantiations only
@@ -618,20 +663,14 @@ __device__ __forceinline__ void step_bwd_pair(PairB& s, bool act0, bool act1, f2
 constexpr int kEntF = HS_EXP_ENTF;    // floats per LDS entry record (22 used): 96 bytes keeps every record 16-byte
 constexpr int kEntB = kEntF * 4;      // aligned (measured on one box: 88-byte records, i.e. split ds_read_b128, +5 %)
 constexpr int kAccF = 12;             // first float of the sums
-#ifdef HS_EXP_LIST8
-typedef uint8_t list_t;               // the per-wave lists hold the entry index, the loop multiplies
-constexpr int kListMul = 1;
-#else
-typedef uint16_t list_t;              // the per-wave lists hold the entry's byte offset
-constexpr int kListMul = kEntB;
-#endif
+
 
 template <bool DEPTH, bool STATS>
 __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
     constexpr int KB = kBatch;
     constexpr int NV = DEPTH ? 10 : 9;      // reduced values per (tile, entry): nine published sums (+ d inverse depth)
     __shared__ __attribute__((aligned(16))) float s_ent[KB * kEntF];
-    __shared__ list_t s_list[2][KB];        // per-wave compacted list of touched staged entries (byte offsets into s_ent)
+    __shared__ uint8_t s_actb[KB];          // activity byte of each staged entry (bit w: wave w's half tile took it)
     __shared__ uint32_t s_max[2];
 
     const int vt = xcd_strip_tile(blockIdx.x, gridDim.x, p.gx);
@@ -644,7 +683,6 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
     const bool in0 = px < p.W && py0 < p.H, in1 = px < p.W && py1 < p.H;
     const float pxf = (float)px;
     const f2 pyf = {(float)py0, (float)py1};
-    const float sxf = (float)sx, syf = (float)sy;
 
     unsigned long long t_start = 0;
     if constexpr (STATS) t_start = wall_clock64();
@@ -681,17 +719,25 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
     const int nb = (n_proc + KB - 1) / KB;
     // only the instance id of the NEXT batch is prefetched (one register); its record is gathered at the
     // top of the batch -- keeping the three float4 in registers across the replay loop costs a wave of occupancy
-    uint32_t id_next = 0;
+    // The forward left one activity byte per sorted pair (bit w: some pixel of wave w's half tile took the entry).  An
+    // entry nobody took is neither gathered nor written out; each wave walks exactly its own takers -- in scalar
+    // registers, as the set bits of two 64-bit masks -- so the half-tile test is not repeated here and no trip is empty.
+    uint32_t id_next = 0, act_next = 0;
     if (nb > 0) {
         const int base = (nb - 1) * KB;
-        if ((int)threadIdx.x < n_proc - base) id_next = p.point_list[range.x + base + threadIdx.x];
+        if ((int)threadIdx.x < n_proc - base) {
+            id_next = p.point_list[range.x + base + threadIdx.x];
+            act_next = p.pair_act[(int64_t)range.x + base + threadIdx.x];
+        }
     }
     for (int bi = nb - 1; bi >= 0; --bi) {
         const int base = bi * KB;
         const int cnt = min(KB, n_proc - base);
         if constexpr (STATS) { if (wave == 0) { ws.v[kStBwdStaged] += cnt; ws.v[kStBwdBatches] += 1; } }
         __syncthreads();  // previous batch's write-out finished
-        if ((int)threadIdx.x < cnt) {
+        const bool taken = (int)threadIdx.x < cnt && act_next != 0;
+        s_actb[threadIdx.x] = (uint8_t)((int)threadIdx.x < cnt ? act_next : 0u);
+        if (taken) {
             const float4* r = p.rec + kRecF4 * (int64_t)id_next;
             float4 ra = r[0], rb = r[1];
             float4 rc = r[2];
@@ -700,31 +746,29 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
             reinterpret_cast<float4*>(my_ent)[0] = ra;
             reinterpret_cast<float4*>(my_ent)[1] = rb;
             reinterpret_cast<float4*>(my_ent)[2] = rc;
+#pragma unroll
+            for (int q = 0; q < 10; q += 2) reinterpret_cast<float2*>(my_ent + kAccF)[q >> 1] = make_float2(0.f, 0.f);  // 8-byte aligned
         }
-#pragma unroll
-        for (int q = 0; q < 10; q += 2) reinterpret_cast<float2*>(my_ent + kAccF)[q >> 1] = make_float2(0.f, 0.f);  // 8-byte aligned
-        if (bi > 0) id_next = p.point_list[range.x + base - KB + threadIdx.x];  // batches below the top are full
+        if (bi > 0) {  // batches below the top are full
+            id_next = p.point_list[range.x + base - KB + threadIdx.x];
+            act_next = p.pair_act[(int64_t)range.x + base - KB + threadIdx.x];
+        }
         __syncthreads();
-        if (base < (int)wave_max) {
-            int n_t = 0;
+        {
+            // this wave's takers among the 128 staged entries: bit `wave` of the activity bytes, as two scalar masks
+            const uint32_t wbit = 1u << wave;
+            uint64_t todo[KB / 64];
 #pragma unroll
-            for (int k = 0; k < KB / 64; ++k) {
-                const int jj = k * 64 + lane;
-                bool touch = false;
-                if (jj < cnt && base + jj < (int)wave_max) {
-                    const float4 a = reinterpret_cast<const float4*>(s_ent + jj * kEntF)[0];
-                    const float4 b = reinterpret_cast<const float4*>(s_ent + jj * kEntF)[1];
-                    touch = halftile_may_touch(a, b, sxf, syf);
-                }
-                const uint64_t mask = __ballot(touch);
-                if constexpr (STATS) ws.v[kStBwdCulled] += __popcll(__ballot(jj < cnt && base + jj < (int)wave_max && !touch));
-                if (touch) s_list[wave][n_t + mask_prefix(mask)] = (list_t)(jj * kListMul);
-                n_t += __popcll(mask);
-            }
+            for (int k = 0; k < KB / 64; ++k) todo[k] = __ballot((s_actb[k * 64 + lane] & wbit) != 0);
+            if constexpr (STATS) ws.v[kStBwdCulled] += (uint32_t)cnt - __popcll(todo[0]) - __popcll(todo[1]);
             // a pixel takes part in entry j of this batch iff base + j < last, i.e. iff j * 96 < (last - base) * 96
             const int lim0 = ((int)s0.last - base) * kEntB, lim1 = ((int)s1.last - base) * kEntB;
-            for (int i = n_t - 1; i >= 0; --i) {  // back to front
-                const int jb = (int)s_list[wave][i] * (kEntB / kListMul);  // uniform across lanes -> broadcast LDS reads below
+#pragma unroll
+            for (int k = KB / 64 - 1; k >= 0; --k)
+            while (todo[k]) {  // back to front: highest set bit first
+                const int bit = 63 - __builtin_clzll(todo[k]);
+                todo[k] &= ~(1ull << bit);
+                const int jb = (k * 64 + bit) * kEntB;  // uniform across lanes -> broadcast LDS reads below
                 const float4 a = *reinterpret_cast<const float4*>(ent + jb);
                 const float4 b = *reinterpret_cast<const float4*>(ent + jb + 16);
                 const float2 c = *reinterpret_cast<const float2*>(ent + jb + 32);
@@ -774,7 +818,7 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
             }
         }
         __syncthreads();
-        if ((int)threadIdx.x < cnt) {
+        if (taken) {
             float v[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int q = 0; q < NV; ++q) v[q] = my_ent[kAccF + q];
@@ -973,6 +1017,7 @@ int launch_render_fwd(const hs_fwd_args& a, const hs_layout& L, hipStream_t s, u
     p.exposure = a.exposure;
     p.out_invdepth = a.out_invdepth;
     p.stats = stats; p.timeline = nullptr;
+    p.pair_act = (uint8_t*)bin + L.pair_act;
     const int grid = p.ntiles * d.n_poses;
     if (stats) {
         if (a.out_invdepth) render_fwd_kernel<true, true><<<grid, kBatch, 0, s>>>(p);
@@ -1028,6 +1073,7 @@ int launch_render_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s, u
     // were cleared by the forward's pair emission; which records get written depends on the forward state alone,
     // so replays of this stage set the same flags again.
     p.pair_flags = (uint8_t*)a.binning + L.pair_flags;
+    p.pair_act = (const uint8_t*)a.binning + L.pair_act;
     p.stats = stats; p.timeline = timeline;
     const int grid = p.ntiles * d.n_poses;
     if (stats) {

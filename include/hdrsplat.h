@@ -204,6 +204,10 @@ typedef struct hs_layout {
     /* pair_flags (binning workspace): u8 per pair slot, cleared by the forward's pair emission, set to 1 by the
      * render backward for the records it wrote */
     int64_t pair_flags;
+    /* pair_act (binning workspace): u8 per SORTED pair, written by the render forward for every entry it staged: bit w
+     * = some pixel of half tile w (rows 8w .. 8w+7 of the tile) took the entry.  The render backward walks exactly
+     * those entries per half tile */
+    int64_t pair_act;
     /* image workspace */
     int64_t final_T, n_contrib, pose_hdr;
     /* bwd workspace */
