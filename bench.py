@@ -125,8 +125,11 @@ def build_step(cfg, rank, world, dev, seed=0):
     )
     dL = sc.dL_dimage.to(dev)
     plist = list(params.values()) + ([exposure, crf] if hdr else [])
-
-    non_sh = [p for k, p in params.items() if k != "shs"] + ([exposure, crf] if hdr else [])
+    # what a view-parallel step sums over the ranks: the gradients of the PARAMETERS.  means2D is not one -- its
+    # "gradient" is this view's screen-space gradient, the densification statistic a trainer accumulates per view
+    # (norm per view, summed at densification time), so it stays on the rank that rendered the view
+    reduced = [p for k, p in params.items() if k != "means2D"] + ([exposure, crf] if hdr else [])
+    non_sh = [p for k, p in params.items() if k not in ("shs", "means2D")] + ([exposure, crf] if hdr else [])
 
     def make_rasterizer(capacity):
         # front ends over the same kernels: plain, and with the SH gradient deferred to the view exchange
@@ -149,7 +152,7 @@ def build_step(cfg, rank, world, dev, seed=0):
             if mode != "allreduce":
                 exchange_view_gradients(non_sh, params["shs"], rast.deferred, algo=algo)
             else:
-                all_reduce_gradients(plist, algo=algo)
+                all_reduce_gradients(reduced, algo=algo)
         state["out"] = out
         return out
 

@@ -362,8 +362,10 @@ def _launch_backward(st: "_State", saved, gcol, ghdr, stages: int, want_pose: bo
                      defer_sh: bool = False, ginvd=None, densify=None, gather_group=None, stats=None,
                      timeline=None) -> dict:
     """Enqueue hs_backward.  All per-Gaussian gradients are carved out of ONE flat fp32 buffer (the
-    layout casualhdrsplat_amd.distributed all-reduces in a single RCCL call): [means3D | means2D |
-    opacities | sh | colors | scales | rotations | cov3D | exposure | crf_table]."""
+    layout casualhdrsplat_amd.distributed all-reduces in a single RCCL call): [means3D | opacities | sh | colors |
+    scales | rotations | cov3D | exposure | crf_table | means2D | pose gradients].  means2D -- the screen-space
+    gradient of THIS view, a densification statistic and not a parameter gradient -- comes after everything a
+    view-parallel step sums over the ranks, so the summed set is one contiguous span without it."""
     lib = L.load()
     m3, op, shs, cp, sc, ro, cv, exp_t, crf_t = saved
     dev = m3.device
@@ -371,10 +373,11 @@ def _launch_backward(st: "_State", saved, gcol, ghdr, stages: int, want_pose: bo
     _, sizes, _ = L.plan(P, M, st.dims.sh_degree, st.W, st.H, st.dims.n_poses, st.dims.capacity, st.dims.crf_K)
     bwd = torch.empty(max(int(sizes.bwd_bytes), 256), dtype=torch.uint8, device=dev)
     hdr = bool(st.flags & L.HS_FLAG_HDR)
-    spec = [("means3D", (P, 3), True), ("means2D", (P, 3), True), ("opacities", (P, 1), True),
+    spec = [("means3D", (P, 3), True), ("opacities", (P, 1), True),
             ("shs", (P, M, 3), shs is not None and not defer_sh), ("colors_precomp", (P, 3), cp is not None),
             ("scales", (P, 3), sc is not None), ("rotations", (P, 4), ro is not None),
             ("cov3D_precomp", (P, 6), cv is not None), ("exposure", (1,), hdr), ("crf_table", (3, st.crf_K), hdr),
+            ("means2D", (P, 3), True),
             ("viewmatrices", (st.dims.n_poses, 16), want_pose), ("projmatrices", (st.dims.n_poses, 16), want_pose),
             ("camposes", (st.dims.n_poses, 3), want_pose)]
     total = 0

@@ -8,22 +8,26 @@ rm -rf $O   # counters are averaged over every file found: never mix runs
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 what=${1:-all}
+STEP="python3 $ROOT/scripts/step_c3.py --steps 3 --capacity 8500000"
 if [ "$what" = pmc ] || [ "$what" = all ]; then
+  # HBM-side traffic: FETCH_SIZE and WRITE_SIZE in separate passes (they do not fit the TCC counter slots together)
   for c in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -- python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/pmc_$c.log 2>&1
+    rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -- $STEP > $O/pmc_$c.log 2>&1
   done
   i=0
   for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" "SQ_ACTIVE_INST_SCA SQ_INSTS_SALU SQ_ACTIVE_INST_LDS SQ_INSTS_LDS" "SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE"; do
     i=$((i+1))
-    rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/pmc_sq$i -- python3 $ROOT/scripts/step_c3.py --steps 3 > $O/pmc_sq$i.log 2>&1
+    rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/pmc_sq$i -- $STEP > $O/pmc_sq$i.log 2>&1
   done
 fi
 if [ "$what" = bench ] || [ "$what" = all ]; then
   python3 $ROOT/bench.py --steps 50 --warmup 5 > $O/bench_c3.json 2> $O/bench_c3.err
-  python3 $ROOT/bench.py --config c4 --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_c4.json 2> $O/bench_c4.err
-  python3 $ROOT/bench.py --config c2 --steps 50 --warmup 5 --no-cpu-baseline > $O/bench_c2.json 2> $O/bench_c2.err
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/stats.log 2>&1
-  HS_BENCH_BACKEND=gloo timeout 600 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 $ROOT/bench.py --gpus 2 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_2rank_gloo_one_gpu.json 2> $O/bench_2rank.err
+  python3 $ROOT/bench.py --config c4 --steps 20 --warmup 3 --no-cpu-baseline --no-extras > $O/bench_c4.json 2> $O/bench_c4.err
+  python3 $ROOT/bench.py --config c2 --steps 50 --warmup 5 --no-cpu-baseline --no-extras > $O/bench_c2.json 2> $O/bench_c2.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras > $O/stats.log 2>&1
+  # plumbing check of the bare multi-GPU invocation on a one-GPU box: bench.py starts its own two ranks (gloo, shared GPU)
+  HS_BENCH_BACKEND=gloo timeout 900 python3 $ROOT/bench.py --gpus 2 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_2rank_gloo_one_gpu.json 2> $O/bench_2rank.err
+  python3 $ROOT/scripts/timeline.py > $O/timeline.txt 2>&1
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 $ROOT/scripts/ubench/valu_rate.hip -o /tmp/valu_rate && /tmp/valu_rate > $O/valu_rate.txt 2>&1 || true
 fi
 ls $O

@@ -29,7 +29,10 @@ if what == "pmc":
             o.write(f"{r[0]},{r[1]:.1f},{r[2]:.1f},{r[3]}\n")
     d = {r[0]: r[3] for r in rows}
     pick = lambda s: next(v for k, v in d.items() if k.startswith(s))
+    import subprocess
+    commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
     json.dump({"c3": {"render_bwd_kernel_hbm_bytes": pick("render_bwd_kernel"), "render_fwd_kernel_hbm_bytes": pick("render_fwd_kernel"),
+                      "source_commit": commit + " (HEAD when the counters were folded; kernels of that tree)",
                       "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (KB units); hbm = (2*FETCH_SIZE + WRITE_SIZE)*1024, "
                                 "the gfx950 FETCH_SIZE half-count correction; per-launch average; counted at the L2-fabric interface (Infinity-Cache hits included)",
                       "source": f"profiles/{tag}_pmc_traffic_c3.csv"}}, open(os.path.join(DST, "pmc_traffic.json"), "w"), indent=1)
@@ -69,6 +72,8 @@ else:
     shutil.copy(st, os.path.join(DST, f"{tag}_bench_c3_kernel_stats.csv"))
     if os.path.exists(os.path.join(SRC, "valu_rate.txt")):
         shutil.copy(os.path.join(SRC, "valu_rate.txt"), os.path.join(DST, f"{tag}_valu_rate.txt"))
+    if os.path.exists(os.path.join(SRC, "timeline.txt")):
+        shutil.copy(os.path.join(SRC, "timeline.txt"), os.path.join(DST, f"{tag}_timeline_render_bwd_c3.txt"))
     for cfg in ("c3", "c4", "c2"):
         d = json.loads(open(os.path.join(DST, f"{tag}_bench_{cfg}.json")).read())
         print(cfg, round(d["value"], 1), d["unit"], round(d["ms_per_step"], 4), "ms", {k: d.get("roofline", {}).get(k) for k in ("frac", "avg_ms", "traffic")})
