@@ -667,10 +667,13 @@ constexpr int kAccF = 12;             // first float of the sums
 
 template <bool DEPTH, bool STATS>
 __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
-    constexpr int KB = kBatch;
+#ifndef HS_EXP_BWD_KB
+#define HS_EXP_BWD_KB 128
+#endif
+    constexpr int KB = HS_EXP_BWD_KB;       // staged entries per batch (<= threads per workgroup)
     constexpr int NV = DEPTH ? 10 : 9;      // reduced values per (tile, entry): nine published sums (+ d inverse depth)
     __shared__ __attribute__((aligned(16))) float s_ent[KB * kEntF];
-    __shared__ uint8_t s_actb[KB];          // activity byte of each staged entry (bit w: wave w's half tile took it)
+    __shared__ uint8_t s_actb[kBatch];      // activity byte of each staged entry (bit w: wave w's half tile took it)
     __shared__ uint32_t s_max[2];
 
     const int vt = xcd_strip_tile(blockIdx.x, gridDim.x, p.gx);
@@ -746,10 +749,13 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
             reinterpret_cast<float4*>(my_ent)[0] = ra;
             reinterpret_cast<float4*>(my_ent)[1] = rb;
             reinterpret_cast<float4*>(my_ent)[2] = rc;
+#ifdef HS_EXP_ATOMIC
+            my_ent[22] = __uint_as_float(id_next);  // A/B build only: the instance the per-pixel atomics go to
+#endif
 #pragma unroll
             for (int q = 0; q < 10; q += 2) reinterpret_cast<float2*>(my_ent + kAccF)[q >> 1] = make_float2(0.f, 0.f);  // 8-byte aligned
         }
-        if (bi > 0) {  // batches below the top are full
+        if (bi > 0 && (int)threadIdx.x < KB) {  // batches below the top are full
             id_next = p.point_list[range.x + base - KB + threadIdx.x];
             act_next = p.pair_act[(int64_t)range.x + base - KB + threadIdx.x];
         }
@@ -757,14 +763,14 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
         {
             // this wave's takers among the 128 staged entries: bit `wave` of the activity bytes, as two scalar masks
             const uint32_t wbit = 1u << wave;
-            uint64_t todo[KB / 64];
+            uint64_t todo[kBatch / 64];
 #pragma unroll
-            for (int k = 0; k < KB / 64; ++k) todo[k] = __ballot((s_actb[k * 64 + lane] & wbit) != 0);
+            for (int k = 0; k < kBatch / 64; ++k) todo[k] = __ballot((s_actb[k * 64 + lane] & wbit) != 0);
             if constexpr (STATS) ws.v[kStBwdCulled] += (uint32_t)cnt - __popcll(todo[0]) - __popcll(todo[1]);
             // a pixel takes part in entry j of this batch iff base + j < last, i.e. iff j * 96 < (last - base) * 96
             const int lim0 = ((int)s0.last - base) * kEntB, lim1 = ((int)s1.last - base) * kEntB;
 #pragma unroll
-            for (int k = KB / 64 - 1; k >= 0; --k)
+            for (int k = kBatch / 64 - 1; k >= 0; --k)
             while (todo[k]) {  // back to front: highest set bit first
                 const int bit = 63 - __builtin_clzll(todo[k]);
                 todo[k] &= ~(1ull << bit);
@@ -813,8 +819,23 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
                     const f2 cd = dch * ps.dLd;
                     g9 = cd.x + cd.y;
                 }
+#ifdef HS_EXP_ATOMIC
+                // A/B build (never shipped; results are not summed correctly downstream): the published design --
+                // every lane adds its nine per-pixel-pair terms straight into the Gaussian's gradient with global
+                // float atomics (here into the instance's 64-byte sum record), no wave reduction, no pair record
+                {
+                    const uint32_t inst = __float_as_uint(*reinterpret_cast<const float*>(ent + jb + 88));
+                    float* sink = reinterpret_cast<float*>(p.pair_grads) + (size_t)inst * 16;
+                    if (act0 || act1) {
+#pragma unroll
+                        for (int q = 0; q < 9; ++q) atomicAdd(sink + q, g[q]);
+                    }
+                    (void)g9; (void)xor32_addr; (void)red_off;
+                }
+#else
                 const float tot = wave_reduce<DEPTH>(g, g9, xor32_addr);
                 if (red_off >= 0) atomicAdd(reinterpret_cast<float*>(ent + jb + red_off), tot);  // 9 (10) lanes, one LDS add
+#endif
             }
         }
         __syncthreads();
