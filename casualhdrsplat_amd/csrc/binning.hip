@@ -69,16 +69,24 @@ __global__ void __launch_bounds__(256) scan_reduce_kernel(const uint32_t* in, in
     if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
 }
 
-// Single block: exclusive scan of block_sums in place; writes the grand total to *total_out (may be null).
+// Single block: exclusive scan of block_sums in place; writes the grand total to *total_out (may be null).  Four
+// consecutive values per thread, so a cloud's few thousand block sums take a handful of barrier rounds.
 __global__ void __launch_bounds__(256) scan_spine_kernel(uint32_t* block_sums, int nblocks, uint32_t* total_out) {
     __shared__ uint32_t s_wave[4];
     uint32_t carry = 0;
-    for (int base = 0; base < nblocks; base += 256) {
-        int i = base + threadIdx.x;
-        uint32_t v = i < nblocks ? block_sums[i] : 0;
+    for (int base = 0; base < nblocks; base += 1024) {
+        const int i = base + threadIdx.x * 4;
+        uint32_t v[4], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[k] = i + k < nblocks ? block_sums[i + k] : 0u; sum += v[k]; }
         uint32_t total;
-        uint32_t incl = block_incl_scan(v, s_wave, &total);
-        if (i < nblocks) block_sums[i] = carry + incl - v;
+        const uint32_t incl = block_incl_scan(sum, s_wave, &total);
+        uint32_t run = carry + incl - sum;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (i + k < nblocks) block_sums[i + k] = run;
+            run += v[k];
+        }
         carry += total;
     }
     if (threadIdx.x == 0 && total_out) *total_out = carry;

@@ -28,7 +28,10 @@ constexpr int kInstF4 = 4;                 // float4 per per-instance sum of the
 constexpr int kRecFloats = 4 * kRecF4;
 constexpr int kPairFloats = 4 * kPairF4;
 constexpr int kInstFloats = 4 * kInstF4;
-constexpr int kSortItems = 16;   // keys per thread per radix block
+#ifndef HS_EXP_SORT_ITEMS
+#define HS_EXP_SORT_ITEMS 16
+#endif
+constexpr int kSortItems = HS_EXP_SORT_ITEMS;   // keys per thread per radix block
 constexpr int kSortBlock = 256;
 constexpr int kSortTile = kSortItems * kSortBlock;  // 4096 keys per block
 
