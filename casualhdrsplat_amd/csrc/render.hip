@@ -675,6 +675,14 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
     __shared__ __attribute__((aligned(16))) float s_ent[KB * kEntF];
     __shared__ uint8_t s_actb[kBatch];      // activity byte of each staged entry (bit w: wave w's half tile took it)
     __shared__ uint32_t s_max[2];
+#ifdef HS_EXP_PG
+    // A/B build: the per-Gaussian-parallel backward (SURVEY.md 7.2 alternative).  Per wave: the upstream gradient,
+    // the replay state and the contributor limit of its 128 pixels, and the wave's takers of a batch in reverse order
+    __shared__ float4 s_pix[2][kBatch];     // {dL0, dL1, dL2, -} of pixel p = row * 16 + col of the half tile
+    __shared__ float2 s_pst[2][kBatch];     // {T, q} of the pixel behind the entries processed so far
+    __shared__ int s_plast[2][kBatch];      // last contributor * 96
+    __shared__ uint16_t s_rlist[2][kBatch];
+#endif
 
     const int vt = xcd_strip_tile(blockIdx.x, gridDim.x, p.gx);
     const int pose = vt / p.ntiles;
@@ -698,6 +706,17 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
 
     const uint32_t wave_max = wave_max_u32(max(s0.last, s1.last));
     if (lane == 0) s_max[wave] = wave_max;
+#ifdef HS_EXP_PG
+    {
+        const int p0 = (lane >> 4) * 32 + (lane & 15), p1 = p0 + 16;
+        s_pix[wave][p0] = make_float4(s0.dL0, s0.dL1, s0.dL2, 0.f);
+        s_pix[wave][p1] = make_float4(s1.dL0, s1.dL1, s1.dL2, 0.f);
+        s_pst[wave][p0] = make_float2(s0.T, s0.q);
+        s_pst[wave][p1] = make_float2(s1.T, s1.q);
+        s_plast[wave][p0] = (int)s0.last * kEntB;
+        s_plast[wave][p1] = (int)s1.last * kEntB;
+    }
+#endif
     __syncthreads();
     const int n_proc = (int)max(s_max[0], s_max[1]);
 
@@ -767,6 +786,73 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
 #pragma unroll
             for (int k = 0; k < kBatch / 64; ++k) todo[k] = __ballot((s_actb[k * 64 + lane] & wbit) != 0);
             if constexpr (STATS) ws.v[kStBwdCulled] += (uint32_t)cnt - __popcll(todo[0]) - __popcll(todo[1]);
+#ifdef HS_EXP_PG
+            {
+                // the wave's takers in reverse (back-to-front) order
+                const int n_t = __popcll(todo[0]) + __popcll(todo[1]);
+#pragma unroll
+                for (int k = 0; k < kBatch / 64; ++k) {
+                    if ((todo[k] >> lane) & 1ull) {
+                        int above = __popcll(todo[k] >> lane) - 1;          // takers above me in this half
+                        if (k == 0) above += __popcll(todo[1]);
+                        s_rlist[wave][above] = (uint16_t)((k * 64 + lane) * kEntB);
+                    }
+                }
+                const int base96 = base * kEntB;
+                for (int g0 = 0; g0 < n_t; g0 += 64) {
+                    // one lane = one Gaussian of the group; the pixels of the half tile stream through the lanes, a
+                    // pixel's replay state handed from lane l - 1 (the entry behind) to lane l one step later
+                    const bool valid = g0 + lane < n_t;
+                    const int jb = valid ? (int)s_rlist[wave][g0 + lane] : 0;
+                    const float4 a = *reinterpret_cast<const float4*>(ent + jb);
+                    const float4 b = *reinterpret_cast<const float4*>(ent + jb + 16);
+                    const float cb = *reinterpret_cast<const float*>(ent + jb + 32);
+                    const int jlim = jb + base96;
+                    float S[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    float T_out = 0.f, q_out = 0.f;
+                    for (int st = 0; st < kBatch + 63; ++st) {
+                        const int pp = st - lane;
+                        const int pc = min(max(pp, 0), kBatch - 1);
+                        const bool in_range = valid && pp >= 0 && pp < kBatch;
+                        // state: lane 0 takes the pixel's from LDS, the others from the lane before
+                        const float2 fresh = s_pst[wave][min(st, kBatch - 1)];
+                        float T_in = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(T_out), 0x138, 0xF, 0xF, false));
+                        float q_in = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(q_out), 0x138, 0xF, 0xF, false));
+                        if (lane == 0) { T_in = fresh.x; q_in = fresh.y; }
+                        const float4 dLp = s_pix[wave][pc];
+                        const int plast = s_plast[wave][pc];
+                        const float fx = (float)(sx + (pc & 15)), fy = (float)(sy + (pc >> 4));
+                        const float dx = a.x - fx, dy = a.y - fy;
+                        const float t = a.z * dx * dx, u = a.w * dx;
+                        const float pw = dy * (b.x * dy + u) + t;
+                        const float G = hs_exp2(pw);
+                        const float al = fminf(kAlphaMax, b.y * G);
+                        const bool act = in_range && (jlim < plast) && (pw <= 0.f) && (al >= kAlphaMin);
+                        const float ae = act ? al : 0.f;
+                        const float rcp = __builtin_amdgcn_rcpf(1.f - ae);
+                        const float T = T_in * rcp;
+                        const float dch = ae * T;
+                        const float cd = (b.z * dLp.x + b.w * dLp.y) + cb * dLp.z;
+                        const float diff = cd - q_in;
+                        const float gd = G * (diff * T);
+                        q_out = act ? q_in + ae * diff : q_in;  // lanes without an entry hold stale LDS: pass the state through
+                        T_out = T;
+                        const float dop = act ? gd : 0.f;
+                        const float sw = b.y * dop;
+                        const float m = sw * dy, n2 = sw * dx;
+                        S[0] += n2; S[1] += m; S[2] += n2 * dx; S[3] += m * dx; S[4] += m * dy; S[5] += dop;
+                        S[6] += dch * dLp.x; S[7] += dch * dLp.y; S[8] += dch * dLp.z;
+                        // the pixel leaves the group behind lane 63 (lanes without an entry pass it through)
+                        if (lane == 63 && pp >= 0 && pp < kBatch) s_pst[wave][pp] = make_float2(T_out, q_out);
+                    }
+                    if (valid) {
+#pragma unroll
+                        for (int q = 0; q < 9; ++q) atomicAdd(reinterpret_cast<float*>(ent + jb + (kAccF + q) * 4), S[q]);
+                    }
+                }
+                (void)xor32_addr; (void)red_off; (void)pxf; (void)pyf;
+            }
+#else
             // a pixel takes part in entry j of this batch iff base + j < last, i.e. iff j * 96 < (last - base) * 96
             const int lim0 = ((int)s0.last - base) * kEntB, lim1 = ((int)s1.last - base) * kEntB;
 #pragma unroll
@@ -837,6 +923,7 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
                 if (red_off >= 0) atomicAdd(reinterpret_cast<float*>(ent + jb + red_off), tot);  // 9 (10) lanes, one LDS add
 #endif
             }
+#endif  // HS_EXP_PG
         }
         __syncthreads();
         if (taken) {

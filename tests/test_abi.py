@@ -127,3 +127,13 @@ def test_host_code_is_clean_under_address_and_ub_sanitizers():
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "asan_host: clean" in r.stdout and "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr
+
+
+@pytest.mark.parametrize("define", ["HS_EXP_PG", "HS_EXP_ATOMIC"])
+def test_ab_variants_of_the_render_backward_still_compile(define, tmp_path):
+    """The two A/B builds profiles/README.md reports (per-Gaussian-parallel backward, global-atomics backward) live in
+    render.hip behind #ifdef: they must keep compiling for gfx950 so the comparison can be repeated."""
+    src = os.path.join(ROOT, "casualhdrsplat_amd", "csrc", "render.hip")
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O1", "-std=c++17", "-fPIC", f"-D{define}=1",
+                        "--cuda-device-only", "-c", src, "-o", str(tmp_path / "v.o")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
