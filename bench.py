@@ -143,6 +143,7 @@ def build_step(cfg, rank, world, dev, seed=0):
     def step():
         mode, algo = state["exchange"]
         rast = state["rast"][mode if world > 1 else "allreduce"]
+        rast.gather_direct = algo == "direct"
         for p in plist:
             p.grad = None
         out = rast(params["means3D"], params["means2D"], params["opacities"], shs=params["shs"],

@@ -162,7 +162,17 @@ def all_reduce_gradients(params: Iterable[torch.Tensor], group=None, average: bo
     return packed.numel()
 
 
-def start_view_gather(view_colors: torch.Tensor, camposes: torch.Tensor, group=None):
+def _gather_rows(out: torch.Tensor, inp: torch.Tensor, group, direct: bool, async_op: bool = False):
+    """out[r * n : (r + 1) * n] = rank r's `inp` (n = inp.shape[0]).  direct: every rank sends its block straight to
+    every peer (a list all-to-all = grouped point-to-point sends over all seven xGMI links at once) instead of the
+    library's ring all-gather; backends without a list all-to-all (gloo) always use the all-gather."""
+    if direct and dist.get_backend(group) == "nccl":
+        world = dist.get_world_size(group)
+        return dist.all_to_all(list(out.chunk(world, dim=0)), [inp] * world, group=group, async_op=async_op)
+    return dist.all_gather_into_tensor(out, inp, group=group, async_op=async_op)
+
+
+def start_view_gather(view_colors: torch.Tensor, camposes: torch.Tensor, group=None, direct: bool = False):
     """Issue the all-gathers of one view-parallel step asynchronously (called from the rasterizer's backward between
     its two halves when GaussianRasterizer(..., gather_group=...) is used).  Returns None when not distributed, else
     (works, colours of all ranks [world*N, P, 3], camera centres of all ranks [world*N, 3])."""
@@ -175,7 +185,7 @@ def start_view_gather(view_colors: torch.Tensor, camposes: torch.Tensor, group=N
     vc = view_colors.contiguous()
     vc_all = torch.empty((world * vc.shape[0],) + tuple(vc.shape[1:]), dtype=vc.dtype, device=vc.device)
     cams_all = torch.empty((world * cams.shape[0], 3), dtype=cams.dtype, device=cams.device)
-    works = [dist.all_gather_into_tensor(vc_all, vc, group=group, async_op=True),
+    works = [_gather_rows(vc_all, vc, group, direct, async_op=True),
              dist.all_gather_into_tensor(cams_all, cams, group=group, async_op=True)]
     return works, vc_all, cams_all
 
@@ -208,7 +218,7 @@ def exchange_view_gradients(params: Iterable[torch.Tensor], shs: torch.Tensor, d
         # rank-major concatenation along dim 0 (the layout every backend accepts)
         vc_all = torch.empty((world * vc.shape[0],) + tuple(vc.shape[1:]), dtype=vc.dtype, device=vc.device)
         cams_all = torch.empty((world * cams.shape[0], 3), dtype=cams.dtype, device=cams.device)
-        dist.all_gather_into_tensor(vc_all, vc.contiguous(), group=group)
+        _gather_rows(vc_all, vc.contiguous(), group, direct=(algo == "direct"))
         dist.all_gather_into_tensor(cams_all, cams.contiguous(), group=group)
         gathered = vc_all.numel() + cams_all.numel()
         vc, cams = vc_all, cams_all

@@ -328,7 +328,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         with _on_device(dev):
             g = _launch_backward(st, saved, gcol, ghdr, L.HS_BWD_ALL, want_pose, galpha,
                                  defer_sh=ctx.deferred is not None, ginvd=ginvd, densify=ctx.densify,
-                                 gather_group=None if ctx.deferred is None else ctx.deferred.get("gather_group"))
+                                 gather_group=None if ctx.deferred is None else ctx.deferred.get("gather_group"),
+                                 gather_direct=bool(ctx.deferred.get("gather_direct")) if ctx.deferred else False)
         if ctx.deferred is not None:
             # view-parallel exchange: hand the per-view colour gradients to distributed.exchange_view_gradients
             ctx.deferred.update(view_colors=g["view_colors"], camposes=st.camposes, means3D=saved[0],
@@ -360,7 +361,7 @@ class _RasterizeGaussians(torch.autograd.Function):
 
 def _launch_backward(st: "_State", saved, gcol, ghdr, stages: int, want_pose: bool = False, galpha=None,
                      defer_sh: bool = False, ginvd=None, densify=None, gather_group=None, stats=None,
-                     timeline=None) -> dict:
+                     timeline=None, gather_direct: bool = False) -> dict:
     """Enqueue hs_backward.  All per-Gaussian gradients are carved out of ONE flat fp32 buffer (the
     layout casualhdrsplat_amd.distributed all-reduces in a single RCCL call): [means3D | opacities | sh | colors |
     scales | rotations | cov3D | exposure | crf_table | means2D | pose gradients].  means2D -- the screen-space
@@ -435,7 +436,7 @@ def _launch_backward(st: "_State", saved, gcol, ghdr, stages: int, want_pose: bo
         from . import distributed as D
         a.stages = L.HS_BWD_RENDER | L.HS_BWD_CRF | L.HS_BWD_SEGSUM
         L.check(lib.hs_backward(C.byref(a), _stream()), "hs_backward[render+segsum]")
-        g["_gather"] = D.start_view_gather(g["view_colors"], st.camposes, gather_group)
+        g["_gather"] = D.start_view_gather(g["view_colors"], st.camposes, gather_group, direct=gather_direct)
         a.stages = L.HS_BWD_PROJECT
         L.check(lib.hs_backward(C.byref(a), _stream()), "hs_backward[project]")
         a.stages = stages
@@ -560,6 +561,7 @@ class GaussianRasterizer(nn.Module):
         # with defer_sh_grad: a torch.distributed process group (or True for the default group) makes the backward
         # start the all-gather of the view colour gradients itself, overlapped with its per-Gaussian half
         self.gather_group = gather_group
+        self.gather_direct = False  # True: that all-gather as 1-hop point-to-point sends (distributed._gather_rows)
         self.densify_stats = densify_stats  # extension: updated in place by every backward (see DensifyStats)
         # extension (newer published rasterizers return (color, radii, invdepths)): append the expected inverse
         # depth image [H,W] = sum_i alpha_i T_i / z_i to the outputs, differentiable
@@ -629,6 +631,7 @@ class GaussianRasterizer(nn.Module):
             self.deferred = {} if self.defer_sh_grad else None
             if self.deferred is not None and self.gather_group is not None:
                 self.deferred["gather_group"] = self.gather_group
+                self.deferred["gather_direct"] = bool(self.gather_direct)
             aux = {"keep_state": self.keep_state}
             outs = rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
                                        cov3D_precomp, rs, self.capacity, self.return_alpha, self.deferred,
