@@ -1048,3 +1048,39 @@ def test_all_optional_outputs_together_are_linear_in_their_gradients():
         s = sum(p[k] for p in parts)
         assert torch.allclose(total[k], s, rtol=2e-4, atol=2e-5 * float(s.abs().max())), k
     assert all(float(p["means3D"].abs().max()) > 0 for p in parts)
+
+
+def test_rccl_entry_points_of_the_exchange_in_a_single_rank_group():
+    """The 1-hop forms of the gradient exchange call RCCL-only entry points (list all-to-all = grouped sends) that the
+    gloo tests cannot reach.  A one-rank "nccl" process group on this GPU runs exactly those calls -- argument shapes,
+    in-place aliasing of the output views, odd lengths -- so a multi-GPU node does not meet them for the first time."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["HS_ROOT"])
+from casualhdrsplat_amd.distributed import all_reduce_direct, _gather_rows, all_reduce_gradients, init_from_env
+os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1)
+for n in (1, 7, 4096, 1000003):
+    x = torch.randn(n, device="cuda"); y = x.clone()
+    all_reduce_direct(x)
+    assert torch.equal(x, y), n
+vc = torch.randn(2, 1001, 3, device="cuda")
+out = torch.empty(2, 1001, 3, device="cuda")
+_gather_rows(out, vc, None, direct=True)
+assert torch.equal(out, vc)
+w = _gather_rows(out.zero_(), vc, None, direct=True, async_op=True); w.wait()
+assert torch.equal(out, vc)
+p = torch.zeros(5, 3, device="cuda", requires_grad=True); p.grad = torch.ones(5, 3, device="cuda")
+assert all_reduce_gradients([p], algo="direct") == 0          # one rank: nothing to exchange
+dist.barrier(); dist.destroy_process_group()
+print("RCCL-ENTRY-POINTS-OK")
+'''
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HS_ROOT=root, MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "RCCL-ENTRY-POINTS-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
