@@ -322,7 +322,7 @@ struct PairF {
 // Returns the lane mask of the lanes in which at least one of the two pixels took the entry.
 template <bool DEPTH>
 __device__ __forceinline__ uint64_t blend_fwd_pair(PairF& s, uint64_t& done0, uint64_t& done1, f2 pw, f2 alpha, float r,
-                                                   float g, float b, float invd, uint32_t idx1) {
+                                                   float g, float b, float invd, uint32_t idx1, int* n_pixels = nullptr) {
     const uint64_t valid0 = ~done0 & __builtin_amdgcn_fcmpf(pw.x, 0.f, kFcmpOLE) &
                             __builtin_amdgcn_fcmpf(alpha.x, kAlphaMin, kFcmpOGE);
     const uint64_t valid1 = ~done1 & __builtin_amdgcn_fcmpf(pw.y, 0.f, kFcmpOLE) &
@@ -342,6 +342,7 @@ __device__ __forceinline__ uint64_t blend_fwd_pair(PairF& s, uint64_t& done0, ui
     s.T = f2{upd0 ? test_T.x : s.T.x, upd1 ? test_T.y : s.T.y};
     s.last0 = upd0 ? idx1 : s.last0;
     s.last1 = upd1 ? idx1 : s.last1;
+    if (n_pixels) *n_pixels = __popcll(cont0) + __popcll(cont1);
     return cont0 | cont1;
 }
 
@@ -444,7 +445,10 @@ __global__ void __launch_bounds__(kBatch) render_fwd_kernel(RenderFwd p) {
             const float al0 = fminf(kAlphaMax, b.y * hs_exp2(pw.x));
             const float al1 = fminf(kAlphaMax, b.y * hs_exp2(pw.y));
             const uint32_t idx48 = (uint32_t)(base48 + jb + kFwdEntF * 4);
-            uint64_t took = blend_fwd_pair<DEPTH>(ps, done0, done1, pw, f2{al0, al1}, b.z, b.w, c.x, DEPTH ? c.y : 0.f, idx48);
+            int n_pix = 0;
+            uint64_t took = blend_fwd_pair<DEPTH>(ps, done0, done1, pw, f2{al0, al1}, b.z, b.w, c.x, DEPTH ? c.y : 0.f, idx48,
+                                                  STATS ? &n_pix : nullptr);
+            if constexpr (STATS) ws.v[kStFwdActivePix] += n_pix;
             const int bit = i - i0;
             // act |= (took != 0) << bit, kept in scalar registers (the compiler turns the plain expression into five
             // vector instructions: it materialises the uniform condition through a VGPR)

@@ -1084,3 +1084,29 @@ print("RCCL-ENTRY-POINTS-OK")
     env = dict(os.environ, HS_ROOT=root, MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "RCCL-ENTRY-POINTS-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_render_stats_counters_are_consistent():
+    """hs_render_stats (the diagnostic instantiation bench.py's VALU roofline relies on): the forward and the backward
+    count the same active (pixel, entry) pairs -- the sum of n_contrib-bounded contributions -- the backward walks only
+    entries the forward marked as taken (no empty trip, never more trips than the forward), and the per-workgroup
+    timeline covers every tile once."""
+    from casualhdrsplat_amd import GaussianRasterizer
+    from casualhdrsplat_amd.rasterizer import render_stats
+    sc = S.make_scene(30000, 400, 232, 1, seed=14)
+    rs, _, _ = Hh.settings_from_scene(sc, "cuda")
+    leaf = {k: getattr(sc, k).cuda().requires_grad_(True) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
+    m2 = torch.zeros(30000, 3, device="cuda", requires_grad=True)
+    out = GaussianRasterizer(rs)(leaf["means3D"], m2, leaf["opacities"], shs=leaf["shs"], scales=leaf["scales"],
+                                 rotations=leaf["rotations"])
+    st = render_stats(out[0], sc.dL_dimage.cuda(), timeline=True)
+    assert st["bwd_active_pixels"] == st["fwd_active_pixels"] > 0
+    assert st["bwd_empty_trips"] == 0 and 0 < st["bwd_trips"] <= st["fwd_trips"]
+    assert sum(st[k] for k in st if k.startswith("bwd_hist_")) == st["bwd_trips"]
+    assert st["bwd_staged"] <= st["fwd_staged"] and st["bwd_batches"] <= st["fwd_batches"]
+    tl = st["bwd_timeline"].numpy()
+    assert tl.shape == (25 * 15, 3) and (tl[:, 1] >= tl[:, 0]).all() and set((tl[:, 2] >> 32) & 0xF) <= set(range(8))
+    # the counting kernels leave the results of the real ones untouched: a backward afterwards matches a fresh run
+    (out[0] * sc.dL_dimage.cuda()).sum().backward()
+    ref = Hh.run_hip(sc)
+    assert np.array_equal(leaf["means3D"].grad.cpu().numpy(), ref["d_means3D"])
