@@ -306,8 +306,11 @@ def offline_profile(cfg_name):
         pmc = json.load(open(tpath)).get(cfg_name)
         if not pmc:
             return None
+        src = os.path.join(ROOT, "casualhdrsplat_amd", "csrc", "render.hip")
+        same = bool(pmc.get("render_hip_sha256")) and \
+            hashlib.sha256(open(src, "rb").read()).hexdigest() == pmc.get("render_hip_sha256")
         return {"from_profiles": True, "file": "profiles/pmc_traffic.json", "source": pmc.get("source"),
-                "source_commit": pmc.get("source_commit"),
+                "source_commit": pmc.get("source_commit"), "same_kernel_source": same,
                 "render_bwd_kernel_hbm_bytes": pmc.get("render_bwd_kernel_hbm_bytes"),
                 "render_fwd_kernel_hbm_bytes": pmc.get("render_fwd_kernel_hbm_bytes"),
                 "render_bwd_kernel_valu_busy_frac": pmc.get("render_bwd_kernel_valu_busy_frac"),
@@ -474,6 +477,12 @@ def main():
         off = offline_profile(args.config)
         if off is not None:
             line["roofline"]["offline_profile"] = off
+            if off.get("same_kernel_source") and off.get("render_bwd_kernel_hbm_bytes"):
+                # counters of an earlier rocprofv3 --pmc pass over this same workload, taken from kernels compiled
+                # from the very render.hip that is loaded now (hash checked); otherwise `traffic` stays null
+                line["roofline"]["traffic"] = off["render_bwd_kernel_hbm_bytes"]
+                line["roofline"]["traffic_note"] = ("bytes per launch at the L2-fabric interface from profiles/pmc_traffic.json "
+                                                    "(separate --pmc passes, gfx950 FETCH_SIZE correction), same render.hip")
         line["stages_ms"] = {k: round(v, 4) for k, v in stages.items()}
         line["render_stats"] = stats
         if world == 1 and not args.no_extras:

@@ -31,7 +31,10 @@ if what == "pmc":
     pick = lambda s: next(v for k, v in d.items() if k.startswith(s))
     import subprocess
     commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+    import hashlib
+    sha = hashlib.sha256(open(os.path.join(ROOT, "casualhdrsplat_amd", "csrc", "render.hip"), "rb").read()).hexdigest()
     json.dump({"c3": {"render_bwd_kernel_hbm_bytes": pick("render_bwd_kernel"), "render_fwd_kernel_hbm_bytes": pick("render_fwd_kernel"),
+                      "render_hip_sha256": sha,
                       "source_commit": commit + " (HEAD when the counters were folded; kernels of that tree)",
                       "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (KB units); hbm = (2*FETCH_SIZE + WRITE_SIZE)*1024, "
                                 "the gfx950 FETCH_SIZE half-count correction; per-launch average; counted at the L2-fabric interface (Infinity-Cache hits included)",

@@ -129,3 +129,24 @@ def test_bench_self_launches_ranks_and_forwards_their_exit_code():
     assert "torch.distributed.run" in r.stderr and "--nproc-per-node=2" in r.stderr
     assert "bench.py needs an MI355X" in r.stderr
     assert not r.stdout.strip().startswith("{")
+
+
+def test_bench_offline_counters_are_tied_to_the_kernel_source(tmp_path, monkeypatch):
+    """`roofline.traffic` may only carry the committed PMC figure while render.hip is the file the counters were
+    collected on (hash recorded by scripts/fold_profiles.py); the committed profile must be current."""
+    import os
+    import bench
+    off = bench.offline_profile("c3")
+    assert off is not None and off["render_bwd_kernel_hbm_bytes"] > 0
+    assert off["same_kernel_source"], "render.hip changed: re-run scripts/collect_profiles.sh pmc + fold_profiles.py"
+    isa = bench.isa_counts()
+    assert isa is not None and not isa.get("stale"), "render.hip changed: re-run scripts/isa_loop_counts.py"
+    # a different source -> the figure is not used
+    root = tmp_path / "r"
+    (root / "profiles").mkdir(parents=True)
+    (root / "casualhdrsplat_amd" / "csrc").mkdir(parents=True)
+    (root / "casualhdrsplat_amd" / "csrc" / "render.hip").write_text("// something else\n")
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")
+    (root / "profiles" / "pmc_traffic.json").write_text(open(src).read())
+    monkeypatch.setattr(bench, "ROOT", str(root))
+    assert bench.offline_profile("c3")["same_kernel_source"] is False
