@@ -160,11 +160,18 @@ __device__ __forceinline__ float radiance_dact(int act, float col, bool was_clam
 // a4.  instance = pose * P + g.
 template <int DEG>
 __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreFwd p) {
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    // Block -> (chunk of 256 Gaussians, pose): workgroups are dealt to the 8 XCDs round-robin by blockIdx, so XCD x runs
+    // its blocks x, x + 8, x + 16, ... in order; those are made the N poses of chunk x, then of chunk x + 8, ... -- the
+    // poses of a chunk follow each other on ONE XCD and read the chunk's SH rows, scales and rotations (236 bytes
+    // per Gaussian at degree 3) through that XCD's L2 once instead of N times from memory.  N = 1: chunk = blockIdx.
+    const int64_t lin = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+    const int pose = seq % p.N;
+    const int64_t g64 = ((int64_t)(seq / p.N) * 8 + xcd) * 256 + threadIdx.x;
     uint32_t ntiles = 0;
-    if (idx < (int64_t)p.P * p.N) {
-    const int pose = (int)((uint32_t)idx / (uint32_t)p.P);  // I < 2^31 (hs_plan): 32-bit division
-    const int g = (int)((uint32_t)idx - (uint32_t)pose * (uint32_t)p.P);
+    if (g64 < (int64_t)p.P) {
+    const int g = (int)g64;
+    const int64_t idx = (int64_t)pose * p.P + g;
     const float* V = p.view + 16 * pose;
     const float* PM = p.proj + 16 * pose;
 
@@ -286,10 +293,10 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreFwd p) {
         p.depth_keys[idx] = my_radius > 0 ? __float_as_uint(depth) : 0xFFFFFFFFu;
         p.depth_vals[idx] = (uint32_t)idx;
     }
-    }  // idx < I
+    }  // g < P
     if (p.depth_keys) {
-        for (int64_t t = idx; t < p.n_vtiles; t += (int64_t)gridDim.x * 256) p.ranges[t] = make_uint2(0u, 0u);
-        if (idx == 0) p.counters->reserved[1] = (uint32_t)((int64_t)p.P * p.N);
+        for (int64_t t = lin; t < p.n_vtiles; t += (int64_t)gridDim.x * 256) p.ranges[t] = make_uint2(0u, 0u);
+        if (lin == 0) p.counters->reserved[1] = (uint32_t)((int64_t)p.P * p.N);
     }
 }
 
@@ -833,8 +840,8 @@ int launch_preprocess_fwd(const hs_fwd_args& a, const hs_layout& L, hipStream_t 
         p.n_vtiles = (int64_t)((d.W + kTile - 1) / kTile) * ((d.H + kTile - 1) / kTile) * d.n_poses;
     }
     if (d.n_poses > 1) HS_HIP_CHECK(hipMemsetAsync(a.radii, 0, sizeof(int) * (size_t)d.P, s));
-    const int64_t I = (int64_t)d.P * d.n_poses;
-    const int grid = ceil_div(I, 256);
+    // chunks of 256 Gaussians, padded to a multiple of the 8 XCDs, times the poses (see the kernel's block map)
+    const int grid = (int)(ceil_div(ceil_div((int64_t)d.P, 256), 8) * 8 * d.n_poses);
     const int deg = a.colors_precomp ? 0 : d.sh_degree;
     switch (deg) {
         case 0: preprocess_fwd_kernel<0><<<grid, 256, 0, s>>>(p); break;

@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench
 dev = torch.device("cuda", 0)
-cfg = bench.CONFIGS["c3"]
+cfg = bench.CONFIGS[sys.argv[1] if len(sys.argv) > 1 else "c3"]
 step, state, make_rasterizer, sc, dL, plist = bench.build_step(cfg, 0, 1, dev)
 out = step(); torch.cuda.synchronize()
 R = bench.derived_counts(out, cfg[1], cfg[2], cfg[5])[0]
