@@ -51,6 +51,7 @@ def lib():
         _lib = C.CDLL(build())
         _lib.hso_scan.restype = C.c_int64
         _lib.hso_threshold_risk.restype = C.c_int64
+        _lib.hso_pixel_reach.restype = C.c_int64
     return _lib
 
 
@@ -161,6 +162,17 @@ def threshold_risk(cam: Camera, fwd: dict, guard_alpha: float = 2e-5, guard_T: f
                                  _p(mm)))
     return dict(n_risky_pixels=n, pix_risk=pix.astype(bool), gauss_risk=gs.astype(bool),
                 min_margin_alpha=float(mm[0]), min_margin_T=float(mm[1]), min_abs_power=float(mm[2]))
+
+
+def pixel_reach(cam: Camera, fwd: dict, pix_mask) -> np.ndarray:
+    """bool [P]: the Gaussians that contribute to the pixels selected by `pix_mask` [H,W] (hso_pixel_reach)."""
+    L = lib()
+    P = fwd["radii"].shape[0]
+    c = cam.cstruct(P, 0)
+    m = np.ascontiguousarray(np.asarray(pix_mask).astype(np.uint8))
+    gs = np.zeros(P, np.uint8)
+    L.hso_pixel_reach(C.byref(c), _p(fwd["ranges"]), _p(fwd["point_list"]), _p(fwd["xy"]), _p(fwd["conic_opacity"]), _p(m), _p(gs))
+    return gs.astype(bool)
 
 
 def backward(cam: Camera, fwd: dict, dL_dcolor_img, means3D, shs=None, colors_precomp=None,

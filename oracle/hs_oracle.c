@@ -487,6 +487,39 @@ int64_t hso_threshold_risk(const hso_camera* c, const uint32_t* ranges, const ui
     return n_risky;
 }
 
+/* Test aid: the Gaussians that contribute to the pixels of `pix_mask` (u8 [H,W], non-zero = selected) -- the rows of
+ * the gradient that a per-pixel decision taken elsewhere (e.g. which interval of the piecewise-linear CRF the pixel's
+ * radiance falls into, a15) can reach.  Marks gauss_out[id] = 1; returns the number of selected pixels. */
+int64_t hso_pixel_reach(const hso_camera* c, const uint32_t* ranges, const uint32_t* point_list, const float* xy,
+                        const float* conic_opacity, const uint8_t* pix_mask, uint8_t* gauss_out) {
+    const int W = c->W, H = c->H;
+    const int gx = (W + HSO_TILE - 1) / HSO_TILE;
+    int64_t n = 0;
+    for (int py = 0; py < H; ++py)
+        for (int px = 0; px < W; ++px) {
+            if (!pix_mask[(size_t)py * W + px]) continue;
+            ++n;
+            int tile = (py / HSO_TILE) * gx + (px / HSO_TILE);
+            uint32_t beg = ranges[2 * tile], end = ranges[2 * tile + 1];
+            float pxf = (float)px, pyf = (float)py;
+            float T = 1.0f;
+            for (uint32_t k = beg; k < end; ++k) {
+                uint32_t id = point_list[k];
+                float dx = xy[2 * id] - pxf, dy = xy[2 * id + 1] - pyf;
+                const float* co = conic_opacity + 4 * id;
+                float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                if (power > 0.0f) continue;
+                float alpha = fminf_(0.99f, co[3] * expf(power));
+                if (alpha < 1.0f / 255.0f) continue;
+                float test_T = T * (1.f - alpha);
+                if (test_T < 0.0001f) break;
+                gauss_out[id] = 1;
+                T = test_T;
+            }
+        }
+    return n;
+}
+
 /* ------------------------------------------------------------------------------------------
  * a10  render backward (per pixel, back to front).  Outputs per Gaussian:
  *   dL_dmean2D [P,2]  in NDC-scaled units (pixel gradient * 0.5*W, 0.5*H),

@@ -185,9 +185,14 @@ GRAD_KEYS = [("means3D", "dL_dmeans3D"), ("means2D", "dL_dmeans2D"), ("opacities
 # worst element up to 1e-2 of max(|x|, 1e-3 RMS) -- the fp32 conditioning of the T / (1 - alpha) recurrences), and
 # within a few 1e-4 of each other.  Bars below = those measurements with headroom, not round numbers.
 STRICT = dict(frac_tol=1e-2, max_tol=1e-2, l2_tol=1e-5)  # measured: frac <= 6e-3, max <= 3e-3, l2 <= 1e-6 (HIP vs C)
-# Gaussians a pixel inside the threshold guard band reaches (oracle.threshold_risk): one of their contributions may
-# legitimately exist in one fp32 implementation and not in the other
-AT_RISK = dict(frac_tol=5e-2, max_tol=1.0, l2_tol=5e-3)
+# Gaussians a pixel inside a guard band reaches (oracle.threshold_risk for the alpha / T thresholds, crf_knot_risk for
+# the interval of the piecewise-linear CRF): one of their contributions may legitimately exist -- or carry the
+# neighbouring CRF slope -- in one fp32 implementation and not in the other.  No bound on the FRACTION of such rows (one
+# flipped pixel changes every Gaussian behind it along that pixel, which can be most of the at-risk set of a small scene)
+# and none on a single element (a contribution present on one side only is of the order of the tensor's typical entry,
+# i.e. up to ~1e3 x the 1e-3-RMS floor small elements are measured against); bounded is the L2 share of the whole
+# tensor by which all at-risk rows together may differ.  2400 random configurations (scripts/soak.sh, 8 seeds) pass.
+AT_RISK = dict(frac_tol=1.0, max_tol=float("inf"), l2_tol=5e-3)
 
 
 def assert_grads_close(got: dict, ref: dict, keys=GRAD_KEYS, frac_tol=None, max_tol=None, l2_tol=None, what="",
@@ -215,18 +220,45 @@ def assert_grads_close(got: dict, ref: dict, keys=GRAD_KEYS, frac_tol=None, max_
             mx, frac = rel_err(gg, rr, floor)
             l2 = float(np.linalg.norm(gg.astype(np.float64) - rr) / max(np.linalg.norm(r.astype(np.float64)), 1e-30))
             report[gk + tag] = (mx, frac, l2)
-            assert frac <= b["frac_tol"] and mx <= b["max_tol"] and l2 <= b["l2_tol"], (what, gk + tag, mx, frac, l2)
+            # the fraction bound always admits two elements (tensors of a few dozen entries: P down to 1 in the sweep)
+            frac_ok = frac <= max(b["frac_tol"], 2.0 / rr.size)
+            assert frac_ok and mx <= b["max_tol"] and l2 <= b["l2_tol"], (what, gk + tag, mx, frac, l2)
     return report
 
 
-def oracle_risk(O, sc: S.Scene, fwds, cams=None, guard_alpha=1e-5, guard_T=5e-5):
-    """Union over the poses of oracle.threshold_risk: (pix_risk [N,H,W], gauss_risk [P])."""
+def crf_knot_risk(sc: S.Scene, hdr_img, guard_knots=2e-4):
+    """bool [H,W]: pixels whose log-exposure u = ln(H dt) of some channel lies within `guard_knots` (in units of the
+    knot spacing) of a knot of the piecewise-linear CRF table, or of the ends of its range.  There the interval -- hence
+    the slope dL/dH is multiplied with -- is a piecewise-constant decision like the alpha / T thresholds: fp32
+    implementations that evaluate ln() or H with different rounding may take the neighbouring interval (relative
+    slope step between neighbours of a 256-knot table: a few per cent)."""
+    K = sc.crf_table.shape[1]
+    umin, umax = sc.crf_range
+    x = float(sc.exposure) * np.asarray(hdr_img, np.float64)
+    u = np.log(np.maximum(x, 1e-30))
+    s = (u - umin) / (umax - umin) * (K - 1)
+    near = np.abs(s - np.round(s)) < guard_knots
+    near &= (s > -1.0) & (s < K)          # far outside the table the slope is zero on both sides
+    return near.any(axis=0)
+
+
+def oracle_risk(O, sc: S.Scene, fwds, cams=None, guard_alpha=1e-5, guard_T=5e-5, crf_images=None):
+    """Union over the poses of oracle.threshold_risk: (pix_risk [N,H,W], gauss_risk [P]).  `crf_images`: the radiance
+    image(s) the CRF is applied to (one per pose, or one mean image for blur_domain='hdr') -- pixels at a knot of
+    the CRF table (crf_knot_risk) put the Gaussians they are composed of at risk as well (in every pose when the
+    image is the mean)."""
     cams = cams or [sc.camera]
     pix, gs = [], None
     for cam, f in zip(cams, fwds):
         r = O.threshold_risk(oracle_camera(O, sc, cam), f, guard_alpha, guard_T)
         pix.append(r["pix_risk"])
         gs = r["gauss_risk"] if gs is None else (gs | r["gauss_risk"])
+    if crf_images is not None:
+        per_pose = len(crf_images) == len(fwds)
+        for k, (cam, f) in enumerate(zip(cams, fwds)):
+            m = crf_knot_risk(sc, crf_images[k] if per_pose else crf_images[0])
+            if m.any():
+                gs = gs | O.pixel_reach(oracle_camera(O, sc, cam), f, m)
     return np.stack(pix), gs
 
 

@@ -148,7 +148,17 @@ def test_against_golden_fixtures(path):
     else:
         assert np.array_equal(st["keys_sorted"].view(np.uint64)[:st["num_rendered"]], z["o_keys_sorted"])
         assert np.array_equal(Hh.bits(st["depths"]), Hh.bits(z["o_depths"]))
-    Hh.assert_grads_close(g, ref, what=os.path.basename(path))
+    at_risk = None
+    if hdr:
+        # the alpha / T decisions of a fixture are guard-banded, the CRF interval of a pixel cannot be (a frame always
+        # has a few pixels within 2e-4 knot spacings of a knot): the Gaussians composing those pixels go to the
+        # at-risk bar, all others stay strict
+        from oracle import c_oracle as O
+        r = Hh.run_oracle_hdr(O, sc, cams, dom, radiance_activation=_act(z))
+        imgs = [r["hdr"]] if dom == "hdr" else [f["color"] for f in r["fwd"]]
+        _, at_risk = Hh.oracle_risk(O, sc, r["fwd"], cams, crf_images=imgs)
+        assert at_risk.mean() < 0.5
+    Hh.assert_grads_close(g, ref, what=os.path.basename(path), at_risk=at_risk)
 
 
 def test_hip_is_as_close_to_fp64_truth_as_the_fp32_oracle(oracle):
@@ -201,7 +211,7 @@ def test_radiance_activations_vs_oracle(oracle, act):
     r = Hh.run_oracle_hdr(oracle, sch, cams, "ldr", radiance_activation=act)
     assert_image_close(g["color"], r["ldr"], act)
     assert_image_close(g["hdr"], r["hdr"], act)
-    pix_risk, gauss_risk = Hh.oracle_risk(oracle, sch, r["fwd"], cams)
+    pix_risk, gauss_risk = Hh.oracle_risk(oracle, sch, r["fwd"], cams, crf_images=[f["color"] for f in r["fwd"]])
     Hh.assert_grads_close(g, r, what=act + " hdr", at_risk=gauss_risk)
     tab = r["dL_dcrf_table"]
     assert Hh.rel_err(g["d_crf_table"], tab, 1e3 * Hh.grad_floor(tab))[0] <= 2e-4
@@ -232,7 +242,7 @@ def test_hdr_with_direct_radiance_gradient(oracle):
     r = Hh.run_oracle_hdr(oracle, sc, dL_hdr=gh.numpy())
     assert_image_close(g["color"], r["ldr"], "ldr")
     assert_image_close(g["hdr"], r["hdr"], "hdr")
-    pix_risk, gauss_risk = Hh.oracle_risk(oracle, sc, r["fwd"])
+    pix_risk, gauss_risk = Hh.oracle_risk(oracle, sc, r["fwd"], crf_images=[r["fwd"][0]["color"]])
     flipped = u32(g["state"]["n_contrib"][0]) != u32(r["fwd"][0]["n_contrib"])
     assert not (flipped & ~pix_risk[0]).any()
     Hh.assert_grads_close(g, r, at_risk=gauss_risk)
@@ -252,7 +262,8 @@ def test_motion_blur_n_poses(oracle, dom):
     assert np.array_equal(g["radii"], np.max(np.stack([f["radii"] for f in r["fwd"]]), axis=0))
     assert_image_close(g["color"], r["ldr"], "ldr")
     assert_image_close(g["hdr"], r["hdr"], "hdr")
-    pix_risk, gauss_risk = Hh.oracle_risk(oracle, sc, r["fwd"], cams)
+    pix_risk, gauss_risk = Hh.oracle_risk(oracle, sc, r["fwd"], cams,
+                                          crf_images=[r["hdr"]] if dom == "hdr" else [f["color"] for f in r["fwd"]])
     for k, f in enumerate(r["fwd"]):
         assert not ((u32(st["n_contrib"][k]) != u32(f["n_contrib"])) & ~pix_risk[k]).any(), k
     Hh.assert_grads_close(g, r, at_risk=gauss_risk)
@@ -864,8 +875,9 @@ def test_randomized_configurations_vs_oracle(oracle):
     """Sweep of small random configurations (sizes that are not multiples of the tile or block sizes, every SH degree,
     1-3 poses, with and without the HDR epilogue, sync and fixed-capacity binning): structure bit-exact, images and
     gradients within the numerical contract.  Catches indexing bugs that the handful of fixed shapes cannot."""
-    rng = np.random.default_rng(2026)
-    for case in range(24):
+    # HS_SWEEP_SEED / HS_SWEEP_CASES: soak runs with other seeds and more cases (scripts/soak.sh)
+    rng = np.random.default_rng(int(os.environ.get("HS_SWEEP_SEED", "2026")))
+    for case in range(int(os.environ.get("HS_SWEEP_CASES", "24"))):
         P = int(rng.integers(1, 3000))
         W, H = int(rng.integers(17, 230)), int(rng.integers(17, 170))
         deg = int(rng.integers(0, 4))
@@ -894,7 +906,7 @@ def test_randomized_configurations_vs_oracle(oracle):
             assert np.array_equal(u32(st["point_list"][:Rtot]), pl), what
             # decisions may differ from the oracle's only on pixels inside its threshold guard band; the gradients of
             # every Gaussian such a pixel does not reach are held to the strict bar -- nothing is skipped
-            pix_risk, gauss_risk = Hh.oracle_risk(oracle, sc, r["fwd"], cams)
+            pix_risk, gauss_risk = Hh.oracle_risk(oracle, sc, r["fwd"], cams, crf_images=[f["color"] for f in r["fwd"]])
             for k, f in enumerate(r["fwd"]):
                 assert not ((u32(st["n_contrib"][k]) != u32(f["n_contrib"])) & ~pix_risk[k]).any(), what
             assert_image_close(g["hdr"], r["hdr"], what)
