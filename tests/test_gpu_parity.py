@@ -873,7 +873,8 @@ SWEEP_BAR = dict(frac_tol=2e-2, l2_tol=2e-5)
 
 def test_randomized_configurations_vs_oracle(oracle):
     """Sweep of small random configurations (sizes that are not multiples of the tile or block sizes, every SH degree,
-    1-3 poses, with and without the HDR epilogue, sync and fixed-capacity binning): structure bit-exact, images and
+    1-3 poses, with and without the HDR epilogue, both blur domains, the three radiance activations, sync and
+    fixed-capacity binning): structure bit-exact, images and
     gradients within the numerical contract.  Catches indexing bugs that the handful of fixed shapes cannot."""
     # HS_SWEEP_SEED / HS_SWEEP_CASES: soak runs with other seeds and more cases (scripts/soak.sh)
     rng = np.random.default_rng(int(os.environ.get("HS_SWEEP_SEED", "2026")))
@@ -884,20 +885,25 @@ def test_randomized_configurations_vs_oracle(oracle):
         n_poses = int(rng.integers(1, 4))
         hdr = bool(rng.integers(0, 2))
         seed = int(rng.integers(0, 1000))
-        what = f"case {case}: P={P} {W}x{H} deg={deg} poses={n_poses} hdr={hdr} seed={seed}"
+        act = ("relu_shift", "relu_shift", "relu_shift", "exp", "softplus")[int(rng.integers(0, 5))]
+        dom = "hdr" if int(rng.integers(0, 3)) == 0 else "ldr"
+        what = f"case {case}: P={P} {W}x{H} deg={deg} poses={n_poses} hdr={hdr} seed={seed} act={act} dom={dom}"
         sc = S.make_scene(P, W, H, deg, seed=seed, hdr=hdr)
+        if act == "exp":
+            sc.shs[:, 0] *= 0.25   # keep e^s inside a sane range (and inside the CRF table's for most Gaussians)
         cams = S.blur_poses(W, H, n_poses, step=0.03) if n_poses > 1 else None
         if hdr or n_poses > 1:
             if not hdr:  # linear-radiance blur: the average of the per-pose oracle renders
-                fs = [Hh.run_oracle(oracle, sc, cam=c, backward=False)[0] for c in cams]
-                g = Hh.run_hip(sc, cameras=cams, backward=False)
+                fs = [Hh.run_oracle(oracle, sc, cam=c, backward=False, radiance_activation=act)[0] for c in cams]
+                g = Hh.run_hip(sc, cameras=cams, backward=False, radiance_activation=act)
                 ref = np.mean(np.stack([f["color"] for f in fs]), axis=0, dtype=np.float64)
                 assert_image_close(g["color"], ref, what)
                 assert np.array_equal(g["radii"], np.max(np.stack([f["radii"] for f in fs]), axis=0)), what
                 continue
-            r = Hh.run_oracle_hdr(oracle, sc, cams, "ldr")
+            r = Hh.run_oracle_hdr(oracle, sc, cams, dom, radiance_activation=act)
             Rtot = sum(f["R"] for f in r["fwd"])
-            g = Hh.run_hip(sc, cameras=cams, hdr=True, capacity=None if case % 2 else Rtot + 7)
+            g = Hh.run_hip(sc, cameras=cams, hdr=True, blur_domain=dom, capacity=None if case % 2 else Rtot + 7,
+                           radiance_activation=act)
             st = g["state"]
             assert st["num_rendered"] == Rtot, what
             for k, f in enumerate(r["fwd"]):
@@ -906,15 +912,16 @@ def test_randomized_configurations_vs_oracle(oracle):
             assert np.array_equal(u32(st["point_list"][:Rtot]), pl), what
             # decisions may differ from the oracle's only on pixels inside its threshold guard band; the gradients of
             # every Gaussian such a pixel does not reach are held to the strict bar -- nothing is skipped
-            pix_risk, gauss_risk = Hh.oracle_risk(oracle, sc, r["fwd"], cams, crf_images=[f["color"] for f in r["fwd"]])
+            imgs = [r["hdr"]] if (dom == "hdr" and n_poses > 1) else [f["color"] for f in r["fwd"]]
+            pix_risk, gauss_risk = Hh.oracle_risk(oracle, sc, r["fwd"], cams, crf_images=imgs)
             for k, f in enumerate(r["fwd"]):
                 assert not ((u32(st["n_contrib"][k]) != u32(f["n_contrib"])) & ~pix_risk[k]).any(), what
             assert_image_close(g["hdr"], r["hdr"], what)
             assert_image_close(g["color"], r["ldr"], what)
             Hh.assert_grads_close(g, r, what=what, at_risk=gauss_risk, **SWEEP_BAR)
         else:
-            f, b = Hh.run_oracle(oracle, sc)
-            g = Hh.run_hip(sc, capacity=None if case % 2 else f["R"] + 1)
+            f, b = Hh.run_oracle(oracle, sc, radiance_activation=act)
+            g = Hh.run_hip(sc, capacity=None if case % 2 else f["R"] + 1, radiance_activation=act)
             st = g["state"]
             assert st["num_rendered"] == f["R"], what
             check_structure(st, f)
