@@ -26,7 +26,8 @@ def settings_from_scene(sc: S.Scene, device, cameras=None, hdr=False, blur_domai
                   camposes=torch.stack([c.campos for c in cameras]).to(device))
     rs = GaussianRasterizationSettings(
         image_height=cam.H, image_width=cam.W, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=sc.bg.to(device),
-        scale_modifier=1.0, viewmatrix=cam.viewmatrix.to(device), projmatrix=cam.projmatrix.to(device),
+        scale_modifier=float(getattr(sc, "scale_modifier", 1.0)), viewmatrix=cam.viewmatrix.to(device),
+        projmatrix=cam.projmatrix.to(device),
         sh_degree=sc.sh_degree, campos=cam.campos.to(device), prefiltered=False, debug=False,
         radiance_activation=radiance_activation, **kw)
     return rs, exposure, crf
@@ -81,7 +82,8 @@ def run_hip(sc: S.Scene, device="cuda", cameras=None, hdr=False, blur_domain="ld
 def oracle_camera(O, sc: S.Scene, cam=None, radiance_activation="relu_shift"):
     cam = cam or sc.camera
     return O.Camera(cam.W, cam.H, cam.tanfovx, cam.tanfovy, cam.viewmatrix.numpy(), cam.projmatrix.numpy(),
-                    cam.campos.numpy(), sc.bg.numpy(), 1.0, sc.sh_degree, radiance_activation=radiance_activation)
+                    cam.campos.numpy(), sc.bg.numpy(), float(getattr(sc, "scale_modifier", 1.0)), sc.sh_degree,
+                    radiance_activation=radiance_activation)
 
 
 def run_oracle(O, sc: S.Scene, cam=None, dL=None, backward=True, use_cov_precomp=None, use_colors_precomp=None,
@@ -222,7 +224,10 @@ def assert_grads_close(got: dict, ref: dict, keys=GRAD_KEYS, frac_tol=None, max_
             report[gk + tag] = (mx, frac, l2)
             # the fraction bound always admits two elements (tensors of a few dozen entries: P down to 1 in the sweep)
             frac_ok = frac <= max(b["frac_tol"], 2.0 / rr.size)
-            assert frac_ok and mx <= b["max_tol"] and l2 <= b["l2_tol"], (what, gk + tag, mx, frac, l2)
+            # ... and the L2 bar of a tensor of n elements is no tighter than 1e-4 / sqrt(n): for a handful of elements the
+            # relative L2 IS the relative error of single fp32 sums (n = 1: one Gaussian's gradient, hundreds of terms)
+            l2_ok = l2 <= max(b["l2_tol"], 1e-4 / np.sqrt(rr.size))
+            assert frac_ok and mx <= b["max_tol"] and l2_ok, (what, gk + tag, mx, frac, l2)
     return report
 
 

