@@ -29,7 +29,7 @@ def settings_from_scene(sc: S.Scene, device, cameras=None, hdr=False, blur_domai
         scale_modifier=float(getattr(sc, "scale_modifier", 1.0)), viewmatrix=cam.viewmatrix.to(device),
         projmatrix=cam.projmatrix.to(device),
         sh_degree=sc.sh_degree, campos=cam.campos.to(device), prefiltered=False, debug=False,
-        radiance_activation=radiance_activation, **kw)
+        antialiasing=bool(getattr(sc, "antialias", False)), radiance_activation=radiance_activation, **kw)
     return rs, exposure, crf
 
 
@@ -81,9 +81,11 @@ def run_hip(sc: S.Scene, device="cuda", cameras=None, hdr=False, blur_domain="ld
 
 def oracle_camera(O, sc: S.Scene, cam=None, radiance_activation="relu_shift"):
     cam = cam or sc.camera
-    return O.Camera(cam.W, cam.H, cam.tanfovx, cam.tanfovy, cam.viewmatrix.numpy(), cam.projmatrix.numpy(),
-                    cam.campos.numpy(), sc.bg.numpy(), float(getattr(sc, "scale_modifier", 1.0)), sc.sh_degree,
-                    radiance_activation=radiance_activation)
+    oc = O.Camera(cam.W, cam.H, cam.tanfovx, cam.tanfovy, cam.viewmatrix.numpy(), cam.projmatrix.numpy(),
+                  cam.campos.numpy(), sc.bg.numpy(), float(getattr(sc, "scale_modifier", 1.0)), sc.sh_degree,
+                  radiance_activation=radiance_activation)
+    oc.antialias = bool(getattr(sc, "antialias", False))
+    return oc
 
 
 def run_oracle(O, sc: S.Scene, cam=None, dL=None, backward=True, use_cov_precomp=None, use_colors_precomp=None,

@@ -895,7 +895,11 @@ def test_randomized_configurations_vs_oracle(oracle):
             sc.bg = torch.from_numpy(rng.random(3).astype(np.float32))     # background colour (default of the scenes: 0)
         if int(rng.integers(0, 3)) == 0:
             sc.scale_modifier = float(rng.uniform(0.5, 1.5))               # the published settings' global scale factor
-        what += f" bg={[round(float(v), 2) for v in sc.bg]} mod={getattr(sc, 'scale_modifier', 1.0):.2f}"
+        if int(rng.integers(0, 4)) == 0:
+            sc.antialias = True                                            # newer published rasterizer: opacity compensation
+        precomp = int(rng.integers(0, 5)) == 0                             # colours and 3D covariances handed in directly
+        what += (f" bg={[round(float(v), 2) for v in sc.bg]} mod={getattr(sc, 'scale_modifier', 1.0):.2f} "
+                 f"aa={getattr(sc, 'antialias', False)} precomp={precomp}")
         cams = S.blur_poses(W, H, n_poses, step=0.03) if n_poses > 1 else None
         if hdr or n_poses > 1:
             if not hdr:  # linear-radiance blur: the average of the per-pose oracle renders
@@ -925,8 +929,15 @@ def test_randomized_configurations_vs_oracle(oracle):
             assert_image_close(g["color"], r["ldr"], what)
             Hh.assert_grads_close(g, r, what=what, at_risk=gauss_risk, **SWEEP_BAR)
         else:
-            f, b = Hh.run_oracle(oracle, sc, radiance_activation=act)
-            g = Hh.run_hip(sc, capacity=None if case % 2 else f["R"] + 1, radiance_activation=act)
+            pre, keys = {}, Hh.GRAD_KEYS
+            if precomp:
+                f0 = Hh.run_oracle(oracle, sc, backward=False)[0]
+                pre = dict(use_colors_precomp=torch.from_numpy(rng.random((P, 3)).astype(np.float32)),
+                           use_cov_precomp=torch.from_numpy(f0["cov3D"].copy()))
+                keys = [("means3D", "dL_dmeans3D"), ("means2D", "dL_dmeans2D"), ("opacities", "dL_dopacity"),
+                        ("colors_precomp", "dL_dcolors_precomp"), ("cov3D_precomp", "dL_dcov3D")]
+            f, b = Hh.run_oracle(oracle, sc, radiance_activation=act, **pre)
+            g = Hh.run_hip(sc, capacity=None if case % 2 else f["R"] + 1, radiance_activation=act, **pre)
             st = g["state"]
             assert st["num_rendered"] == f["R"], what
             check_structure(st, f)
@@ -935,7 +946,7 @@ def test_randomized_configurations_vs_oracle(oracle):
             assert np.array_equal(u32(st["ranges"]), u32(f["ranges"])), what
             pix_risk, gauss_risk = Hh.oracle_risk(oracle, sc, [f])
             check_image(g["color"], f["color"], u32(st["n_contrib"][0]), u32(f["n_contrib"]), what, pix_risk[0])
-            Hh.assert_grads_close(g, b, what=what, at_risk=gauss_risk, **SWEEP_BAR)
+            Hh.assert_grads_close(g, b, keys=keys, what=what, at_risk=gauss_risk, **SWEEP_BAR)
 
 
 def test_c_abi_from_a_plain_cpp_host(tmp_path, oracle):
