@@ -79,6 +79,29 @@ def run_hip(sc: S.Scene, device="cuda", cameras=None, hdr=False, blur_domain="ld
     return res
 
 
+def make_wild(sc: S.Scene, rng) -> S.Scene:
+    """Perturbs a synthetic scene (whose Gaussians are all in view, sigma 0.5-8 px) into the cases a real one has:
+    Gaussians behind the camera or closer than the 0.2 cull distance, far outside the image, huge and minute ones,
+    fully transparent and fully opaque ones, and exact duplicates (equal depth keys: the stable sort order decides)."""
+    P = sc.means3D.shape[0]
+    if P < 8:
+        return sc
+    pick = lambda frac: torch.from_numpy(rng.random(P) < frac)
+    m = pick(0.08); sc.means3D[m, 2] = -sc.means3D[m, 2]                       # behind the camera
+    m = pick(0.05); sc.means3D[m, 2] = torch.from_numpy(rng.uniform(0.0, 0.25, int(m.sum())).astype(np.float32))
+    m = pick(0.08); sc.means3D[m, 0] *= float(rng.uniform(3.0, 20.0))          # far off to the side
+    m = pick(0.08); sc.scales[m] *= float(rng.uniform(10.0, 40.0))             # covers a large part of the image
+    m = pick(0.08); sc.scales[m] *= 0.01                                        # far below a pixel
+    m = pick(0.05); sc.opacities[m] = 0.0
+    m = pick(0.05); sc.opacities[m] = 1.0
+    m = pick(0.10)
+    src = torch.from_numpy(rng.integers(0, P, P))
+    for name in ("means3D", "scales", "rotations"):                            # duplicates: same geometry, own colour
+        t = getattr(sc, name)
+        t[m] = t[src[m]]
+    return sc
+
+
 def oracle_camera(O, sc: S.Scene, cam=None, radiance_activation="relu_shift"):
     cam = cam or sc.camera
     oc = O.Camera(cam.W, cam.H, cam.tanfovx, cam.tanfovy, cam.viewmatrix.numpy(), cam.projmatrix.numpy(),

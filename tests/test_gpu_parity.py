@@ -895,11 +895,14 @@ def test_randomized_configurations_vs_oracle(oracle):
             sc.bg = torch.from_numpy(rng.random(3).astype(np.float32))     # background colour (default of the scenes: 0)
         if int(rng.integers(0, 3)) == 0:
             sc.scale_modifier = float(rng.uniform(0.5, 1.5))               # the published settings' global scale factor
+        wild = int(rng.integers(0, 3)) == 0
+        if wild:
+            sc = Hh.make_wild(sc, rng)
         if int(rng.integers(0, 4)) == 0:
             sc.antialias = True                                            # newer published rasterizer: opacity compensation
         precomp = int(rng.integers(0, 5)) == 0                             # colours and 3D covariances handed in directly
         what += (f" bg={[round(float(v), 2) for v in sc.bg]} mod={getattr(sc, 'scale_modifier', 1.0):.2f} "
-                 f"aa={getattr(sc, 'antialias', False)} precomp={precomp}")
+                 f"aa={getattr(sc, 'antialias', False)} precomp={precomp} wild={wild}")
         cams = S.blur_poses(W, H, n_poses, step=0.03) if n_poses > 1 else None
         if hdr or n_poses > 1:
             if not hdr:  # linear-radiance blur: the average of the per-pose oracle renders
