@@ -1,0 +1,30 @@
+"""Development aid (GPU box): a c2-sized 'wild' scene (tests/helpers.make_wild) against the C oracle."""
+import os, sys, time
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import helpers as Hh
+from casualhdrsplat_amd import synthetic as S
+from oracle import c_oracle as O
+u32 = lambda a: np.asarray(a).view(np.uint32) if np.asarray(a).dtype != np.uint32 else np.asarray(a)
+for seed, deg, hdr in ((1, 3, False), (2, 1, True)):
+    rng = np.random.default_rng(seed)
+    sc = Hh.make_wild(S.make_scene(100_000, 800, 800, deg, seed=seed, hdr=hdr), rng)
+    t0 = time.time()
+    if hdr:
+        r = Hh.run_oracle_hdr(O, sc); f = r["fwd"][0]; ref = r
+    else:
+        f, ref = Hh.run_oracle(O, sc)
+    t1 = time.time()
+    g = Hh.run_hip(sc, hdr=hdr)
+    st = g["state"]
+    assert st["num_rendered"] == f["R"]
+    assert np.array_equal(u32(st["point_list"][:f["R"]]), u32(f["point_list"])) and np.array_equal(u32(st["ranges"]), u32(f["ranges"]))
+    assert np.array_equal(g["radii"], f["radii"])
+    pix_risk, gauss_risk = Hh.oracle_risk(O, sc, [f], crf_images=[f["color"]] if hdr else None)
+    flips = (u32(st["n_contrib"][0]) != u32(f["n_contrib"]))
+    assert not (flips & ~pix_risk[0]).any()
+    rep = Hh.assert_grads_close(g, ref, at_risk=gauss_risk, what=f"wild c2 seed {seed}")
+    print(f"seed {seed} deg {deg} hdr {hdr}: R={f['R']} max tiles/G {int(f['tiles_touched'].max())} visible {int((f['radii']>0).sum())} "
+          f"flips {int(flips.sum())} risky px {int(pix_risk.sum())} at-risk G {int(gauss_risk.sum())} oracle {t1-t0:.1f}s")
+    print("   ", {k: tuple(float('%.2g' % x) for x in v) for k, v in rep.items()})
