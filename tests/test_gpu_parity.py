@@ -898,11 +898,14 @@ def test_randomized_configurations_vs_oracle(oracle):
         wild = int(rng.integers(0, 3)) == 0
         if wild:
             sc = Hh.make_wild(sc, rng)
+        deep = int(rng.integers(0, 4)) == 0
+        if deep:
+            sc.opacities *= float(rng.uniform(0.02, 0.1))   # faint layers: long contributor lists, no early termination
         if int(rng.integers(0, 4)) == 0:
             sc.antialias = True                                            # newer published rasterizer: opacity compensation
         precomp = int(rng.integers(0, 5)) == 0                             # colours and 3D covariances handed in directly
         what += (f" bg={[round(float(v), 2) for v in sc.bg]} mod={getattr(sc, 'scale_modifier', 1.0):.2f} "
-                 f"aa={getattr(sc, 'antialias', False)} precomp={precomp} wild={wild}")
+                 f"aa={getattr(sc, 'antialias', False)} precomp={precomp} wild={wild} deep={deep}")
         cams = S.blur_poses(W, H, n_poses, step=0.03) if n_poses > 1 else None
         if hdr or n_poses > 1:
             if not hdr:  # linear-radiance blur: the average of the per-pose oracle renders
