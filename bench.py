@@ -204,9 +204,11 @@ def _cpu_full_frame(cfg, seed=0):
 
 
 def cpu_baseline(sc, cfg, n_tiles_sample=96, with_c2=False):
-    """Pure-PyTorch CPU autograd rasterizer: c1 in full (median of 5); `value` = the c3
-    frame on a bounded sample (full preprocess + binning of the frame, then forward+backward of every k-th tile,
-    extrapolated to images/s of the whole frame); c2 in full only with --cpu-c2 (it takes 2.5 minutes on the 128
+    """CPU baseline of the bench configuration.  `value` = the C oracle (one thread) on the whole frame
+    (_c_oracle_frame); `torch_port` = the pure-PyTorch CPU autograd rasterizer of BASELINE.md section 3 on a bounded
+    sample of the same frame (full preprocess + binning, then forward+backward of every k-th tile, extrapolated to
+    images/s of the whole frame) -- 17x slower on 128 cores than the C oracle on one; c1 in full with the PyTorch
+    rasterizer (median of 5); c2 in full only with --cpu-c2 (it takes 2.5 minutes on the 128
     host cores of the MI355X box -- profiles/ holds that run -- and the default run must stay short)."""
     import torch
     from oracle import torch_rasterizer as TR
@@ -240,15 +242,49 @@ def cpu_baseline(sc, cfg, n_tiles_sample=96, with_c2=False):
         out["c2_full"] = {"images_per_s": 1.0 / t, "seconds": t, "workload": "100k Gaussians, 800x800, SH 0, LDR, fwd+bwd, whole frame"}
     else:
         out["c2_full"] = {"skipped": "run with --cpu-c2 (about 150 s of CPU time); last measured: profiles/r02_cpu_baseline_c2.json"}
-    out.update({
+    torch_port = {
         "value": 1.0 / t_full, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-        "host_cpus": os.cpu_count(),
         "sample": (f"pure-PyTorch fp32 autograd rasterizer (oracle/torch_rasterizer.py): full preprocess+binning of "
                    f"the {P}-Gaussian {W}x{H} frame ({t_pre:.1f} s) + fwd+bwd of {len(tiles)} of {ntiles} tiles "
                    f"({t_tiles:.1f} s, backward also covers preprocess); value extrapolates the tile part to all tiles"),
-        "measured_seconds": time.time() - t_start,
-    })
+    }
+    c_port = _c_oracle_frame(sc, cfg) if n_poses == 1 else None
+    if c_port is not None:
+        # the faster of the two CPU restatements is the baseline: the C oracle on ONE core renders the frame in a
+        # fraction of the time the PyTorch rasterizer needs on all of them
+        out.update(c_port)
+        out["torch_port"] = torch_port
+    else:
+        out.update(torch_port)
+    out["host_cpus"] = os.cpu_count()
+    out["measured_seconds"] = time.time() - t_start
     return out
+
+
+def _c_oracle_frame(sc, cfg):
+    """The C restatement (oracle/hs_oracle.c, single thread) on the WHOLE frame of the bench configuration: preprocess,
+    binning, render forward, tone-map forward/backward (HDR configs) and the full backward -- the same work as one GPU
+    step.  About half a minute at c3."""
+    import numpy as np
+    from oracle import c_oracle as O
+    P, W, H, deg, hdr, n_poses = cfg
+    cam = sc.camera
+    ocam = O.Camera(W, H, cam.tanfovx, cam.tanfovy, cam.viewmatrix.numpy(), cam.projmatrix.numpy(), cam.campos.numpy(),
+                    sc.bg.numpy(), 1.0, deg)
+    kw = dict(shs=sc.shs.numpy(), scales=sc.scales.numpy(), rotations=sc.rotations.numpy())
+    means, opac, dL = sc.means3D.numpy(), sc.opacities.numpy(), sc.dL_dimage.numpy()
+    t0 = time.time()
+    f = O.forward(ocam, means, opac, **kw)
+    if hdr:
+        dt, tab, (umin, umax) = float(sc.exposure), sc.crf_table.numpy(), sc.crf_range
+        O.tonemap_fwd(f["color"], dt, tab, umin, umax)
+        dL = O.tonemap_bwd(f["color"], dt, tab, umin, umax, dL)[0]
+    O.backward(ocam, f, np.ascontiguousarray(dL, dtype=np.float32), means, **kw)
+    t = time.time() - t0
+    return {"value": 1.0 / t, "unit": "images/s", "cores": 1, "kind": "port",
+            "sample": (f"C oracle (oracle/hs_oracle.c, one thread), the whole {P}-Gaussian {W}x{H} frame: preprocess + "
+                       f"binning + render forward + {'tone-map + ' if hdr else ''}full backward in {t:.1f} s "
+                       f"(R = {int(f['R'])} pairs) -- no sampling, no extrapolation")}
 
 
 def isa_counts():
