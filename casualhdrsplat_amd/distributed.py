@@ -37,9 +37,19 @@ def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        kw = {}
         if backend == "nccl":
-            torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            dev_index = local % max(torch.cuda.device_count(), 1)
+            torch.cuda.set_device(dev_index)
+            kw["device_id"] = torch.device("cuda", dev_index)   # binds the communicator to this rank's GPU up front
+        # a collective that one rank never enters must end the job, not hang it (HS_DIST_TIMEOUT_S, default 5 minutes)
+        import datetime
+        kw["timeout"] = datetime.timedelta(seconds=float(os.environ.get("HS_DIST_TIMEOUT_S", "300")))
+        try:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+        except TypeError:  # a torch without `device_id`
+            kw.pop("device_id", None)
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, world, local
 
 
