@@ -292,6 +292,225 @@ __global__ void __launch_bounds__(kSortBlock) radix_scatter_kernel(const K* keys
     }
 }
 
+// ---------------------------------------------------------------- single-sweep radix passes
+// One kernel per pass instead of histogram + scan + scatter: the digit totals of ALL passes are counted once, up front
+// (they do not depend on the order of the keys), and a block learns how many keys with its digit lie in EARLIER blocks
+// by decoupled look-back over a status array -- every block publishes the per-digit counts of its 4096 keys as soon as
+// it has ranked them (flag 1 = "my count"), walks back over its predecessors adding their words until it meets one
+// flagged 2 = "inclusive prefix up to and including me", then publishes its own inclusive prefix.  Count and flag share
+// one 32-bit word (2 + 30 bits), written and read with agent-scope atomics, so no ordering between separate words
+// is needed (and no fence: a __threadfence() writes back the XCD's whole L2).  Progress: workgroups are dispatched
+// in blockIdx order on every XCD, so the lowest unfinished block is always resident, and a block waits only for words
+// that its predecessors publish before they themselves wait.
+// Measured alternatives (c3 tile sort, us per pass; the three-kernel pass: 76): this walk with 8 words in flight 42,
+// with 16 / 32 in flight 48 / 55; group sums (one word per 32 blocks and digit, filled by returning atomics, plus a
+// member counter) instead of inclusive prefixes 85.
+constexpr int kLook = 8;
+constexpr uint32_t kStAgg = 1u << 30, kStIncl = 2u << 30, kStMask = (1u << 30) - 1u;
+
+__device__ __forceinline__ void st_publish(uint32_t* p, uint32_t v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint32_t st_read(const uint32_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// words of one pass: one per (block, digit)
+__host__ __device__ __forceinline__ int64_t sweep_pass_words(int64_t nblk) { return nblk * 256; }
+
+// The digit totals are kept in kGhistCopies copies (a block adds to copy blockIdx % kGhistCopies, readers sum them): a few
+// thousand blocks adding to the same 256 words one after the other is a serial chain of same-address atomics.
+constexpr int kGhistCopies = 16;
+constexpr int kGhistWords = kGhistCopies * 8 * 256;   // [copy][pass <= 8][digit]
+
+// Digit totals of every pass: ghist[pass * 256 + digit].  One 4096-key tile per workgroup.
+template <typename K>
+__global__ void __launch_bounds__(kHistThreads) radix_ghist_kernel(const K* keys, const uint32_t* n_dev, int nbits,
+                                                                   int passes, uint32_t* ghist) {
+    __shared__ uint32_t s_hist[8 * 256];
+    const int64_t n = *n_dev;
+    const int64_t base = (int64_t)blockIdx.x * kSortTile;
+    if (base >= n) return;
+    for (int i = threadIdx.x; i < passes * 256; i += kHistThreads) s_hist[i] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < kSortTile / kHistThreads; ++i) {
+        const int64_t k = base + i * kHistThreads + threadIdx.x;
+        const bool valid = k < n;
+        const K key = valid ? keys[k] : (K)0;
+        const uint64_t vm = __ballot(valid);
+        int pass = 0;
+        for (int shift = 0, w = 0; shift < nbits; shift += w, ++pass) {
+            w = (nbits - shift + (passes - pass) - 1) / (passes - pass);
+            const uint32_t d = digit_of<K>(key, shift, (1u << w) - 1u);
+            // (nearly) constant digits -- exponent bits of depth, high tile bits -- would serialise the wave's LDS
+            // atomics on one bin: when the whole wave agrees, one lane adds the count
+            const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
+            if (__ballot(valid && d != d0) == 0ull) {
+                if ((threadIdx.x & 63) == 0 && vm) atomicAdd(&s_hist[pass * 256 + d0], (uint32_t)__popcll(vm));
+            } else if (valid) {
+                atomicAdd(&s_hist[pass * 256 + d], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t* mine = ghist + (blockIdx.x % kGhistCopies) * (8 * 256);
+    for (int i = threadIdx.x; i < passes * 256; i += kHistThreads) {
+        const uint32_t c = s_hist[i];
+        if (c) atomicAdd(&mine[i], c);
+    }
+}
+
+// One pass: rank the block's keys (stable: wave w owns keys [w*1024, (w+1)*1024), 16 rounds of 64 consecutive keys),
+// publish / look back, reorder through LDS, write each digit's run contiguously.
+template <typename K>
+__global__ void __launch_bounds__(kSortBlock) radix_sweep_kernel(const K* keys_in, const uint32_t* vals_in, K* keys_out,
+                                                                 uint32_t* vals_out, const uint32_t* n_dev, int shift,
+                                                                 uint32_t mask, uint32_t* status, const uint32_t* ghist) {
+    __shared__ uint32_t s_cnt[4][256];    // per-wave digit counters -> per-wave exclusive offsets
+    __shared__ uint32_t s_dstart[256];    // block-local start of each digit's run
+    __shared__ uint32_t s_gbase[256];     // global start of this block's run of each digit
+    __shared__ K s_keys[kSortTile];
+    __shared__ uint32_t s_vals[kSortTile];
+    __shared__ uint32_t s_wave[4];
+
+    const int64_t n = *n_dev;
+    const int64_t base = (int64_t)blockIdx.x * kSortTile;
+    if (base >= n) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cnt_block = (int)min((int64_t)kSortTile, n - base);
+    uint32_t* const my_status = status + (int64_t)blockIdx.x * 256 + threadIdx.x;
+
+#pragma unroll
+    for (int w = 0; w < 4; ++w) s_cnt[w][threadIdx.x] = 0;
+    uint32_t digit_base;   // keys of the whole array with a smaller digit
+    {
+        uint32_t tot = 0;
+#pragma unroll
+        for (int c = 0; c < kGhistCopies; ++c) tot += ghist[c * (8 * 256) + threadIdx.x];
+        uint32_t all;
+        digit_base = block_incl_scan(tot, s_wave, &all) - tot;   // (contains the barrier that orders the clears above)
+    }
+
+    K key[kSortItems];
+    uint32_t val[kSortItems];
+    uint16_t rank[kSortItems];
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    const int wbase = wave * (kSortTile / 4);
+#pragma unroll
+    for (int i = 0; i < kSortItems; ++i) {
+        const int loc = wbase + i * 64 + lane;
+        const bool valid = loc < cnt_block;
+        key[i] = valid ? keys_in[base + loc] : (K) ~(K)0;
+        val[i] = valid ? vals_in[base + loc] : 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < kSortItems; ++i) {
+        const int loc = wbase + i * 64 + lane;
+        const bool valid = loc < cnt_block;
+        const uint32_t d = digit_of<K>(key[i], shift, mask);
+        uint64_t peers = __ballot(valid);   // match-any: lanes holding the same digit
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const uint64_t m = __ballot((d >> b) & 1u);
+            peers &= ((d >> b) & 1u) ? m : ~m;
+        }
+        const uint32_t before = s_cnt[wave][d];
+        const uint32_t below = __popcll(peers & lt_mask);
+        rank[i] = (uint16_t)(before + below);
+        // the last peer publishes the new count (all peers read `before` first: same wave, in-order LDS)
+        if (valid && (peers >> lane) == 1ull) s_cnt[wave][d] = before + below + 1;
+    }
+    __syncthreads();
+    uint32_t my_tot;
+    {   // per digit: the block's count goes out first, then the offsets over waves and the block-local run starts
+        const uint32_t c0 = s_cnt[0][threadIdx.x], c1 = s_cnt[1][threadIdx.x], c2 = s_cnt[2][threadIdx.x],
+                       c3 = s_cnt[3][threadIdx.x];
+        my_tot = c0 + c1 + c2 + c3;
+        st_publish(my_status, (blockIdx.x == 0 ? kStIncl : kStAgg) | my_tot);
+        s_cnt[0][threadIdx.x] = 0; s_cnt[1][threadIdx.x] = c0; s_cnt[2][threadIdx.x] = c0 + c1;
+        s_cnt[3][threadIdx.x] = c0 + c1 + c2;
+        uint32_t total;
+        const uint32_t incl = block_incl_scan(my_tot, s_wave, &total);
+        s_dstart[threadIdx.x] = incl - my_tot;
+    }
+    __syncthreads();
+    // reorder through LDS while the predecessors' words arrive
+#pragma unroll
+    for (int i = 0; i < kSortItems; ++i) {
+        const int loc = wbase + i * 64 + lane;
+        if (loc < cnt_block) {
+            const uint32_t d = digit_of<K>(key[i], shift, mask);
+            const uint32_t pos = s_dstart[d] + s_cnt[wave][d] + rank[i];
+            s_keys[pos] = key[i];
+            s_vals[pos] = val[i];
+        }
+    }
+    {   // look-back: keys with this thread's digit in earlier blocks (kLook words requested at once: the walk is bound
+        // by the latency of these uncached loads -- with hundreds of blocks ranking at the same time the nearest
+        // inclusive prefix is far behind)
+        uint32_t excl = 0;
+        bool done = threadIdx.x > mask;   // a digit no key of this pass can have: nothing to look up
+        for (int p = (int)blockIdx.x - 1; p >= 0 && !done; p -= kLook) {
+            uint32_t v[kLook];
+#pragma unroll
+            for (int j = 0; j < kLook; ++j)
+                v[j] = p - j >= 0 ? st_read(status + (int64_t)(p - j) * 256 + threadIdx.x) : kStIncl;
+#pragma unroll
+            for (int j = 0; j < kLook; ++j) {
+                if (done) break;
+                uint32_t x = v[j];
+                while ((x & ~kStMask) == 0u) {
+                    __builtin_amdgcn_s_sleep(1);
+                    x = st_read(status + (int64_t)(p - j) * 256 + threadIdx.x);
+                }
+                excl += x & kStMask;
+                done = (x & ~kStMask) == kStIncl;
+            }
+        }
+        if (blockIdx.x != 0) st_publish(my_status, kStIncl | (excl + my_tot));
+        s_gbase[threadIdx.x] = digit_base + excl;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int i = 0; i < kSortItems; ++i) {
+        const int pos = i * kSortBlock + threadIdx.x;
+        if (pos < cnt_block) {
+            const K k = s_keys[pos];
+            const uint32_t d = digit_of<K>(k, shift, mask);
+            const int64_t dst = (int64_t)s_gbase[d] + (pos - s_dstart[d]);
+            keys_out[dst] = k;
+            vals_out[dst] = s_vals[pos];
+        }
+    }
+}
+
+// `tmp`: sort_tmp_bytes(n_launch).  `ghist_ready`: the caller has already zeroed `tmp` and filled the digit totals.
+template <typename K>
+int radix_sort_sweep(K* k0, uint32_t* v0, K* k1, uint32_t* v1, const uint32_t* n_dev, int64_t n_launch, int nbits,
+                     void* tmp, hipStream_t s, bool ghist_ready = false) {
+    if (n_launch <= 0) return HS_OK;
+    const int nblk = ceil_div(n_launch, kSortTile);
+    const int passes = sort_passes(nbits);
+    uint32_t* ghist = (uint32_t*)tmp;                                   // [kGhistCopies][8][256]
+    uint32_t* status = ghist + kGhistWords;                             // [passes][sweep_pass_words(nblk)]
+    const int64_t pw = sweep_pass_words(nblk);
+    if (!ghist_ready) {
+        HS_HIP_CHECK(hipMemsetAsync(tmp, 0, ((size_t)kGhistWords + (size_t)passes * pw) * 4, s));
+        radix_ghist_kernel<K><<<nblk, kHistThreads, 0, s>>>(k0, n_dev, nbits, passes, ghist);
+    }
+    K* kin = k0; uint32_t* vin = v0; K* kout = k1; uint32_t* vout = v1;
+    int pass = 0;
+    for (int shift = 0, w = 0; shift < nbits; shift += w, ++pass) {
+        w = (nbits - shift + (passes - pass) - 1) / (passes - pass);
+        radix_sweep_kernel<K><<<nblk, kSortBlock, 0, s>>>(kin, vin, kout, vout, n_dev, shift, (1u << w) - 1u,
+                                                          status + (int64_t)pass * pw, ghist + 256 * pass);
+        HS_LAUNCH_CHECK();
+        K* tk = kin; kin = kout; kout = tk;
+        uint32_t* tv = vin; vin = vout; vout = tv;
+    }
+    return HS_OK;
+}
+
 template <typename K>
 int radix_sort(K* k0, uint32_t* v0, K* k1, uint32_t* v1, const uint32_t* n_dev, int64_t n_launch, int nbits,
                void* tmp, hipStream_t s) {
@@ -331,8 +550,10 @@ __global__ void __launch_bounds__(256) depth_keys_kernel(int64_t I, const float*
 // Tile rectangles and pair counts of the instances, gathered into depth order (one 8-byte gather per instance;
 // everything the emission needs afterwards is read coalesced).
 __global__ void __launch_bounds__(256) gather_binfo_kernel(int64_t I, const uint32_t* inst_sorted, const uint2* binfo,
-                                                           uint2* srect, uint32_t* ts) {
+                                                           uint2* srect, uint32_t* ts, uint32_t* zero, int64_t n_zero) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    // digit totals and status words of the tile sort that follows the emission (radix_sort_sweep): cleared here
+    for (int64_t t = i; t < n_zero; t += (int64_t)gridDim.x * 256) zero[t] = 0u;
     if (i >= I) return;
     const uint2 b = binfo[inst_sorted[i]];
     srect[i] = b;
@@ -351,7 +572,9 @@ __global__ void __launch_bounds__(256) emit_pairs_kernel(int64_t I, int P, int g
                                                          const uint32_t* inst_sorted, const uint32_t* block_excl,
                                                          uint32_t* offs_sorted,
                                                          const uint2* srect, uint32_t* tile_keys, uint32_t* vals,
-                                                         uint8_t* pair_flags, hs_counters* counters, uint64_t capacity) {
+                                                         uint8_t* pair_flags, hs_counters* counters, uint64_t capacity,
+                                                         uint32_t* ghist, int nbits, int passes) {
+    __shared__ uint32_t s_hist[4 * 256];   // digit totals of the tile sort's passes (<= 4), this block's pairs
     __shared__ uint32_t s_beg[4][64];
     __shared__ uint2 s_rect[4][64];
     __shared__ uint32_t s_inst[4][64];
@@ -360,6 +583,7 @@ __global__ void __launch_bounds__(256) emit_pairs_kernel(int64_t I, int P, int g
     // overflowing call emits nothing, sorts nothing (n_sort = 0) and renders empty; the host sees counters.overflow
     // and replays with a larger capacity.  One thread publishes the verdict for the later kernels.
     const bool overflow = (uint64_t)counters->num_rendered > capacity;
+    for (int t = threadIdx.x; t < passes * 256; t += 256) s_hist[t] = 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         counters->overflow = overflow ? 1u : 0u;
         counters->reserved[0] = overflow ? 0u : counters->num_rendered;
@@ -402,9 +626,30 @@ __global__ void __launch_bounds__(256) emit_pairs_kernel(int64_t I, int P, int g
         const uint32_t ty = t / w, tx = t - ty * w;
         const uint32_t idx = s_inst[wave][k];
         const uint32_t tile_base = (idx / (uint32_t)P) * (uint32_t)(gx * gy);
-        tile_keys[pos] = tile_base + ((r.x >> 16) + ty) * (uint32_t)gx + (r.x & 0xFFFFu) + tx;
+        const uint32_t key = tile_base + ((r.x >> 16) + ty) * (uint32_t)gx + (r.x & 0xFFFFu) + tx;
+        tile_keys[pos] = key;
         vals[pos] = idx;
         pair_flags[pos] = 0;  // "gradient record written" flag of this slot, set by the render backward
+        // digit totals for the single-sweep tile sort (same digit layout as radix_sort_sweep).  The lanes of a wave hold
+        // neighbouring tiles of a few Gaussians: when they all agree on a digit, one lane adds the count
+        int pass = 0;
+        for (int shift = 0, w = 0; shift < nbits; shift += w, ++pass) {
+            w = (nbits - shift + (passes - pass) - 1) / (passes - pass);
+            const uint32_t dgt = (key >> shift) & ((1u << w) - 1u);
+            const uint32_t d0 = __builtin_amdgcn_readfirstlane(dgt);
+            const uint64_t act = __ballot(true);
+            if (__ballot(dgt != d0) == 0ull) {
+                if (lane == (int)__builtin_ctzll(act)) atomicAdd(&s_hist[pass * 256 + d0], (uint32_t)__popcll(act));
+            } else {
+                atomicAdd(&s_hist[pass * 256 + dgt], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t* mine = ghist + (blockIdx.x % kGhistCopies) * (8 * 256);
+    for (int t = threadIdx.x; t < passes * 256; t += 256) {
+        const uint32_t c = s_hist[t];
+        if (c) atomicAdd(&mine[t], c);
     }
 }
 
@@ -429,12 +674,20 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(const uint32_t* tiles,
 
 int64_t sort_tmp_bytes(int64_t n) {
     const int64_t nblk = ceil_div(n > 0 ? n : 1, kSortTile);
-    return align_up(256 * nblk * 4, 256) + 8 * 256 * 4;
+    // digit totals of up to 8 passes + one status word per (pass, block, digit); the classic three-kernel passes
+    // (HS_EXP_SORT_CLASSIC) need a 256 x nblk histogram + totals, which fits in the same space
+    return kGhistWords * 4 + align_up(8 * sweep_pass_words(nblk) * 4, 256);
 }
+
+#ifdef HS_EXP_SORT_CLASSIC
+#define HS_RADIX_SORT radix_sort
+#else
+#define HS_RADIX_SORT radix_sort_sweep
+#endif
 
 int launch_radix_sort(uint64_t* k0, uint32_t* v0, uint64_t* k1, uint32_t* v1, const uint32_t* n_dev,
                       int64_t n_launch, int nbits, void* tmp, hipStream_t s) {
-    return radix_sort<uint64_t>(k0, v0, k1, v1, n_dev, n_launch, nbits, tmp, s);
+    return HS_RADIX_SORT<uint64_t>(k0, v0, k1, v1, n_dev, n_launch, nbits, tmp, s);
 }
 
 // a5 in instance order, as the published pipeline lays it out: offsets[i] = sum_{j<=i} tiles_touched[j], total =
@@ -474,6 +727,8 @@ int launch_binning(const hs_fwd_args& a, const hs_layout& L, hipStream_t s) {
     if (!prepared)
         depth_keys_kernel<<<ceil_div(I, 256), 256, 0, s>>>(I, (const float*)(geom + L.depth), (const int*)(geom + L.radii),
                                                            dk0, dv0);
+    // (three-kernel passes here: with only I / 4096 blocks per pass the look-back of a single-sweep pass costs as much
+    // as the histogram and scan kernels it replaces -- measured 4 x 19 + 12 us against 4 x 22)
     int rc = radix_sort<uint32_t>(dk0, dv0, dk1, dv1, n_inst, I, 32, tmp, s);
     if (rc != HS_OK) return rc;
     const uint32_t* inst_sorted = dv0;
@@ -481,15 +736,19 @@ int launch_binning(const hs_fwd_args& a, const hs_layout& L, hipStream_t s) {
     uint32_t* ts = dk1;      // tiles touched in depth order (reuses the depth-key scratch)
     uint32_t* offs = dv1;    // inclusive scan of ts
     uint2* srect = (uint2*)(bin + L.srect);
-    gather_binfo_kernel<<<ceil_div(I, 256), 256, 0, s>>>(I, inst_sorted, (const uint2*)(geom + L.binfo), srect, ts);
+    // the tile sort below runs single-sweep passes: its digit totals are counted by the emission, its scratch (totals +
+    // status words) is cleared by this gather
+    const int tbits = tile_bits((uint32_t)ntiles);
+    const int passes = sort_passes(tbits);
+    const int64_t n_zero = d.capacity > 0 ? kGhistWords + (int64_t)passes * sweep_pass_words(ceil_div(d.capacity, kSortTile)) : 0;
+    gather_binfo_kernel<<<ceil_div(I, 256), 256, 0, s>>>(I, inst_sorted, (const uint2*)(geom + L.binfo), srect, ts,
+                                                         (uint32_t*)tmp, n_zero);
     // pair offsets in depth order: block sums + their exclusive scan here, the rest inside the emission
     uint32_t* spine = (uint32_t*)(geom + L.scan_spine);
     const int eblk = ceil_div(I, 256);
     scan_reduce256_kernel<<<eblk, 256, 0, s>>>(ts, I, spine);
     scan_spine_kernel<<<1, 256, 0, s>>>(spine, eblk, &counters->num_rendered);  // total = R
     // the tile sort must end in (keys_sorted, point_list): start from A when the pass count is even
-    const int tbits = tile_bits((uint32_t)ntiles);
-    const int passes = sort_passes(tbits);
     uint32_t* kA = (uint32_t*)(bin + L.keys_sorted);
     uint32_t* vA = (uint32_t*)(bin + L.point_list);
     uint32_t* kB = (uint32_t*)(bin + L.keys_unsorted);
@@ -499,10 +758,15 @@ int launch_binning(const hs_fwd_args& a, const hs_layout& L, hipStream_t s) {
     uint32_t* k1 = (passes % 2 == 0) ? kB : kA;
     uint32_t* v1 = (passes % 2 == 0) ? vB : vA;
     emit_pairs_kernel<<<eblk, 256, 0, s>>>(I, d.P, gx, gy, (float4*)(geom + L.rec), inst_sorted, spine, offs, srect,
-                                           k0, v0, (uint8_t*)(bin + L.pair_flags), counters, (uint64_t)d.capacity);
+                                           k0, v0, (uint8_t*)(bin + L.pair_flags), counters, (uint64_t)d.capacity,
+                                           (uint32_t*)tmp, tbits, passes);
     HS_LAUNCH_CHECK();
     // 3. stable sort by tile id only
+#ifdef HS_EXP_SORT_CLASSIC
     rc = radix_sort<uint32_t>(k0, v0, k1, v1, n_sort, d.capacity, tbits, tmp, s);
+#else
+    rc = radix_sort_sweep<uint32_t>(k0, v0, k1, v1, n_sort, d.capacity, tbits, tmp, s, /*ghist_ready=*/true);
+#endif
     if (rc != HS_OK) return rc;
     if (d.capacity > 0) {
         tile_ranges_kernel<<<ceil_div(d.capacity, 256), 256, 0, s>>>(kA, n_sort, ranges);
