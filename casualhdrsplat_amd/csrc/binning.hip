@@ -137,7 +137,7 @@ int scan_u32(const uint32_t* in, int64_t n, uint32_t* spine, uint32_t* out, uint
 __global__ void __launch_bounds__(256) bin_prepare_kernel(hs_counters* c, uint32_t n_inst, uint2* ranges, int64_t ntiles) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < ntiles) ranges[i] = make_uint2(0u, 0u);
-    if (i == 0) c->reserved[1] = n_inst;
+    if (i == 0) { c->reserved[1] = n_inst; c->reserved[2] = 0u; c->reserved[3] = 0u; }
 }
 
 // ---------------------------------------------------------------- radix sort passes (a7)

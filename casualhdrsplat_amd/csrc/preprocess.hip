@@ -296,7 +296,10 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreFwd p) {
     }  // g < P
     if (p.depth_keys) {
         for (int64_t t = lin; t < p.n_vtiles; t += (int64_t)gridDim.x * 256) p.ranges[t] = make_uint2(0u, 0u);
-        if (lin == 0) p.counters->reserved[1] = (uint32_t)((int64_t)p.P * p.N);
+        if (lin == 0) {
+            p.counters->reserved[1] = (uint32_t)((int64_t)p.P * p.N);
+            p.counters->reserved[2] = 0u; p.counters->reserved[3] = 0u;   // tile-queue counters of the render kernels
+        }
     }
 }
 

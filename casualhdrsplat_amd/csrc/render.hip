@@ -566,6 +566,7 @@ struct RenderBwd {
     unsigned long long* stats;     // STATS instantiations only
     unsigned long long* timeline;  // STATS instantiations only, may be null: {start, end (100 MHz clock), XCC | CU ids}
                                    // per workgroup
+    uint32_t* queue;               // counter of the tail queue (zeroed by the forward's first kernel, then self-resetting)
 };
 
 // Upstream gradient w.r.t. this pose's radiance H_ch at one pixel (the HDR prologue).
@@ -664,6 +665,7 @@ __device__ __forceinline__ void step_bwd_pair(PairB& s, bool act0, bool act1, f2
 #ifndef HS_EXP_ENTF
 #define HS_EXP_ENTF 24
 #endif
+constexpr int kTailPct = 8;           // share of the tiles handed out by the queue (see the kernel)
 constexpr int kEntF = HS_EXP_ENTF;    // floats per LDS entry record (22 used): 96 bytes keeps every record 16-byte
 constexpr int kEntB = kEntF * 4;      // aligned (measured on one box: 88-byte records, i.e. split ds_read_b128, +5 %)
 constexpr int kAccF = 12;             // first float of the sums
@@ -688,7 +690,30 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
     __shared__ uint16_t s_rlist[2][kBatch];
 #endif
 
-    const int vt = xcd_strip_tile(blockIdx.x, gridDim.x, p.gx);
+    // The last kTailPct per cent of the tiles are not bound to a workgroup (hence, through blockIdx, to an XCD): the
+    // workgroups behind the static part take them from a queue, one after the other, until it is empty, so an XCD that
+    // runs faster (the eight dies of a package finish equal work up to 8 % apart, and which ones are slow differs from
+    // package to package) takes more of them.  The counter resets itself: the n_tail workers make n_tail successful
+    // fetches in total and one failing fetch each, and the very last of those 2 n_tail fetches writes the zero back.
+    // Measured at c3: -3 % on this kernel at 8 %, the same at 4 and 12 %, nothing at 25 %; the forward LOSES 2 % with
+    // the same queue and keeps its static map.
+    __shared__ uint32_t s_q;
+    const int n_tail = (int)((int64_t)gridDim.x * kTailPct / 100);
+    const int n_static = (int)gridDim.x - n_tail;
+    for (;;) {
+    int bidx = blockIdx.x;
+    if ((int)blockIdx.x >= n_static) {
+        __syncthreads();   // the previous tile of this worker is finished by every thread
+        if (threadIdx.x == 0) {
+            const uint32_t q = atomicAdd(p.queue, 1u);
+            if (q == 2u * (uint32_t)n_tail - 1u) atomicExch(p.queue, 0u);
+            s_q = q;
+        }
+        __syncthreads();
+        if (s_q >= (uint32_t)n_tail) return;
+        bidx = n_static + (int)s_q;
+    }
+    const int vt = xcd_strip_tile(bidx, gridDim.x, p.gx);
     const int pose = vt / p.ntiles;
     const int tile = vt - pose * p.ntiles;
     const int tx = tile % p.gx, ty = tile / p.gx;
@@ -968,6 +993,8 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
             p.timeline[3 * blockIdx.x + 2] = ((unsigned long long)xcc << 32) | hw;
         }
     }
+    if ((int)blockIdx.x < n_static) return;
+    }   // next tile of the queue
 }
 
 // CRF-table and exposure gradients (a15 backward), bitwise reproducible.
@@ -1187,6 +1214,7 @@ int launch_render_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s, u
     p.pair_flags = (uint8_t*)a.binning + L.pair_flags;
     p.pair_act = (const uint8_t*)a.binning + L.pair_act;
     p.stats = stats; p.timeline = timeline;
+    p.queue = &((hs_counters*)((char*)a.geom + L.counters))->reserved[3];
     const int grid = p.ntiles * d.n_poses;
     if (stats) {
         if (a.dL_dout_invdepth) render_bwd_kernel<true, true><<<grid, kBatch, 0, s>>>(p);
