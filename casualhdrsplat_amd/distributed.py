@@ -41,7 +41,8 @@ def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
         if backend == "nccl":
             dev_index = local % max(torch.cuda.device_count(), 1)
             torch.cuda.set_device(dev_index)
-            kw["device_id"] = torch.device("cuda", dev_index)   # binds the communicator to this rank's GPU up front
+            if os.environ.get("HS_DIST_BIND_DEVICE") == "1":   # eager communicator bound to this rank's GPU (opt-in)
+                kw["device_id"] = torch.device("cuda", dev_index)
         # a collective that one rank never enters must end the job, not hang it (HS_DIST_TIMEOUT_S, default 5 minutes)
         import datetime
         kw["timeout"] = datetime.timedelta(seconds=float(os.environ.get("HS_DIST_TIMEOUT_S", "300")))
