@@ -431,6 +431,33 @@ def test_run_to_run_bitwise_determinism():
     assert np.abs(a["d_crf_table"]).max() > 0 and float(np.abs(a["d_exposure"]).max()) > 0
 
 
+def test_backward_replays_give_identical_gradients():
+    """The render backward hands its last tiles out through a queue whose counter resets itself, and the tile sort's
+    scratch is cleared inside the forward: re-enqueueing the backward (or single stages of it) on the state of ONE
+    forward -- what bench.py's stage timing and a retained-graph second backward do -- must give the same bits every
+    time, whichever workgroups took the queued tiles."""
+    from casualhdrsplat_amd import GaussianRasterizer, _lib as L
+    from casualhdrsplat_amd.rasterizer import replay_backward, replay_forward
+    dev = "cuda"
+    sc = S.make_scene(60000, 720, 400, 2, seed=17, hdr=True)     # 1125 tiles: 90 of them go through the queue
+    rs, expo, crf = Hh.settings_from_scene(sc, dev, hdr=True, requires_grad=True)
+    leaves = [getattr(sc, k).to(dev).requires_grad_(True) for k in ("means3D", "opacities", "shs", "scales", "rotations")]
+    out = GaussianRasterizer(rs)(leaves[0], torch.zeros(60000, 3, device=dev, requires_grad=True), leaves[1],
+                                 shs=leaves[2], scales=leaves[3], rotations=leaves[4])
+    dL = sc.dL_dimage.to(dev)
+    ref = None
+    for rep in range(6):
+        if rep == 3:   # the forward's own stages replayed in between (binning scratch, activity bytes rewritten)
+            replay_forward(out[0], L.HS_STAGE_BIN | L.HS_STAGE_RENDER)
+        g = replay_backward(out[0], dL) if rep % 2 == 0 else (replay_backward(out[0], dL, L.HS_BWD_RENDER | L.HS_BWD_CRF),
+                                                             replay_backward(out[0], dL))[1]
+        flat = g["_flat"].detach().cpu().numpy().copy()
+        if ref is None:
+            ref = flat
+            assert np.abs(ref).max() > 0
+        assert np.array_equal(Hh.bits(flat), Hh.bits(ref)), rep
+
+
 def test_crf_gradient_blur_domains_run_to_run_and_tiny_gradients():
     """The fixed-point CRF-gradient accumulation scales itself to each block's largest |dL/dLDR|: a loss gradient
     eight orders of magnitude smaller gives the same table gradient up to that factor (no underflow to zero), for
