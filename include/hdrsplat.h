@@ -97,7 +97,8 @@ typedef struct hs_sizes {
 typedef struct hs_counters {
     uint32_t num_rendered; /* R = sum of tiles_touched over all instances */
     uint32_t overflow;     /* set by HS_STAGE_BIN when R > capacity */
-    uint32_t reserved[6];  /* [0] = pairs actually binned (R, or 0 on overflow) */
+    uint32_t reserved[6];  /* [0] = pairs actually binned (R, or 0 on overflow); [1] = instance count of the depth sort;
+                              [3] = tile-queue counter of the render backward (zero between launches); others unused */
 } hs_counters;
 
 typedef struct hs_fwd_args {
