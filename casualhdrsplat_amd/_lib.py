@@ -76,7 +76,7 @@ class hs_layout(C.Structure):
         "counters", "rec", "depth", "radii", "tiles_touched", "offsets", "cov3D", "clamped", "scan_spine", "binfo",
         "keys_sorted", "point_list", "keys_unsorted", "vals_unsorted", "ranges", "sort_tmp", "depth_keys", "depth_vals", "srect",
         "pair_flags", "pair_act",
-        "final_T", "n_contrib", "pose_hdr",
+        "final_T", "n_contrib", "pose_hdr", "tile_work", "tile_order",
         "pair_grads", "crf_partials", "inst_grads", "pose_partials")]
 
 

@@ -68,6 +68,8 @@ static int plan(const hs_dims& d, hs_sizes* sz, hs_layout* L) {
     l.final_T = carve(HW * d.n_poses * 4);
     l.n_contrib = carve(HW * d.n_poses * 4);
     l.pose_hdr = carve(HW * 3 * 4 * (d.n_poses + (d.n_poses > 1 ? 1 : 0)));
+    l.tile_work = carve(vtiles * 4);
+    l.tile_order = carve(vtiles * 4);
     sz->image_bytes = o;
     // backward scratch
     o = 0;

@@ -269,6 +269,7 @@ struct RenderFwd {
     unsigned long long* stats;  // STATS instantiations only
     unsigned long long* timeline;
     uint8_t* pair_act;          // out: per sorted pair, bit w = some pixel of wave w's half tile took the entry
+    uint32_t* tile_work;        // out: per (pose, tile), the (half tile, entry) trips that found a taker
 };
 
 constexpr int kBatch = 128;  // staged entries per trip = threads per workgroup
@@ -382,6 +383,7 @@ __global__ void __launch_bounds__(kBatch) render_fwd_kernel(RenderFwd p) {
     __shared__ int s_alive[2][2];
     __shared__ uint16_t s_list[2][KB];  // per-wave compacted list of staged entries that can touch its half tile (byte offsets)
     __shared__ uint8_t s_taken[2][KB];  // [wave][entry]: some pixel of the wave took the entry
+    __shared__ uint32_t s_work[2];      // per wave: entries it took (= trips of the backward on this half tile)
 
     const int vt = xcd_strip_tile(blockIdx.x, gridDim.x, p.gx);  // virtual tile = pose * ntiles + tile
     const int pose = vt / p.ntiles;
@@ -463,6 +465,7 @@ __global__ void __launch_bounds__(kBatch) render_fwd_kernel(RenderFwd p) {
         return act;
     };
     s_taken[0][threadIdx.x] = 0; s_taken[1][threadIdx.x] = 0;
+    uint32_t n_taken = 0;
     int it = 0, base = 0;
     for (; base < n; base += KB, ++it) {
         const bool wave_alive = (done0 & done1) != ~0ull;
@@ -507,12 +510,16 @@ __global__ void __launch_bounds__(kBatch) render_fwd_kernel(RenderFwd p) {
             const uint64_t t1 = ((done0 & done1) != ~0ull && n_t > 64) ? walk(64, n_t, base * kFwdEntF * 4) : 0ull;
             if ((t0 >> lane) & 1ull) s_taken[wave][s_list[wave][lane] / (kFwdEntF * 4)] = 1;
             if ((t1 >> lane) & 1ull) s_taken[wave][s_list[wave][64 + lane] / (kFwdEntF * 4)] = 1;
+            n_taken += (uint32_t)(__popcll(t0) + __popcll(t1));
         }
     }
     if (it > 0 && base >= n) {  // the loop ran out of entries: the last batch's activity is still in LDS
         __syncthreads();
         flush_activity(base - KB, n - (base - KB));
     }
+    if (lane == 0) s_work[wave] = n_taken;
+    __syncthreads();
+    if (threadIdx.x == 0) p.tile_work[vt] = s_work[0] + s_work[1];
     PixF s0, s1;
     // `last` was kept as (contributor number) * 48
     s0.T = ps.T.x; s0.C0 = ps.C0.x; s0.C1 = ps.C1.x; s0.C2 = ps.C2.x; s0.last = ps.last0 / (kFwdEntF * 4);
@@ -553,6 +560,76 @@ __global__ void __launch_bounds__(256) resolve_kernel(int64_t HW, int N, int fla
     }
 }
 
+// Which tile each workgroup of the render backward processes.  Block x of 8 handles the tiles the strip map gives to
+// XCD x (blocks b = x, x + 8, ... of the launch): the workgroups of the static part (b < n_static) keep that XCD's tiles
+// in strip order EXCEPT its lightest ones, which go to the queue the last workgroups serve (render_bwd_kernel) -- the
+// launch then ends on short tiles, and its tail is as long as one of those instead of an average one.  Weight of a
+// tile = the trips the forward counted on it; "lightest" by a histogram of the weights (two trips per bin; ties inside
+// the threshold bin are broken by arrival, any choice is as good).  The order is a permutation of the tiles whatever
+// the weights are, and results do not depend on it.
+__global__ void __launch_bounds__(1024) order_tiles_kernel(int nb, int gx, int n_static, const uint32_t* work,
+                                                           uint32_t* order) {
+    constexpr int kBins = 1024, kT = 1024;
+    __shared__ uint32_t s_hist[kBins];
+    __shared__ uint32_t s_scan[kT / 64];
+    __shared__ uint32_t s_thr_bin, s_thr_take, s_cnt_thr, s_cnt_q;
+    const int x = blockIdx.x, t = threadIdx.x;
+    const int per = nb / 8, rem = nb % 8;
+    const int cnt = per + (x < rem ? 1 : 0);                               // tiles (= blocks) of XCD x
+    const int n_keep = n_static > x ? (n_static - x + 7) / 8 : 0;          // ... of which static
+    const int n_light = cnt - n_keep;
+    int q_base = 0;                                                        // this XCD's slice of the queue
+    for (int y = 0; y < x; ++y) q_base += (per + (y < rem ? 1 : 0)) - (n_static > y ? (n_static - y + 7) / 8 : 0);
+    const int E = (cnt + kT - 1) / kT;                                     // consecutive tiles per thread
+    const int k0 = t * E, k1 = min(cnt, (t + 1) * E);
+    if (E > 64) {   // (more than 65536 tiles per XCD: no selection, the queue takes the last tiles of the strip order)
+        for (int k = k0; k < k1; ++k) order[x + 8 * k] = (uint32_t)xcd_strip_tile(x + 8 * k, nb, gx);
+        return;
+    }
+    auto block_excl_scan = [&](uint32_t v, uint32_t* total) -> uint32_t {  // 1024 threads
+        uint32_t incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t u = __shfl_up(incl, d); if ((t & 63) >= d) incl += u; }
+        __syncthreads();
+        if ((t & 63) == 63) s_scan[t >> 6] = incl;
+        __syncthreads();
+        uint32_t add = 0, tot = 0;
+        for (int w = 0; w < kT / 64; ++w) { const uint32_t c = s_scan[w]; if (w < (t >> 6)) add += c; tot += c; }
+        *total = tot;
+        return add + incl - v;
+    };
+    auto bin_of = [&](int k) { return (int)min((uint32_t)(kBins - 1), work[xcd_strip_tile(x + 8 * k, nb, gx)] >> 1); };
+    s_hist[t] = 0;
+    if (t == 0) { s_thr_bin = 0; s_thr_take = 0; s_cnt_thr = 0; s_cnt_q = 0; }
+    __syncthreads();
+    for (int k = k0; k < k1; ++k) atomicAdd(&s_hist[bin_of(k)], 1u);
+    __syncthreads();
+    {   // threshold bin: the n_light lightest tiles = all bins below it + `take` tiles of the bin itself
+        uint32_t tot;
+        const uint32_t h = s_hist[t];
+        const uint32_t below = block_excl_scan(h, &tot);
+        if (below < (uint32_t)n_light && below + h >= (uint32_t)n_light) { s_thr_bin = t; s_thr_take = (uint32_t)n_light - below; }
+    }
+    __syncthreads();
+    const int thr = (int)s_thr_bin;
+    const uint32_t take = s_thr_take;
+    uint64_t light_mask = 0;
+    uint32_t kept = 0;
+    for (int k = k0; k < k1; ++k) {
+        const int b = bin_of(k);
+        const bool light = n_light > 0 && (b < thr || (b == thr && atomicAdd(&s_cnt_thr, 1u) < take));
+        light_mask |= (uint64_t)light << (k - k0);
+        kept += !light;
+    }
+    uint32_t tot_kept;
+    uint32_t kpos = block_excl_scan(kept, &tot_kept);   // kept tiles stay in strip order
+    for (int k = k0; k < k1; ++k) {
+        const uint32_t vt = (uint32_t)xcd_strip_tile(x + 8 * k, nb, gx);
+        if ((light_mask >> (k - k0)) & 1ull) order[n_static + q_base + (int)atomicAdd(&s_cnt_q, 1u)] = vt;
+        else order[x + 8 * (int)kpos++] = vt;
+    }
+}
+
 struct RenderBwd {
     int W, H, gx, gy, ntiles, N, flags;
     const uint2* ranges; const uint32_t* point_list; const float4* rec; const float* bg;
@@ -567,6 +644,7 @@ struct RenderBwd {
     unsigned long long* timeline;  // STATS instantiations only, may be null: {start, end (100 MHz clock), XCC | CU ids}
                                    // per workgroup
     uint32_t* queue;               // counter of the tail queue (zeroed by the forward's first kernel, then self-resetting)
+    const uint32_t* tile_order;    // workgroup -> (pose, tile), written by order_tiles_kernel after the forward
 };
 
 // Upstream gradient w.r.t. this pose's radiance H_ch at one pixel (the HDR prologue).
@@ -713,7 +791,7 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
         if (s_q >= (uint32_t)n_tail) return;
         bidx = n_static + (int)s_q;
     }
-    const int vt = xcd_strip_tile(bidx, gridDim.x, p.gx);
+    const int vt = p.tile_order ? (int)p.tile_order[bidx] : xcd_strip_tile(bidx, gridDim.x, p.gx);
     const int pose = vt / p.ntiles;
     const int tile = vt - pose * p.ntiles;
     const int tx = tile % p.gx, ty = tile / p.gx;
@@ -1138,6 +1216,11 @@ __global__ void __launch_bounds__(256) crf_reduce_kernel(const float* partials, 
 
 }  // namespace
 
+// Ending the launch on its lightest tiles pays while the launch is a few rounds of workgroups long (c3: 8160 workgroups
+// over 3072 slots, -4 % on the backward for an 8 us ordering kernel); with many rounds (c4: 65280) the tail is a small
+// part of the span and the ordering costs more than it returns (measured +42 / -36 us): the strip order stays.
+static bool orders_tiles(int grid) { return grid <= 6 * 3072; }
+
 int launch_render_fwd(const hs_fwd_args& a, const hs_layout& L, hipStream_t s, unsigned long long* stats) {
     // (the forward records no timeline)
     const hs_dims& d = a.dims;
@@ -1157,6 +1240,7 @@ int launch_render_fwd(const hs_fwd_args& a, const hs_layout& L, hipStream_t s, u
     p.out_invdepth = a.out_invdepth;
     p.stats = stats; p.timeline = nullptr;
     p.pair_act = (uint8_t*)bin + L.pair_act;
+    p.tile_work = (uint32_t*)(img + L.tile_work);
     const int grid = p.ntiles * d.n_poses;
     if (stats) {
         if (a.out_invdepth) render_fwd_kernel<true, true><<<grid, kBatch, 0, s>>>(p);
@@ -1164,6 +1248,11 @@ int launch_render_fwd(const hs_fwd_args& a, const hs_layout& L, hipStream_t s, u
     } else if (a.out_invdepth) render_fwd_kernel<true, false><<<grid, kBatch, 0, s>>>(p);
     else render_fwd_kernel<false, false><<<grid, kBatch, 0, s>>>(p);
     HS_LAUNCH_CHECK();
+    if (orders_tiles(grid)) {   // the order in which the render backward will take the tiles (render_bwd_kernel)
+        const int n_static = grid - (int)((int64_t)grid * kTailPct / 100);
+        order_tiles_kernel<<<8, 1024, 0, s>>>(grid, p.gx, n_static, p.tile_work, (uint32_t*)(img + L.tile_order));
+        HS_LAUNCH_CHECK();
+    }
     if (d.n_poses > 1) {
         const int64_t HW = (int64_t)d.W * d.H;
         resolve_kernel<<<ceil_div(3 * HW, 256), 256, 0, s>>>(HW, d.n_poses, a.flags, p.pose_hdr, p.crf, a.exposure,
@@ -1215,6 +1304,7 @@ int launch_render_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s, u
     p.pair_act = (const uint8_t*)a.binning + L.pair_act;
     p.stats = stats; p.timeline = timeline;
     p.queue = &((hs_counters*)((char*)a.geom + L.counters))->reserved[3];
+    p.tile_order = orders_tiles(p.ntiles * d.n_poses) ? (const uint32_t*)(img + L.tile_order) : nullptr;
     const int grid = p.ntiles * d.n_poses;
     if (stats) {
         if (a.dL_dout_invdepth) render_bwd_kernel<true, true><<<grid, kBatch, 0, s>>>(p);

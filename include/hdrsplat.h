@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define HS_VERSION 200
+#define HS_VERSION 201
 
 #define HS_OK 0
 #define HS_EINVAL (-1)    /* bad argument (null pointer, bad shape, unsupported degree ...) */
@@ -211,6 +211,10 @@ typedef struct hs_layout {
     int64_t pair_act;
     /* image workspace */
     int64_t final_T, n_contrib, pose_hdr;
+    /* tile_work: u32 per (pose, tile): (half tile, entry) trips the render forward counted on it = what the render
+     * backward will replay; tile_order: u32 per render-backward workgroup: the (pose, tile) it processes (the forward
+     * orders the tiles so that each XCD's lightest ones run last, see render.hip) */
+    int64_t tile_work, tile_order;
     /* bwd workspace */
     /* inst_grads: 12 floats per instance, the per-instance sum of its (flagged) pair records */
     int64_t pair_grads, crf_partials, inst_grads, pose_partials;
