@@ -287,6 +287,18 @@ def _c_oracle_frame(sc, cfg):
                        f"(R = {int(f['R'])} pairs) -- no sampling, no extrapolation")}
 
 
+def kernel_source_hash(path):
+    """SHA-256 of a kernel source with blank and comment-only lines dropped: the committed ISA counts and PMC counters
+    (profiles/) stay attached to the CODE they were taken on when only a comment changes."""
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for ln in f:
+            t = ln.strip()
+            if t and not t.startswith(b"//"):
+                h.update(t + b"\n")
+    return h.hexdigest()
+
+
 def isa_counts():
     """Per-trip vector-instruction counts of the two compositing loops (scripts/isa_loop_counts.py reads them from
     the compiler's ISA for gfx950 and commits them as profiles/isa_loop_counts.json).  They are a property of the
@@ -297,7 +309,7 @@ def isa_counts():
     try:
         d = json.load(open(path))
         src = os.path.join(ROOT, "casualhdrsplat_amd", "csrc", "render.hip")
-        d["stale"] = hashlib.sha256(open(src, "rb").read()).hexdigest() != d.get("render_hip_sha256")
+        d["stale"] = kernel_source_hash(src) != d.get("render_hip_sha256")
         return d
     except Exception:
         return None
@@ -344,7 +356,7 @@ def offline_profile(cfg_name):
             return None
         src = os.path.join(ROOT, "casualhdrsplat_amd", "csrc", "render.hip")
         same = bool(pmc.get("render_hip_sha256")) and \
-            hashlib.sha256(open(src, "rb").read()).hexdigest() == pmc.get("render_hip_sha256")
+            kernel_source_hash(src) == pmc.get("render_hip_sha256")
         return {"from_profiles": True, "file": "profiles/pmc_traffic.json", "source": pmc.get("source"),
                 "source_commit": pmc.get("source_commit"), "same_kernel_source": same,
                 "render_bwd_kernel_hbm_bytes": pmc.get("render_bwd_kernel_hbm_bytes"),

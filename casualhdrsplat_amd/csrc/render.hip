@@ -15,12 +15,17 @@
 //    walks that list with the entry index in a VGPR (broadcast ds_read_b128);
 //  * workgroups map to tiles through an XCD strip permutation (two-tile-row strips dealt round-robin to the XCDs) so
 //    that the tiles one XCD works on are neighbours and share its L2;
+//  * the forward records which staged entries each half tile actually took (one byte per sorted pair) and how many
+//    trips each tile cost; the backward replays exactly those entries, walked as set bits of scalar masks;
 //  * backward: no global atomics.  Per (wave, Gaussian) nine partial sums are formed in-lane over the pixel
-//    pair, reduced across the 64 lanes with v_permlane32_swap / v_permlane16_swap halving steps plus bank-masked
-//    DPP adds (~24 instructions for all nine), parked in a per-wave LDS plane, combined over the two waves
-//    in fixed order and written as ONE record (a 64-byte sector) per (tile, instance) pair at the pair's
-//    duplicateWithKeys slot; preprocess-backward then sums each instance's contiguous slots.  Gradients are
-//    bitwise reproducible run to run.
+//    pair, reduced across the 64 lanes by halving steps ordered by price (bank-masked DPP adds first, then
+//    v_permlane32_swap / v_permlane16_swap: 21 instructions for all ten values), added to the entry's LDS record
+//    (two addends per word: order-independent) and written as ONE record (a 64-byte sector) per (tile, instance)
+//    pair at the pair's duplicateWithKeys slot; preprocess-backward then sums each instance's contiguous slots.
+//    Gradients are bitwise reproducible run to run;
+//  * the backward's launch ends on light tiles taken from a queue: each XCD keeps its strip-ordered tiles except its
+//    lightest 8 % (order_tiles_kernel, from the forward's trip counts), which the last workgroups of the launch take
+//    one after the other -- faster XCDs take more, and the tail is one short tile long.
 //
 // This TU is compiled with FMA contraction on; every integer decision it makes (pair slot addressing) uses
 // add/div-only expressions that contraction cannot change.

@@ -32,7 +32,9 @@ if what == "pmc":
     import subprocess
     commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
     import hashlib
-    sha = hashlib.sha256(open(os.path.join(ROOT, "casualhdrsplat_amd", "csrc", "render.hip"), "rb").read()).hexdigest()
+    sys.path.insert(0, ROOT)
+    from bench import kernel_source_hash
+    sha = kernel_source_hash(os.path.join(ROOT, "casualhdrsplat_amd", "csrc", "render.hip"))
     json.dump({"c3": {"render_bwd_kernel_hbm_bytes": pick("render_bwd_kernel"), "render_fwd_kernel_hbm_bytes": pick("render_fwd_kernel"),
                       "render_hip_sha256": sha,
                       "source_commit": commit + " (HEAD when the counters were folded; kernels of that tree)",

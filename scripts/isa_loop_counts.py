@@ -30,6 +30,17 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 TRANS = ("v_exp_", "v_log_", "v_rcp_", "v_rsq_", "v_sqrt_", "v_sin_", "v_cos_")
 
 
+def kernel_source_hash(path):
+    """Same rule as bench.kernel_source_hash: blank and comment-only lines do not count."""
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for ln in f:
+            t = ln.strip()
+            if t and not t.startswith(b"//"):
+                h.update(t + b"\n")
+    return h.hexdigest()
+
+
 def device_asm() -> str:
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "render.s")
@@ -155,7 +166,7 @@ def main():
     asm = device_asm()
     fns = functions(asm)
     out = {"source": "scripts/isa_loop_counts.py (hipcc -O3 -ffp-contract=fast -S --cuda-device-only, gfx950)",
-           "render_hip_sha256": hashlib.sha256(open(SRC, "rb").read()).hexdigest(),
+           "render_hip_sha256": kernel_source_hash(SRC),
            "issue_cycle_model": "4 cycles per wave64 vector instruction, 8 for transcendental and v_permlane*_swap "
                                 "(profiles/r01b_valu_rate.txt)"}
     for kern in ("render_fwd_kernel", "render_bwd_kernel"):
