@@ -381,8 +381,12 @@ __device__ __forceinline__ void write_pixel_fwd(const RenderFwd& p, const PixF& 
 // one (scalar-computed) byte offset addresses all of it.
 constexpr int kFwdEntF = 12;
 
+// The plain instantiation needs 69 vector registers as written, one wave per SIMD short of the eight that 64 allow;
+// asked for eight, the compiler fits it into 64 without a spill (the inverse-depth and diagnostic instantiations
+// would spill: they keep what they get).  Measured: -6 us at c3.
 template <bool DEPTH, bool STATS>
-__global__ void __launch_bounds__(kBatch) render_fwd_kernel(RenderFwd p) {
+__global__ void __launch_bounds__(kBatch) __attribute__((amdgpu_waves_per_eu((DEPTH || STATS) ? 1 : 8)))
+render_fwd_kernel(RenderFwd p) {
     constexpr int KB = kBatch;
     __shared__ __attribute__((aligned(16))) float s_ent[KB * kFwdEntF];
     __shared__ int s_alive[2][2];
@@ -1083,19 +1087,20 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
 // CRF-table and exposure gradients (a15 backward), bitwise reproducible.
 // grid = (ceil(HW / 4096), planes): blockIdx.y selects the (pose, channel) image plane, each block owns 4096 consecutive
 // pixels of it, 16 per thread, all held in registers.  A pixel whose log-exposure falls between knots i and i+1 adds
-// (1 - f) g to dL/dtable[i] and f g to dL/dtable[i+1].  Both weights travel in ONE 64-bit LDS atomic per run of pixels
-// that share an interval (neighbouring pixels of a natural image mostly do): they are converted to fixed point with a
-// power-of-two scale derived from the block's own max |g| (19 bits below 2^31, so 4096 addends cannot overflow a 32-bit
-// field) and packed as  (q1 << 32) + q0  with q0 sign-extended -- integer adds commute, so the block's table does not
-// depend on the order in which lanes reach the LDS, unlike the float atomics this replaces; the fields are split
-// again, turned back into floats and written as the block's partial row.  Quantisation step = 2^-19 of the block's
+// (1 - f) g to dL/dtable[i] and f g to dL/dtable[i+1].  Both weights are added once per run of pixels that share an
+// interval (neighbouring pixels of a natural image mostly do), as 32-bit FIXED-POINT integers with a power-of-two
+// scale derived from the block's own max |g| (19 bits below 2^31, so 4096 addends cannot overflow a field) --
+// integer adds commute, so the block's table does not depend on the order in which lanes reach the LDS, unlike the
+// float atomics this replaces (and a CU retires integer LDS atomics several times faster than float or 64-bit
+// ones); the two fields of an interval are turned back into floats and written as the block's partial row.  Quantisation step = 2^-19 of the block's
 // largest |g|, unbiased.  Exposure gradient and the clamped ends of the table: per-thread float sums in pixel order,
 // fixed DPP tree over the wave, the four waves added in wave order.  crf_reduce_kernel adds the blocks in a fixed order.
 constexpr int kCrfPixPerBlock = 4096;
 
 __global__ void __launch_bounds__(256) crf_grad_kernel(int64_t HW, int N, int flags, const float* pose_hdr, Crf crf,
                                                        const float* exposure, const float* dL_dcolor, float* partials) {
-    extern __shared__ unsigned long long s_tab64[];  // K - 1 intervals
+    extern __shared__ unsigned long long s_tab64[];  // K - 1 intervals: two 32-bit fixed-point fields each
+    int* const s_tab32 = reinterpret_cast<int*>(s_tab64);
     __shared__ float s_wave[4][4];
     __shared__ float s_max[4];
     const int K = crf.K;
@@ -1148,8 +1153,10 @@ __global__ void __launch_bounds__(256) crf_grad_kernel(int64_t HW, int N, int fl
     int run = -1;              // knot interval of the pending run (-1: none)
     float r0 = 0.f, r1 = 0.f;  // pending contributions to table[run], table[run + 1]
     auto flush = [&]() {
-        const long long q0 = (long long)__float2int_rn(r0 * to_fix), q1 = (long long)__float2int_rn(r1 * to_fix);
-        atomicAdd(&s_tab64[run], (unsigned long long)((q1 << 32) + q0));
+        // two 32-bit integer LDS atomics (a CU retires them several times faster than one 64-bit or float atomic,
+        // profiles/README.md "lane groups"); 19 bits below 2^31 leave room for the block's 4096 addends per field
+        atomicAdd(&s_tab32[2 * run], __float2int_rn(r0 * to_fix));
+        atomicAdd(&s_tab32[2 * run + 1], __float2int_rn(r1 * to_fix));
     };
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
@@ -1183,11 +1190,8 @@ __global__ void __launch_bounds__(256) crf_grad_kernel(int64_t HW, int N, int fl
             v = ((s_wave[0][0] + s_wave[1][0]) + s_wave[2][0]) + s_wave[3][0];
         } else {
             long long acc = 0;  // field 0 of interval k + field 1 of interval k - 1
-            if (k < K - 1) acc += (long long)(int)(uint32_t)(s_tab64[k] & 0xFFFFFFFFull);
-            if (k > 0) {
-                const long long w = (long long)s_tab64[k - 1];
-                acc += (w - (long long)(int)(uint32_t)((unsigned long long)w & 0xFFFFFFFFull)) >> 32;
-            }
+            if (k < K - 1) acc += (long long)s_tab32[2 * k];
+            if (k > 0) acc += (long long)s_tab32[2 * (k - 1) + 1];
             v = (float)acc * from_fix;
             if (k == 0) v += ((s_wave[0][1] + s_wave[1][1]) + s_wave[2][1]) + s_wave[3][1];
             if (k == K - 1) v += ((s_wave[0][2] + s_wave[1][2]) + s_wave[2][2]) + s_wave[3][2];
