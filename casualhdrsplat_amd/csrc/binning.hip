@@ -727,15 +727,10 @@ int launch_binning(const hs_fwd_args& a, const hs_layout& L, hipStream_t s) {
     if (!prepared)
         depth_keys_kernel<<<ceil_div(I, 256), 256, 0, s>>>(I, (const float*)(geom + L.depth), (const int*)(geom + L.radii),
                                                            dk0, dv0);
-    // (three-kernel passes for a frame's worth of instances: with only I / 4096 = 245 blocks per pass the look-back of a
-    // single-sweep pass costs as much as the histogram and scan kernels it replaces -- measured 4 x 19 + 12 us against
-    // 4 x 22 at c3; many poses per frame make it worth it)
-#ifndef HS_EXP_DEPTH_SWEEP_BLOCKS
-#define HS_EXP_DEPTH_SWEEP_BLOCKS 1024
-#endif
-    int rc = ceil_div(I, kSortTile) >= HS_EXP_DEPTH_SWEEP_BLOCKS
-                 ? radix_sort_sweep<uint32_t>(dk0, dv0, dk1, dv1, n_inst, I, 32, tmp, s)
-                 : radix_sort<uint32_t>(dk0, dv0, dk1, dv1, n_inst, I, 32, tmp, s);
+    // (single-sweep passes here too: at c3's 245 blocks they cost what the three-kernel passes cost -- 4 x 17 + 12 us
+    // against 4 x 22 -- but take 6 launches instead of 12, and with few blocks (c2: 25) or many (c4: 1953) they are
+    // faster; HS_EXP_SORT_CLASSIC keeps the three-kernel passes for A/B)
+    int rc = HS_RADIX_SORT<uint32_t>(dk0, dv0, dk1, dv1, n_inst, I, 32, tmp, s);
     if (rc != HS_OK) return rc;
     const uint32_t* inst_sorted = dv0;
     // 2. pair offsets in depth order, then emission
