@@ -134,8 +134,10 @@ int scan_u32(const uint32_t* in, int64_t n, uint32_t* spine, uint32_t* out, uint
 
 // Start of the binning stage: the instance count for the depth sort, and cleared tile ranges (tiles without pairs
 // must read (0,0)).
-__global__ void __launch_bounds__(256) bin_prepare_kernel(hs_counters* c, uint32_t n_inst, uint2* ranges, int64_t ntiles) {
+__global__ void __launch_bounds__(256) bin_prepare_kernel(hs_counters* c, uint32_t n_inst, uint2* ranges, int64_t ntiles,
+                                                          uint32_t* zero, int64_t n_zero) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    for (int64_t t = i; t < n_zero; t += (int64_t)gridDim.x * 256) zero[t] = 0u;   // scratch of the depth sort
     if (i < ntiles) ranges[i] = make_uint2(0u, 0u);
     if (i == 0) { c->reserved[1] = n_inst; c->reserved[2] = 0u; c->reserved[3] = 0u; }
 }
@@ -314,13 +316,9 @@ __device__ __forceinline__ void st_publish(uint32_t* p, uint32_t v) {
 __device__ __forceinline__ uint32_t st_read(const uint32_t* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// words of one pass: one per (block, digit)
-__host__ __device__ __forceinline__ int64_t sweep_pass_words(int64_t nblk) { return nblk * 256; }
-
 // The digit totals are kept in kGhistCopies copies (a block adds to copy blockIdx % kGhistCopies, readers sum them): a few
 // thousand blocks adding to the same 256 words one after the other is a serial chain of same-address atomics.
-constexpr int kGhistCopies = 16;
-constexpr int kGhistWords = kGhistCopies * 8 * 256;   // [copy][pass <= 8][digit]
+// (kGhistCopies, kGhistWords: hs_common.h)
 
 // Digit totals of every pass: ghist[pass * 256 + digit].  One 4096-key tile per workgroup.
 template <typename K>
@@ -484,20 +482,19 @@ __global__ void __launch_bounds__(kSortBlock) radix_sweep_kernel(const K* keys_i
     }
 }
 
-// `tmp`: sort_tmp_bytes(n_launch).  `ghist_ready`: the caller has already zeroed `tmp` and filled the digit totals.
+// `tmp`: sort_tmp_bytes(n_launch).  `zeroed`: an earlier kernel cleared sort_scratch_words(n_launch, passes) words of
+// it; `ghist_ready`: ... and the digit totals have been counted into it as well.
 template <typename K>
 int radix_sort_sweep(K* k0, uint32_t* v0, K* k1, uint32_t* v1, const uint32_t* n_dev, int64_t n_launch, int nbits,
-                     void* tmp, hipStream_t s, bool ghist_ready = false) {
+                     void* tmp, hipStream_t s, bool zeroed = false, bool ghist_ready = false) {
     if (n_launch <= 0) return HS_OK;
     const int nblk = ceil_div(n_launch, kSortTile);
     const int passes = sort_passes(nbits);
     uint32_t* ghist = (uint32_t*)tmp;                                   // [kGhistCopies][8][256]
     uint32_t* status = ghist + kGhistWords;                             // [passes][sweep_pass_words(nblk)]
     const int64_t pw = sweep_pass_words(nblk);
-    if (!ghist_ready) {
-        HS_HIP_CHECK(hipMemsetAsync(tmp, 0, ((size_t)kGhistWords + (size_t)passes * pw) * 4, s));
-        radix_ghist_kernel<K><<<nblk, kHistThreads, 0, s>>>(k0, n_dev, nbits, passes, ghist);
-    }
+    if (!zeroed && !ghist_ready) HS_HIP_CHECK(hipMemsetAsync(tmp, 0, ((size_t)kGhistWords + (size_t)passes * pw) * 4, s));
+    if (!ghist_ready) radix_ghist_kernel<K><<<nblk, kHistThreads, 0, s>>>(k0, n_dev, nbits, passes, ghist);
     K* kin = k0; uint32_t* vin = v0; K* kout = k1; uint32_t* vout = v1;
     int pass = 0;
     for (int shift = 0, w = 0; shift < nbits; shift += w, ++pass) {
@@ -716,21 +713,27 @@ int launch_binning(const hs_fwd_args& a, const hs_layout& L, hipStream_t s) {
     uint2* ranges = (uint2*)(bin + L.ranges);
     // when preprocess ran in this same call it already wrote the depth keys, the instance count and cleared ranges
     const bool prepared = (a.stages & HS_STAGE_PREPROCESS) != 0;
-    if (!prepared) bin_prepare_kernel<<<ceil_div(ntiles, 256), 256, 0, s>>>(counters, (uint32_t)I, ranges, ntiles);
+    void* tmp = bin + L.sort_tmp;
+    if (!prepared)
+        bin_prepare_kernel<<<ceil_div(ntiles, 256), 256, 0, s>>>(counters, (uint32_t)I, ranges, ntiles, (uint32_t*)tmp,
+                                                                 sort_scratch_words(I, 4));
 
     // 1. instances by depth (stable, 32-bit keys -> 4 passes: result back in the first buffer pair)
     uint32_t* dk0 = (uint32_t*)(bin + L.depth_keys);
     uint32_t* dv0 = (uint32_t*)(bin + L.depth_vals);
     uint32_t* dk1 = dk0 + I;
     uint32_t* dv1 = dv0 + I;
-    void* tmp = bin + L.sort_tmp;
     if (!prepared)
         depth_keys_kernel<<<ceil_div(I, 256), 256, 0, s>>>(I, (const float*)(geom + L.depth), (const int*)(geom + L.radii),
                                                            dk0, dv0);
     // (single-sweep passes here too: at c3's 245 blocks they cost what the three-kernel passes cost -- 4 x 17 + 12 us
     // against 4 x 22 -- but take 6 launches instead of 12, and with few blocks (c2: 25) or many (c4: 1953) they are
     // faster; HS_EXP_SORT_CLASSIC keeps the three-kernel passes for A/B)
-    int rc = HS_RADIX_SORT<uint32_t>(dk0, dv0, dk1, dv1, n_inst, I, 32, tmp, s);
+#ifdef HS_EXP_SORT_CLASSIC
+    int rc = radix_sort<uint32_t>(dk0, dv0, dk1, dv1, n_inst, I, 32, tmp, s);
+#else
+    int rc = radix_sort_sweep<uint32_t>(dk0, dv0, dk1, dv1, n_inst, I, 32, tmp, s, /*zeroed=*/true);   // by preprocess / bin_prepare
+#endif
     if (rc != HS_OK) return rc;
     const uint32_t* inst_sorted = dv0;
     // 2. pair offsets in depth order, then emission
@@ -741,7 +744,7 @@ int launch_binning(const hs_fwd_args& a, const hs_layout& L, hipStream_t s) {
     // status words) is cleared by this gather
     const int tbits = tile_bits((uint32_t)ntiles);
     const int passes = sort_passes(tbits);
-    const int64_t n_zero = d.capacity > 0 ? kGhistWords + (int64_t)passes * sweep_pass_words(ceil_div(d.capacity, kSortTile)) : 0;
+    const int64_t n_zero = sort_scratch_words(d.capacity, passes);
     gather_binfo_kernel<<<ceil_div(I, 256), 256, 0, s>>>(I, inst_sorted, (const uint2*)(geom + L.binfo), srect, ts,
                                                          (uint32_t*)tmp, n_zero);
     // pair offsets in depth order: block sums + their exclusive scan here, the rest inside the emission
@@ -766,7 +769,7 @@ int launch_binning(const hs_fwd_args& a, const hs_layout& L, hipStream_t s) {
 #ifdef HS_EXP_SORT_CLASSIC
     rc = radix_sort<uint32_t>(k0, v0, k1, v1, n_sort, d.capacity, tbits, tmp, s);
 #else
-    rc = radix_sort_sweep<uint32_t>(k0, v0, k1, v1, n_sort, d.capacity, tbits, tmp, s, /*ghist_ready=*/true);
+    rc = radix_sort_sweep<uint32_t>(k0, v0, k1, v1, n_sort, d.capacity, tbits, tmp, s, /*zeroed=*/true, /*ghist_ready=*/true);
 #endif
     if (rc != HS_OK) return rc;
     if (d.capacity > 0) {

@@ -60,6 +60,14 @@ int launch_mark_visible(int P, const float* means3D, const float* view, uint8_t*
 int launch_sh_backward_views(int P, int M, int deg, int V, const float* means3D, const float* camposes,
                              const float* view_colors, float* d_shs, hipStream_t s);
 
+// Scratch of the single-sweep radix passes (binning.hip): digit totals in kGhistCopies copies of [pass <= 8][256], then one
+// status word per (pass, block, digit).  sort_scratch_words(n, passes) = the words a sort of n keys needs cleared.
+constexpr int kGhistCopies = 16;
+constexpr int kGhistWords = kGhistCopies * 8 * 256;
+__host__ __device__ inline int64_t sweep_pass_words(int64_t nblk) { return nblk * 256; }
+static inline int64_t sort_scratch_words(int64_t n, int passes) {
+    return n > 0 ? kGhistWords + (int64_t)passes * sweep_pass_words((n + kSortTile - 1) / kSortTile) : 0;
+}
 int64_t sort_tmp_bytes(int64_t n);
 // Stable LSD radix sort of (u64 key, u32 value) pairs on bits [0,nbits) (hs_sort_pairs; the forward uses the u32-key
 // instantiation in binning.hip).  Ping-pongs between (k0,v0) and (k1,v1); the result lands in (k0,v0) when

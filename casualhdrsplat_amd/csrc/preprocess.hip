@@ -146,6 +146,7 @@ struct PreFwd {
     // single-enqueue forward (binning workspace already there): the start of the binning stage rides along --
     // depth-sort keys/values of the instances, the instance count word, cleared tile ranges; else null
     uint32_t* depth_keys; uint32_t* depth_vals; hs_counters* counters; uint2* ranges; int64_t n_vtiles;
+    uint32_t* sort_zero; int64_t n_sort_zero;   // scratch of the depth sort that follows (binning.hip), cleared here
     bool antialias;
     int act;  // radiance activation: 0 relu_shift, 1 exp, 2 softplus
 };
@@ -296,6 +297,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreFwd p) {
     }  // g < P
     if (p.depth_keys) {
         for (int64_t t = lin; t < p.n_vtiles; t += (int64_t)gridDim.x * 256) p.ranges[t] = make_uint2(0u, 0u);
+        for (int64_t t = lin; t < p.n_sort_zero; t += (int64_t)gridDim.x * 256) p.sort_zero[t] = 0u;
         if (lin == 0) {
             p.counters->reserved[1] = (uint32_t)((int64_t)p.P * p.N);
             p.counters->reserved[2] = 0u; p.counters->reserved[3] = 0u;   // tile-queue counters of the render kernels
@@ -836,11 +838,14 @@ int launch_preprocess_fwd(const hs_fwd_args& a, const hs_layout& L, hipStream_t 
     p.antialias = (a.flags & HS_FLAG_ANTIALIAS) != 0;
     p.act = (a.flags & HS_FLAG_RADIANCE_EXP) ? 1 : (a.flags & HS_FLAG_RADIANCE_SOFTPLUS) ? 2 : 0;
     p.depth_keys = nullptr; p.depth_vals = nullptr; p.counters = nullptr; p.ranges = nullptr; p.n_vtiles = 0;
+    p.sort_zero = nullptr; p.n_sort_zero = 0;
     if ((a.stages & HS_STAGE_BIN) && a.binning) {
         char* bin = (char*)a.binning;
         p.depth_keys = (uint32_t*)(bin + L.depth_keys); p.depth_vals = (uint32_t*)(bin + L.depth_vals);
         p.counters = (hs_counters*)(geom + L.counters); p.ranges = (uint2*)(bin + L.ranges);
         p.n_vtiles = (int64_t)((d.W + kTile - 1) / kTile) * ((d.H + kTile - 1) / kTile) * d.n_poses;
+        p.sort_zero = (uint32_t*)(bin + L.sort_tmp);
+        p.n_sort_zero = sort_scratch_words((int64_t)d.P * d.n_poses, 4);
     }
     if (d.n_poses > 1) HS_HIP_CHECK(hipMemsetAsync(a.radii, 0, sizeof(int) * (size_t)d.P, s));
     // chunks of 256 Gaussians, padded to a multiple of the 8 XCDs, times the poses (see the kernel's block map)
