@@ -76,7 +76,15 @@ def _f32c(t: Optional[torch.Tensor], dev) -> Optional[torch.Tensor]:
     return t
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream(dev=None) -> int:
+    """Raw HIP stream handle of the current PyTorch stream (the direct binding is ~10x cheaper per call than building a
+    torch.cuda.Stream object, and a step asks twice)."""
+    if _raw_stream is not None:
+        idx = torch.cuda.current_device() if dev is None or dev.index is None else dev.index
+        return _raw_stream(idx)
     return torch.cuda.current_stream(dev).cuda_stream
 
 
