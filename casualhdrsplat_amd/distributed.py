@@ -43,9 +43,9 @@ def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
             torch.cuda.set_device(dev_index)
             if os.environ.get("HS_DIST_BIND_DEVICE") == "1":   # eager communicator bound to this rank's GPU (opt-in)
                 kw["device_id"] = torch.device("cuda", dev_index)
-        # a collective that one rank never enters must end the job, not hang it (HS_DIST_TIMEOUT_S, default 5 minutes)
+        # a collective that one rank never enters must end the job, not hang it (HS_DIST_TIMEOUT_S, default 15 minutes: ranks of a fresh box may start minutes apart)
         import datetime
-        kw["timeout"] = datetime.timedelta(seconds=float(os.environ.get("HS_DIST_TIMEOUT_S", "300")))
+        kw["timeout"] = datetime.timedelta(seconds=float(os.environ.get("HS_DIST_TIMEOUT_S", "900")))
         try:
             dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
         except TypeError:  # a torch without `device_id`
