@@ -461,6 +461,23 @@ def test_backward_replays_give_identical_gradients():
             assert np.array_equal(Hh.bits(got[k]), Hh.bits(ref[k])), (rep, k)
 
 
+def test_frame_of_14400_tiles_vs_oracle(oracle):
+    """2560 x 1440 = 14400 tiles: more than 1024 tiles per XCD, so the tile-ordering kernel walks two tiles per thread,
+    and still a few-round launch, so the backward takes its tiles through the ordered list and the queue.  Against the
+    oracle: structure bit-exact, image and gradients within the contract."""
+    P, W, H, deg = 40000, 2560, 1440, 1
+    sc = S.make_scene(P, W, H, deg, seed=23)
+    f, b = Hh.run_oracle(oracle, sc)
+    g = Hh.run_hip(sc, capacity=f["R"] + 1000)
+    st = g["state"]
+    assert st["num_rendered"] == f["R"]
+    check_structure(st, f)
+    assert np.array_equal(u32(st["point_list"][:f["R"]]), u32(f["point_list"])) and np.array_equal(u32(st["ranges"]), u32(f["ranges"]))
+    pix_risk, gauss_risk = Hh.oracle_risk(oracle, sc, [f])
+    check_image(g["color"], f["color"], u32(st["n_contrib"][0]), u32(f["n_contrib"]), "14400 tiles", pix_risk[0])
+    Hh.assert_grads_close(g, b, what="14400 tiles", at_risk=gauss_risk)
+
+
 def test_crf_gradient_blur_domains_run_to_run_and_tiny_gradients():
     """The fixed-point CRF-gradient accumulation scales itself to each block's largest |dL/dLDR|: a loss gradient
     eight orders of magnitude smaller gives the same table gradient up to that factor (no underflow to zero), for
