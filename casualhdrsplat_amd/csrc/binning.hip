@@ -14,10 +14,12 @@
 // bit for bit the order of the 64-bit sort.  Tests compare point_list / ranges / reconstructed 64-bit keys with
 // the oracle's single 64-bit stable sort.
 //
-// The radix passes are wave64 kernels: a 256-bin LDS histogram kernel (which also accumulates digit totals), a
-// 256-block row scan, and a scatter kernel that ranks keys with 64-bit ballots (match-any over the digit bits),
-// reorders the 4096-key block through LDS and writes each digit's run contiguously.  Element counts are read
-// from device memory so the host never has to know R to launch (grids are sized by capacity).
+// The radix passes are wave64 kernels.  One kernel per pass (radix_sweep_kernel): it ranks the keys of a 4096-key block
+// with 64-bit ballots (match-any over the digit bits), learns how many keys with each digit lie in earlier blocks by
+// decoupled look-back over a status array, reorders the block through LDS and writes each digit's run contiguously;
+// the digit totals of all passes are counted once up front (by the pair emission for the tile sort).  The older
+// three-kernel passes (histogram, 256-block row scan, scatter) remain behind HS_EXP_SORT_CLASSIC for A/B.  Element
+// counts are read from device memory so the host never has to know R to launch (grids are sized by capacity).
 #include "hs_common.h"
 
 namespace hs {
