@@ -2,6 +2,7 @@
 // carving and kernel sequencing.  Nothing here allocates device memory or synchronises.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "hs_common.h"
@@ -9,6 +10,14 @@
 namespace hs {
 
 static thread_local char g_err[512] = "";
+
+int fault_injection() {
+    static const int mode = [] {
+        const char* e = getenv("HS_FAULT_INJECT");
+        return (e && !strcmp(e, "sort_ticket")) ? 1 : 0;
+    }();
+    return mode;
+}
 
 void set_error(const char* fmt, ...) {
     va_list ap;
@@ -29,8 +38,9 @@ static int plan(const hs_dims& d, hs_sizes* sz, hs_layout* L) {
     const int64_t I = (int64_t)d.P * d.n_poses;
     const int64_t gx = (d.W + kTile - 1) / kTile, gy = (d.H + kTile - 1) / kTile;
     const int64_t vtiles = gx * gy * d.n_poses;
-    if (I >= (1ll << 31) || vtiles >= (1ll << 31) || d.capacity >= (1ll << 32)) {
-        set_error("hs_plan: problem too large for 32-bit instance / pair indices");
+    // 2^30: a status word of the radix passes carries a 30-bit count next to its 2-bit flag (binning.hip)
+    if (I >= (1ll << 30) || vtiles >= (1ll << 31) || d.capacity >= (1ll << 30)) {
+        set_error("hs_plan: problem too large (instances and binning capacity must stay below 2^30)");
         return HS_EINVAL;
     }
     const int64_t HW = (int64_t)d.W * d.H;
@@ -51,14 +61,15 @@ static int plan(const hs_dims& d, hs_sizes* sz, hs_layout* L) {
     sz->geom_bytes = o;
     // binning
     o = 0;
-    l.keys_sorted = carve(d.capacity * 4);
-    l.point_list = carve(d.capacity * 4);
-    l.keys_unsorted = carve(d.capacity * 4);
-    l.vals_unsorted = carve(d.capacity * 4);
+    // keys_sorted | point_list together are also packed buffer A of the tile sort (8 bytes per pair), pairs_tmp is B
+    l.keys_sorted = carve(2 * align_up(d.capacity * 4, 256));
+    l.point_list = l.keys_sorted + align_up(d.capacity * 4, 256);
+    l.pairs_tmp = carve(d.capacity * 8);
     l.ranges = carve(vtiles * 8);
     l.sort_tmp = carve(sort_tmp_bytes(d.capacity > I ? d.capacity : I));
-    l.depth_keys = carve(2 * I * 4);
-    l.depth_vals = carve(2 * I * 4);
+    l.depth_pairs = carve(2 * I * 8);
+    l.inst_sorted = carve(I * 4);
+    l.offs_sorted = carve(I * 4);
     l.srect = carve(I * 8);
     l.pair_flags = carve(d.capacity);  // cleared by the pair emission, set by the render backward
     l.pair_act = carve(d.capacity);    // written by the render forward, read by the render backward
@@ -152,7 +163,10 @@ int hs_forward(const hs_fwd_args* a, void* hip_stream) {
         rc = check_common(a->dims, a->means3D, a->shs, a->colors_precomp, a->scales, a->rotations, a->cov3D_precomp,
                           a->viewmatrices, a->projmatrices, a->camposes, a->bg, "hs_forward");
         if (rc) return rc;
-        if (!a->opacities || !a->radii) { set_error("hs_forward: null opacities/radii"); return HS_EINVAL; }
+        if (!a->opacities || ((a->stages & HS_STAGE_PREPROCESS) && !a->radii)) {  // radii is written by preprocess only
+            set_error("hs_forward: null opacities/radii");
+            return HS_EINVAL;
+        }
     }
     if (!a->geom || !a->bg) { set_error("hs_forward: null geom/bg"); return HS_EINVAL; }
     if ((a->flags & HS_FLAG_HDR) && (!a->exposure || !a->crf_table || a->crf_K < 2 || a->crf_K > 4096 || !(a->crf_umax > a->crf_umin))) {
@@ -298,22 +312,24 @@ int64_t hs_sort_tmp_bytes(int64_t n) { return sort_tmp_bytes(n) + 256 + 2 * alig
 
 int hs_sort_pairs(const uint64_t* keys_in, const uint32_t* vals_in, uint64_t* keys_out, uint32_t* vals_out,
                   int64_t n, int32_t nbits, void* tmp, void* hip_stream) {
-    if (n < 0 || nbits < 1 || nbits > 64 || (n > 0 && (!keys_in || !vals_in || !keys_out || !vals_out || !tmp))) {
+    if (n < 0 || n >= (1ll << 30) || nbits < 1 || nbits > 64 || (n > 0 && (!keys_in || !vals_in || !keys_out || !vals_out || !tmp))) {
         set_error("hs_sort_pairs: bad argument");
         return HS_EINVAL;
     }
     if (n == 0) return HS_OK;
     hipStream_t s = (hipStream_t)hip_stream;
     char* t = (char*)tmp;
-    uint32_t* n_dev = (uint32_t*)t; t += 256;
+    uint32_t* n_dev = (uint32_t*)t;        // [0] element count, [1] fail word (2 = a look-back gave up: results invalid)
+    uint32_t* fail_word = n_dev + 1; t += 256;
     uint64_t* kb = (uint64_t*)t; t += align_up(n * 8, 256);
     uint32_t* vb = (uint32_t*)t; t += align_up(n * 4, 256);
     uint64_t* ka = (uint64_t*)t; t += align_up(n * 8, 256);
     uint32_t* va = (uint32_t*)t; t += align_up(n * 4, 256);
     HS_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)n_dev, (int)(uint32_t)n, 1, s));
+    HS_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)fail_word, 0, 1, s));
     HS_HIP_CHECK(hipMemcpyAsync(ka, keys_in, (size_t)n * 8, hipMemcpyDeviceToDevice, s));
     HS_HIP_CHECK(hipMemcpyAsync(va, vals_in, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
-    int rc = launch_radix_sort(ka, va, kb, vb, n_dev, n, nbits, t, s);
+    int rc = launch_radix_sort(ka, va, kb, vb, n_dev, n, nbits, t, fail_word, s);
     if (rc) return rc;
     const bool in_a = sort_passes(nbits) % 2 == 0;
     HS_HIP_CHECK(hipMemcpyAsync(keys_out, in_a ? ka : kb, (size_t)n * 8, hipMemcpyDeviceToDevice, s));

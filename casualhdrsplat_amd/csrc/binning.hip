@@ -14,12 +14,14 @@
 // bit for bit the order of the 64-bit sort.  Tests compare point_list / ranges / reconstructed 64-bit keys with
 // the oracle's single 64-bit stable sort.
 //
-// The radix passes are wave64 kernels.  One kernel per pass (radix_sweep_kernel): it ranks the keys of a 4096-key block
-// with 64-bit ballots (match-any over the digit bits), learns how many keys with each digit lie in earlier blocks by
+// The radix passes are wave64 kernels.  One kernel per pass (radix_sweep_kernel): it ranks the keys of a block with
+// 64-bit ballots (match-any over the digit bits), learns how many keys with each digit lie in earlier blocks by
 // decoupled look-back over a status array, reorders the block through LDS and writes each digit's run contiguously;
-// the digit totals of all passes are counted once up front (by the pair emission for the tile sort).  The older
-// three-kernel passes (histogram, 256-block row scan, scatter) remain behind HS_EXP_SORT_CLASSIC for A/B.  Element
-// counts are read from device memory so the host never has to know R to launch (grids are sized by capacity).
+// the digit totals of all passes are counted once up front (by the pair emission for the tile sort).  The pipeline's
+// two sorts move (key, value) as ONE 8-byte element, so a digit run is written as one contiguous stretch instead of
+// two half as long, and their last pass writes only what is read afterwards (the instance list; tile ids + instance
+// list).  Element counts are read from device memory so the host never has to know R to launch (grids are sized by
+// capacity).  (The older three-kernel passes -- histogram, row scan, scatter -- are profiles/r02_sort_three_kernel_passes.patch.)
 #include "hs_common.h"
 
 namespace hs {
@@ -141,7 +143,7 @@ __global__ void __launch_bounds__(256) bin_prepare_kernel(hs_counters* c, uint32
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     for (int64_t t = i; t < n_zero; t += (int64_t)gridDim.x * 256) zero[t] = 0u;   // scratch of the depth sort
     if (i < ntiles) ranges[i] = make_uint2(0u, 0u);
-    if (i == 0) { c->reserved[1] = n_inst; c->reserved[2] = 0u; c->reserved[3] = 0u; }
+    if (i == 0) { c->overflow = 0u; c->reserved[1] = n_inst; c->reserved[2] = 0u; c->reserved[3] = 0u; }
 }
 
 // ---------------------------------------------------------------- radix sort passes (a7)
@@ -150,167 +152,25 @@ __device__ __forceinline__ uint32_t digit_of(K k, int shift, uint32_t mask) {
     return (uint32_t)(k >> shift) & mask;
 }
 
-// hist[digit * nblk + blk] = number of keys of block `blk` with that digit; totals[digit] += the same.
-constexpr int kHistThreads = 1024;  // one 4096-key sort tile per workgroup, 4 keys per thread: short dependent chains
-template <typename K>
-__global__ void __launch_bounds__(kHistThreads) radix_hist_kernel(const K* keys, const uint32_t* n_dev, int shift,
-                                                                  uint32_t mask, uint32_t* hist, int nblk) {
-    __shared__ uint32_t s_hist[256];
-    const int64_t n = *n_dev;
-    const int64_t base = (int64_t)blockIdx.x * kSortTile;
-    if (threadIdx.x < 256) s_hist[threadIdx.x] = 0;
-    __syncthreads();
-    if (base < n) {
-#pragma unroll
-        for (int i = 0; i < kSortTile / kHistThreads; ++i) {
-            const int64_t k = base + i * kHistThreads + threadIdx.x;
-            const bool valid = k < n;
-            const uint32_t d = valid ? digit_of<K>(keys[k], shift, mask) : 0u;
-            // digits that are (nearly) constant over a pass -- exponent bits of depth, high tile bits -- would
-            // serialise 64 LDS atomics on one bin: when the whole wave agrees, one lane adds the count
-            const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
-            const uint64_t vm = __ballot(valid);
-            if (__ballot(valid && d != d0) == 0ull) {
-                if ((threadIdx.x & 63) == 0 && vm) atomicAdd(&s_hist[d0], (uint32_t)__popcll(vm));
-            } else if (valid) {
-                atomicAdd(&s_hist[d], 1u);
-            }
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x < 256) hist[(int64_t)threadIdx.x * nblk + blockIdx.x] = s_hist[threadIdx.x];
-}
-
-// One block per digit: exclusive scan of that digit's row over blocks (in place) and the digit's total.  The
-// offset of all smaller digits is added by the scatter kernel from totals[] (no global atomics, no grid sync).
-__global__ void __launch_bounds__(256) radix_scan_kernel(uint32_t* hist, int nblk, uint32_t* totals) {
-    __shared__ uint32_t s_wave[4];
-    const int d = blockIdx.x;
-    uint32_t carry = 0;
-    uint32_t* row = hist + (int64_t)d * nblk;
-    for (int base = 0; base < nblk; base += 256) {
-        const int i = base + threadIdx.x;
-        const uint32_t v = i < nblk ? row[i] : 0;
-        uint32_t total;
-        const uint32_t incl = block_incl_scan(v, s_wave, &total);
-        if (i < nblk) row[i] = carry + incl - v;
-        carry += total;
-    }
-    if (threadIdx.x == 0) totals[d] = carry;
-}
-
-// Scatter: stable within the block (wave w owns keys [w*1024, (w+1)*1024) of the block, processed in
-// 16 rounds of 64 consecutive keys), stable across blocks through the scanned histogram.
-template <typename K>
-__global__ void __launch_bounds__(kSortBlock) radix_scatter_kernel(const K* keys_in, const uint32_t* vals_in,
-                                                                   K* keys_out, uint32_t* vals_out,
-                                                                   const uint32_t* n_dev, int shift, uint32_t mask,
-                                                                   const uint32_t* hist, const uint32_t* totals, int nblk) {
-    __shared__ uint32_t s_cnt[4][256];    // per-wave digit counters -> per-wave exclusive offsets
-    __shared__ uint32_t s_dstart[256];    // block-local start of each digit's run
-    __shared__ uint32_t s_gbase[256];     // global start of this block's run of each digit
-    __shared__ K s_keys[kSortTile];
-    __shared__ uint32_t s_vals[kSortTile];
-    __shared__ uint32_t s_wave[4];
-
-    const int64_t n = *n_dev;
-    const int64_t base = (int64_t)blockIdx.x * kSortTile;
-    if (base >= n) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int cnt_block = (int)min((int64_t)kSortTile, n - base);
-
-#pragma unroll
-    for (int w = 0; w < 4; ++w) s_cnt[w][threadIdx.x] = 0;
-    {   // global start of this block's run of digit d = (keys with a smaller digit) + (same digit in earlier blocks)
-        const uint32_t tot = totals[threadIdx.x];
-        uint32_t all;
-        const uint32_t incl = block_incl_scan(tot, s_wave, &all);
-        s_gbase[threadIdx.x] = (incl - tot) + hist[(int64_t)threadIdx.x * nblk + blockIdx.x];
-    }
-    __syncthreads();
-
-    K key[kSortItems];
-    uint32_t val[kSortItems];
-    uint16_t rank[kSortItems];
-    const uint64_t lt_mask = (1ull << lane) - 1ull;
-    const int wbase = wave * (kSortTile / 4);
-#pragma unroll
-    for (int i = 0; i < kSortItems; ++i) {
-        const int loc = wbase + i * 64 + lane;
-        const bool valid = loc < cnt_block;
-        key[i] = valid ? keys_in[base + loc] : (K) ~(K)0;
-        val[i] = valid ? vals_in[base + loc] : 0u;
-    }
-#pragma unroll
-    for (int i = 0; i < kSortItems; ++i) {
-        const int loc = wbase + i * 64 + lane;
-        const bool valid = loc < cnt_block;
-        const uint32_t d = digit_of<K>(key[i], shift, mask);
-        // match-any: lanes holding the same digit
-        uint64_t peers = __ballot(valid);
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const uint64_t m = __ballot((d >> b) & 1u);
-            peers &= ((d >> b) & 1u) ? m : ~m;
-        }
-        const uint32_t before = s_cnt[wave][d];
-        const uint32_t below = __popcll(peers & lt_mask);
-        rank[i] = (uint16_t)(before + below);
-        // the last peer publishes the new count (all peers read `before` first: same wave, in-order LDS)
-        if (valid && (peers >> lane) == 1ull) s_cnt[wave][d] = before + below + 1;
-    }
-    __syncthreads();
-    // per-digit: exclusive offsets over waves and the block-local run starts
-    {
-        const uint32_t c0 = s_cnt[0][threadIdx.x], c1 = s_cnt[1][threadIdx.x], c2 = s_cnt[2][threadIdx.x],
-                       c3 = s_cnt[3][threadIdx.x];
-        const uint32_t tot = c0 + c1 + c2 + c3;
-        s_cnt[0][threadIdx.x] = 0; s_cnt[1][threadIdx.x] = c0; s_cnt[2][threadIdx.x] = c0 + c1;
-        s_cnt[3][threadIdx.x] = c0 + c1 + c2;
-        uint32_t total;
-        const uint32_t incl = block_incl_scan(tot, s_wave, &total);
-        s_dstart[threadIdx.x] = incl - tot;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < kSortItems; ++i) {
-        const int loc = wbase + i * 64 + lane;
-        if (loc < cnt_block) {
-            const uint32_t d = digit_of<K>(key[i], shift, mask);
-            const uint32_t pos = s_dstart[d] + s_cnt[wave][d] + rank[i];
-            s_keys[pos] = key[i];
-            s_vals[pos] = val[i];
-        }
-    }
-    __syncthreads();
-#pragma unroll 4
-    for (int i = 0; i < kSortItems; ++i) {
-        const int pos = i * kSortBlock + threadIdx.x;
-        if (pos < cnt_block) {
-            const K k = s_keys[pos];
-            const uint32_t d = digit_of<K>(k, shift, mask);
-            const int64_t dst = (int64_t)s_gbase[d] + (pos - s_dstart[d]);
-            keys_out[dst] = k;
-            vals_out[dst] = s_vals[pos];
-        }
-    }
-}
-
-// ---------------------------------------------------------------- single-sweep radix passes
 // One kernel per pass instead of histogram + scan + scatter: the digit totals of ALL passes are counted once, up front
 // (they do not depend on the order of the keys), and a block learns how many keys with its digit lie in EARLIER blocks
-// by decoupled look-back over a status array -- every block publishes the per-digit counts of its 4096 keys as soon as
+// by decoupled look-back over a status array -- every block publishes the per-digit counts of its keys as soon as
 // it has ranked them (flag 1 = "my count"), walks back over its predecessors adding their words until it meets one
 // flagged 2 = "inclusive prefix up to and including me", then publishes its own inclusive prefix.  Count and flag share
-// one 32-bit word (2 + 30 bits), written and read with agent-scope atomics, so no ordering between separate words
-// is needed (and no fence: a __threadfence() writes back the XCD's whole L2).  Progress: workgroups are dispatched
-// in blockIdx order on every XCD, so the lowest unfinished block is always resident, and a block waits only for words
-// that its predecessors publish before they themselves wait.
+// one 32-bit word (2 + 30 bits: hs_plan rejects sorts of 2^30 or more elements), written and read with agent-scope
+// atomics, so no ordering between separate words is needed (and no fence: a __threadfence() writes back the XCD's
+// whole L2).
+// Progress.  A block's place in the chain is NOT its blockIdx -- nothing promises that workgroups start in blockIdx
+// order -- but a ticket drawn from a per-pass counter when the block starts (one atomic per block, the counter is
+// cleared with the rest of the scratch): ticket p < b means block p is already running, so everything block b waits for
+// is published by blocks that never wait for b.  The wait is bounded all the same (kSpinLimit polls, about a second):
+// a status array that some stray write damaged ends in `fail_word` = 2 (hs_counters.overflow for the pipeline: the
+// frame renders empty and the host reports it) instead of a hung GPU.
 // Measured alternatives (c3 tile sort, us per pass; the three-kernel pass: 76): this walk with 8 words in flight 42,
 // with 16 / 32 in flight 48 / 55; group sums (one word per 32 blocks and digit, filled by returning atomics, plus a
 // member counter) instead of inclusive prefixes 85.
-constexpr int kLook = 8;
 constexpr uint32_t kStAgg = 1u << 30, kStIncl = 2u << 30, kStMask = (1u << 30) - 1u;
+constexpr int kSpinLimit = 1 << 20;
 
 __device__ __forceinline__ void st_publish(uint32_t* p, uint32_t v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -320,23 +180,29 @@ __device__ __forceinline__ uint32_t st_read(const uint32_t* p) {
 }
 // The digit totals are kept in kGhistCopies copies (a block adds to copy blockIdx % kGhistCopies, readers sum them): a few
 // thousand blocks adding to the same 256 words one after the other is a serial chain of same-address atomics.
-// (kGhistCopies, kGhistWords: hs_common.h)
+// (kGhistCopies, kGhistWords, kTicketWords: hs_common.h)
 
-// Digit totals of every pass: ghist[pass * 256 + digit].  One 4096-key tile per workgroup.
-template <typename K>
-__global__ void __launch_bounds__(kHistThreads) radix_ghist_kernel(const K* keys, const uint32_t* n_dev, int nbits,
+// Digit totals of every pass: ghist[pass * 256 + digit].  4096 elements per workgroup.  PACKED: the keys are the .x of
+// (key, value) pairs.
+constexpr int kHistThreads = 1024, kHistTile = 4096;
+template <typename K, bool PACKED>
+__global__ void __launch_bounds__(kHistThreads) radix_ghist_kernel(const void* keys_v, const uint32_t* n_dev, int nbits,
                                                                    int passes, uint32_t* ghist) {
     __shared__ uint32_t s_hist[8 * 256];
     const int64_t n = *n_dev;
-    const int64_t base = (int64_t)blockIdx.x * kSortTile;
+    const int64_t base = (int64_t)blockIdx.x * kHistTile;
     if (base >= n) return;
     for (int i = threadIdx.x; i < passes * 256; i += kHistThreads) s_hist[i] = 0;
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < kSortTile / kHistThreads; ++i) {
+    for (int i = 0; i < kHistTile / kHistThreads; ++i) {
         const int64_t k = base + i * kHistThreads + threadIdx.x;
         const bool valid = k < n;
-        const K key = valid ? keys[k] : (K)0;
+        K key = (K)0;
+        if (valid) {
+            if constexpr (PACKED) key = (K) reinterpret_cast<const uint2*>(keys_v)[k].x;
+            else key = reinterpret_cast<const K*>(keys_v)[k];
+        }
         const uint64_t vm = __ballot(valid);
         int pass = 0;
         for (int shift = 0, w = 0; shift < nbits; shift += w, ++pass) {
@@ -360,51 +226,71 @@ __global__ void __launch_bounds__(kHistThreads) radix_ghist_kernel(const K* keys
     }
 }
 
-// One pass: rank the block's keys (stable: wave w owns keys [w*1024, (w+1)*1024), 16 rounds of 64 consecutive keys),
-// publish / look back, reorder through LDS, write each digit's run contiguously.
-template <typename K>
-__global__ void __launch_bounds__(kSortBlock) radix_sweep_kernel(const K* keys_in, const uint32_t* vals_in, K* keys_out,
-                                                                 uint32_t* vals_out, const uint32_t* n_dev, int shift,
-                                                                 uint32_t mask, uint32_t* status, const uint32_t* ghist) {
+// One pass: rank the block's keys (stable: wave w owns ITEMS * 64 consecutive keys of the block, ITEMS rounds of 64
+// consecutive keys), publish / look back, reorder through LDS, write each digit's run contiguously.
+//   PACKED_IN : `in_keys` holds (key, value) uint2 elements (K = uint32_t), else K keys with the values in `in_vals`;
+//   PACKED_OUT: `out_keys` receives uint2 elements, else keys go to `out_keys` (skipped when null) and values to
+//               `out_vals`.
+//   LOOK      : status words a thread requests at once during the look-back.
+template <typename K, int ITEMS, int LOOK, bool PACKED_IN, bool PACKED_OUT>
+__global__ void __launch_bounds__(kSortBlock) radix_sweep_kernel(const void* in_keys, const uint32_t* in_vals,
+                                                                 void* out_keys, uint32_t* out_vals, const uint32_t* n_dev,
+                                                                 int shift, uint32_t mask, uint32_t* status,
+                                                                 const uint32_t* ghist, uint32_t* ticket,
+                                                                 uint32_t* fail_word, uint32_t* kill_word) {
+    constexpr int TILE = ITEMS * kSortBlock;
     __shared__ uint32_t s_cnt[4][256];    // per-wave digit counters -> per-wave exclusive offsets
     __shared__ uint32_t s_dstart[256];    // block-local start of each digit's run
     __shared__ uint32_t s_gbase[256];     // global start of this block's run of each digit
-    __shared__ K s_keys[kSortTile];
-    __shared__ uint32_t s_vals[kSortTile];
+    __shared__ K s_keys[TILE];
+    __shared__ uint32_t s_vals[TILE];
     __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_ticket, s_fail;
 
-    const int64_t n = *n_dev;
-    const int64_t base = (int64_t)blockIdx.x * kSortTile;
-    if (base >= n) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int cnt_block = (int)min((int64_t)kSortTile, n - base);
-    uint32_t* const my_status = status + (int64_t)blockIdx.x * 256 + threadIdx.x;
-
+    if (threadIdx.x == 0) { s_ticket = atomicAdd(ticket, 1u); s_fail = 0u; }
 #pragma unroll
     for (int w = 0; w < 4; ++w) s_cnt[w][threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t n = *n_dev;
+    const int bid = (int)s_ticket;         // this block's place in the look-back chain (see above)
+    const int64_t base = (int64_t)bid * TILE;
+    if (base >= n) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cnt_block = (int)min((int64_t)TILE, n - base);
+    uint32_t* const my_status = status + (int64_t)bid * 256 + threadIdx.x;
+
     uint32_t digit_base;   // keys of the whole array with a smaller digit
     {
         uint32_t tot = 0;
 #pragma unroll
         for (int c = 0; c < kGhistCopies; ++c) tot += ghist[c * (8 * 256) + threadIdx.x];
         uint32_t all;
-        digit_base = block_incl_scan(tot, s_wave, &all) - tot;   // (contains the barrier that orders the clears above)
+        digit_base = block_incl_scan(tot, s_wave, &all) - tot;
     }
 
-    K key[kSortItems];
-    uint32_t val[kSortItems];
-    uint16_t rank[kSortItems];
+    K key[ITEMS];
+    uint32_t val[ITEMS];
+    uint16_t rank[ITEMS];
     const uint64_t lt_mask = (1ull << lane) - 1ull;
-    const int wbase = wave * (kSortTile / 4);
+    const int wbase = wave * (TILE / 4);
 #pragma unroll
-    for (int i = 0; i < kSortItems; ++i) {
+    for (int i = 0; i < ITEMS; ++i) {
         const int loc = wbase + i * 64 + lane;
         const bool valid = loc < cnt_block;
-        key[i] = valid ? keys_in[base + loc] : (K) ~(K)0;
-        val[i] = valid ? vals_in[base + loc] : 0u;
+        key[i] = (K) ~(K)0;
+        val[i] = 0u;
+        if (valid) {
+            if constexpr (PACKED_IN) {
+                const uint2 e = reinterpret_cast<const uint2*>(in_keys)[base + loc];
+                key[i] = (K)e.x; val[i] = e.y;
+            } else {
+                key[i] = reinterpret_cast<const K*>(in_keys)[base + loc];
+                val[i] = in_vals[base + loc];
+            }
+        }
     }
 #pragma unroll
-    for (int i = 0; i < kSortItems; ++i) {
+    for (int i = 0; i < ITEMS; ++i) {
         const int loc = wbase + i * 64 + lane;
         const bool valid = loc < cnt_block;
         const uint32_t d = digit_of<K>(key[i], shift, mask);
@@ -426,7 +312,7 @@ __global__ void __launch_bounds__(kSortBlock) radix_sweep_kernel(const K* keys_i
         const uint32_t c0 = s_cnt[0][threadIdx.x], c1 = s_cnt[1][threadIdx.x], c2 = s_cnt[2][threadIdx.x],
                        c3 = s_cnt[3][threadIdx.x];
         my_tot = c0 + c1 + c2 + c3;
-        st_publish(my_status, (blockIdx.x == 0 ? kStIncl : kStAgg) | my_tot);
+        st_publish(my_status, (bid == 0 ? kStIncl : kStAgg) | my_tot);
         s_cnt[0][threadIdx.x] = 0; s_cnt[1][threadIdx.x] = c0; s_cnt[2][threadIdx.x] = c0 + c1;
         s_cnt[3][threadIdx.x] = c0 + c1 + c2;
         uint32_t total;
@@ -436,7 +322,7 @@ __global__ void __launch_bounds__(kSortBlock) radix_sweep_kernel(const K* keys_i
     __syncthreads();
     // reorder through LDS while the predecessors' words arrive
 #pragma unroll
-    for (int i = 0; i < kSortItems; ++i) {
+    for (int i = 0; i < ITEMS; ++i) {
         const int loc = wbase + i * 64 + lane;
         if (loc < cnt_block) {
             const uint32_t d = digit_of<K>(key[i], shift, mask);
@@ -445,123 +331,132 @@ __global__ void __launch_bounds__(kSortBlock) radix_sweep_kernel(const K* keys_i
             s_vals[pos] = val[i];
         }
     }
-    {   // look-back: keys with this thread's digit in earlier blocks (kLook words requested at once: the walk is bound
+    {   // look-back: keys with this thread's digit in earlier blocks (LOOK words requested at once: the walk is bound
         // by the latency of these uncached loads -- with hundreds of blocks ranking at the same time the nearest
         // inclusive prefix is far behind)
         uint32_t excl = 0;
         bool done = threadIdx.x > mask;   // a digit no key of this pass can have: nothing to look up
-        for (int p = (int)blockIdx.x - 1; p >= 0 && !done; p -= kLook) {
-            uint32_t v[kLook];
+        bool failed = false;
+        for (int p = bid - 1; p >= 0 && !done; p -= LOOK) {
+            uint32_t v[LOOK];
 #pragma unroll
-            for (int j = 0; j < kLook; ++j)
+            for (int j = 0; j < LOOK; ++j)
                 v[j] = p - j >= 0 ? st_read(status + (int64_t)(p - j) * 256 + threadIdx.x) : kStIncl;
 #pragma unroll
-            for (int j = 0; j < kLook; ++j) {
+            for (int j = 0; j < LOOK; ++j) {
                 if (done) break;
                 uint32_t x = v[j];
+                int polls = 0;
                 while ((x & ~kStMask) == 0u) {
+                    if (++polls > kSpinLimit) { failed = true; break; }
                     __builtin_amdgcn_s_sleep(1);
                     x = st_read(status + (int64_t)(p - j) * 256 + threadIdx.x);
                 }
+                if (failed) { done = true; break; }
                 excl += x & kStMask;
                 done = (x & ~kStMask) == kStIncl;
             }
         }
-        if (blockIdx.x != 0) st_publish(my_status, kStIncl | (excl + my_tot));
+        if (failed) {   // a predecessor's word never arrived: give up, tell the host, let the successors pass
+            s_fail = 1u;
+            atomicMax(fail_word, 2u);
+            if (kill_word) *kill_word = 0u;
+        }
+        if (bid != 0) st_publish(my_status, kStIncl | ((excl + my_tot) & kStMask));
         s_gbase[threadIdx.x] = digit_base + excl;
     }
     __syncthreads();
+    if (s_fail) return;
 #pragma unroll 4
-    for (int i = 0; i < kSortItems; ++i) {
+    for (int i = 0; i < ITEMS; ++i) {
         const int pos = i * kSortBlock + threadIdx.x;
         if (pos < cnt_block) {
             const K k = s_keys[pos];
             const uint32_t d = digit_of<K>(k, shift, mask);
             const int64_t dst = (int64_t)s_gbase[d] + (pos - s_dstart[d]);
-            keys_out[dst] = k;
-            vals_out[dst] = s_vals[pos];
+            if constexpr (PACKED_OUT) {
+                reinterpret_cast<uint2*>(out_keys)[dst] = make_uint2((uint32_t)k, s_vals[pos]);
+            } else {
+                if (out_keys) reinterpret_cast<K*>(out_keys)[dst] = k;
+                out_vals[dst] = s_vals[pos];
+            }
         }
     }
 }
 
-// `tmp`: sort_tmp_bytes(n_launch).  `zeroed`: an earlier kernel cleared sort_scratch_words(n_launch, passes) words of
-// it; `ghist_ready`: ... and the digit totals have been counted into it as well.
-template <typename K>
-int radix_sort_sweep(K* k0, uint32_t* v0, K* k1, uint32_t* v1, const uint32_t* n_dev, int64_t n_launch, int nbits,
-                     void* tmp, hipStream_t s, bool zeroed = false, bool ghist_ready = false) {
-    if (n_launch <= 0) return HS_OK;
-    const int nblk = ceil_div(n_launch, kSortTile);
-    const int passes = sort_passes(nbits);
-    uint32_t* ghist = (uint32_t*)tmp;                                   // [kGhistCopies][8][256]
-    uint32_t* status = ghist + kGhistWords;                             // [passes][sweep_pass_words(nblk)]
-    const int64_t pw = sweep_pass_words(nblk);
-    if (!zeroed && !ghist_ready) HS_HIP_CHECK(hipMemsetAsync(tmp, 0, ((size_t)kGhistWords + (size_t)passes * pw) * 4, s));
-    if (!ghist_ready) radix_ghist_kernel<K><<<nblk, kHistThreads, 0, s>>>(k0, n_dev, nbits, passes, ghist);
-    K* kin = k0; uint32_t* vin = v0; K* kout = k1; uint32_t* vout = v1;
-    int pass = 0;
-    for (int shift = 0, w = 0; shift < nbits; shift += w, ++pass) {
-        w = (nbits - shift + (passes - pass) - 1) / (passes - pass);
-        radix_sweep_kernel<K><<<nblk, kSortBlock, 0, s>>>(kin, vin, kout, vout, n_dev, shift, (1u << w) - 1u,
-                                                          status + (int64_t)pass * pw, ghist + 256 * pass);
-        HS_LAUNCH_CHECK();
-        K* tk = kin; kin = kout; kout = tk;
-        uint32_t* tv = vin; vin = vout; vout = tv;
+// Scratch of a sort (`tmp`: sort_tmp_bytes(n_launch)): digit totals, one ticket counter per pass, status words.
+struct SortScratch {
+    uint32_t* ghist; uint32_t* tickets; uint32_t* status; int64_t pass_words;
+    SortScratch(void* tmp, int64_t n_launch, int tile) {
+        ghist = (uint32_t*)tmp;                       // [kGhistCopies][8][256]
+        tickets = ghist + kGhistWords;                // [8] (+ padding)
+        status = tickets + kTicketWords;              // [passes][sweep_pass_words(nblk)]
+        pass_words = sweep_pass_words((n_launch + tile - 1) / tile);
     }
-    return HS_OK;
-}
+};
 
-template <typename K>
-int radix_sort(K* k0, uint32_t* v0, K* k1, uint32_t* v1, const uint32_t* n_dev, int64_t n_launch, int nbits,
-               void* tmp, hipStream_t s) {
+// Stable LSD sort of packed (u32 key, u32 value) elements on key bits [0, nbits): ping-pongs between the packed
+// buffers p0 (input) and p1; the LAST pass writes the values to `vals_out` and, when `keys_out` is given, the keys to
+// `keys_out` (its source is p0 when the pass count is odd, else p1 -- the caller makes sure the outputs do not overlay
+// that buffer).  `zeroed`: an earlier kernel cleared sort_scratch_words(n_launch, passes, ITEMS * 256) words of `tmp`;
+// `ghist_ready`: ... and the digit totals have been counted into it as well.
+template <int ITEMS, int LOOK>
+int radix_sort_packed(uint2* p0, uint2* p1, uint32_t* keys_out, uint32_t* vals_out, const uint32_t* n_dev, int64_t n_launch,
+                      int nbits, void* tmp, uint32_t* fail_word, uint32_t* kill_word, hipStream_t s, bool zeroed,
+                      bool ghist_ready) {
     if (n_launch <= 0) return HS_OK;
-    const int nblk = ceil_div(n_launch, kSortTile);
+    constexpr int TILE = ITEMS * kSortBlock;
+    const int nblk = ceil_div(n_launch, TILE);
     const int passes = sort_passes(nbits);
-    uint32_t* hist = (uint32_t*)tmp;
-    uint32_t* totals = (uint32_t*)((char*)tmp + align_up(256 * (int64_t)nblk * 4, 256));  // [passes][256]
-    K* kin = k0; uint32_t* vin = v0; K* kout = k1; uint32_t* vout = v1;
-    // the passes share the key bits evenly (13 tile bits -> 7 + 6, not 8 + 5): fewer bins in the first pass mean
-    // longer digit runs per 4096-key block, i.e. wider contiguous stores
+    const SortScratch sc(tmp, n_launch, TILE);
+    if (!zeroed) HS_HIP_CHECK(hipMemsetAsync(tmp, 0, (size_t)sort_scratch_words(n_launch, passes, TILE) * 4, s));
+    if (!ghist_ready)
+        radix_ghist_kernel<uint32_t, true><<<ceil_div(n_launch, kHistTile), kHistThreads, 0, s>>>(p0, n_dev, nbits, passes, sc.ghist);
+    uint2* in = p0; uint2* out = p1;
     int pass = 0;
     for (int shift = 0, w = 0; shift < nbits; shift += w, ++pass) {
         w = (nbits - shift + (passes - pass) - 1) / (passes - pass);
-        const uint32_t mask = (1u << w) - 1u;
-        uint32_t* tot = totals + 256 * pass;
-        radix_hist_kernel<K><<<nblk, kHistThreads, 0, s>>>(kin, n_dev, shift, mask, hist, nblk);
-        radix_scan_kernel<<<256, 256, 0, s>>>(hist, nblk, tot);
-        radix_scatter_kernel<K><<<nblk, kSortBlock, 0, s>>>(kin, vin, kout, vout, n_dev, shift, mask, hist, tot, nblk);
+        uint32_t* st = sc.status + (int64_t)pass * sc.pass_words;
+        if (pass == passes - 1)
+            radix_sweep_kernel<uint32_t, ITEMS, LOOK, true, false><<<nblk, kSortBlock, 0, s>>>(
+                in, nullptr, keys_out, vals_out, n_dev, shift, (1u << w) - 1u, st, sc.ghist + 256 * pass, sc.tickets + pass,
+                fail_word, kill_word);
+        else
+            radix_sweep_kernel<uint32_t, ITEMS, LOOK, true, true><<<nblk, kSortBlock, 0, s>>>(
+                in, nullptr, out, nullptr, n_dev, shift, (1u << w) - 1u, st, sc.ghist + 256 * pass, sc.tickets + pass,
+                fail_word, kill_word);
         HS_LAUNCH_CHECK();
-        K* tk = kin; kin = kout; kout = tk;
-        uint32_t* tv = vin; vin = vout; vout = tv;
+        uint2* t = in; in = out; out = t;
     }
     return HS_OK;
 }
 
 // ---------------------------------------------------------------- split tile sort (a6 + a7)
-// Depth keys of the instances: culled instances get the largest key so they sort to the end.
-__global__ void __launch_bounds__(256) depth_keys_kernel(int64_t I, const float* depth, const int* radii, uint32_t* keys,
-                                                         uint32_t* vals) {
+// Depth keys of the instances as (key, instance) elements: culled instances get the largest key so they sort to the end.
+__global__ void __launch_bounds__(256) depth_keys_kernel(int64_t I, const float* depth, const int* radii, uint2* pairs) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= I) return;
-    keys[i] = radii[i] > 0 ? __float_as_uint(depth[i]) : 0xFFFFFFFFu;
-    vals[i] = (uint32_t)i;
+    pairs[i] = make_uint2(radii[i] > 0 ? __float_as_uint(depth[i]) : 0xFFFFFFFFu, (uint32_t)i);
 }
 
 // Tile rectangles and pair counts of the instances, gathered into depth order (one 8-byte gather per instance;
 // everything the emission needs afterwards is read coalesced).
 __global__ void __launch_bounds__(256) gather_binfo_kernel(int64_t I, const uint32_t* inst_sorted, const uint2* binfo,
-                                                           uint2* srect, uint32_t* ts, uint32_t* zero, int64_t n_zero) {
+                                                           uint2* srect, uint32_t* ts, uint32_t* zero, int64_t n_zero,
+                                                           const hs_counters* counters) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    // digit totals and status words of the tile sort that follows the emission (radix_sort_sweep): cleared here
+    // digit totals, tickets and status words of the tile sort that follows the emission: cleared here
     for (int64_t t = i; t < n_zero; t += (int64_t)gridDim.x * 256) zero[t] = 0u;
     if (i >= I) return;
-    const uint2 b = binfo[inst_sorted[i]];
+    // a depth sort that gave up (overflow = 2) left no instance list: every instance counts as culled, nothing is emitted
+    const uint2 b = counters->overflow >= 2u ? make_uint2(0u, 0u) : binfo[inst_sorted[i]];
     srect[i] = b;
     ts[i] = (b.y & 0xFFFFu) * (b.y >> 16);
 }
 
 // duplicateWithKeys walking the instances in depth order.  A wave owns 64 consecutive instances, whose pair slots
-// form ONE contiguous range; its lanes walk that range slot by slot (fully coalesced stores), finding each slot's
-// owner by binary search over the 64 slot starts in LDS and its tile from the owner's rectangle (row-major, the
+// form ONE contiguous range; its lanes walk that range slot by slot (fully coalesced 8-byte stores), finding each
+// slot's owner by binary search over the 64 slot starts in LDS and its tile from the owner's rectangle (row-major, the
 // published emission order).  Also records where each instance's slots start (render-backward addresses its
 // gradient records with it; the segmented sum walks them).
 // The inclusive scan of the depth-ordered pair counts (a5 on the order the pairs are laid out in) is finished HERE: the
@@ -570,7 +465,7 @@ __global__ void __launch_bounds__(256) gather_binfo_kernel(int64_t I, const uint
 __global__ void __launch_bounds__(256) emit_pairs_kernel(int64_t I, int P, int gx, int gy, float4* rec,
                                                          const uint32_t* inst_sorted, const uint32_t* block_excl,
                                                          uint32_t* offs_sorted,
-                                                         const uint2* srect, uint32_t* tile_keys, uint32_t* vals,
+                                                         const uint2* srect, uint2* pairs,
                                                          uint8_t* pair_flags, hs_counters* counters, uint64_t capacity,
                                                          uint32_t* ghist, int nbits, int passes) {
     __shared__ uint32_t s_hist[4 * 256];   // digit totals of the tile sort's passes (<= 4), this block's pairs
@@ -580,11 +475,12 @@ __global__ void __launch_bounds__(256) emit_pairs_kernel(int64_t I, int P, int g
     __shared__ uint32_t s_wsum[4];
     // num_rendered (total of the depth-ordered scan just before this launch) against the binning capacity: an
     // overflowing call emits nothing, sorts nothing (n_sort = 0) and renders empty; the host sees counters.overflow
-    // and replays with a larger capacity.  One thread publishes the verdict for the later kernels.
+    // and replays with a larger capacity.  One thread publishes the verdict for the later kernels.  (overflow = 2, a
+    // depth sort that gave up, stays: gather_binfo_kernel then made every pair count zero.)
     const bool overflow = (uint64_t)counters->num_rendered > capacity;
     for (int t = threadIdx.x; t < passes * 256; t += 256) s_hist[t] = 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        counters->overflow = overflow ? 1u : 0u;
+        if (overflow) counters->overflow = 1u;
         counters->reserved[0] = overflow ? 0u : counters->num_rendered;
     }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -626,10 +522,9 @@ __global__ void __launch_bounds__(256) emit_pairs_kernel(int64_t I, int P, int g
         const uint32_t idx = s_inst[wave][k];
         const uint32_t tile_base = (idx / (uint32_t)P) * (uint32_t)(gx * gy);
         const uint32_t key = tile_base + ((r.x >> 16) + ty) * (uint32_t)gx + (r.x & 0xFFFFu) + tx;
-        tile_keys[pos] = key;
-        vals[pos] = idx;
+        pairs[pos] = make_uint2(key, idx);
         pair_flags[pos] = 0;  // "gradient record written" flag of this slot, set by the render backward
-        // digit totals for the single-sweep tile sort (same digit layout as radix_sort_sweep).  The lanes of a wave hold
+        // digit totals for the single-sweep tile sort (same digit layout as radix_sort_packed).  The lanes of a wave hold
         // neighbouring tiles of a few Gaussians: when they all agree on a digit, one lane adds the count
         int pass = 0;
         for (int shift = 0, w = 0; shift < nbits; shift += w, ++pass) {
@@ -653,40 +548,67 @@ __global__ void __launch_bounds__(256) emit_pairs_kernel(int64_t I, int P, int g
 }
 
 // ---------------------------------------------------------------- tile ranges (a8)
+// Four consecutive sorted tile ids per thread (one 16-byte load; the id before the first comes from the neighbouring
+// lane): ranges[t] = [first, last + 1) of tile t's run; tiles without pairs keep the (0, 0) they were cleared to.
 __global__ void __launch_bounds__(256) tile_ranges_kernel(const uint32_t* tiles, const uint32_t* n_dev, uint2* ranges) {
     const int64_t n = *n_dev;
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t t = tiles[i];
-    if (i == 0) ranges[t].x = 0;
-    else {
-        const uint32_t tp = tiles[i - 1];
-        if (t != tp) {
-            ranges[tp].y = (uint32_t)i;
-            ranges[t].x = (uint32_t)i;
-        }
+    const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    const int lane = threadIdx.x & 63;
+    uint32_t t[4] = {0u, 0u, 0u, 0u};
+    if (i0 + 4 <= n) {
+        const uint4 q = *reinterpret_cast<const uint4*>(tiles + i0);
+        t[0] = q.x; t[1] = q.y; t[2] = q.z; t[3] = q.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t[k] = i0 + k < n ? tiles[i0 + k] : 0u;
     }
-    if (i == n - 1) ranges[t].y = (uint32_t)n;
+    uint32_t prev = __shfl_up(t[3], 1);
+    if (lane == 0 && i0 > 0 && i0 < n) prev = tiles[i0 - 1];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int64_t i = i0 + k;
+        if (i < n) {
+            if (i == 0) ranges[t[k]].x = 0;
+            else if (t[k] != prev) { ranges[prev].y = (uint32_t)i; ranges[t[k]].x = (uint32_t)i; }
+            if (i == n - 1) ranges[t[k]].y = (uint32_t)n;
+        }
+        prev = t[k];
+    }
 }
 
 }  // namespace
 
 int64_t sort_tmp_bytes(int64_t n) {
-    const int64_t nblk = ceil_div(n > 0 ? n : 1, kSortTile);
-    // digit totals of up to 8 passes + one status word per (pass, block, digit); the classic three-kernel passes
-    // (HS_EXP_SORT_CLASSIC) need a 256 x nblk histogram + totals, which fits in the same space
-    return kGhistWords * 4 + align_up(8 * sweep_pass_words(nblk) * 4, 256);
+    // sized for the smallest radix block any of the sorts uses (most blocks, hence most status words)
+    return align_up(sort_scratch_words(n > 0 ? n : 1, 8, kSortTileMin) * 4, 256);
 }
 
-#ifdef HS_EXP_SORT_CLASSIC
-#define HS_RADIX_SORT radix_sort
-#else
-#define HS_RADIX_SORT radix_sort_sweep
-#endif
-
+// hs_sort_pairs: stable LSD radix sort of (u64 key, u32 value) pairs with the same pass kernel (keys and values in
+// separate arrays).  Ping-pongs between (k0,v0) and (k1,v1); the result lands in (k0,v0) when sort_passes(nbits) is
+// even, else in (k1,v1).  `fail_word`: device word that reads 2 afterwards if a look-back gave up.
 int launch_radix_sort(uint64_t* k0, uint32_t* v0, uint64_t* k1, uint32_t* v1, const uint32_t* n_dev,
-                      int64_t n_launch, int nbits, void* tmp, hipStream_t s) {
-    return HS_RADIX_SORT<uint64_t>(k0, v0, k1, v1, n_dev, n_launch, nbits, tmp, s);
+                      int64_t n_launch, int nbits, void* tmp, uint32_t* fail_word, hipStream_t s) {
+    if (n_launch <= 0) return HS_OK;
+    constexpr int ITEMS = kU64SortItems, TILE = ITEMS * kSortBlock;
+    const int nblk = ceil_div(n_launch, TILE);
+    const int passes = sort_passes(nbits);
+    const SortScratch sc(tmp, n_launch, TILE);
+    HS_HIP_CHECK(hipMemsetAsync(tmp, 0, (size_t)sort_scratch_words(n_launch, passes, TILE) * 4, s));
+    if (fault_injection() == 1)   // tests only (HS_FAULT_INJECT=sort_ticket): chain position 0 is never handed out
+        HS_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)sc.tickets, 1, 1, s));
+    radix_ghist_kernel<uint64_t, false><<<ceil_div(n_launch, kHistTile), kHistThreads, 0, s>>>(k0, n_dev, nbits, passes, sc.ghist);
+    uint64_t* kin = k0; uint32_t* vin = v0; uint64_t* kout = k1; uint32_t* vout = v1;
+    int pass = 0;
+    for (int shift = 0, w = 0; shift < nbits; shift += w, ++pass) {
+        w = (nbits - shift + (passes - pass) - 1) / (passes - pass);
+        radix_sweep_kernel<uint64_t, ITEMS, 8, false, false><<<nblk, kSortBlock, 0, s>>>(
+            kin, vin, kout, vout, n_dev, shift, (1u << w) - 1u, sc.status + (int64_t)pass * sc.pass_words,
+            sc.ghist + 256 * pass, sc.tickets + pass, fail_word, nullptr);
+        HS_LAUNCH_CHECK();
+        uint64_t* tk = kin; kin = kout; kout = tk;
+        uint32_t* tv = vin; vin = vout; vout = tv;
+    }
+    return HS_OK;
 }
 
 // a5 in instance order, as the published pipeline lays it out: offsets[i] = sum_{j<=i} tiles_touched[j], total =
@@ -710,72 +632,62 @@ int launch_binning(const hs_fwd_args& a, const hs_layout& L, hipStream_t s) {
     const int gx = (d.W + kTile - 1) / kTile, gy = (d.H + kTile - 1) / kTile;
     const int64_t ntiles = (int64_t)gx * gy * d.n_poses;
     hs_counters* counters = (hs_counters*)(geom + L.counters);
-    const uint32_t* n_sort = &counters->reserved[0];
+    uint32_t* n_sort = &counters->reserved[0];
     const uint32_t* n_inst = &counters->reserved[1];
     uint2* ranges = (uint2*)(bin + L.ranges);
     // when preprocess ran in this same call it already wrote the depth keys, the instance count and cleared ranges
     const bool prepared = (a.stages & HS_STAGE_PREPROCESS) != 0;
     void* tmp = bin + L.sort_tmp;
+    constexpr int kDepthTile = kDepthSortItems * kSortBlock, kPairTile = kPairSortItems * kSortBlock;
     if (!prepared)
         bin_prepare_kernel<<<ceil_div(ntiles, 256), 256, 0, s>>>(counters, (uint32_t)I, ranges, ntiles, (uint32_t*)tmp,
-                                                                 sort_scratch_words(I, 4));
+                                                                 sort_scratch_words(I, 4, kDepthTile));
 
-    // 1. instances by depth (stable, 32-bit keys -> 4 passes: result back in the first buffer pair)
-    uint32_t* dk0 = (uint32_t*)(bin + L.depth_keys);
-    uint32_t* dv0 = (uint32_t*)(bin + L.depth_vals);
-    uint32_t* dk1 = dk0 + I;
-    uint32_t* dv1 = dv0 + I;
+    // 1. instances by depth (stable, 32-bit keys -> 4 passes over (key, instance) elements; the last one leaves only
+    //    the instance list)
+    uint2* dp0 = (uint2*)(bin + L.depth_pairs);
+    uint2* dp1 = dp0 + I;
+    uint32_t* inst_sorted = (uint32_t*)(bin + L.inst_sorted);
     if (!prepared)
-        depth_keys_kernel<<<ceil_div(I, 256), 256, 0, s>>>(I, (const float*)(geom + L.depth), (const int*)(geom + L.radii),
-                                                           dk0, dv0);
-    // (single-sweep passes here too: at c3's 245 blocks they cost what the three-kernel passes cost -- 4 x 17 + 12 us
-    // against 4 x 22 -- but take 6 launches instead of 12, and with few blocks (c2: 25) or many (c4: 1953) they are
-    // faster; HS_EXP_SORT_CLASSIC keeps the three-kernel passes for A/B)
-#ifdef HS_EXP_SORT_CLASSIC
-    int rc = radix_sort<uint32_t>(dk0, dv0, dk1, dv1, n_inst, I, 32, tmp, s);
-#else
-    int rc = radix_sort_sweep<uint32_t>(dk0, dv0, dk1, dv1, n_inst, I, 32, tmp, s, /*zeroed=*/true);   // by preprocess / bin_prepare
-#endif
+        depth_keys_kernel<<<ceil_div(I, 256), 256, 0, s>>>(I, (const float*)(geom + L.depth), (const int*)(geom + L.radii), dp0);
+    int rc = radix_sort_packed<kDepthSortItems, kDepthSortLook>(dp0, dp1, nullptr, inst_sorted, n_inst, I, 32, tmp,
+                                                               &counters->overflow, nullptr, s, /*zeroed=*/true,
+                                                               /*ghist_ready=*/false);   // cleared by preprocess / bin_prepare
     if (rc != HS_OK) return rc;
-    const uint32_t* inst_sorted = dv0;
     // 2. pair offsets in depth order, then emission
-    uint32_t* ts = dk1;      // tiles touched in depth order (reuses the depth-key scratch)
-    uint32_t* offs = dv1;    // inclusive scan of ts
+    uint32_t* ts = (uint32_t*)dp0;   // tiles touched in depth order (the depth sort's buffers are free again)
+    uint32_t* offs = (uint32_t*)(bin + L.offs_sorted);   // inclusive scan of ts; the backward's segmented sum walks it
     uint2* srect = (uint2*)(bin + L.srect);
     // the tile sort below runs single-sweep passes: its digit totals are counted by the emission, its scratch (totals +
-    // status words) is cleared by this gather
+    // tickets + status words) is cleared by this gather
     const int tbits = tile_bits((uint32_t)ntiles);
     const int passes = sort_passes(tbits);
-    const int64_t n_zero = sort_scratch_words(d.capacity, passes);
+    const int64_t n_zero = sort_scratch_words(d.capacity, passes, kPairTile);
     gather_binfo_kernel<<<ceil_div(I, 256), 256, 0, s>>>(I, inst_sorted, (const uint2*)(geom + L.binfo), srect, ts,
-                                                         (uint32_t*)tmp, n_zero);
+                                                         (uint32_t*)tmp, n_zero, counters);
     // pair offsets in depth order: block sums + their exclusive scan here, the rest inside the emission
     uint32_t* spine = (uint32_t*)(geom + L.scan_spine);
     const int eblk = ceil_div(I, 256);
     scan_reduce256_kernel<<<eblk, 256, 0, s>>>(ts, I, spine);
     scan_spine_kernel<<<1, 256, 0, s>>>(spine, eblk, &counters->num_rendered);  // total = R
-    // the tile sort must end in (keys_sorted, point_list): start from A when the pass count is even
-    uint32_t* kA = (uint32_t*)(bin + L.keys_sorted);
-    uint32_t* vA = (uint32_t*)(bin + L.point_list);
-    uint32_t* kB = (uint32_t*)(bin + L.keys_unsorted);
-    uint32_t* vB = (uint32_t*)(bin + L.vals_unsorted);
-    uint32_t* k0 = (passes % 2 == 0) ? kA : kB;
-    uint32_t* v0 = (passes % 2 == 0) ? vA : vB;
-    uint32_t* k1 = (passes % 2 == 0) ? kB : kA;
-    uint32_t* v1 = (passes % 2 == 0) ? vB : vA;
+    // the last pass writes (keys_sorted, point_list), which overlay packed buffer A: it must read buffer B, so the
+    // emission starts in A when the pass count is even
+    uint2* pA = (uint2*)(bin + L.keys_sorted);
+    uint2* pB = (uint2*)(bin + L.pairs_tmp);
+    uint2* p0 = (passes % 2 == 0) ? pA : pB;
+    uint2* p1 = (passes % 2 == 0) ? pB : pA;
     emit_pairs_kernel<<<eblk, 256, 0, s>>>(I, d.P, gx, gy, (float4*)(geom + L.rec), inst_sorted, spine, offs, srect,
-                                           k0, v0, (uint8_t*)(bin + L.pair_flags), counters, (uint64_t)d.capacity,
+                                           p0, (uint8_t*)(bin + L.pair_flags), counters, (uint64_t)d.capacity,
                                            (uint32_t*)tmp, tbits, passes);
     HS_LAUNCH_CHECK();
     // 3. stable sort by tile id only
-#ifdef HS_EXP_SORT_CLASSIC
-    rc = radix_sort<uint32_t>(k0, v0, k1, v1, n_sort, d.capacity, tbits, tmp, s);
-#else
-    rc = radix_sort_sweep<uint32_t>(k0, v0, k1, v1, n_sort, d.capacity, tbits, tmp, s, /*zeroed=*/true, /*ghist_ready=*/true);
-#endif
+    uint32_t* keys_sorted = (uint32_t*)(bin + L.keys_sorted);
+    rc = radix_sort_packed<kPairSortItems, kPairSortLook>(p0, p1, keys_sorted, (uint32_t*)(bin + L.point_list), n_sort,
+                                                         d.capacity, tbits, tmp, &counters->overflow, n_sort, s,
+                                                         /*zeroed=*/true, /*ghist_ready=*/true);
     if (rc != HS_OK) return rc;
     if (d.capacity > 0) {
-        tile_ranges_kernel<<<ceil_div(d.capacity, 256), 256, 0, s>>>(kA, n_sort, ranges);
+        tile_ranges_kernel<<<ceil_div(d.capacity, 1024), 256, 0, s>>>(keys_sorted, n_sort, ranges);
         HS_LAUNCH_CHECK();
     }
     return HS_OK;

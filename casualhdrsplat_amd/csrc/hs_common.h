@@ -28,12 +28,22 @@ constexpr int kInstF4 = 4;                 // float4 per per-instance sum of the
 constexpr int kRecFloats = 4 * kRecF4;
 constexpr int kPairFloats = 4 * kPairF4;
 constexpr int kInstFloats = 4 * kInstF4;
-#ifndef HS_EXP_SORT_ITEMS
-#define HS_EXP_SORT_ITEMS 16
+// Radix passes (binning.hip): 256 threads per block, ITEMS elements per thread; LOOK = status words a thread requests at
+// once during the decoupled look-back.  Tunables of the three sorts (HS_TUNE_*: A/B builds only):
+#ifndef HS_TUNE_DEPTH_ITEMS
+#define HS_TUNE_DEPTH_ITEMS 16
 #endif
-constexpr int kSortItems = HS_EXP_SORT_ITEMS;   // keys per thread per radix block
+#ifndef HS_TUNE_DEPTH_LOOK
+#define HS_TUNE_DEPTH_LOOK 8
+#endif
+#ifndef HS_TUNE_PAIR_LOOK
+#define HS_TUNE_PAIR_LOOK 8
+#endif
 constexpr int kSortBlock = 256;
-constexpr int kSortTile = kSortItems * kSortBlock;  // 4096 keys per block
+constexpr int kDepthSortItems = HS_TUNE_DEPTH_ITEMS, kDepthSortLook = HS_TUNE_DEPTH_LOOK;  // instances by depth
+constexpr int kPairSortItems = 16, kPairSortLook = HS_TUNE_PAIR_LOOK;                      // (tile, instance) pairs by tile
+constexpr int kU64SortItems = 16;                                                           // hs_sort_pairs
+constexpr int kSortTileMin = (kDepthSortItems < 16 ? kDepthSortItems : 16) * kSortBlock;    // smallest radix block in use
 
 static inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
@@ -60,21 +70,26 @@ int launch_mark_visible(int P, const float* means3D, const float* view, uint8_t*
 int launch_sh_backward_views(int P, int M, int deg, int V, const float* means3D, const float* camposes,
                              const float* view_colors, float* d_shs, hipStream_t s);
 
-// Scratch of the single-sweep radix passes (binning.hip): digit totals in kGhistCopies copies of [pass <= 8][256], then one
-// status word per (pass, block, digit).  sort_scratch_words(n, passes) = the words a sort of n keys needs cleared.
+// Scratch of the single-sweep radix passes (binning.hip): digit totals in kGhistCopies copies of [pass <= 8][256], one
+// ticket counter per pass (a block's place in the look-back chain), then one status word per (pass, block, digit).
+// sort_scratch_words(n, passes, tile) = the words a sort of n elements in blocks of `tile` needs cleared.
 constexpr int kGhistCopies = 16;
 constexpr int kGhistWords = kGhistCopies * 8 * 256;
+constexpr int kTicketWords = 64;
 __host__ __device__ inline int64_t sweep_pass_words(int64_t nblk) { return nblk * 256; }
-static inline int64_t sort_scratch_words(int64_t n, int passes) {
-    return n > 0 ? kGhistWords + (int64_t)passes * sweep_pass_words((n + kSortTile - 1) / kSortTile) : 0;
+static inline int64_t sort_scratch_words(int64_t n, int passes, int tile) {
+    return n > 0 ? kGhistWords + kTicketWords + (int64_t)passes * sweep_pass_words((n + tile - 1) / tile) : 0;
 }
 int64_t sort_tmp_bytes(int64_t n);
-// Stable LSD radix sort of (u64 key, u32 value) pairs on bits [0,nbits) (hs_sort_pairs; the forward uses the u32-key
-// instantiation in binning.hip).  Ping-pongs between (k0,v0) and (k1,v1); the result lands in (k0,v0) when
-// sort_passes(nbits) is even, else in (k1,v1).  `n_dev` points at the device-resident element count (<= n_launch);
-// `hist` must hold sort_tmp_bytes(n_launch).
+// Stable LSD radix sort of (u64 key, u32 value) pairs on bits [0,nbits) (hs_sort_pairs; the forward sorts packed
+// (u32 key, u32 value) elements with the same pass kernel).  Ping-pongs between (k0,v0) and (k1,v1); the result lands
+// in (k0,v0) when sort_passes(nbits) is even, else in (k1,v1).  `n_dev` points at the device-resident element count
+// (<= n_launch); `tmp` must hold sort_tmp_bytes(n_launch); *fail_word reads 2 afterwards if a look-back gave up.
 int launch_radix_sort(uint64_t* k0, uint32_t* v0, uint64_t* k1, uint32_t* v1, const uint32_t* n_dev,
-                      int64_t n_launch, int nbits, void* hist, hipStream_t s);
+                      int64_t n_launch, int nbits, void* tmp, uint32_t* fail_word, hipStream_t s);
+// Test hook (HS_FAULT_INJECT in the environment, read once): 0 = none, 1 = "sort_ticket": hs_sort_pairs starts its first
+// pass with ticket 1, so chain position 0 never publishes and the bounded look-back must give up.
+int fault_injection();
 static inline int sort_passes(int nbits) { return (nbits + 7) / 8; }
 
 // ---- small device helpers ----

@@ -145,7 +145,7 @@ struct PreFwd {
     int* radii_out;
     // single-enqueue forward (binning workspace already there): the start of the binning stage rides along --
     // depth-sort keys/values of the instances, the instance count word, cleared tile ranges; else null
-    uint32_t* depth_keys; uint32_t* depth_vals; hs_counters* counters; uint2* ranges; int64_t n_vtiles;
+    uint2* depth_pairs; hs_counters* counters; uint2* ranges; int64_t n_vtiles;
     uint32_t* sort_zero; int64_t n_sort_zero;   // scratch of the depth sort that follows (binning.hip), cleared here
     bool antialias;
     int act;  // radiance activation: 0 relu_shift, 1 exp, 2 softplus
@@ -154,7 +154,7 @@ struct PreFwd {
 // d colour / d s of the radiance activation, from the stored colour (and the clamp bit for relu_shift)
 __device__ __forceinline__ float radiance_dact(int act, float col, bool was_clamped) {
     if (act == 1) return col;
-    if (act == 2) return 1.0f - expf(-col);
+    if (act == 2) return -expm1f(-col);  // sigmoid(s) = 1 - e^-softplus(s); expm1: exact also where col < 6e-8 (dark Gaussians)
     return was_clamped ? 0.f : 1.f;
 }
 
@@ -290,15 +290,14 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreFwd p) {
     p.clamped[idx] = clampbits;
     if (p.N == 1) p.radii_out[g] = my_radius;
     else if (my_radius > 0) atomicMax(p.radii_out + g, my_radius);
-    if (p.depth_keys) {  // culled instances get the largest key so they sort to the end
-        p.depth_keys[idx] = my_radius > 0 ? __float_as_uint(depth) : 0xFFFFFFFFu;
-        p.depth_vals[idx] = (uint32_t)idx;
-    }
+    if (p.depth_pairs)   // (depth bits, instance) for the depth sort; culled instances get the largest key: they sort to the end
+        p.depth_pairs[idx] = make_uint2(my_radius > 0 ? __float_as_uint(depth) : 0xFFFFFFFFu, (uint32_t)idx);
     }  // g < P
-    if (p.depth_keys) {
+    if (p.depth_pairs) {
         for (int64_t t = lin; t < p.n_vtiles; t += (int64_t)gridDim.x * 256) p.ranges[t] = make_uint2(0u, 0u);
         for (int64_t t = lin; t < p.n_sort_zero; t += (int64_t)gridDim.x * 256) p.sort_zero[t] = 0u;
         if (lin == 0) {
+            p.counters->overflow = 0u;
             p.counters->reserved[1] = (uint32_t)((int64_t)p.P * p.N);
             p.counters->reserved[2] = 0u; p.counters->reserved[3] = 0u;   // tile-queue counters of the render kernels
         }
@@ -837,15 +836,15 @@ int launch_preprocess_fwd(const hs_fwd_args& a, const hs_layout& L, hipStream_t 
     p.binfo = (uint2*)(geom + L.binfo);
     p.antialias = (a.flags & HS_FLAG_ANTIALIAS) != 0;
     p.act = (a.flags & HS_FLAG_RADIANCE_EXP) ? 1 : (a.flags & HS_FLAG_RADIANCE_SOFTPLUS) ? 2 : 0;
-    p.depth_keys = nullptr; p.depth_vals = nullptr; p.counters = nullptr; p.ranges = nullptr; p.n_vtiles = 0;
+    p.depth_pairs = nullptr; p.counters = nullptr; p.ranges = nullptr; p.n_vtiles = 0;
     p.sort_zero = nullptr; p.n_sort_zero = 0;
     if ((a.stages & HS_STAGE_BIN) && a.binning) {
         char* bin = (char*)a.binning;
-        p.depth_keys = (uint32_t*)(bin + L.depth_keys); p.depth_vals = (uint32_t*)(bin + L.depth_vals);
+        p.depth_pairs = (uint2*)(bin + L.depth_pairs);
         p.counters = (hs_counters*)(geom + L.counters); p.ranges = (uint2*)(bin + L.ranges);
         p.n_vtiles = (int64_t)((d.W + kTile - 1) / kTile) * ((d.H + kTile - 1) / kTile) * d.n_poses;
         p.sort_zero = (uint32_t*)(bin + L.sort_tmp);
-        p.n_sort_zero = sort_scratch_words((int64_t)d.P * d.n_poses, 4);
+        p.n_sort_zero = sort_scratch_words((int64_t)d.P * d.n_poses, 4, kDepthSortItems * kSortBlock);
     }
     if (d.n_poses > 1) HS_HIP_CHECK(hipMemsetAsync(a.radii, 0, sizeof(int) * (size_t)d.P, s));
     // chunks of 256 Gaussians, padded to a multiple of the 8 XCDs, times the poses (see the kernel's block map)
@@ -879,8 +878,9 @@ int launch_preprocess_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t 
     if (segsum) {
         const int64_t I = (int64_t)d.P * d.n_poses;
         const char* bin = (const char*)a.binning;
-        const uint32_t* dv0 = (const uint32_t*)(bin + L.depth_vals);
-        pair_segsum_kernel<<<ceil_div(4 * I, 256), 256, 0, s>>>(I, dv0, dv0 + I, (const float4*)((const char*)a.bwd + L.pair_grads),
+        pair_segsum_kernel<<<ceil_div(4 * I, 256), 256, 0, s>>>(I, (const uint32_t*)(bin + L.inst_sorted),
+                                                           (const uint32_t*)(bin + L.offs_sorted),
+                                                           (const float4*)((const char*)a.bwd + L.pair_grads),
                                                            (const uint8_t*)bin + L.pair_flags,
                                                            (float4*)((char*)a.bwd + L.inst_grads),
                                                            (const hs_counters*)(geom + L.counters), p.radii_inst, p.clamped,

@@ -174,11 +174,7 @@ __device__ __forceinline__ float wave_reduce(const float* g, float g9, int xor32
     float w0, w1, w2;
     reduce_in_rows<TEN>(g, g9, w0, w1, w2);
     const float u0 = halve32(w0, w1);  // lanes 0-31: w0 over bit 5, lanes 32-63: w1 over bit 5
-#ifdef HS_EXP_SWAP_SINGLE
-    const float u1 = halve32(w2, w2);
-#else
     const float u1 = w2 + __int_as_float(__builtin_amdgcn_ds_bpermute(xor32_addr, __float_as_int(w2)));
-#endif
     const float t = halve16(u0, u1);   // rows 0, 2: u0 over bit 4 ; rows 1, 3: u1 over bit 4
     return reduce_in_quads(t);
 }
@@ -749,33 +745,19 @@ __device__ __forceinline__ void step_bwd_pair(PairB& s, bool act0, bool act1, f2
 //   [12..21] the nine (ten) sums of the entry: zeroed per batch, each wave ADDS its totals (ds_add_f32).  At most two
 //   adds reach a word and 0 + x + y does not depend on their order, so the result is still bitwise reproducible -- and
 //   one set of sums instead of one per wave is what keeps the kernel at 12.8 KB of LDS (six waves per SIMD).
-#ifndef HS_EXP_ENTF
-#define HS_EXP_ENTF 24
-#endif
 constexpr int kTailPct = 8;           // share of the tiles handed out by the queue (see the kernel)
-constexpr int kEntF = HS_EXP_ENTF;    // floats per LDS entry record (22 used): 96 bytes keeps every record 16-byte
+constexpr int kEntF = 24;             // floats per LDS entry record (22 used): 96 bytes keeps every record 16-byte
 constexpr int kEntB = kEntF * 4;      // aligned (measured on one box: 88-byte records, i.e. split ds_read_b128, +5 %)
 constexpr int kAccF = 12;             // first float of the sums
 
 
 template <bool DEPTH, bool STATS>
 __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
-#ifndef HS_EXP_BWD_KB
-#define HS_EXP_BWD_KB 128
-#endif
-    constexpr int KB = HS_EXP_BWD_KB;       // staged entries per batch (<= threads per workgroup)
+    constexpr int KB = kBatch;              // staged entries per batch (<= threads per workgroup)
     constexpr int NV = DEPTH ? 10 : 9;      // reduced values per (tile, entry): nine published sums (+ d inverse depth)
     __shared__ __attribute__((aligned(16))) float s_ent[KB * kEntF];
     __shared__ uint8_t s_actb[kBatch];      // activity byte of each staged entry (bit w: wave w's half tile took it)
     __shared__ uint32_t s_max[2];
-#ifdef HS_EXP_PG
-    // A/B build: the per-Gaussian-parallel backward (SURVEY.md 7.2 alternative).  Per wave: the upstream gradient,
-    // the replay state and the contributor limit of its 128 pixels, and the wave's takers of a batch in reverse order
-    __shared__ float4 s_pix[2][kBatch];     // {dL0, dL1, dL2, -} of pixel p = row * 16 + col of the half tile
-    __shared__ float2 s_pst[2][kBatch];     // {T, q} of the pixel behind the entries processed so far
-    __shared__ int s_plast[2][kBatch];      // last contributor * 96
-    __shared__ uint16_t s_rlist[2][kBatch];
-#endif
 
     // The last kTailPct per cent of the tiles are not bound to a workgroup (hence, through blockIdx, to an XCD): the
     // workgroups behind the static part take them from a queue, one after the other, until it is empty, so an XCD that
@@ -822,17 +804,6 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
 
     const uint32_t wave_max = wave_max_u32(max(s0.last, s1.last));
     if (lane == 0) s_max[wave] = wave_max;
-#ifdef HS_EXP_PG
-    {
-        const int p0 = (lane >> 4) * 32 + (lane & 15), p1 = p0 + 16;
-        s_pix[wave][p0] = make_float4(s0.dL0, s0.dL1, s0.dL2, 0.f);
-        s_pix[wave][p1] = make_float4(s1.dL0, s1.dL1, s1.dL2, 0.f);
-        s_pst[wave][p0] = make_float2(s0.T, s0.q);
-        s_pst[wave][p1] = make_float2(s1.T, s1.q);
-        s_plast[wave][p0] = (int)s0.last * kEntB;
-        s_plast[wave][p1] = (int)s1.last * kEntB;
-    }
-#endif
     __syncthreads();
     const int n_proc = (int)max(s_max[0], s_max[1]);
 
@@ -884,9 +855,6 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
             reinterpret_cast<float4*>(my_ent)[0] = ra;
             reinterpret_cast<float4*>(my_ent)[1] = rb;
             reinterpret_cast<float4*>(my_ent)[2] = rc;
-#ifdef HS_EXP_ATOMIC
-            my_ent[22] = __uint_as_float(id_next);  // A/B build only: the instance the per-pixel atomics go to
-#endif
 #pragma unroll
             for (int q = 0; q < 10; q += 2) reinterpret_cast<float2*>(my_ent + kAccF)[q >> 1] = make_float2(0.f, 0.f);  // 8-byte aligned
         }
@@ -902,73 +870,6 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
 #pragma unroll
             for (int k = 0; k < kBatch / 64; ++k) todo[k] = __ballot((s_actb[k * 64 + lane] & wbit) != 0);
             if constexpr (STATS) ws.v[kStBwdCulled] += (uint32_t)cnt - __popcll(todo[0]) - __popcll(todo[1]);
-#ifdef HS_EXP_PG
-            {
-                // the wave's takers in reverse (back-to-front) order
-                const int n_t = __popcll(todo[0]) + __popcll(todo[1]);
-#pragma unroll
-                for (int k = 0; k < kBatch / 64; ++k) {
-                    if ((todo[k] >> lane) & 1ull) {
-                        int above = __popcll(todo[k] >> lane) - 1;          // takers above me in this half
-                        if (k == 0) above += __popcll(todo[1]);
-                        s_rlist[wave][above] = (uint16_t)((k * 64 + lane) * kEntB);
-                    }
-                }
-                const int base96 = base * kEntB;
-                for (int g0 = 0; g0 < n_t; g0 += 64) {
-                    // one lane = one Gaussian of the group; the pixels of the half tile stream through the lanes, a
-                    // pixel's replay state handed from lane l - 1 (the entry behind) to lane l one step later
-                    const bool valid = g0 + lane < n_t;
-                    const int jb = valid ? (int)s_rlist[wave][g0 + lane] : 0;
-                    const float4 a = *reinterpret_cast<const float4*>(ent + jb);
-                    const float4 b = *reinterpret_cast<const float4*>(ent + jb + 16);
-                    const float cb = *reinterpret_cast<const float*>(ent + jb + 32);
-                    const int jlim = jb + base96;
-                    float S[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                    float T_out = 0.f, q_out = 0.f;
-                    for (int st = 0; st < kBatch + 63; ++st) {
-                        const int pp = st - lane;
-                        const int pc = min(max(pp, 0), kBatch - 1);
-                        const bool in_range = valid && pp >= 0 && pp < kBatch;
-                        // state: lane 0 takes the pixel's from LDS, the others from the lane before
-                        const float2 fresh = s_pst[wave][min(st, kBatch - 1)];
-                        float T_in = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(T_out), 0x138, 0xF, 0xF, false));
-                        float q_in = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(q_out), 0x138, 0xF, 0xF, false));
-                        if (lane == 0) { T_in = fresh.x; q_in = fresh.y; }
-                        const float4 dLp = s_pix[wave][pc];
-                        const int plast = s_plast[wave][pc];
-                        const float fx = (float)(sx + (pc & 15)), fy = (float)(sy + (pc >> 4));
-                        const float dx = a.x - fx, dy = a.y - fy;
-                        const float t = a.z * dx * dx, u = a.w * dx;
-                        const float pw = dy * (b.x * dy + u) + t;
-                        const float G = hs_exp2(pw);
-                        const float al = fminf(kAlphaMax, b.y * G);
-                        const bool act = in_range && (jlim < plast) && (pw <= 0.f) && (al >= kAlphaMin);
-                        const float ae = act ? al : 0.f;
-                        const float rcp = __builtin_amdgcn_rcpf(1.f - ae);
-                        const float T = T_in * rcp;
-                        const float dch = ae * T;
-                        const float cd = (b.z * dLp.x + b.w * dLp.y) + cb * dLp.z;
-                        const float diff = cd - q_in;
-                        const float gd = G * (diff * T);
-                        q_out = act ? q_in + ae * diff : q_in;  // lanes without an entry hold stale LDS: pass the state through
-                        T_out = T;
-                        const float dop = act ? gd : 0.f;
-                        const float sw = b.y * dop;
-                        const float m = sw * dy, n2 = sw * dx;
-                        S[0] += n2; S[1] += m; S[2] += n2 * dx; S[3] += m * dx; S[4] += m * dy; S[5] += dop;
-                        S[6] += dch * dLp.x; S[7] += dch * dLp.y; S[8] += dch * dLp.z;
-                        // the pixel leaves the group behind lane 63 (lanes without an entry pass it through)
-                        if (lane == 63 && pp >= 0 && pp < kBatch) s_pst[wave][pp] = make_float2(T_out, q_out);
-                    }
-                    if (valid) {
-#pragma unroll
-                        for (int q = 0; q < 9; ++q) atomicAdd(reinterpret_cast<float*>(ent + jb + (kAccF + q) * 4), S[q]);
-                    }
-                }
-                (void)xor32_addr; (void)red_off; (void)pxf; (void)pyf;
-            }
-#else
             // a pixel takes part in entry j of this batch iff base + j < last, i.e. iff j * 96 < (last - base) * 96
             const int lim0 = ((int)s0.last - base) * kEntB, lim1 = ((int)s1.last - base) * kEntB;
 #pragma unroll
@@ -1021,25 +922,9 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
                     const f2 cd = dch * ps.dLd;
                     g9 = cd.x + cd.y;
                 }
-#ifdef HS_EXP_ATOMIC
-                // A/B build (never shipped; results are not summed correctly downstream): the published design --
-                // every lane adds its nine per-pixel-pair terms straight into the Gaussian's gradient with global
-                // float atomics (here into the instance's 64-byte sum record), no wave reduction, no pair record
-                {
-                    const uint32_t inst = __float_as_uint(*reinterpret_cast<const float*>(ent + jb + 88));
-                    float* sink = reinterpret_cast<float*>(p.pair_grads) + (size_t)inst * 16;
-                    if (act0 || act1) {
-#pragma unroll
-                        for (int q = 0; q < 9; ++q) atomicAdd(sink + q, g[q]);
-                    }
-                    (void)g9; (void)xor32_addr; (void)red_off;
-                }
-#else
                 const float tot = wave_reduce<DEPTH>(g, g9, xor32_addr);
                 if (red_off >= 0) atomicAdd(reinterpret_cast<float*>(ent + jb + red_off), tot);  // 9 (10) lanes, one LDS add
-#endif
             }
-#endif  // HS_EXP_PG
         }
         __syncthreads();
         if (taken) {

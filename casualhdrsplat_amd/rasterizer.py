@@ -161,6 +161,9 @@ class _Pending:
             self.n, self.overflow = int(self.host[0]) & 0xFFFFFFFF, int(self.host[1])
             _PINNED_POOL.append(self.host)
             self.host = None
+        if self.overflow >= 2:
+            raise RuntimeError("libhdrsplat: a radix pass of the binning stage gave up waiting for a predecessor's status "
+                               "word (hs_counters.overflow = 2: damaged sort scratch); the frame was rendered empty")
         return self.n, self.overflow != 0
 
     def check(self, where: str = ""):
@@ -348,8 +351,10 @@ class _RasterizeGaussians(torch.autograd.Function):
             # step cannot be repaired here -- raise, and let the rasterizer grow its capacity for the next call
             n, over = st.pending.resolve()
             if over:
-                if ctx.aux is not None:
-                    ctx.aux["grow_to"] = grown_capacity(n)
+                if ctx.aux is not None and ctx.aux.get("cell") is not None:
+                    # the rasterizer's own cell, not this call's bookkeeping: other forwards may have run in between
+                    cell = ctx.aux["cell"]
+                    cell["grow_to"] = max(int(cell.get("grow_to") or 0), grown_capacity(n))
                 raise BinningOverflow(n, st.pending.capacity, " and this backward belongs to that empty frame (the "
                                       "rasterizer has grown its capacity for the following calls)")
             st.num_rendered = n
@@ -465,6 +470,7 @@ def replay_forward(out_tensor: torch.Tensor, stages: int = L.HS_STAGE_RENDER) ->
     scratch_radii = torch.empty(max(st.dims.P, 1), dtype=torch.int32, device=out_tensor.device)
     a.out_hdr, a.radii, a.out_invdepth = _ptr(scratch_hdr), scratch_radii.data_ptr(), None
     L.check(L.load().hs_forward(C.byref(a), _stream()), "hs_forward[replay]")
+    a.out_hdr, a.radii = None, None  # scratch dies with this call
 
 
 def replay_backward(out_tensor: torch.Tensor, grad_color: torch.Tensor, stages: int = L.HS_BWD_ALL,
@@ -498,6 +504,7 @@ def render_stats(out_tensor: torch.Tensor, grad_color: torch.Tensor, grad_hdr: O
     scratch_hdr = torch.empty_like(out_tensor) if (st.flags & L.HS_FLAG_HDR) else None
     a.out_hdr, a.out_invdepth = _ptr(scratch_hdr), None
     L.check(L.load().hs_render_stats(C.byref(a), None, stats.data_ptr(), None, _stream()), "hs_render_stats[fwd]")
+    a.out_hdr = None  # the scratch image dies with this call: never leave its address in the saved argument struct
     d = st.dims
     n_wg = ((d.W + L.HS_TILE - 1) // L.HS_TILE) * ((d.H + L.HS_TILE - 1) // L.HS_TILE) * d.n_poses
     tl = torch.zeros(n_wg, 3, dtype=torch.int64, device=dev) if timeline else None
@@ -584,6 +591,7 @@ class GaussianRasterizer(nn.Module):
         self.deferred: Optional[dict] = None
         self.keep_state = keep_state
         self._last: dict = {}       # bookkeeping of the latest forward (pending counters, optional state)
+        self._cell: dict = {}       # shared with every call's backward: an overflow found there asks for a larger capacity
         self.overflow_replays = 0   # forwards that were replayed with a grown capacity
 
     @property
@@ -632,7 +640,7 @@ class GaussianRasterizer(nn.Module):
         scales = empty if scales is None else scales
         rotations = empty if rotations is None else rotations
         cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
-        grow = self._last.get("grow_to")  # an overflow found by the previous call's backward
+        grow = self._cell.pop("grow_to", None)  # an overflow found by the backward of ANY earlier call of this rasterizer
         if grow is not None and self.capacity is not None:
             self.capacity = max(int(self.capacity), int(grow))
         while True:
@@ -640,7 +648,7 @@ class GaussianRasterizer(nn.Module):
             if self.deferred is not None and self.gather_group is not None:
                 self.deferred["gather_group"] = self.gather_group
                 self.deferred["gather_direct"] = bool(self.gather_direct)
-            aux = {"keep_state": self.keep_state}
+            aux = {"keep_state": self.keep_state, "cell": self._cell}
             outs = rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
                                        cov3D_precomp, rs, self.capacity, self.return_alpha, self.deferred,
                                        self.return_invdepth, self.densify_stats, aux)
@@ -698,7 +706,12 @@ def inspect_state(out_tensor) -> dict:
     # the published sort key (tile << 32) | depth_bits, rebuilt from the two halves the split sort keeps
     dbits = depths.view(torch.int32).to(torch.int64)[pl.to(torch.int64)] & 0xFFFFFFFF
     keys_sorted = (tile_sorted << 32) | dbits
+    # per-pose radiance images the CRF / blur average read (slot N: the pose mean, when N > 1); None when not kept
+    n_img = d.n_poses + (1 if d.n_poses > 1 else 0)
+    pose_hdr = (view(st.image, lay.pose_hdr, n_img * 3 * d.W * d.H, torch.float32).reshape(n_img, 3, d.H, d.W)
+                if ((st.flags & L.HS_FLAG_HDR) or d.n_poses > 1) else None)
     return dict(
+        pose_hdr=pose_hdr,
         num_rendered=R,
         rec=rec, xy=rec[:, 0:2], conic_opacity=torch.stack([rec[:, 2], rec[:, 3], rec[:, 4], rec[:, 5]], 1),
         rgb=rec[:, 6:9], depths=depths,

@@ -32,7 +32,10 @@
 extern "C" {
 #endif
 
-#define HS_VERSION 201
+/* libhdrsplat.so is built with -fvisibility=hidden: the hs_* entry points below are its only exported symbols */
+#define HS_API __attribute__((visibility("default")))
+
+#define HS_VERSION 300
 
 #define HS_OK 0
 #define HS_EINVAL (-1)    /* bad argument (null pointer, bad shape, unsupported degree ...) */
@@ -72,7 +75,7 @@ extern "C" {
  * relu_shift = max(s + 0.5, 0), the published rule (unbounded above, clamped below with the clamp mask zeroing the
  * gradient).  Precomputed colours pass through unchanged. */
 #define HS_FLAG_RADIANCE_EXP 16       /* colour = e^s            (always positive; d colour / d s = colour) */
-#define HS_FLAG_RADIANCE_SOFTPLUS 32  /* colour = ln(1 + e^s)    (d colour / d s = sigmoid(s) = 1 - e^-colour) */
+#define HS_FLAG_RADIANCE_SOFTPLUS 32  /* colour = ln(1 + e^s)    (d colour / d s = sigmoid(s) = -expm1(-colour)) */
 
 typedef struct hs_dims {
     int32_t P;         /* Gaussians */
@@ -96,7 +99,8 @@ typedef struct hs_sizes {
 /* First bytes of the geometry workspace; the host may read them after HS_STAGE_PREPROCESS. */
 typedef struct hs_counters {
     uint32_t num_rendered; /* R = sum of tiles_touched over all instances */
-    uint32_t overflow;     /* set by HS_STAGE_BIN when R > capacity */
+    uint32_t overflow;     /* HS_STAGE_BIN: 1 = R > capacity; 2 = a radix pass gave up waiting for a predecessor's status
+                              word (damaged scratch).  Either way the frame is rendered empty */
     uint32_t reserved[6];  /* [0] = pairs actually binned (R, or 0 on overflow); [1] = instance count of the depth sort;
                               [3] = tile-queue counter of the render backward (zero between launches); others unused */
 } hs_counters;
@@ -199,9 +203,12 @@ typedef struct hs_layout {
     /* geom workspace; arrays are indexed by instance = pose * P + gaussian */
     int64_t counters, rec, depth, radii, tiles_touched, offsets, cov3D, clamped, scan_spine, binfo;
     /* binning workspace: keys_sorted = u32 tile id of each sorted pair, point_list = u32 instance of each sorted
-     * pair (the sort key of the published algorithm is (tile << 32) | depth_bits[instance]); depth_keys/depth_vals
-     * = the instances sorted by depth (2 x I u32 each, second halves are scratch) */
-    int64_t keys_sorted, point_list, keys_unsorted, vals_unsorted, ranges, sort_tmp, depth_keys, depth_vals, srect;
+     * pair (the sort key of the published algorithm is (tile << 32) | depth_bits[instance]); pairs_tmp = scratch of the
+     * tile sort ((tile, instance) as 8-byte elements; keys_sorted | point_list double as its other buffer);
+     * depth_pairs = scratch of the depth sort (2 x I 8-byte (depth bits, instance) elements), inst_sorted = the
+     * instances in depth order (u32 x I), offs_sorted = inclusive scan of their pair counts in that order (u32 x I:
+     * instance inst_sorted[i] owns the pair slots [offs_sorted[i-1], offs_sorted[i])) */
+    int64_t keys_sorted, point_list, pairs_tmp, ranges, sort_tmp, depth_pairs, inst_sorted, offs_sorted, srect;
     /* pair_flags (binning workspace): u8 per pair slot, cleared by the forward's pair emission, set to 1 by the
      * render backward for the records it wrote */
     int64_t pair_flags;
@@ -220,12 +227,12 @@ typedef struct hs_layout {
     int64_t pair_grads, crf_partials, inst_grads, pose_partials;
 } hs_layout;
 
-int hs_version(void);
-const char* hs_last_error(void);
-int hs_plan(const hs_dims* dims, hs_sizes* sizes, hs_layout* layout /* may be NULL */);
-int hs_forward(const hs_fwd_args* args, void* hip_stream);
-int hs_backward(const hs_bwd_args* args, void* hip_stream);
-int hs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, uint8_t* visible,
+HS_API int hs_version(void);
+HS_API const char* hs_last_error(void);
+HS_API int hs_plan(const hs_dims* dims, hs_sizes* sizes, hs_layout* layout /* may be NULL */);
+HS_API int hs_forward(const hs_fwd_args* args, void* hip_stream);
+HS_API int hs_backward(const hs_bwd_args* args, void* hip_stream);
+HS_API int hs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, uint8_t* visible,
                     void* hip_stream);
 
 /* SH-coefficient gradient from per-view colour gradients (the multi-GPU exchange of SURVEY.md 8e, where ranks
@@ -233,7 +240,7 @@ int hs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, ui
  *   dL_dshs[g, k, c] = sum_{v < V} Y_k(normalize(means3D[g] - camposes[v])) * dL_dview_colors[v, g, c],
  * views added in ascending order, k < (sh_degree+1)^2, rows k >= that are zeroed.  Same basis and per-view
  * arithmetic as the SH part of hs_backward, so V = 1 reproduces its dL_dshs bit for bit. */
-int hs_sh_backward_views(int32_t P, int32_t M, int32_t sh_degree, int32_t V, const float* means3D,
+HS_API int hs_sh_backward_views(int32_t P, int32_t M, int32_t sh_degree, int32_t V, const float* means3D,
                          const float* camposes /* [V,3] */, const float* dL_dview_colors /* [V,P,3] */,
                          float* dL_dshs /* [P,M,3] */, void* hip_stream);
 
@@ -245,15 +252,17 @@ int hs_sh_backward_views(int32_t P, int32_t M, int32_t sh_degree, int32_t V, con
  *   [10] entries staged (per tile)  [11] staging batches  [12..17] forward: trips, empty, active pixels, culled,
  *   staged, batches.  bench.py derives lane utilisation and the VALU roofline from them. */
 #define HS_RENDER_STATS 24
-int hs_render_stats(const hs_fwd_args* fwd /* or NULL */, const hs_bwd_args* bwd /* or NULL */, uint64_t* stats,
+HS_API int hs_render_stats(const hs_fwd_args* fwd /* or NULL */, const hs_bwd_args* bwd /* or NULL */, uint64_t* stats,
                     uint64_t* bwd_timeline /* or NULL: per workgroup of the backward launch (tiles x poses of them)
                                               {start, end} on the 100 MHz device clock and (XCC id << 32 | HW_ID) */,
                     void* hip_stream);
 
-/* Bench/test only: stable LSD radix sort of (u64 key, u32 value) pairs on bits [0, nbits), using the
- * same kernels as HS_STAGE_BIN.  tmp must hold hs_sort_tmp_bytes(n).  Result in keys_out/vals_out. */
-int64_t hs_sort_tmp_bytes(int64_t n);
-int hs_sort_pairs(const uint64_t* keys_in, const uint32_t* vals_in, uint64_t* keys_out, uint32_t* vals_out,
+/* Bench/test only: stable LSD radix sort of (u64 key, u32 value) pairs on bits [0, nbits), n < 2^30, using the
+ * same pass kernel as HS_STAGE_BIN.  tmp must hold hs_sort_tmp_bytes(n).  Result in keys_out/vals_out.  The u32 at
+ * byte 4 of tmp reads 2 afterwards if a pass gave up waiting (results invalid), else 0.  HS_FAULT_INJECT=sort_ticket
+ * in the environment (tests) provokes exactly that. */
+HS_API int64_t hs_sort_tmp_bytes(int64_t n);
+HS_API int hs_sort_pairs(const uint64_t* keys_in, const uint32_t* vals_in, uint64_t* keys_out, uint32_t* vals_out,
                   int64_t n, int32_t nbits, void* tmp, void* hip_stream);
 
 #ifdef __cplusplus

@@ -164,14 +164,17 @@ def threshold_risk(cam: Camera, fwd: dict, guard_alpha: float = 2e-5, guard_T: f
                 min_margin_alpha=float(mm[0]), min_margin_T=float(mm[1]), min_abs_power=float(mm[2]))
 
 
-def pixel_reach(cam: Camera, fwd: dict, pix_mask) -> np.ndarray:
-    """bool [P]: the Gaussians that contribute to the pixels selected by `pix_mask` [H,W] (hso_pixel_reach)."""
+def pixel_reach(cam: Camera, fwd: dict, pix_mask, whole_list: bool = False, guard_alpha: float = 1e-5) -> np.ndarray:
+    """bool [P]: the Gaussians that contribute to the pixels selected by `pix_mask` [H,W] (hso_pixel_reach).
+    whole_list: every entry of those pixels' tile lists that ANY fp32 implementation may have blended (alpha within
+    guard_alpha of the 1/255 threshold or above, no early termination) instead of this oracle's own contributors."""
     L = lib()
     P = fwd["radii"].shape[0]
     c = cam.cstruct(P, 0)
     m = np.ascontiguousarray(np.asarray(pix_mask).astype(np.uint8))
     gs = np.zeros(P, np.uint8)
-    L.hso_pixel_reach(C.byref(c), _p(fwd["ranges"]), _p(fwd["point_list"]), _p(fwd["xy"]), _p(fwd["conic_opacity"]), _p(m), _p(gs))
+    L.hso_pixel_reach(C.byref(c), _p(fwd["ranges"]), _p(fwd["point_list"]), _p(fwd["xy"]), _p(fwd["conic_opacity"]), _p(m), _p(gs),
+                      C.c_int(int(whole_list)), C.c_float(guard_alpha))
     return gs.astype(bool)
 
 

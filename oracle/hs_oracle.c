@@ -59,7 +59,8 @@ typedef struct {
 /* d colour / d s of the radiance activation, from the stored colour (and the clamp bit for relu_shift) */
 static inline float radiance_dact(int act, float col, int was_clamped) {
     if (act == 1) return col;                       /* d e^s = e^s */
-    if (act == 2) return 1.0f - expf(-col);         /* sigmoid(s) = 1 - e^{-softplus(s)} */
+    if (act == 2) return -expm1f(-col);             /* sigmoid(s) = 1 - e^{-softplus(s)}; expm1 keeps it exact for dark
+                                                       Gaussians (col < 6e-8, where 1 - expf(-col) rounds to 0) */
     return was_clamped ? 0.f : 1.f;
 }
 
@@ -489,9 +490,14 @@ int64_t hso_threshold_risk(const hso_camera* c, const uint32_t* ranges, const ui
 
 /* Test aid: the Gaussians that contribute to the pixels of `pix_mask` (u8 [H,W], non-zero = selected) -- the rows of
  * the gradient that a per-pixel decision taken elsewhere (e.g. which interval of the piecewise-linear CRF the pixel's
- * radiance falls into, a15) can reach.  Marks gauss_out[id] = 1; returns the number of selected pixels. */
+ * radiance falls into, a15) can reach.  whole_list = 0: the contributors under THIS implementation's decisions (up to
+ * the terminating entry).  whole_list != 0: every entry of the pixel's tile list that contributes under ANY admissible
+ * decision -- alpha within `guard_alpha` (relative) of 1/255 or above, no termination -- i.e. the rows another fp32
+ * implementation that decided differently on this pixel may have touched.  Marks gauss_out[id] = 1; returns the number
+ * of selected pixels. */
 int64_t hso_pixel_reach(const hso_camera* c, const uint32_t* ranges, const uint32_t* point_list, const float* xy,
-                        const float* conic_opacity, const uint8_t* pix_mask, uint8_t* gauss_out) {
+                        const float* conic_opacity, const uint8_t* pix_mask, uint8_t* gauss_out, int whole_list,
+                        float guard_alpha) {
     const int W = c->W, H = c->H;
     const int gx = (W + HSO_TILE - 1) / HSO_TILE;
     int64_t n = 0;
@@ -508,6 +514,12 @@ int64_t hso_pixel_reach(const hso_camera* c, const uint32_t* ranges, const uint3
                 float dx = xy[2 * id] - pxf, dy = xy[2 * id + 1] - pyf;
                 const float* co = conic_opacity + 4 * id;
                 float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                if (whole_list) {
+                    if (power > 1e-6f) continue;
+                    float alpha = fminf_(0.99f, co[3] * expf(power));
+                    if ((double)alpha * 255.0 >= 1.0 - guard_alpha) gauss_out[id] = 1;
+                    continue;
+                }
                 if (power > 0.0f) continue;
                 float alpha = fminf_(0.99f, co[3] * expf(power));
                 if (alpha < 1.0f / 255.0f) continue;

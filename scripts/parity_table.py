@@ -1,8 +1,10 @@
 """Gradient-accuracy table: for each tensor, the error of the HIP path and of the fp32 C oracle
 against the float64 PyTorch-autograd rasterizer on the same inputs -- max, 99.9th percentile and relative L2 of
 |x - truth| / max(|truth|, 1e-3 RMS) -- on guard-banded scenes (no decision of any pixel within the guard band of a
-threshold, so all three implementations take identical decisions) and on larger scenes restricted to the Gaussians no
-at-risk pixel reaches.  Runs on the MI355X box; writes profiles/r02_parity_table.json.
+threshold, so all three implementations take identical decisions) and on larger scenes restricted to the rows the
+tests hold to the strict bar: every Gaussian NOT on the tile list of a pixel where HIP and oracle actually decided
+differently (helpers.decision_masks; `strict_share` = their share of all rows).  Runs on the MI355X box; writes
+gpurun_out/r03_parity_table.json (committed as profiles/r03_parity_table.json).
 usage: python scripts/parity_table.py [--big]"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -40,9 +42,9 @@ def guarded_seed(P, W, H, deg, start=0, tries=400):
 out = {"note": __doc__.split("usage")[0].strip(), "cases": []}
 cases = [("c1 (1k Gaussians, 128x128, SH3) guard-banded", 1000, 128, 128, 3, True),
          ("600 Gaussians, 96x96, SH1, guard-banded", 600, 96, 96, 1, True),
-         ("5k Gaussians, 200x136, SH2, Gaussians off the guard band", 5000, 200, 136, 2, False)]
+         ("5k Gaussians, 200x136, SH2, rows off the differing pixels", 5000, 200, 136, 2, False)]
 if "--big" in sys.argv:
-    cases.append(("c2 (100k Gaussians, 800x800, SH0), Gaussians off the guard band", 100000, 800, 800, 0, False))
+    cases.append(("c2 (100k Gaussians, 800x800, SH0), rows off the differing pixels", 100000, 800, 800, 0, False))
 for name, P, W, H, deg, guard in cases:
     seed = guarded_seed(P, W, H, deg) if guard else 0
     if seed is None:
@@ -55,8 +57,10 @@ for name, P, W, H, deg, guard in cases:
     color64, st64, g64 = torch_run(sc, torch.float64)
     same_decisions = int((st64["n_contrib"].numpy() != f["n_contrib"]).sum())
     flips_hip = int((g["state"]["n_contrib"][0].astype(np.int64) != f["n_contrib"].astype(np.int64)).sum())
-    rows = ~risk["gauss_risk"]
-    case = {"case": name, "seed": seed, "risky_pixels": risk["n_risky_pixels"], "gaussians_compared": int(rows.sum()), "P": P,
+    m = Hh.decision_masks(O, sc, [f], g["state"], what=name)
+    rows = ~m["rows"]
+    case = {"case": name, "seed": seed, "guard_band_pixels": risk["n_risky_pixels"], "differing_pixels": m["n_differ"],
+            "gaussians_compared": int(rows.sum()), "strict_share": float(rows.mean()), "P": P,
             "n_contrib_mismatch_fp64_vs_c": same_decisions, "n_contrib_mismatch_hip_vs_c": flips_hip, "tensors": {},
             "seconds": None}
     for k, ok in KEYS:
@@ -72,4 +76,4 @@ for name, P, W, H, deg, guard in cases:
               f" C/fp64 max {t['c_fp32_vs_fp64']['max']:.2e} p999 {t['c_fp32_vs_fp64']['p999']:.2e} l2 {t['c_fp32_vs_fp64']['l2']:.2e} frac {t['c_fp32_vs_fp64']['frac_gt_1e-4']:.1e} |"
               f" hip/C max {t['hip_vs_c_fp32']['max']:.2e} p999 {t['hip_vs_c_fp32']['p999']:.2e} frac {t['hip_vs_c_fp32']['frac_gt_1e-4']:.1e}")
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r02_parity_table.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r03_parity_table.json"), "w"), indent=1)

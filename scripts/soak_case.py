@@ -25,8 +25,9 @@ g_lin = Hh.run_hip(sc2)
 _, st64, g64 = torch_run(sc, torch.float64, dL=torch.from_numpy(dH))
 print("n_contrib flips hip/oracle:", int((g_hdr["state"]["n_contrib"][0].astype(np.uint32) != f["n_contrib"]).sum()),
       " fp64/oracle:", int((st64["n_contrib"].numpy() != f["n_contrib"]).sum()))
-pix_risk, gauss_risk = Hh.oracle_risk(O, sc, [f])
-print("risky pixels", int(pix_risk.sum()), "risky gaussians", int(gauss_risk.sum()))
+m = Hh.decision_masks(O, sc, [f], g_hdr["state"], crf_got=[g_hdr["hdr"]], crf_ref=[f["color"]])
+print("guard-band pixels", int(m["pix_risk"].sum()), "differing pixels", m["n_differ"], "CRF-knot pixels", m["n_knot_pixels"],
+      "rows off the strict bar", int(m["rows"].sum()))
 for k, ok in Hh.GRAD_KEYS:
     truth = g64[k].reshape(r[ok].shape).astype(np.float64)
     def err(x, ref=truth):

@@ -21,10 +21,10 @@ for seed, deg, hdr in ((1, 3, False), (2, 1, True)):
     assert st["num_rendered"] == f["R"]
     assert np.array_equal(u32(st["point_list"][:f["R"]]), u32(f["point_list"])) and np.array_equal(u32(st["ranges"]), u32(f["ranges"]))
     assert np.array_equal(g["radii"], f["radii"])
-    pix_risk, gauss_risk = Hh.oracle_risk(O, sc, [f], crf_images=[f["color"]] if hdr else None)
-    flips = (u32(st["n_contrib"][0]) != u32(f["n_contrib"]))
-    assert not (flips & ~pix_risk[0]).any()
-    rep = Hh.assert_grads_close(g, ref, at_risk=gauss_risk, what=f"wild c2 seed {seed}")
+    m = Hh.decision_masks(O, sc, [f], st, crf_got=[g["hdr"]] if hdr else None, crf_ref=[f["color"]] if hdr else None,
+                          what=f"wild c2 seed {seed}")
+    rep = Hh.assert_grads_close(g, ref, at_risk=m["rows"], min_strict=0.95, what=f"wild c2 seed {seed}")
     print(f"seed {seed} deg {deg} hdr {hdr}: R={f['R']} max tiles/G {int(f['tiles_touched'].max())} visible {int((f['radii']>0).sum())} "
-          f"flips {int(flips.sum())} risky px {int(pix_risk.sum())} at-risk G {int(gauss_risk.sum())} oracle {t1-t0:.1f}s")
-    print("   ", {k: tuple(float('%.2g' % x) for x in v) for k, v in rep.items()})
+          f"differing px {m['n_differ']} guard-band px {int(m['pix_risk'].sum())} CRF-knot px {m['n_knot_pixels']} "
+          f"rows off the strict bar {int(m['rows'].sum())} oracle {t1-t0:.1f}s")
+    print("   ", {k: (tuple(float('%.2g' % x) for x in v) if isinstance(v, tuple) else round(v, 4)) for k, v in rep.items()})

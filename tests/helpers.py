@@ -4,6 +4,8 @@ The HIP path is casualhdrsplat_amd (product).  The oracle (oracle/) is only ever
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -212,27 +214,32 @@ GRAD_KEYS = [("means3D", "dL_dmeans3D"), ("means2D", "dL_dmeans2D"), ("opacities
 # worst element up to 1e-2 of max(|x|, 1e-3 RMS) -- the fp32 conditioning of the T / (1 - alpha) recurrences), and
 # within a few 1e-4 of each other.  Bars below = those measurements with headroom, not round numbers.
 STRICT = dict(frac_tol=1e-2, max_tol=1e-2, l2_tol=1e-5)  # measured: frac <= 6e-3, max <= 3e-3, l2 <= 1e-6 (HIP vs C)
-# Gaussians a pixel inside a guard band reaches (oracle.threshold_risk for the alpha / T thresholds, crf_knot_risk for
-# the interval of the piecewise-linear CRF): one of their contributions may legitimately exist -- or carry the
-# neighbouring CRF slope -- in one fp32 implementation and not in the other.  No bound on the FRACTION of such rows (one
-# flipped pixel changes every Gaussian behind it along that pixel, which can be most of the at-risk set of a small scene)
-# and none on a single element (a contribution present on one side only is of the order of the tensor's typical entry,
-# i.e. up to ~1e3 x the 1e-3-RMS floor small elements are measured against); bounded is the L2 share of the whole
-# tensor by which all at-risk rows together may differ.  2400 random configurations (scripts/soak.sh, 8 seeds) pass.
-AT_RISK = dict(frac_tol=1.0, max_tol=float("inf"), l2_tol=5e-3)
+# Rows (Gaussians) that leave the strict bar -- ONLY those reached by a pixel on which the two implementations
+# demonstrably decided differently (decision_masks: contributor count or transmittance differs, which must itself lie
+# inside the oracle's threshold guard band), or by a pixel within rounding distance of a CRF knot (the interval, hence
+# the slope dL/dH is multiplied with, is the one decision no output reveals).  One flipped contribution is at most
+# alpha = 1/255 of a pixel term (a skip) or T < 1e-2 of one (a termination), a neighbouring CRF slope a few per cent of
+# one: bounded per element by 10 x max(|ref|, 1e-3 RMS) -- i.e. 1e-2 of the tensor's RMS for elements below the floor --
+# and together by the L2 share of the tensor they may change.  No bound on the fraction WITHIN those rows (a flipped
+# pixel changes every Gaussian along it), but the rows themselves must stay few: `min_strict`.
+AT_RISK = dict(frac_tol=1.0, max_tol=10.0, l2_tol=5e-3)
 
 
 def assert_grads_close(got: dict, ref: dict, keys=GRAD_KEYS, frac_tol=None, max_tol=None, l2_tol=None, what="",
-                       at_risk=None):
+                       at_risk=None, min_strict=None):
     """Gradient parity against the oracle.  Per tensor: the fraction of elements beyond 1e-4 relative (floor 1e-3 *
     tensor RMS) <= frac_tol, the worst element <= max_tol, relative L2 <= l2_tol (defaults: STRICT).  `at_risk`: bool
-    [P] from oracle.threshold_risk -- those Gaussians (rows) are held to AT_RISK instead, all others to the strict
-    bar; without it every row is strict."""
+    [P] (decision_masks()["rows"]) -- those Gaussians (rows) are held to AT_RISK instead, all others to the strict
+    bar; without it every row is strict.  `min_strict`: the share of rows that must be on the strict bar."""
     bar = dict(STRICT)
     for k, v in (("frac_tol", frac_tol), ("max_tol", max_tol), ("l2_tol", l2_tol)):
         if v is not None:
             bar[k] = v
     report = {}
+    if at_risk is not None:
+        report["strict_share"] = 1.0 - float(at_risk.mean()) if at_risk.size else 1.0
+        if min_strict is not None:
+            assert report["strict_share"] >= min_strict, (what, "rows on the strict bar", report["strict_share"])
     for gk, rk in keys:
         r = np.asarray(ref[rk])
         g = np.asarray(got["d_" + gk]).reshape(r.shape)
@@ -253,43 +260,95 @@ def assert_grads_close(got: dict, ref: dict, keys=GRAD_KEYS, frac_tol=None, max_
             # relative L2 IS the relative error of single fp32 sums (n = 1: one Gaussian's gradient, hundreds of terms)
             l2_ok = l2 <= max(b["l2_tol"], 1e-4 / np.sqrt(rr.size))
             assert frac_ok and mx <= b["max_tol"] and l2_ok, (what, gk + tag, mx, frac, l2)
+    if os.environ.get("HS_PARITY_REPORT"):
+        print("PARITY", what, {k: (tuple(float(f"{x:.3g}") for x in v) if isinstance(v, tuple) else round(v, 4))
+                               for k, v in report.items()}, flush=True)
     return report
 
 
-def crf_knot_risk(sc: S.Scene, hdr_img, guard_knots=2e-4):
-    """bool [H,W]: pixels whose log-exposure u = ln(H dt) of some channel lies within `guard_knots` (in units of the
-    knot spacing) of a knot of the piecewise-linear CRF table, or of the ends of its range.  There the interval -- hence
-    the slope dL/dH is multiplied with -- is a piecewise-constant decision like the alpha / T thresholds: fp32
-    implementations that evaluate ln() or H with different rounding may take the neighbouring interval (relative
-    slope step between neighbours of a 256-knot table: a few per cent)."""
+def crf_region(sc: S.Scene, u32):
+    """Region of the piecewise-linear CRF a log-exposure u (float32 array) falls into, with exactly the fp32 operations of
+    the kernels and the oracle (a15: s = (u - umin) / (umax - umin) * (K - 1)): -1 below the table, K - 1 above it
+    (slope zero there), else the interval index min(floor(s), K - 2)."""
     K = sc.crf_table.shape[1]
-    umin, umax = sc.crf_range
-    x = float(sc.exposure) * np.asarray(hdr_img, np.float64)
-    u = np.log(np.maximum(x, 1e-30))
-    s = (u - umin) / (umax - umin) * (K - 1)
-    near = np.abs(s - np.round(s)) < guard_knots
-    near &= (s > -1.0) & (s < K)          # far outside the table the slope is zero on both sides
-    return near.any(axis=0)
+    umin, umax = np.float32(sc.crf_range[0]), np.float32(sc.crf_range[1])
+    sv = (np.asarray(u32, np.float32) - umin) / (umax - umin) * np.float32(K - 1)
+    idx = np.minimum(np.floor(sv), K - 2).astype(np.int64)
+    idx = np.where(sv > 0, idx, -1)
+    return np.where(sv >= K - 1, K - 1, idx)
 
 
-def oracle_risk(O, sc: S.Scene, fwds, cams=None, guard_alpha=1e-5, guard_T=5e-5, crf_images=None):
-    """Union over the poses of oracle.threshold_risk: (pix_risk [N,H,W], gauss_risk [P]).  `crf_images`: the radiance
-    image(s) the CRF is applied to (one per pose, or one mean image for blur_domain='hdr') -- pixels at a knot of
-    the CRF table (crf_knot_risk) put the Gaussians they are composed of at risk as well (in every pose when the
-    image is the mean)."""
+def crf_interval_risk(sc: S.Scene, hdr_got, hdr_ref, ulps=4):
+    """bool [H,W]: pixels whose CRF interval -- hence the slope dL/dH is multiplied with, a piecewise-constant decision
+    like the alpha / T thresholds -- is not provably the same in both implementations.  The interval is a monotone fp32
+    function of u = ln(H dt); the two sides differ (i) in H (observable: both radiance images are compared here) and
+    (ii) in ln() itself (v_log_f32 * ln 2 on the GPU, glibc logf in the oracle: within ~2 ulp of each other, NOT
+    observable -- the CRF is continuous across a knot, no output reveals the interval).  So: at risk = the region of
+    u(H_hip) differs from that of u(H_oracle), or either u lies within `ulps` ulp of a region boundary (evaluated with
+    the kernels' own fp32 arithmetic, crf_region).  About 1e-4 of the pixels -- a quarter of the fixed 2e-4-knot band
+    of round 2."""
+    dt = np.float32(float(sc.exposure))
+
+    def u_of(h):
+        x = np.asarray(h, np.float32) * dt
+        return np.log(np.maximum(x, np.float32(1e-8)))
+
+    def ambiguous(u):
+        step = np.spacing(np.abs(u)).astype(np.float32) * np.float32(ulps)
+        return crf_region(sc, u + step) != crf_region(sc, u - step)
+
+    ug, ur = u_of(hdr_got), u_of(hdr_ref)
+    return ((crf_region(sc, ug) != crf_region(sc, ur)) | ambiguous(ug) | ambiguous(ur)).any(axis=0)
+
+
+def oracle_risk(O, sc: S.Scene, fwds, cams=None, guard_alpha=1e-5, guard_T=5e-5):
+    """Union over the poses of oracle.threshold_risk: (pix_risk [N,H,W], gauss_risk [P]) -- the guard band of the frame:
+    where another fp32 implementation MAY decide differently.  Which rows actually leave the strict gradient bar is
+    decided by decision_masks (where it DID)."""
     cams = cams or [sc.camera]
     pix, gs = [], None
     for cam, f in zip(cams, fwds):
         r = O.threshold_risk(oracle_camera(O, sc, cam), f, guard_alpha, guard_T)
         pix.append(r["pix_risk"])
         gs = r["gauss_risk"] if gs is None else (gs | r["gauss_risk"])
-    if crf_images is not None:
-        per_pose = len(crf_images) == len(fwds)
-        for k, (cam, f) in enumerate(zip(cams, fwds)):
-            m = crf_knot_risk(sc, crf_images[k] if per_pose else crf_images[0])
-            if m.any():
-                gs = gs | O.pixel_reach(oracle_camera(O, sc, cam), f, m)
     return np.stack(pix), gs
+
+
+def decision_masks(O, sc: S.Scene, fwds, st, cams=None, crf_got=None, crf_ref=None, what=""):
+    """Where the HIP path (`st`: inspect_state as numpy) and the oracle (`fwds`: one forward dict per pose) took
+    different decisions, and which gradient rows that excuses.
+      differs [N,H,W]  pixels whose contributor count differs or whose final transmittance is off by more than 2e-3
+                       relative (identical decisions leave T within ~2e-4: fp32 products of (1 - alpha <= 0.99); ONE
+                       skipped or extra contributor changes it by >= 1/255).  Asserted to lie inside the oracle's
+                       threshold guard band (pix_risk): a difference anywhere else is a bug, not rounding.
+      rows [P]         Gaussians on the tile lists of those pixels that either implementation may have blended there
+                       (oracle.pixel_reach(whole_list=True)), plus -- crf_got / crf_ref: lists of the radiance images
+                       the CRF is applied to, per pose or ONE mean image -- the oracle's contributors of the pixels
+                       whose CRF interval is not provably the same (crf_interval_risk).
+    Everything else is held to the STRICT gradient bar."""
+    cams = cams or [sc.camera]
+    pix_risk, _ = oracle_risk(O, sc, fwds, cams)
+    P = fwds[0]["radii"].shape[0]
+    rows = np.zeros(P, bool)
+    differs = np.zeros_like(pix_risk)
+    for k, (cam, f) in enumerate(zip(cams, fwds)):
+        nc = np.asarray(st["n_contrib"][k]).astype(np.int64) & 0xFFFFFFFF
+        Tg, Tr = np.asarray(st["final_T"][k], np.float64), np.asarray(f["final_T"], np.float64)
+        d = (nc != f["n_contrib"].astype(np.int64)) | (np.abs(Tg - Tr) > 2e-3 * np.abs(Tr))
+        assert not (d & ~pix_risk[k]).any(), (what, "pose", k, "a decision differs OUTSIDE the guard band", int((d & ~pix_risk[k]).sum()))
+        differs[k] = d
+        if d.any():
+            rows |= O.pixel_reach(oracle_camera(O, sc, cam), f, d, whole_list=True)
+    n_knot = 0
+    if crf_ref is not None:
+        per_pose = len(crf_ref) == len(fwds)
+        for k, (cam, f) in enumerate(zip(cams, fwds)):
+            j = k if per_pose else 0
+            m = crf_interval_risk(sc, crf_got[j], crf_ref[j])
+            n_knot += int(m.sum())
+            if m.any():
+                rows |= O.pixel_reach(oracle_camera(O, sc, cam), f, m)
+    return dict(pix_risk=pix_risk, differs=differs, rows=rows, n_differ=int(differs.sum()), n_knot_pixels=n_knot)
 
 
 def guarded_scene(O, P, W, H, deg, seed=0, hdr=False, cams_fn=None, tries=2000, **kw):

@@ -180,3 +180,28 @@ def test_c_oracle_radiance_activations_match_fp64_autograd(oracle, act):
         assert frac < 2e-2 and mx < 3e-2, (k, mx, frac)
         l2 = np.linalg.norm(b[ok].astype(np.float64) - ref) / max(np.linalg.norm(ref), 1e-30)
         assert l2 < 5e-5, (k, l2)
+
+
+def test_softplus_gradient_of_dark_gaussians(oracle):
+    """radiance_activation='softplus' far below zero (s = -17 .. -25: colour 4e-8 .. 1e-11): d colour / d s = sigmoid(s)
+    must come out as ~colour, not as the 0 that 1 - expf(-colour) rounds to in fp32 -- dark Gaussians would stop
+    receiving SH gradient.  The C oracle's SH-gradient rows of those Gaussians against float64 autograd, relative to
+    the rows themselves (they are far below the tensor-wide floor of the other tests)."""
+    P, W, H, deg = 300, 64, 48, 1
+    sc = S.make_scene(P, W, H, deg, seed=33)
+    dark = torch.arange(P) % 3 == 0
+    sc.shs[dark, 0] = torch.linspace(-25.0, -17.0, int(dark.sum()))[:, None] / 0.28209479177387814
+    sc.shs[dark, 1:] = 0.0
+    f, b = Hh.run_oracle(oracle, sc, radiance_activation="softplus")
+    dt = torch.float64
+    leaves = {k: getattr(sc, k).to(dt).clone().requires_grad_(True) for k in ["means3D", "opacities", "shs", "scales", "rotations"]}
+    color = TR.rasterize(torch_view(sc.camera, dt), leaves["means3D"], leaves["opacities"], deg, sc.bg, shs=leaves["shs"],
+                         scales=leaves["scales"], rotations=leaves["rotations"], radiance_activation="softplus")
+    (color * sc.dL_dimage.to(dt)).sum().backward()
+    want = leaves["shs"].grad.numpy()[:, 0]
+    got = b["dL_dshs"][:, 0]
+    rows = dark.numpy() & (f["radii"] > 0) & (np.abs(want).max(axis=1) > 0)
+    assert rows.sum() > 50
+    assert 1e-13 < f["rgb"][rows].max() < 1e-7                      # the regime where 1 - expf(-col) is exactly 0
+    rel = np.abs(got[rows] - want[rows]).max(axis=1) / np.abs(want[rows]).max(axis=1)
+    assert rel.max() < 2e-3, float(rel.max())
