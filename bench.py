@@ -45,6 +45,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
+HBM_MEASURED_GBS = 6290.0  # the guide's measured float4 copy rate: the practical ceiling
 # VALU issue peak: 256 CUs x 4 SIMDs, one wave64 vector instruction per 4 cycles per SIMD (16 lanes/clk), 2.4 GHz
 N_SIMD, CLK_HZ, CYCLES_PER_VALU = 1024, 2.4e9, 4.0
 VALU_PEAK_WAVE_INSTR_PER_S = N_SIMD * CLK_HZ / CYCLES_PER_VALU
@@ -142,14 +143,14 @@ def build_step(cfg, rank, world, dev, seed=0):
 
     def step():
         mode, algo = state["exchange"]
-        rast = state["rast"][mode if world > 1 else "allreduce"]
+        rast = state["rast"][mode if (world > 1 and mode != "none") else "allreduce"]
         rast.gather_direct = algo == "direct"
         for p in plist:
             p.grad = None
         out = rast(params["means3D"], params["means2D"], params["opacities"], shs=params["shs"],
                    scales=params["scales"], rotations=params["rotations"])
         torch.autograd.backward(out[0], grad_tensors=dL)
-        if world > 1:
+        if world > 1 and mode != "none":   # ("none": the probe's yardstick, a step without the exchange)
             if mode != "allreduce":
                 exchange_view_gradients(non_sh, params["shs"], rast.deferred, algo=algo)
             else:
@@ -158,6 +159,28 @@ def build_step(cfg, rank, world, dev, seed=0):
         return out
 
     return step, state, make_rasterizer, sc, dL, plist
+
+
+def whole_step_bytes(cfg, R, Rp, vtiles, n_visible):
+    """Algorithmic bytes of ONE whole step (every row of the table; I = P x poses instances): what a
+    perfect implementation must move, whatever this one moves.  Sort = one ideal pass (24 R)."""
+    P, W, H, deg, hdr, n_poses = cfg
+    M = (deg + 1) ** 2
+    I, WH = P * n_poses, W * H * n_poses
+    in_row = 12 + 12 + 16 + 4 + 12 * M                     # means, scales, rotation, opacity, SH coefficients
+    parts = {
+        "preprocess_fwd": in_row * I + 75 * n_visible,
+        "scan": 8 * I,
+        "duplicate_with_keys": 20 * I + 12 * R,
+        "sort_one_ideal_pass": 24 * R,
+        "tile_ranges": 8 * R + 8 * vtiles,
+        "render_fwd": 40 * Rp + 20 * WH + 8 * vtiles,
+        "render_bwd": 76 * Rp + 20 * WH,
+        "preprocess_bwd": (in_row + 60) * I + in_row * P,
+        "hdr_images": (2 * 12 * WH) if hdr else 0,
+    }
+    parts["total"] = sum(parts.values())
+    return parts
 
 
 def derived_counts(out, W, H, n_poses):
@@ -204,12 +227,12 @@ def _cpu_full_frame(cfg, seed=0):
 
 
 def cpu_baseline(sc, cfg, n_tiles_sample=96, with_c2=False):
-    """CPU baseline of the bench configuration.  `value` = the C oracle (one thread) on the whole frame
-    (_c_oracle_frame); `torch_port` = the pure-PyTorch CPU autograd rasterizer of BASELINE.md section 3 on a bounded
-    sample of the same frame (full preprocess + binning, then forward+backward of every k-th tile, extrapolated to
-    images/s of the whole frame) -- 17x slower on 128 cores than the C oracle on one; c1 in full with the PyTorch
-    rasterizer (median of 5); c2 in full only with --cpu-c2 (it takes 2.5 minutes on the 128
-    host cores of the MI355X box -- profiles/ holds that run -- and the default run must stay short)."""
+    """CPU baseline of the bench configuration.  `value` = the pure-PyTorch CPU autograd rasterizer of BASELINE.md
+    section 3 (oracle/torch_rasterizer.py) on the box's host cores, on a bounded sample of the same frame (full preprocess
+    + binning, then forward+backward of every k-th tile, extrapolated to images/s of the whole frame);
+    `c_oracle_single_thread` = the C oracle (one thread) on the WHOLE frame (_c_oracle_frame), no sampling; c1 in full
+    with the PyTorch rasterizer (median of 5); c2 in full only with --cpu-c2 (it takes 2.5 minutes on the 128 host cores
+    of the MI355X box -- profiles/ holds that run -- and the default run must stay short)."""
     import torch
     from oracle import torch_rasterizer as TR
     P, W, H, deg, hdr, n_poses = cfg
@@ -248,14 +271,12 @@ def cpu_baseline(sc, cfg, n_tiles_sample=96, with_c2=False):
                    f"the {P}-Gaussian {W}x{H} frame ({t_pre:.1f} s) + fwd+bwd of {len(tiles)} of {ntiles} tiles "
                    f"({t_tiles:.1f} s, backward also covers preprocess); value extrapolates the tile part to all tiles"),
     }
-    c_port = _c_oracle_frame(sc, cfg) if n_poses == 1 else None
-    if c_port is not None:
-        # the faster of the two CPU restatements is the baseline: the C oracle on ONE core renders the frame in a
-        # fraction of the time the PyTorch rasterizer needs on all of them
-        out.update(c_port)
-        out["torch_port"] = torch_port
-    else:
-        out.update(torch_port)
+    # the headline baseline is the one BASELINE.json's north_star words: the pure-PyTorch CPU rasterizer on the box's host
+    # cores (bounded sample, extrapolated); the C oracle on ONE core -- the whole frame, no sampling, and ~50x faster than
+    # the PyTorch rasterizer on all cores -- is reported next to it
+    out.update(torch_port)
+    if n_poses == 1:
+        out["c_oracle_single_thread"] = _c_oracle_frame(sc, cfg)
     out["host_cpus"] = os.cpu_count()
     out["measured_seconds"] = time.time() - t_start
     return out
@@ -368,6 +389,105 @@ def offline_profile(cfg_name):
         return None
 
 
+EXCHANGES = [("allreduce", "rccl"), ("views", "rccl"), ("views_overlap", "rccl"),       # library collectives only ...
+             ("allreduce", "direct"), ("views", "direct"), ("views_overlap", "direct")]  # ... then the 1-hop all-to-all forms
+
+
+def exchange_bytes(mode, world, cfg, crf_K=256):
+    """Bytes one rank SENDS per step with an exchange strategy (ring / 1-hop all-reduce of n bytes: 2 (w-1)/w n; all-gather
+    of n bytes per rank: (w-1) n) and the payload it is made of -- from the tensor sizes, not from a measurement."""
+    P, W, H, deg, hdr, n_poses = cfg
+    M = (deg + 1) ** 2
+    other = P * (3 + 1 + 3 + 4) + (1 + 3 * crf_K if hdr else 0)          # means3D, opacity, scales, rotations, exposure, CRF table
+    sh = P * M * 3
+    if mode == "allreduce":
+        payload = {"all_reduced_bytes": 4 * (other + sh), "all_gathered_bytes_per_rank": 0}
+    else:
+        payload = {"all_reduced_bytes": 4 * other, "all_gathered_bytes_per_rank": 4 * (n_poses * P * 3 + n_poses * 3)}
+    sent = 2 * (world - 1) / world * payload["all_reduced_bytes"] + (world - 1) * payload["all_gathered_bytes_per_rank"]
+    return {**payload, "sent_per_rank_bytes": int(sent)}
+
+
+def choose_exchange(step, state, barrier, dev, rank, world, backend, cfg):
+    """Which gradient exchange the timed steps use (config c5).  HS_BENCH_EXCHANGE=<mode>/<algo> pins one and skips the
+    probe.  Otherwise: measure, don't guess -- a few whole steps with each strategy on this node's links, safest first
+    (plain library all-reduce of the flat gradient buffer, which also is the fallback), the fastest wins; MAX over ranks,
+    and a strategy counts only if EVERY rank finished it, so all ranks decide alike.  Guards for an unattended run:
+      * every probe step is timed on its own; a strategy whose FIRST step takes more than 20 x the step without any
+        exchange (or raises, or -- the 1-hop forms -- does not reproduce dist.all_reduce on a test vector) is dropped on
+        all ranks before it can cost more;
+      * HS_BENCH_PROBE=safe restricts the probe to the library-only strategies.
+    "allreduce" = all-reduce of the flat per-Gaussian gradient buffer; "views" = all-reduce of the non-SH part +
+    all-gather of per-view colour gradients, SH gradient rebuilt locally; "views_overlap" = the same with the all-gather
+    started inside the backward, under its per-Gaussian half; "rccl" / "direct" = library ring vs 1-hop all-to-all."""
+    import torch
+    import torch.distributed as dist
+    from casualhdrsplat_amd.distributed import validate_direct
+
+    def agree(vals):   # MAX over ranks of a few floats
+        t = torch.tensor(vals, dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(v) for v in t.tolist()]
+
+    def timed_steps(n):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step()
+        barrier()
+        return (time.perf_counter() - t0) / n * 1e3
+
+    info = {"backend": backend, "bytes": {f"{m}/{a}": exchange_bytes(m, world, cfg) for m, a in EXCHANGES if a == "rccl"}}
+    pinned = os.environ.get("HS_BENCH_EXCHANGE", "").strip()
+    if pinned:
+        mode, _, algo = pinned.partition("/")
+        if (mode, algo) not in EXCHANGES:
+            raise SystemExit(f"HS_BENCH_EXCHANGE={pinned!r}: expected one of {['/'.join(e) for e in EXCHANGES]}")
+        state["exchange"] = (mode, algo)
+        info.update(choice=pinned, pinned=True, step_ms={})
+        return info
+    # the step without any exchange: the yardstick of the per-strategy cap
+    state["exchange"] = ("none", "rccl")
+    step()
+    base_ms = agree([timed_steps(2)])[0]
+    cap_ms = 20.0 * base_ms
+    candidates = [e for e in EXCHANGES if e[1] == "rccl"] if os.environ.get("HS_BENCH_PROBE") == "safe" else list(EXCHANGES)
+    direct_ok = None
+    times, dropped = {}, {}
+    for mode, algo in candidates:
+        name = f"{mode}/{algo}"
+        state["exchange"] = (mode, algo)
+        ok, first_ms, avg_ms, err = 1.0, 0.0, 0.0, ""
+        try:  # a strategy the backend cannot run must not take the run down with it
+            if algo == "direct":
+                if direct_ok is None:
+                    direct_ok = validate_direct(dev)
+                if not direct_ok:
+                    raise RuntimeError("all_reduce_direct does not reproduce dist.all_reduce on this backend")
+            first_ms = timed_steps(1)
+        except RuntimeError as e:
+            ok, err = 0.0, str(e)[:200]
+        first_ms, bad = agree([first_ms, 1.0 - ok])
+        if bad or first_ms > cap_ms:
+            dropped[name] = err or ("failed on another rank" if bad else f"first step {first_ms:.1f} ms > cap {cap_ms:.1f} ms")
+            continue
+        try:
+            avg_ms = timed_steps(3)
+        except RuntimeError as e:
+            ok, err = 0.0, str(e)[:200]
+        avg_ms, bad = agree([avg_ms, 1.0 - ok])
+        if bad:
+            dropped[name] = err or "failed on another rank"
+            continue
+        times[name] = avg_ms
+    best = min(times, key=times.get) if times else "allreduce/rccl"
+    state["exchange"] = tuple(best.split("/"))
+    if rank == 0 and dropped:
+        print(f"[bench] exchange strategies dropped: {dropped}", file=sys.stderr)
+    info.update(choice=best, step_ms=times, dropped=dropped, no_exchange_step_ms=base_ms, first_step_cap_ms=cap_ms)
+    return info
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -418,40 +538,7 @@ def main():
 
     allreduce_info = None
     if world > 1:
-        # measure, don't guess: time a few whole steps with each gradient exchange on this node's links and keep the
-        # fastest (max over ranks, so every rank takes the same decision).  "allreduce" = all-reduce of the flat
-        # per-Gaussian gradient buffer; "views" = all-reduce of the non-SH part + all-gather of per-view colour
-        # gradients with the SH gradient rebuilt locally; "views_overlap" = the same with the all-gather started
-        # inside the backward, under its per-Gaussian half; "rccl" / "direct" = library ring vs 1-hop all-to-all form
-        times = {}
-        errors = {}
-        for mode in ("allreduce", "views", "views_overlap"):
-            for algo in ("rccl", "direct"):
-                state["exchange"] = (mode, algo)
-                ok, dt_ = 1.0, 0.0
-                try:  # a strategy the backend cannot run must not take the run down with it
-                    step()
-                    barrier()
-                    t0 = time.perf_counter()
-                    for _ in range(3):
-                        step()
-                    barrier()
-                    dt_ = time.perf_counter() - t0
-                except RuntimeError as e:
-                    ok = 0.0
-                    errors[f"{mode}/{algo}"] = str(e)[:200]
-                # every rank learns whether ALL ranks finished the strategy (a one-sided failure must not leave the
-                # ranks with different choices), and the slowest rank's time
-                t = torch.tensor([dt_, -ok], dtype=torch.float64, device=dev)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                if float(t[1].item()) == -1.0:
-                    times[f"{mode}/{algo}"] = float(t[0].item()) / 3 * 1e3
-                elif rank == 0:
-                    print(f"[bench] exchange {mode}/{algo} unavailable: {errors.get(f'{mode}/{algo}', 'failed on another rank')}",
-                          file=sys.stderr)
-        best = min(times, key=times.get) if times else "allreduce/rccl"
-        state["exchange"] = tuple(best.split("/"))
-        allreduce_info = {"choice": best, "step_ms": times, "backend": backend}
+        allreduce_info = choose_exchange(step, state, barrier, dev, rank, world, backend, cfg)
 
     for _ in range(args.warmup):
         step()
@@ -509,9 +596,18 @@ def main():
         bytes_bwd = 76 * Rp + 20 * WH
         bytes_fwd = 40 * Rp + 20 * WH + 8 * vtiles
         ach = bytes_bwd / (bwd_ms * 1e-3) / 1e9
+        from casualhdrsplat_amd import inspect_state
+        n_visible = int((inspect_state(out[0])["radii"] > 0).sum())
+        step_bytes = whole_step_bytes(cfg, R, Rp, vtiles, n_visible)
+        step_gbs = step_bytes["total"] / (ms_per_step * 1e-3) / 1e9
         line["roofline"] = {
             "kernel": "render_bwd_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": ach / HBM_PEAK_GBS,
+            "frac_hbm_measured": ach / HBM_MEASURED_GBS, "peak_hbm_measured": HBM_MEASURED_GBS,
+            "whole_step": {"algorithmic_bytes": step_bytes, "ms_per_step": ms_per_step, "achieved": step_gbs,
+                           "frac": step_gbs / HBM_PEAK_GBS, "frac_hbm_measured": step_gbs / HBM_MEASURED_GBS,
+                           "note": "sum of SURVEY.md 8(d)'s per-stage algorithmic bytes / the timed step (all kernels, "
+                                   "host gaps included)"},
             "traffic": None,  # PMC counters cannot be read inside a timed run: see `offline_profile`
             "algorithmic_bytes": bytes_bwd, "avg_ms": bwd_ms, "median_ms": bwd_med,
             "note": "the kernel is VALU-issue bound (roofline.valu; DESIGN.md 4), not HBM bound",
@@ -519,6 +615,7 @@ def main():
                         "avg_ms": fwd_ms + bwd_ms,
                         "achieved": (bytes_fwd + bytes_bwd) / ((fwd_ms + bwd_ms) * 1e-3) / 1e9,
                         "frac": (bytes_fwd + bytes_bwd) / ((fwd_ms + bwd_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "frac_hbm_measured": (bytes_fwd + bytes_bwd) / ((fwd_ms + bwd_ms) * 1e-3) / 1e9 / HBM_MEASURED_GBS,
                         "pair_evals_per_s": 2 * E / ((fwd_ms + bwd_ms) * 1e-3)},
             "valu": valu_roofline(stats, isa_counts(), fwd_ms, bwd_ms),
         }

@@ -36,7 +36,11 @@ def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
+        if "MASTER_PORT" not in os.environ:
+            # no silent default: a fixed port collides with any other job on the node, and ranks started by hand cannot
+            # agree on a free one by themselves (torch.distributed.run sets it; bench.py's own launcher picks a free port)
+            raise RuntimeError("init_from_env: WORLD_SIZE > 1 but MASTER_PORT is not set -- launch the ranks with "
+                               "`python -m torch.distributed.run --master-addr 127.0.0.1 --master-port <free port> ...`")
         kw = {}
         if backend == "nccl":
             dev_index = local % max(torch.cuda.device_count(), 1)
@@ -103,6 +107,27 @@ def all_reduce_direct(flat: torch.Tensor, group=None) -> None:
         dist.all_reduce(flat[main:], op=dist.ReduceOp.SUM, group=group)
 
 
+def validate_direct(device, group=None, n: int = 100003) -> bool:
+    """all_reduce_direct against the library all-reduce on a test vector (odd length: the leftover path runs too), on every
+    rank; True only if ALL ranks reproduce it (sums of `world` integers-valued floats: exact in any order).  Called once
+    before the 1-hop form is trusted with gradients (autotune_all_reduce, bench.py's probe)."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    g = torch.Generator().manual_seed(1234 + rank)
+    x = torch.randint(-1000, 1000, (n,), generator=g).to(torch.float32).to(device)
+    want = x.clone()
+    dist.all_reduce(want, op=dist.ReduceOp.SUM, group=group)
+    ok = 1.0
+    try:
+        all_reduce_direct(x, group)
+        ok = 1.0 if torch.equal(x, want) else 0.0
+    except RuntimeError:
+        ok = 0.0
+    t = torch.tensor([ok], dtype=torch.float32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return bool(t.item() == 1.0) and world >= 1
+
+
 _ALGO = {"choice": "rccl"}
 
 
@@ -114,7 +139,10 @@ def autotune_all_reduce(flat: torch.Tensor, group=None, iters: int = 3) -> str:
     scratch = torch.zeros_like(flat)
     sync = torch.cuda.synchronize if flat.is_cuda else (lambda: None)
     times = {}
-    for name, fn in (("rccl", lambda: dist.all_reduce(scratch, group=group)), ("direct", lambda: all_reduce_direct(scratch, group))):
+    candidates = [("rccl", lambda: dist.all_reduce(scratch, group=group))]
+    if validate_direct(flat.device, group):   # never trust the 1-hop form with gradients before it reproduced the library's sum
+        candidates.append(("direct", lambda: all_reduce_direct(scratch, group)))
+    for name, fn in candidates:
         fn()
         dist.barrier(group)
         sync()
@@ -125,7 +153,7 @@ def autotune_all_reduce(flat: torch.Tensor, group=None, iters: int = 3) -> str:
         t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=flat.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
         times[name] = float(t.item()) / iters
-    _ALGO["choice"] = "direct" if times["direct"] < times["rccl"] else "rccl"
+    _ALGO["choice"] = "direct" if times.get("direct", float("inf")) < times["rccl"] else "rccl"
     _ALGO["times_ms"] = {k: v * 1e3 for k, v in times.items()}
     return _ALGO["choice"]
 

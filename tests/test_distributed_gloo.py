@@ -200,3 +200,54 @@ def test_reducing_a_subset_of_the_flat_buffer_leaves_its_neighbours_alone():
         assert p.exitcode == 0
     # two exchanges in a row (direct, then library): rank sums 1+2 = 3, then 3+3 = 6, times the slice's marker
     assert got == [6.0 * (i + 1) for i in range(6)] * 2, got
+
+
+def _worker_validate(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import casualhdrsplat_amd.distributed as D
+    D.init_from_env("gloo")
+    ok = D.validate_direct(torch.device("cpu"))
+    # a 1-hop form that returns wrong sums on ONE rank must be rejected on EVERY rank, and autotune must then keep the library
+    real = D.all_reduce_direct
+
+    def broken(flat, group=None):
+        real(flat, group)
+        if rank == 1:
+            flat[0] += 1.0
+    D.all_reduce_direct = broken
+    bad = D.validate_direct(torch.device("cpu"))
+    choice = D.autotune_all_reduce(torch.zeros(5000), iters=1)
+    D.all_reduce_direct = real
+    q.put((rank, ok, bad, choice))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_direct_all_reduce_is_validated_against_the_library_before_use():
+    """the 1-hop reduce-scatter + all-gather is only trusted after it reproduced dist.all_reduce on a test
+    vector on every rank (bench.py's probe and autotune_all_reduce both ask validate_direct first)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_validate, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert got == [(0, True, False, "rccl"), (1, True, False, "rccl")], got
+
+
+def test_init_from_env_refuses_to_guess_a_master_port(monkeypatch):
+    """No silent MASTER_PORT=29500: hand-started ranks must name the rendezvous port (torchrun and bench.py's launcher do)."""
+    from casualhdrsplat_amd.distributed import init_from_env
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.delenv("MASTER_PORT", raising=False)
+    with pytest.raises(RuntimeError, match="MASTER_PORT"):
+        init_from_env("gloo")
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    assert init_from_env("gloo") == (0, 1, 0)

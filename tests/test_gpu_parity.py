@@ -532,6 +532,72 @@ def test_device_radix_sort_matches_stable_reference():
         assert torch.equal(ko.cpu(), keys[order]) and torch.equal(vo.cpu().long(), order), (n, nbits)
 
 
+def test_radix_look_back_gives_up_instead_of_hanging():
+    """SURVEY.md section 5 (bounded spins): HS_FAULT_INJECT=sort_ticket starts the first pass of hs_sort_pairs with ticket 1,
+    so chain position 0 never publishes its status words -- the situation a damaged scratch array produces.  The blocks
+    behind it must stop polling after their bound, report 2 in the fail word and return; the call must not hang."""
+    import subprocess
+    import sys
+    code = r"""
+import os, sys, time, torch
+sys.path.insert(0, os.environ["HS_ROOT"])
+from casualhdrsplat_amd import _lib as L
+lib = L.load()
+n = 3 * 4096 + 17
+keys = torch.randint(0, 1 << 40, (n,), dtype=torch.int64, device="cuda")
+vals = torch.arange(n, dtype=torch.int32, device="cuda")
+ko, vo = torch.empty_like(keys), torch.empty_like(vals)
+tmp = torch.zeros(int(lib.hs_sort_tmp_bytes(n)), dtype=torch.uint8, device="cuda")
+t0 = time.time()
+L.check(lib.hs_sort_pairs(keys.data_ptr(), vals.data_ptr(), ko.data_ptr(), vo.data_ptr(), n, 40, tmp.data_ptr(),
+                          torch.cuda.current_stream().cuda_stream), "hs_sort_pairs")
+torch.cuda.synchronize()
+print("FAIL-WORD", int(tmp[:8].view(torch.int32)[1]), "SECONDS %.1f" % (time.time() - t0))
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for inject, want in (("sort_ticket", 2), ("", 0)):
+        env = dict(os.environ, HS_ROOT=root, HS_FAULT_INJECT=inject)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        assert f"FAIL-WORD {want} " in r.stdout, r.stdout[-500:]
+
+
+def test_overflow_found_by_a_backward_reaches_the_rasterizer_after_other_forwards():
+    """The capacity request of an overflowed training step lives in the rasterizer, not in the bookkeeping of its latest
+    forward: a second forward (an eval render, another view) between the overflowing forward and its backward must not
+    lose it."""
+    from casualhdrsplat_amd import BinningOverflow
+    sc = S.make_scene(20000, 320, 200, 1, seed=5)
+    R = Hh.run_hip(sc)["state"]["num_rendered"]
+    rast, leaf, call = _rasterizer_and_inputs(sc, R // 2, requires_grad=True)
+    out_a = call()                      # overflows (training forward: nobody looks yet)
+    out_b = call()                      # another forward of the same rasterizer replaces its `_last` bookkeeping
+    with pytest.raises(BinningOverflow):
+        (out_a[0] * sc.dL_dimage.cuda()).sum().backward()
+    del out_b
+    out = call()                        # grown by the failed backward's verdict although it was not the latest forward
+    assert rast.capacity >= R and rast.last_num_rendered == R
+    (out[0] * sc.dL_dimage.cuda()).sum().backward()
+
+
+def test_softplus_gradient_of_dark_gaussians_vs_oracle(oracle):
+    """radiance_activation='softplus' with SH sums far below zero (colour 1e-11 .. 4e-8): the SH-gradient rows of those
+    Gaussians are ~colour x basis x dL/dcolour, far below the tensor-wide floor of the other tests -- compared here row
+    by row, relative to the row (1 - expf(-colour) would make them exactly zero)."""
+    P = 3000
+    sc = S.make_scene(P, 160, 112, 1, seed=33)
+    dark = torch.arange(P) % 3 == 0
+    sc.shs[dark, 0] = torch.linspace(-25.0, -17.0, int(dark.sum()))[:, None] / 0.28209479177387814
+    sc.shs[dark, 1:] = 0.0
+    g = Hh.run_hip(sc, radiance_activation="softplus")
+    f, b = Hh.run_oracle(oracle, sc, radiance_activation="softplus")
+    want, got = b["dL_dshs"][:, 0], g["d_shs"][:, 0]
+    rows = dark.numpy() & (f["radii"] > 0) & (np.abs(want).max(axis=1) > 0)
+    assert rows.sum() > 500 and 1e-13 < f["rgb"][rows].max() < 1e-7
+    rel = np.abs(got[rows] - want[rows]).max(axis=1) / np.abs(want[rows]).max(axis=1)
+    assert np.percentile(rel, 99) < 1e-3 and rel.max() < 5e-2, (float(np.percentile(rel, 99)), float(rel.max()))
+
+
 def test_full_size_properties_c3():
     """BASELINE c3 size (1M Gaussians, 1080p, deg 3, HDR): properties that need no oracle."""
     from casualhdrsplat_amd import GaussianRasterizer, inspect_state
@@ -810,6 +876,17 @@ def test_bench_bare_multi_gpu_invocation_launches_its_own_ranks():
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
     ex = d["config"]["gradient_exchange"]
     assert ex["choice"] in ex["step_ms"] and len(ex["step_ms"]) >= 2, ex
+    # every strategy that was kept stayed under the probe's cap; the dropped ones say why
+    assert all(t <= ex["first_step_cap_ms"] for t in ex["step_ms"].values()) and isinstance(ex["dropped"], dict), ex
+    assert ex["bytes"]["views/rccl"]["sent_per_rank_bytes"] < ex["bytes"]["allreduce/rccl"]["sent_per_rank_bytes"]
+    # HS_BENCH_EXCHANGE pins a strategy and skips the probe (what an unattended 8-GPU run can fall back on)
+    env["HS_BENCH_EXCHANGE"] = "views/rccl"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", "c2", "--steps", "2",
+                        "--warmup", "1", "--no-cpu-baseline", "--kernel-iters", "2"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    ex = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])["config"]["gradient_exchange"]
+    assert ex["choice"] == "views/rccl" and ex["pinned"] is True and ex["step_ms"] == {}, ex
 
 
 def test_steps_do_not_leak_device_memory():

@@ -150,3 +150,17 @@ def test_bench_offline_counters_are_tied_to_the_kernel_source(tmp_path, monkeypa
     (root / "profiles" / "pmc_traffic.json").write_text(open(src).read())
     monkeypatch.setattr(bench, "ROOT", str(root))
     assert bench.offline_profile("c3")["same_kernel_source"] is False
+
+
+def test_bench_exchange_bytes_and_probe_order():
+    """config c5 bookkeeping: the probe tries the library-only strategies first (allreduce/rccl first of all: it is also the
+    fallback), and the bytes a rank sends per step follow from the tensor sizes (P x 59 fp32 = 236 MB
+    all-reduced at c3; the view form all-reduces P x 11 fp32 and all-gathers 12 B per Gaussian and view)."""
+    import bench
+    assert bench.EXCHANGES[0] == ("allreduce", "rccl") and [a for _, a in bench.EXCHANGES[:3]] == ["rccl"] * 3
+    b = bench.exchange_bytes("allreduce", 8, bench.CONFIGS["c3"])
+    assert b["all_reduced_bytes"] == 4 * (1_000_000 * 59 + 1 + 3 * 256) and b["all_gathered_bytes_per_rank"] == 0
+    assert b["sent_per_rank_bytes"] == int(2 * 7 / 8 * b["all_reduced_bytes"])
+    v = bench.exchange_bytes("views", 8, bench.CONFIGS["c3"])
+    assert v["all_reduced_bytes"] == 4 * (1_000_000 * 11 + 1 + 3 * 256) and v["all_gathered_bytes_per_rank"] == 4 * (3_000_000 + 3)
+    assert v["sent_per_rank_bytes"] < 0.55 * b["sent_per_rank_bytes"]
