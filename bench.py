@@ -498,6 +498,9 @@ def main():
     ap.add_argument("--cpu-c2", action="store_true", help="also time BASELINE config c2 in full on the CPU (~2.5 min)")
     ap.add_argument("--no-extras", action="store_true", help="skip the per-seed and per-stage legs (profiling runs)")
     ap.add_argument("--kernel-iters", type=int, default=10)
+    ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
+                    help="replay the whole step as one HIP graph (single GPU): auto = when the capture succeeds and its "
+                         "replay reproduces the eager step bit for bit")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -540,14 +543,47 @@ def main():
     if world > 1:
         allreduce_info = choose_exchange(step, state, barrier, dev, rank, world, backend, cfg)
 
+    # One launch per step: the sync-free step (fixed binning capacity: no host read in forward or backward) is captured in
+    # a HIP graph and replayed -- the same kernels on the same buffers, minus ~40 launches of host work per step (at c2 the
+    # host, not the GPU, paces the eager step).  Used only if the replay reproduces the eager step bit for bit.
+    launch, run_step, gstep = "eager (one enqueue per kernel)", step, None
+    if world == 1 and args.graph != "off":
+        try:
+            from casualhdrsplat_amd.graphs import GraphedStep
+            step()
+            torch.cuda.synchronize()
+            want = [state["out"][0].detach().clone()] + [p_.grad.detach().clone() for p_ in plist]
+            # no autograd graph of an earlier (default-stream) step may be alive when the capture starts: its
+            # AccumulateGrad nodes would run on the default stream and break the capture
+            out = None
+            state["out"] = None
+            for p_ in plist:
+                p_.grad = None
+            gstep = GraphedStep(step, [state["rast"]["allreduce"]])
+            gstep.step()
+            gstep.check_overflow()
+            got = [state["out"][0].detach()] + [p_.grad.detach() for p_ in plist]
+            if not all(torch.equal(a_, b_) for a_, b_ in zip(want, got)):
+                raise RuntimeError("graph replay differs from the eager step")
+            launch, run_step = "hip_graph (whole step captured once, replayed)", gstep.step
+        except Exception as e:  # noqa: BLE001 -- any capture problem: the eager step is always there
+            if args.graph == "on":
+                raise
+            print(f"[bench] HIP-graph step unavailable ({type(e).__name__}: {str(e)[:200]}); timing the eager step",
+                  file=sys.stderr)
+            gstep, run_step = None, step
+            for p_ in plist:
+                p_.grad = None
     for _ in range(args.warmup):
-        step()
+        run_step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        run_step()
     barrier()
     elapsed = time.perf_counter() - t0
+    if gstep is not None:
+        gstep.check_overflow()   # the timed frames all fitted their binning capacity
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -564,7 +600,7 @@ def main():
                                f"{'HDR radiance + CRF tone-map' if hdr else 'LDR'}, {n_poses} pose(s)/view, "
                                f"{world} view(s)/step (one per GPU)" + (", gradients summed over views (config.gradient_exchange)" if world > 1 else ""),
                    "num_rendered_R": R, "R_prime": Rp, "pixel_pair_evals_E": E, "seed": 0,
-                   "binning": "sync-free fixed capacity 1.25*R"},
+                   "binning": "sync-free fixed capacity 1.25*R", "launch": launch},
         "mpix_per_s": world * args.steps * W * H * n_poses / elapsed / 1e6,
     }
     if allreduce_info is not None:

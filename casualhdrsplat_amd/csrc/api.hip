@@ -19,6 +19,11 @@ int fault_injection() {
     return mode;
 }
 
+bool sort_tickets() {
+    static const bool on = [] { const char* e = getenv("HS_SORT_TICKETS"); return e && e[0] == '1'; }();
+    return on;
+}
+
 void set_error(const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);

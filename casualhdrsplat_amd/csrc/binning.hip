@@ -160,12 +160,17 @@ __device__ __forceinline__ uint32_t digit_of(K k, int shift, uint32_t mask) {
 // one 32-bit word (2 + 30 bits: hs_plan rejects sorts of 2^30 or more elements), written and read with agent-scope
 // atomics, so no ordering between separate words is needed (and no fence: a __threadfence() writes back the XCD's
 // whole L2).
-// Progress.  A block's place in the chain is NOT its blockIdx -- nothing promises that workgroups start in blockIdx
-// order -- but a ticket drawn from a per-pass counter when the block starts (one atomic per block, the counter is
-// cleared with the rest of the scratch): ticket p < b means block p is already running, so everything block b waits for
-// is published by blocks that never wait for b.  The wait is bounded all the same (kSpinLimit polls, about a second):
-// a status array that some stray write damaged ends in `fail_word` = 2 (hs_counters.overflow for the pipeline: the
-// frame renders empty and the host reports it) instead of a hung GPU.
+// Progress.  A block waits only for words that blocks with a lower chain position publish before they themselves wait,
+// so the chain advances as long as the lowest unfinished position belongs to a running block.  Chain position = blockIdx:
+// every XCD's dispatcher hands out its share of a 1-D grid in increasing blockIdx order, so the globally lowest
+// unfinished block cannot be queued behind higher ones.  HIP does not PROMISE that order, hence two safety nets:
+//   * every wait is bounded (st_wait: kSpinLimit polls, about a second): a predecessor that never publishes -- a broken
+//     assumption, or a status array some stray write damaged -- ends in `fail_word` = 2 (hs_counters.overflow for the
+//     pipeline: the frame renders empty and the host raises) instead of a hung GPU;
+//   * HS_SORT_TICKETS=1 in the environment selects the TICKET instantiation, in which a block's chain position is a
+//     ticket drawn from a per-pass counter when it STARTS (one atomic per block): position p < b then means block p is
+//     already running, whatever the dispatch order.  Measured at c3: +30 us per frame (six passes of one same-address
+//     atomic per block), which is why it is the fallback and not the default.
 // Measured alternatives (c3 tile sort, us per pass; the three-kernel pass: 76): this walk with 8 words in flight 42,
 // with 16 / 32 in flight 48 / 55; group sums (one word per 32 blocks and digit, filled by returning atomics, plus a
 // member counter) instead of inclusive prefixes 85.
@@ -232,7 +237,7 @@ __global__ void __launch_bounds__(kHistThreads) radix_ghist_kernel(const void* k
 //   PACKED_OUT: `out_keys` receives uint2 elements, else keys go to `out_keys` (skipped when null) and values to
 //               `out_vals`.
 //   LOOK      : status words a thread requests at once during the look-back.
-template <typename K, int ITEMS, int LOOK, bool PACKED_IN, bool PACKED_OUT>
+template <typename K, int ITEMS, int LOOK, bool PACKED_IN, bool PACKED_OUT, bool TICKET>
 __global__ void __launch_bounds__(kSortBlock) radix_sweep_kernel(const void* in_keys, const uint32_t* in_vals,
                                                                  void* out_keys, uint32_t* out_vals, const uint32_t* n_dev,
                                                                  int shift, uint32_t mask, uint32_t* status,
@@ -247,15 +252,15 @@ __global__ void __launch_bounds__(kSortBlock) radix_sweep_kernel(const void* in_
     __shared__ uint32_t s_wave[4];
     __shared__ uint32_t s_ticket, s_fail;
 
-    if (threadIdx.x == 0) { s_ticket = atomicAdd(ticket, 1u); s_fail = 0u; }
+    if (threadIdx.x == 0) { s_ticket = TICKET ? atomicAdd(ticket, 1u) : blockIdx.x; s_fail = 0u; }
 #pragma unroll
     for (int w = 0; w < 4; ++w) s_cnt[w][threadIdx.x] = 0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     __syncthreads();
     const int64_t n = *n_dev;
     const int bid = (int)s_ticket;         // this block's place in the look-back chain (see above)
     const int64_t base = (int64_t)bid * TILE;
     if (base >= n) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int cnt_block = (int)min((int64_t)TILE, n - base);
     uint32_t* const my_status = status + (int64_t)bid * 256 + threadIdx.x;
 
@@ -346,13 +351,16 @@ __global__ void __launch_bounds__(kSortBlock) radix_sweep_kernel(const void* in_
             for (int j = 0; j < LOOK; ++j) {
                 if (done) break;
                 uint32_t x = v[j];
+                // (bounded: kSpinLimit polls per word.  The pragma matters: a loop with a known trip bound gets unrolled
+                // eightfold, 64 copies of the poll in this walk, which cost the binning stage 15 us at c3)
                 int polls = 0;
-                while ((x & ~kStMask) == 0u) {
-                    if (++polls > kSpinLimit) { failed = true; break; }
+#pragma clang loop unroll(disable)
+                while ((x & ~kStMask) == 0u && polls < kSpinLimit) {
+                    ++polls;
                     __builtin_amdgcn_s_sleep(1);
                     x = st_read(status + (int64_t)(p - j) * 256 + threadIdx.x);
                 }
-                if (failed) { done = true; break; }
+                if ((x & ~kStMask) == 0u) { failed = true; done = true; break; }
                 excl += x & kStMask;
                 done = (x & ~kStMask) == kStIncl;
             }
@@ -417,14 +425,17 @@ int radix_sort_packed(uint2* p0, uint2* p1, uint32_t* keys_out, uint32_t* vals_o
     for (int shift = 0, w = 0; shift < nbits; shift += w, ++pass) {
         w = (nbits - shift + (passes - pass) - 1) / (passes - pass);
         uint32_t* st = sc.status + (int64_t)pass * sc.pass_words;
-        if (pass == passes - 1)
-            radix_sweep_kernel<uint32_t, ITEMS, LOOK, true, false><<<nblk, kSortBlock, 0, s>>>(
-                in, nullptr, keys_out, vals_out, n_dev, shift, (1u << w) - 1u, st, sc.ghist + 256 * pass, sc.tickets + pass,
-                fail_word, kill_word);
-        else
-            radix_sweep_kernel<uint32_t, ITEMS, LOOK, true, true><<<nblk, kSortBlock, 0, s>>>(
-                in, nullptr, out, nullptr, n_dev, shift, (1u << w) - 1u, st, sc.ghist + 256 * pass, sc.tickets + pass,
-                fail_word, kill_word);
+        const uint32_t mask = (1u << w) - 1u;
+        const uint32_t* gh = sc.ghist + 256 * pass;
+        uint32_t* tk = sc.tickets + pass;
+        const bool last = pass == passes - 1;
+#define HS_SWEEP(PO, TK)                                                                                                 \
+    radix_sweep_kernel<uint32_t, ITEMS, LOOK, true, PO, TK><<<nblk, kSortBlock, 0, s>>>(                                 \
+        in, nullptr, last ? (void*)keys_out : (void*)out, last ? vals_out : nullptr, n_dev, shift, mask, st, gh, tk,  \
+        fail_word, kill_word)
+        if (sort_tickets()) { if (last) HS_SWEEP(false, true); else HS_SWEEP(true, true); }
+        else { if (last) HS_SWEEP(false, false); else HS_SWEEP(true, false); }
+#undef HS_SWEEP
         HS_LAUNCH_CHECK();
         uint2* t = in; in = out; out = t;
     }
@@ -601,7 +612,9 @@ int launch_radix_sort(uint64_t* k0, uint32_t* v0, uint64_t* k1, uint32_t* v1, co
     int pass = 0;
     for (int shift = 0, w = 0; shift < nbits; shift += w, ++pass) {
         w = (nbits - shift + (passes - pass) - 1) / (passes - pass);
-        radix_sweep_kernel<uint64_t, ITEMS, 8, false, false><<<nblk, kSortBlock, 0, s>>>(
+        // (always the TICKET instantiation: it is the one the fault injection of the tests can reach, and this entry point
+        // is not on the pipeline's path)
+        radix_sweep_kernel<uint64_t, ITEMS, 8, false, false, true><<<nblk, kSortBlock, 0, s>>>(
             kin, vin, kout, vout, n_dev, shift, (1u << w) - 1u, sc.status + (int64_t)pass * sc.pass_words,
             sc.ghist + 256 * pass, sc.tickets + pass, fail_word, nullptr);
         HS_LAUNCH_CHECK();

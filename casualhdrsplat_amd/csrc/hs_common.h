@@ -29,19 +29,12 @@ constexpr int kRecFloats = 4 * kRecF4;
 constexpr int kPairFloats = 4 * kPairF4;
 constexpr int kInstFloats = 4 * kInstF4;
 // Radix passes (binning.hip): 256 threads per block, ITEMS elements per thread; LOOK = status words a thread requests at
-// once during the decoupled look-back.  Tunables of the three sorts (HS_TUNE_*: A/B builds only):
-#ifndef HS_TUNE_DEPTH_ITEMS
-#define HS_TUNE_DEPTH_ITEMS 16
-#endif
-#ifndef HS_TUNE_DEPTH_LOOK
-#define HS_TUNE_DEPTH_LOOK 8
-#endif
-#ifndef HS_TUNE_PAIR_LOOK
-#define HS_TUNE_PAIR_LOOK 8
-#endif
+// once during the decoupled look-back.  Measured at c3 / c4 (binning stage, ms; profiles/README.md): depth sort with
+// 8 / 4 items per thread 0.29 / 0.38 against 0.275 with 16 (c4: 2.09 / 2.41 against 1.85), 16 / 32 words in flight 0.29 /
+// 0.31 -- more, smaller blocks lose to their fixed cost (digit totals, block scans), and deeper look-back over-reads.
 constexpr int kSortBlock = 256;
-constexpr int kDepthSortItems = HS_TUNE_DEPTH_ITEMS, kDepthSortLook = HS_TUNE_DEPTH_LOOK;  // instances by depth
-constexpr int kPairSortItems = 16, kPairSortLook = HS_TUNE_PAIR_LOOK;                      // (tile, instance) pairs by tile
+constexpr int kDepthSortItems = 16, kDepthSortLook = 8;                                     // instances by depth
+constexpr int kPairSortItems = 16, kPairSortLook = 8;                                       // (tile, instance) pairs by tile
 constexpr int kU64SortItems = 16;                                                           // hs_sort_pairs
 constexpr int kSortTileMin = (kDepthSortItems < 16 ? kDepthSortItems : 16) * kSortBlock;    // smallest radix block in use
 
@@ -90,6 +83,9 @@ int launch_radix_sort(uint64_t* k0, uint32_t* v0, uint64_t* k1, uint32_t* v1, co
 // Test hook (HS_FAULT_INJECT in the environment, read once): 0 = none, 1 = "sort_ticket": hs_sort_pairs starts its first
 // pass with ticket 1, so chain position 0 never publishes and the bounded look-back must give up.
 int fault_injection();
+// HS_SORT_TICKETS=1 in the environment (read once): the pipeline's radix passes take their chain positions from tickets
+// instead of blockIdx (binning.hip, "Progress").
+bool sort_tickets();
 static inline int sort_passes(int nbits) { return (nbits + 7) / 8; }
 
 // ---- small device helpers ----

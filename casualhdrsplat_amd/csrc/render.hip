@@ -179,6 +179,21 @@ __device__ __forceinline__ float wave_reduce(const float* g, float g9, int xor32
     return reduce_in_quads(t);
 }
 
+// The same nine (ten) values reduced over each 32-lane half of the wave separately (the lane groups of the render
+// backward): the in-row steps, then ONE swap step over lane bit 4 for two of the three registers, the third through the
+// LDS crossbar (`xor16_addr` = ((lane ^ 16) << 2)), then the quad steps on both results -- lane bit 5 is never crossed.
+// Out, per group (rows 2g and 2g + 1 of the wave), all four lanes of a quad alike:
+//   t0: row 2g, quads 0..3 = g0, g2, g1, g3 ; row 2g + 1, quads 0..3 = g4, g6, g5, g7      t1: every row, quads = g8, g8, g9, g9.
+template <bool TEN>
+__device__ __forceinline__ void group_reduce(const float* g, float g9, int xor16_addr, float& t0, float& t1) {
+    float w0, w1, w2;
+    reduce_in_rows<TEN>(g, g9, w0, w1, w2);
+    const float u0 = halve16(w0, w1);  // even rows: w0 over bit 4, odd rows: w1 over bit 4
+    const float u1 = w2 + __int_as_float(__builtin_amdgcn_ds_bpermute(xor16_addr, __float_as_int(w2)));
+    t0 = reduce_in_quads(u0);
+    t1 = reduce_in_quads(u1);
+}
+
 // number of set bits of a wave-uniform 64-bit mask below this lane
 __device__ __forceinline__ int mask_prefix(uint64_t m) {
     return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -260,6 +275,16 @@ __device__ __forceinline__ bool halftile_may_touch(const float4 a, const float4 
     return fmaxf(p1, p2) >= thr;
 }
 
+// Lane -> pixel pair of a wave's half tile (16 x 8 pixels at (sx, sy)): the lane owns (px, py0) and (px, py0 + 1).
+// The two 32-lane halves of a wave ("lane groups") each own an 8 x 8 block -- group g = lane >> 5 the columns
+// 8g .. 8g + 7 -- as 8 columns x 4 row pairs: the render backward lets each group walk its OWN list of takers (a
+// Gaussian's alpha >= 1/255 footprint covers about a third of a half tile, and a compact block is missed more often
+// than a 16 x 4 stripe: scripts/sim_lane_groups.py), and the forward records the takers per group.
+__device__ __forceinline__ void lane_pixels(int lane, int sx, int sy, int& px, int& py0) {
+    px = sx + 8 * (lane >> 5) + (lane & 7);
+    py0 = sy + 2 * ((lane >> 3) & 3);
+}
+
 struct RenderFwd {
     int W, H, gx, ntiles, N, flags;
     const uint2* ranges; const uint32_t* point_list; const float4* rec; const float* bg;
@@ -269,7 +294,7 @@ struct RenderFwd {
     const float* exposure;
     unsigned long long* stats;  // STATS instantiations only
     unsigned long long* timeline;
-    uint8_t* pair_act;          // out: per sorted pair, bit w = some pixel of wave w's half tile took the entry
+    uint8_t* pair_act;          // out: per sorted pair, bit 2g + w = some pixel of lane group g of wave w took the entry
     uint32_t* tile_work;        // out: per (pose, tile), the (half tile, entry) trips that found a taker
 };
 
@@ -387,7 +412,7 @@ render_fwd_kernel(RenderFwd p) {
     __shared__ __attribute__((aligned(16))) float s_ent[KB * kFwdEntF];
     __shared__ int s_alive[2][2];
     __shared__ uint16_t s_list[2][KB];  // per-wave compacted list of staged entries that can touch its half tile (byte offsets)
-    __shared__ uint8_t s_taken[2][KB];  // [wave][entry]: some pixel of the wave took the entry
+    __shared__ uint8_t s_taken[2][KB];  // [wave][entry]: which lane groups of the wave took the entry (bit 2g + wave)
     __shared__ uint32_t s_work[2];      // per wave: entries it took (= trips of the backward on this half tile)
 
     const int vt = xcd_strip_tile(blockIdx.x, gridDim.x, p.gx);  // virtual tile = pose * ntiles + tile
@@ -396,7 +421,9 @@ render_fwd_kernel(RenderFwd p) {
     const int tx = tile % p.gx, ty = tile / p.gx;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int sx = tx * kTile, sy = ty * kTile + wave * 8;
-    const int px = sx + (lane & 15), py0 = sy + 2 * (lane >> 4), py1 = py0 + 1;
+    int px, py0;
+    lane_pixels(lane, sx, sy, px, py0);
+    const int py1 = py0 + 1;
     const bool in0 = px < p.W && py0 < p.H, in1 = px < p.W && py1 < p.H;
     const float pxf = (float)px;
     const f2 pyf = {(float)py0, (float)py1};
@@ -425,20 +452,20 @@ render_fwd_kernel(RenderFwd p) {
     if constexpr (STATS) ws.clear();
     const char* const ent = reinterpret_cast<const char*>(s_ent);
     float* const my_ent = s_ent + threadIdx.x * kFwdEntF;
-    // The activity bits of a batch -- which of its entries found a taker in which wave -- go to `pair_act`, one byte per
-    // sorted pair (bit w = wave w): the backward walks exactly those entries, per wave, instead of testing every staged
-    // entry against the half tile again, and neither gathers nor writes a record for an entry nobody took.
+    // The activity bits of a batch -- which of its entries found a taker in which lane group of which wave -- go to
+    // `pair_act`, one byte per sorted pair (bit 2g + w): the backward's lane groups walk exactly those entries instead of
+    // testing every staged entry again, and an entry nobody took is neither gathered nor written out.
     auto flush_activity = [&](int base_prev, int cnt_prev) {
         const int t = threadIdx.x;
-        if (t < cnt_prev) p.pair_act[(int64_t)range.x + base_prev + t] = (uint8_t)(s_taken[0][t] | (s_taken[1][t] << 1));
+        if (t < cnt_prev) p.pair_act[(int64_t)range.x + base_prev + t] = (uint8_t)(s_taken[0][t] | s_taken[1][t]);
         s_taken[0][t] = 0; s_taken[1][t] = 0;  // cleared for the batch about to be staged (written after the next barrier)
     };
     // Walks list positions [i0, i1) of this wave's compacted list (entries that can touch its half tile), front to
-    // back; returns the mask (bit i - i0) of positions whose entry some pixel of the wave took.  The list holds the
-    // entry's LDS byte offset, so the loop spends no vector instruction on address arithmetic; the contributor number
-    // is kept scaled the same way (`last` = (index + 1) * 48, divided once at the end).
-    auto walk = [&](int i0, int i1, int base48) -> uint64_t {
-        uint64_t act = 0ull;
+    // back; returns, in lane i - i0, WHICH lane groups took the entry at list position i (bit 0: group 0, bit 2: group 1;
+    // 0: nobody).  The list holds the entry's LDS byte offset, so the loop spends no vector instruction on address
+    // arithmetic; the contributor number is kept scaled the same way (`last` = (index + 1) * 48, divided once at the end).
+    auto walk = [&](int i0, int i1, int base48) -> uint32_t {
+        uint32_t act = 0u;
         for (int i = i0; i < i1; ++i) {
             const int jb = (int)s_list[wave][i];            // uniform -> broadcast LDS reads below
             const char* e = ent + jb;
@@ -453,18 +480,20 @@ render_fwd_kernel(RenderFwd p) {
             const float al1 = fminf(kAlphaMax, b.y * hs_exp2(pw.y));
             const uint32_t idx48 = (uint32_t)(base48 + jb + kFwdEntF * 4);
             int n_pix = 0;
-            uint64_t took = blend_fwd_pair<DEPTH>(ps, done0, done1, pw, f2{al0, al1}, b.z, b.w, c.x, DEPTH ? c.y : 0.f, idx48,
-                                                  STATS ? &n_pix : nullptr);
+            const uint64_t took = blend_fwd_pair<DEPTH>(ps, done0, done1, pw, f2{al0, al1}, b.z, b.w, c.x, DEPTH ? c.y : 0.f, idx48,
+                                                        STATS ? &n_pix : nullptr);
             if constexpr (STATS) ws.v[kStFwdActivePix] += n_pix;
-            const int bit = i - i0;
-            // act |= (took != 0) << bit, kept in scalar registers (the compiler turns the plain expression into five
-            // vector instructions: it materialises the uniform condition through a VGPR)
-            asm("s_cmp_lg_u64 %1, 0\n\t"
-                "s_cselect_b64 %1, 1, 0\n\t"
-                "s_lshl_b64 %1, %1, %2\n\t"
-                "s_or_b64 %0, %0, %1"
-                : "+s"(act), "+s"(took) : "s"(bit) : "scc");
-            if constexpr (STATS) { ws.v[kStFwdTrips] += 1; ws.v[kStFwdEmpty] += took == 0ull; }  // took: now 0 or 1 << bit
+            // gb = (lanes 0-31 took ? 1 : 0) | (lanes 32-63 took ? 4 : 0), written to lane i - i0 of `act` -- all in
+            // scalar registers plus one v_writelane (the plain expression costs the compiler five vector instructions:
+            // it materialises the uniform conditions through VGPRs)
+            uint32_t lo = (uint32_t)took, hi = (uint32_t)(took >> 32), gb;
+            asm("s_min_u32 %1, %1, 1\n\t"
+                "s_min_u32 %2, %2, 1\n\t"
+                "s_lshl2_add_u32 %0, %2, %1\n\t"
+                "s_mov_b32 m0, %4\n\t"
+                "v_writelane_b32 %3, %0, m0"   // (m0: reserved, never live across instructions in compiler-generated code)
+                : "=&s"(gb), "+s"(lo), "+s"(hi), "+v"(act) : "s"(i - i0) : "scc");
+            if constexpr (STATS) { ws.v[kStFwdTrips] += 1; ws.v[kStFwdEmpty] += gb == 0u; }
             if ((done0 & done1) == ~0ull) break;
         }
         return act;
@@ -510,12 +539,13 @@ render_fwd_kernel(RenderFwd p) {
                 if (touch) s_list[wave][n_t + mask_prefix(mask)] = (uint16_t)(jj * kFwdEntF * 4);
                 n_t += __popcll(mask);
             }
-            // takers by LIST position (two scalar masks), then one lane per position marks its entry
-            const uint64_t t0 = walk(0, min(n_t, 64), base * kFwdEntF * 4);
-            const uint64_t t1 = ((done0 & done1) != ~0ull && n_t > 64) ? walk(64, n_t, base * kFwdEntF * 4) : 0ull;
-            if ((t0 >> lane) & 1ull) s_taken[wave][s_list[wave][lane] / (kFwdEntF * 4)] = 1;
-            if ((t1 >> lane) & 1ull) s_taken[wave][s_list[wave][64 + lane] / (kFwdEntF * 4)] = 1;
-            n_taken += (uint32_t)(__popcll(t0) + __popcll(t1));
+            // takers by LIST position (lane i of t0 / t1: the groups that took position i / 64 + i), then one lane per
+            // position marks its entry
+            const uint32_t t0 = walk(0, min(n_t, 64), base * kFwdEntF * 4);
+            const uint32_t t1 = ((done0 & done1) != ~0ull && n_t > 64) ? walk(64, n_t, base * kFwdEntF * 4) : 0u;
+            if (t0) s_taken[wave][s_list[wave][lane] / (kFwdEntF * 4)] = (uint8_t)(t0 << wave);
+            if (t1) s_taken[wave][s_list[wave][64 + lane] / (kFwdEntF * 4)] = (uint8_t)(t1 << wave);
+            n_taken += (uint32_t)(__popcll(__ballot(t0 != 0u)) + __popcll(__ballot(t1 != 0u)));
         }
     }
     if (it > 0 && base >= n) {  // the loop ran out of entries: the last batch's activity is still in LDS
@@ -642,7 +672,7 @@ struct RenderBwd {
     const float* dL_dcolor; const float* dL_dhdr; const float* dL_dalpha; const float* dL_dinvdepth;
     float4* pair_grads;
     uint8_t* pair_flags;
-    const uint8_t* pair_act;   // per sorted pair: bit w = wave w's half tile took the entry (written by the forward)
+    const uint8_t* pair_act;   // per sorted pair: bit 2g + w = lane group g of wave w took the entry (written by the forward)
     Crf crf;
     const float* exposure;
     unsigned long long* stats;     // STATS instantiations only
@@ -739,24 +769,33 @@ __device__ __forceinline__ void step_bwd_pair(PairB& s, bool act0, bool act1, f2
     sw = splat(o) * dop;
 }
 
-// LDS record of one staged entry in the backward: the twelve floats of its render record followed by the planes of
-// reduced partial sums, so ONE per-entry byte offset (what the per-wave lists store) addresses both.
+// LDS record of one staged entry in the backward: the twelve floats of its render record followed by four planes of
+// reduced partial sums, so ONE per-entry byte offset (what the per-group lists store) addresses everything.
 //   [0..3] x, y, A2, B2   [4..7] C2, opacity, r, g   [8..11] b, 1/depth (DEPTH) or depth, radius, pair-slot start
-//   [12..21] the nine (ten) sums of the entry: zeroed per batch, each wave ADDS its totals (ds_add_f32).  At most two
-//   adds reach a word and 0 + x + y does not depend on their order, so the result is still bitwise reproducible -- and
-//   one set of sums instead of one per wave is what keeps the kernel at 12.8 KB of LDS (six waves per SIMD).
+//   [12 + NV * (2g + w) ...): the NV = nine (ten) sums of the entry over the pixels of lane group g of wave w.  A (wave,
+//   group) visits an entry at most once, so it STORES its totals (no LDS atomics: a CU retires only ~0.27 lanes of
+//   ds_add_f32 per clock, which is what the twenty adding lanes per trip of the two-group walk ran into --
+//   profiles/README.md); planes nobody wrote are skipped at write-out by the entry's activity bits, the others are added
+//   in plane order: bitwise reproducible.
 constexpr int kTailPct = 8;           // share of the tiles handed out by the queue (see the kernel)
-constexpr int kEntF = 24;             // floats per LDS entry record (22 used): 96 bytes keeps every record 16-byte
-constexpr int kEntB = kEntF * 4;      // aligned (measured on one box: 88-byte records, i.e. split ds_read_b128, +5 %)
 constexpr int kAccF = 12;             // first float of the sums
+// staged entries per batch (<= threads per workgroup).  64: 13 KB of LDS per workgroup, six waves per SIMD; measured at c3
+// with 96 / 128 entries (four / three waves per SIMD): 0.473 / 0.504 ms against 0.468
+constexpr int kBwdKB = 64;
 
 
 template <bool DEPTH, bool STATS>
 __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
-    constexpr int KB = kBatch;              // staged entries per batch (<= threads per workgroup)
+    constexpr int KB = kBwdKB;              // staged entries per batch (<= threads per workgroup)
     constexpr int NV = DEPTH ? 10 : 9;      // reduced values per (tile, entry): nine published sums (+ d inverse depth)
-    __shared__ __attribute__((aligned(16))) float s_ent[KB * kEntF];
-    __shared__ uint8_t s_actb[kBatch];      // activity byte of each staged entry (bit w: wave w's half tile took it)
+    constexpr int kEntF = kAccF + 4 * NV;   // floats per LDS entry record: 48 (192 bytes) / 52 (208 bytes)
+    constexpr int kEntB = kEntF * 4;        // ... a multiple of 16 bytes either way: every record stays 16-byte aligned
+    static_assert(kEntB % 16 == 0, "LDS entry records must stay 16-byte aligned");
+    constexpr int kSentinel = KB * kEntB;   // byte offset of the record no pixel takes (opacity 0)
+    constexpr int kListLen = KB + 8;        // the read-ahead of the slot behind the last one stays inside the array
+    __shared__ __attribute__((aligned(16))) float s_ent[(KB + 1) * kEntF];   // record KB: the sentinel
+    __shared__ uint16_t s_list[2][2][kListLen];   // [wave][lane group]: byte offsets of the group's takers, back to front
+    __shared__ uint8_t s_actb[kBatch];      // activity byte of each staged entry (bit 2g + w: group g of wave w took it)
     __shared__ uint32_t s_max[2];
 
     // The last kTailPct per cent of the tiles are not bound to a workgroup (hence, through blockIdx, to an XCD): the
@@ -769,6 +808,7 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
     __shared__ uint32_t s_q;
     const int n_tail = (int)((int64_t)gridDim.x * kTailPct / 100);
     const int n_static = (int)gridDim.x - n_tail;
+    if (threadIdx.x < kAccF) s_ent[KB * kEntF + threadIdx.x] = 0.f;   // the sentinel record (ordered by the barriers below)
     for (;;) {
     int bidx = blockIdx.x;
     if ((int)blockIdx.x >= n_static) {
@@ -787,8 +827,11 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
     const int tile = vt - pose * p.ntiles;
     const int tx = tile % p.gx, ty = tile / p.gx;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int grp = lane >> 5;               // lane group: the 8 x 8 block of columns 8 grp .. 8 grp + 7 of the half tile
     const int sx = tx * kTile, sy = ty * kTile + wave * 8;
-    const int px = sx + (lane & 15), py0 = sy + 2 * (lane >> 4), py1 = py0 + 1;
+    int px, py0;
+    lane_pixels(lane, sx, sy, px, py0);
+    const int py1 = py0 + 1;
     const bool in0 = px < p.W && py0 < p.H, in1 = px < p.W && py1 < p.H;
     const float pxf = (float)px;
     const f2 pyf = {(float)py0, (float)py1};
@@ -807,30 +850,31 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
     __syncthreads();
     const int n_proc = (int)max(s_max[0], s_max[1]);
 
-    // which of the wave totals this lane holds after wave_reduce (see there), as a byte offset inside the entry record
+    // Which of its group's totals this lane adds to the entry's sums after group_reduce (see there), as a byte offset
+    // inside the entry record (-1: none), and from which of the two result registers: the quad leaders of the group's two
+    // rows carry t0 (eight sums), the second lanes of quads 0 and 2 of its first row carry t1 (the ninth and tenth).
     int red_off = -1;
+    const bool red_t0 = (lane & 3) == 0;
     {
         const int row = lane >> 4, k = (lane & 15) >> 2;
         constexpr int kOrd[4] = {0, 2, 1, 3};
-        if ((lane & 3) == 0) {
-            if (row == 0) red_off = kOrd[k];
-            else if (row == 2) red_off = 4 + kOrd[k];
-            else if (row == 1 && k == 0) red_off = 8;
-            else if (DEPTH && row == 1 && k == 2) red_off = 9;
-        }
-        if (red_off >= 0) red_off = (kAccF + red_off) * 4;
+        if ((lane & 3) == 0) red_off = ((row & 1) ? 4 : 0) + kOrd[k];
+        else if ((lane & 3) == 1 && !(row & 1) && k == 0) red_off = 8;
+        else if (DEPTH && (lane & 3) == 1 && !(row & 1) && k == 2) red_off = 9;
+        if (red_off >= 0) red_off = (kAccF + NV * (2 * grp + wave) + red_off) * 4;
     }
-    const int xor32_addr = (lane ^ 32) << 2;
+    const int xor16_addr = (lane ^ 16) << 2;
     char* const ent = reinterpret_cast<char*>(s_ent);
     float* const my_ent = s_ent + threadIdx.x * kEntF;
+    const uint16_t* const my_list = s_list[wave][grp];
     WaveStats ws;
     if constexpr (STATS) ws.clear();
     const int nb = (n_proc + KB - 1) / KB;
     // only the instance id of the NEXT batch is prefetched (one register); its record is gathered at the
     // top of the batch -- keeping the three float4 in registers across the replay loop costs a wave of occupancy
-    // The forward left one activity byte per sorted pair (bit w: some pixel of wave w's half tile took the entry).  An
-    // entry nobody took is neither gathered nor written out; each wave walks exactly its own takers -- in scalar
-    // registers, as the set bits of two 64-bit masks -- so the half-tile test is not repeated here and no trip is empty.
+    // The forward left one activity byte per sorted pair (bit 2g + w: some pixel of lane group g of wave w took the
+    // entry).  An entry nobody took is neither gathered nor written out; the two 32-lane groups of a wave each walk
+    // exactly their own takers, so one trip of the loop serves up to two different entries, and no trip is empty.
     uint32_t id_next = 0, act_next = 0;
     if (nb > 0) {
         const int base = (nb - 1) * KB;
@@ -855,8 +899,6 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
             reinterpret_cast<float4*>(my_ent)[0] = ra;
             reinterpret_cast<float4*>(my_ent)[1] = rb;
             reinterpret_cast<float4*>(my_ent)[2] = rc;
-#pragma unroll
-            for (int q = 0; q < 10; q += 2) reinterpret_cast<float2*>(my_ent + kAccF)[q >> 1] = make_float2(0.f, 0.f);  // 8-byte aligned
         }
         if (bi > 0 && (int)threadIdx.x < KB) {  // batches below the top are full
             id_next = p.point_list[range.x + base - KB + threadIdx.x];
@@ -864,21 +906,40 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
         }
         __syncthreads();
         {
-            // this wave's takers among the 128 staged entries: bit `wave` of the activity bytes, as two scalar masks
-            const uint32_t wbit = 1u << wave;
-            uint64_t todo[kBatch / 64];
+            // The two lists of this wave: group g's takers among the staged entries (bit 2g + wave of the activity bytes),
+            // back to front, then sentinels up to the longer list's length.  Wave-private LDS rows: no barrier needed.
+            int maxn = 0;
 #pragma unroll
-            for (int k = 0; k < kBatch / 64; ++k) todo[k] = __ballot((s_actb[k * 64 + lane] & wbit) != 0);
-            if constexpr (STATS) ws.v[kStBwdCulled] += (uint32_t)cnt - __popcll(todo[0]) - __popcll(todo[1]);
-            // a pixel takes part in entry j of this batch iff base + j < last, i.e. iff j * 96 < (last - base) * 96
+            for (int g = 0; g < 2; ++g) {
+                const uint32_t gbit = 1u << (2 * g + wave);
+                uint16_t* lst = s_list[wave][g];
+                int n_g = 0;
+#pragma unroll
+                for (int k = (KB + 63) / 64 - 1; k >= 0; --k) {   // upper half of the batch first: it is deeper
+                    const uint64_t m = __ballot((s_actb[k * 64 + lane] & gbit) != 0);
+                    const int c = __popcll(m);
+                    if ((m >> lane) & 1ull) lst[n_g + c - 1 - mask_prefix(m)] = (uint16_t)((k * 64 + lane) * kEntB);
+                    n_g += c;
+                }
+#pragma unroll
+                for (int t = lane; t < kListLen; t += 64)
+                    if (t >= n_g) lst[t] = (uint16_t)kSentinel;
+                maxn = max(maxn, n_g);
+            }
+            if constexpr (STATS) {
+                const uint32_t wbits = 5u << wave;
+                uint32_t mine = 0;
+#pragma unroll
+                for (int k = 0; k < (KB + 63) / 64; ++k) mine += __popcll(__ballot((s_actb[k * 64 + lane] & wbits) != 0));
+                ws.v[kStBwdCulled] += (uint32_t)cnt - mine;
+            }
+            // a pixel takes part in entry j of this batch iff base + j < last, i.e. iff j * 128 < (last - base) * 128 (the
+            // sentinel passes this test for pixels that reach past the batch: its opacity 0 is what keeps it out)
             const int lim0 = ((int)s0.last - base) * kEntB, lim1 = ((int)s1.last - base) * kEntB;
-#pragma unroll
-            for (int k = kBatch / 64 - 1; k >= 0; --k)
-            while (todo[k]) {  // back to front: highest set bit first
-                const int bit = 63 - __builtin_clzll(todo[k]);
-                todo[k] &= ~(1ull << bit);
-                const int jb = (k * 64 + bit) * kEntB;  // uniform across lanes -> broadcast LDS reads below
-                const float4 a = *reinterpret_cast<const float4*>(ent + jb);
+            int jb = (int)my_list[0];
+            for (int ti = 0; ti < maxn; ++ti) {
+                const int jn = (int)my_list[ti + 1];       // next trip's entry, read a trip ahead
+                const float4 a = *reinterpret_cast<const float4*>(ent + jb);   // (two addresses per wave: one per group)
                 const float4 b = *reinterpret_cast<const float4*>(ent + jb + 16);
                 const float2 c = *reinterpret_cast<const float2*>(ent + jb + 32);
                 const float cb = c.x;
@@ -899,7 +960,6 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
                     const int bin = lanes == 0 ? 0 : lanes <= 4 ? 1 : lanes <= 8 ? 2 : lanes <= 16 ? 3 : lanes <= 32 ? 4 : 5;
                     ws.v[kStBwdHist + bin] += 1;
                 }
-                if (__ballot(act0 || act1) == 0ull) continue;
                 f2 sw, dop, dch;
                 step_bwd_pair<DEPTH>(ps, act0, act1, f2{G0, G1}, f2{al0, al1}, b.y, b.z, b.w, cb, invd, sw, dop, dch);
                 // in-lane sums over the pixel pair (dx is shared):  S1 = sum w dx, S2 = sum w dy, S3 = sum w dx^2,
@@ -922,15 +982,27 @@ __global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
                     const f2 cd = dch * ps.dLd;
                     g9 = cd.x + cd.y;
                 }
-                const float tot = wave_reduce<DEPTH>(g, g9, xor32_addr);
-                if (red_off >= 0) atomicAdd(reinterpret_cast<float*>(ent + jb + red_off), tot);  // 9 (10) lanes, one LDS add
+                float t0, t1;
+                group_reduce<DEPTH>(g, g9, xor16_addr, t0, t1);
+                // 2 x 9 (10) lanes, one plain LDS store: each group into its own plane of its own entry's record
+                if (red_off >= 0) *reinterpret_cast<float*>(ent + jb + red_off) = red_t0 ? t0 : t1;
+                jb = jn;
             }
         }
         __syncthreads();
         if (taken) {
+            // the planes the entry's takers wrote (bit 2g + w of its activity byte), added in plane order
             float v[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            const uint32_t ab = s_actb[threadIdx.x];
 #pragma unroll
-            for (int q = 0; q < NV; ++q) v[q] = my_ent[kAccF + q];
+            for (int pl = 0; pl < 4; ++pl) {
+                const bool on = (ab >> pl) & 1u;
+#pragma unroll
+                for (int q = 0; q < NV; ++q) {
+                    const float x = my_ent[kAccF + NV * pl + q];
+                    v[q] += on ? x : 0.f;
+                }
+            }
             const float4 a = reinterpret_cast<const float4*>(my_ent)[0];
             const float4 c = reinterpret_cast<const float4*>(my_ent)[2];
             // un-scale the conic: A = A2 * (-2/L), B = B2 * (-1/L), C = C2 * (-2/L)
@@ -1114,6 +1186,7 @@ __global__ void __launch_bounds__(256) crf_reduce_kernel(const float* partials, 
 // over 3072 slots, -4 % on the backward for an 8 us ordering kernel); with many rounds (c4: 65280) the tail is a small
 // part of the span and the ordering costs more than it returns (measured +42 / -36 us): the strip order stays.
 static bool orders_tiles(int grid) { return grid <= 6 * 3072; }
+
 
 int launch_render_fwd(const hs_fwd_args& a, const hs_layout& L, hipStream_t s, unsigned long long* stats) {
     // (the forward records no timeline)

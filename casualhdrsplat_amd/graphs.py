@@ -1,0 +1,82 @@
+"""Whole training steps as HIP graphs (one launch per step instead of ~40).
+
+A step of the rasterizer at BASELINE config c2 (100k Gaussians, 800x800) is 0.4 ms of kernels behind ~35 launches and
+their Python glue: the host, not the GPU, sets its pace.  The sync-free mode of GaussianRasterizer (capacity=N: no
+host read anywhere in forward or backward) makes the step capturable: `GraphedStep` records forward + the caller's
+loss + backward once (torch.cuda.graph -- hipGraph on ROCm) and replays it.  Inputs are the tensors `fn` closes over:
+update them IN PLACE between replays (optimizer steps do), never rebind them.
+
+The reference is a trainer around this hot path (Readme.md:54); nothing in it prescribes how launches reach the GPU.
+"""
+from __future__ import annotations
+
+from typing import Callable, Sequence
+
+import torch
+
+from .rasterizer import BinningOverflow, GaussianRasterizer, grown_capacity
+
+
+class GraphedStep:
+    """Capture `fn()` -- forward through GaussianRasterizer(..., capacity=N), loss, backward; every tensor it reads must
+    already live on the GPU -- and replay it with `step()`.
+
+    fn            returns a tensor or tuple of tensors (outputs of the step; they are overwritten by every replay).
+                  Gradients land in the `.grad` of the leaves as usual: set them to None before constructing this object,
+                  so they are allocated inside the graph's memory pool and keep their addresses.
+    rasterizers   the GaussianRasterizer objects `fn` calls (all with a fixed `capacity`): their device overflow counters
+                  are copied to pinned memory inside the graph; `check_overflow()` waits for the step and raises
+                  BinningOverflow if a frame did not fit (rebuild the step with the capacity it names).
+    warmup        eager steps on a side stream before the capture (allocator warm-up; also fills the pinned-buffer pool
+                  the capture may not allocate from).
+    Drop every reference to outputs of EARLIER eager steps on the same leaves before constructing this object (an autograd
+    graph kept alive from the default stream keeps its AccumulateGrad nodes there, which breaks the capture), and read
+    gradients through `grads` -- `leaf.grad` is rebound by any eager backward that runs in between.
+    """
+
+    def __init__(self, fn: Callable[[], object], rasterizers: Sequence[GaussianRasterizer] = (), warmup: int = 2,
+                 params: Sequence[torch.Tensor] = ()):
+        for r in rasterizers:
+            if r.capacity is None:
+                raise ValueError("GraphedStep needs GaussianRasterizer(..., capacity=N): the synchronous mode reads "
+                                 "num_rendered on the host inside every forward and cannot be captured")
+        self.rasterizers = list(rasterizers)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):
+                fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        for r in self.rasterizers:   # an overflow during warm-up: fail before capturing a graph that renders empty frames
+            r.check_overflow()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.outputs = fn()
+        # the forwards captured above left their counter copies pending (nobody may wait inside a capture)
+        self._pending = [r._last.get("pending") for r in self.rasterizers]
+        # `params`: the leaves whose gradients the step produces -- `grads` are the static tensors every replay rewrites
+        self.grads = [p.grad for p in params]
+
+    def step(self):
+        """Enqueue one replay; returns the (static) outputs of `fn`."""
+        self.graph.replay()
+        return self.outputs
+
+    __call__ = step
+
+    def check_overflow(self) -> list:
+        """Wait for the latest replay and return num_rendered per rasterizer; raises BinningOverflow if one overflowed."""
+        torch.cuda.current_stream().synchronize()
+        counts = []
+        for r, p in zip(self.rasterizers, self._pending):
+            if p is None or p.host is None:
+                counts.append(None)
+                continue
+            n, over = int(p.host[0]) & 0xFFFFFFFF, int(p.host[1])
+            if over >= 2:
+                raise RuntimeError("libhdrsplat: a radix pass of the binning stage gave up (hs_counters.overflow = 2)")
+            if over:
+                raise BinningOverflow(n, p.capacity, f"; rebuild the GraphedStep with capacity >= {grown_capacity(n)}")
+            counts.append(n)
+        return counts

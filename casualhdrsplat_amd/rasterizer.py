@@ -259,6 +259,9 @@ def _run_forward(settings: GaussianRasterizationSettings, means3D, opacities, sh
     a.binning, a.image = binning.data_ptr(), image.data_ptr()
     L.check(lib.hs_forward(C.byref(a), stream), "hs_forward")
     if not sync_mode:
+        if not _PINNED_POOL and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("GaussianRasterizer inside a graph capture needs one eager step first (graphs.GraphedStep "
+                               "does that): page-locked memory cannot be allocated while a stream is capturing")
         host = _PINNED_POOL.pop() if _PINNED_POOL else torch.empty(2, dtype=torch.int32).pin_memory()
         host.copy_(geom[:8].view(torch.int32), non_blocking=True)
         ev = torch.cuda.Event()
@@ -345,7 +348,8 @@ class _RasterizeGaussians(torch.autograd.Function):
             # view-parallel exchange: hand the per-view colour gradients to distributed.exchange_view_gradients
             ctx.deferred.update(view_colors=g["view_colors"], camposes=st.camposes, means3D=saved[0],
                                 M=st.dims.M, sh_degree=st.dims.sh_degree, flat=g["_flat"], gather=g.get("_gather"))
-        if st.pending is not None:
+        if st.pending is not None and not torch.cuda.is_current_stream_capturing():
+            # (inside a graph capture nobody may wait: graphs.GraphedStep.check_overflow reads the counters after a replay)
             # sync-free mode: the kernels are already queued; only now look at the forward's counters.  An overflowed
             # forward handed the caller an EMPTY frame, so the loss this gradient belongs to is already wrong: the
             # step cannot be repaired here -- raise, and let the rasterizer grow its capacity for the next call

@@ -29,4 +29,6 @@ res["step_ms"], res["step_med"] = t
 if a.stats and hasattr(L.load(), "hs_render_stats"):
     st = render_stats(out[0], dL)
     res["bwd_trips"], res["bwd_empty"] = st["bwd_trips"], st["bwd_empty_trips"]
+    res["bwd_lane_util"] = st["bwd_active_pixels"] / (128.0 * max(st["bwd_trips"], 1))
+    res["fwd_trips"] = st["fwd_trips"]
 print(json.dumps({k: (round(v, 4) if isinstance(v, float) else v) for k, v in res.items()}))

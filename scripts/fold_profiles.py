@@ -1,9 +1,11 @@
 """Turns gpurun_out/prof_final/ (scripts/collect_profiles.sh) into the tracked files of profiles/ (development aid).
-usage: python scripts/fold_profiles.py pmc|bench <round-tag>"""
+usage: python scripts/fold_profiles.py pmc|bench <round-tag> [c3|c2|c4]"""
 import collections, csv, glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC, DST = os.path.join(ROOT, "gpurun_out", "prof_final"), os.path.join(ROOT, "profiles")
 what, tag = sys.argv[1], sys.argv[2]
+CFG = sys.argv[3] if len(sys.argv) > 3 else "c3"
+SRC = os.path.join(ROOT, "gpurun_out", "prof_final" if CFG == "c3" else "prof_final_" + CFG)
+DST = os.path.join(ROOT, "profiles")
 
 
 def counters(sub):
@@ -23,7 +25,7 @@ if what == "pmc":
             continue
         f, w = fetch.get(k, {}).get("FETCH_SIZE", 0.0), write.get(k, {}).get("WRITE_SIZE", 0.0)
         rows.append((k, f, w, int((2 * f + w) * 1024)))
-    with open(os.path.join(DST, f"{tag}_pmc_traffic_c3.csv"), "w") as o:
+    with open(os.path.join(DST, f"{tag}_pmc_traffic_{CFG}.csv"), "w") as o:
         o.write("kernel,FETCH_SIZE_KB_raw_avg,WRITE_SIZE_KB_avg,hbm_bytes_per_launch(2*FETCH+WRITE)\n")
         for r in rows:
             o.write(f"{r[0]},{r[1]:.1f},{r[2]:.1f},{r[3]}\n")
@@ -35,12 +37,18 @@ if what == "pmc":
     sys.path.insert(0, ROOT)
     from bench import kernel_source_hash
     sha = kernel_source_hash(os.path.join(ROOT, "casualhdrsplat_amd", "csrc", "render.hip"))
-    json.dump({"c3": {"render_bwd_kernel_hbm_bytes": pick("render_bwd_kernel"), "render_fwd_kernel_hbm_bytes": pick("render_fwd_kernel"),
+    tpath = os.path.join(DST, "pmc_traffic.json")
+    allcfg = json.load(open(tpath)) if os.path.exists(tpath) else {}
+    allcfg.update({CFG: {"render_bwd_kernel_hbm_bytes": pick("render_bwd_kernel"), "render_fwd_kernel_hbm_bytes": pick("render_fwd_kernel"),
                       "render_hip_sha256": sha,
                       "source_commit": commit + " (HEAD when the counters were folded; kernels of that tree)",
                       "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (KB units); hbm = (2*FETCH_SIZE + WRITE_SIZE)*1024, "
                                 "the gfx950 FETCH_SIZE half-count correction; per-launch average; counted at the L2-fabric interface (Infinity-Cache hits included)",
-                      "source": f"profiles/{tag}_pmc_traffic_c3.csv"}}, open(os.path.join(DST, "pmc_traffic.json"), "w"), indent=1)
+                      "source": f"profiles/{tag}_pmc_traffic_{CFG}.csv"}})
+    json.dump(allcfg, open(tpath, "w"), indent=1)
+    if CFG != "c3":
+        print(json.dumps(allcfg[CFG], indent=1))
+        sys.exit(0)
     with open(os.path.join(DST, f"{tag}_pmc_sq_c3.csv"), "w") as o:
         o.write("kernel,counter,avg_per_launch\n")
         for i in range(1, 5):
@@ -63,6 +71,11 @@ if what == "pmc":
     tj["c3"]["valu_method"] = "SQ_ACTIVE_INST_VALU * 4 / (1024 SIMDs * GRBM_GUI_ACTIVE / 8 XCDs), profiles/%s_pmc_sq_c3.csv" % tag
     json.dump(tj, open(os.path.join(DST, "pmc_traffic.json"), "w"), indent=1)
     print(open(os.path.join(DST, "pmc_traffic.json")).read())
+elif CFG != "c3":   # kernel stats of the bench command at another BASELINE config
+    cands = glob.glob(os.path.join(SRC, "stats", "*", "*_kernel_stats.csv"))
+    assert len(cands) == 1, cands
+    shutil.copy(cands[0], os.path.join(DST, f"{tag}_bench_{CFG}_kernel_stats.csv"))
+    print("copied", cands[0])
 else:
     for cfg in ("c3", "c4", "c2"):
         line = open(os.path.join(SRC, f"bench_{cfg}.json")).read().strip().splitlines()[-1]

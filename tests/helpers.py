@@ -219,10 +219,11 @@ STRICT = dict(frac_tol=1e-2, max_tol=1e-2, l2_tol=1e-5)  # measured: frac <= 6e-
 # inside the oracle's threshold guard band), or by a pixel within rounding distance of a CRF knot (the interval, hence
 # the slope dL/dH is multiplied with, is the one decision no output reveals).  One flipped contribution is at most
 # alpha = 1/255 of a pixel term (a skip) or T < 1e-2 of one (a termination), a neighbouring CRF slope a few per cent of
-# one: bounded per element by 10 x max(|ref|, 1e-3 RMS) -- i.e. 1e-2 of the tensor's RMS for elements below the floor --
-# and together by the L2 share of the tensor they may change.  No bound on the fraction WITHIN those rows (a flipped
-# pixel changes every Gaussian along it), but the rows themselves must stay few: `min_strict`.
-AT_RISK = dict(frac_tol=1.0, max_tol=10.0, l2_tol=5e-3)
+# one: bounded per element by 1 x max(|ref|, 1e-3 RMS) -- i.e. 1e-3 of the tensor's RMS for elements below the floor --
+# and together by the L2 share of the tensor they may change (measured on the MI355X over the fixed tests and the sweep:
+# worst element 0.02, L2 4e-5).  No bound on the fraction WITHIN those rows (a flipped pixel changes every Gaussian along
+# it), but the rows themselves must stay few: `min_strict`.
+AT_RISK = dict(frac_tol=1.0, max_tol=1.0, l2_tol=5e-4)
 
 
 def assert_grads_close(got: dict, ref: dict, keys=GRAD_KEYS, frac_tol=None, max_tol=None, l2_tol=None, what="",
