@@ -347,12 +347,27 @@ __global__ void __launch_bounds__(kSortBlock) radix_sweep_kernel(const void* in_
 #pragma unroll
             for (int j = 0; j < LOOK; ++j)
                 v[j] = p - j >= 0 ? st_read(status + (int64_t)(p - j) * 256 + threadIdx.x) : kStIncl;
+            // fast path: all LOOK words are published already (the usual case once the chain is moving) -- no loop, no
+            // branch per word: add counts up to and including the first inclusive prefix
+            bool all_ready = true;
+#pragma unroll
+            for (int j = 0; j < LOOK; ++j) all_ready = all_ready && (v[j] & ~kStMask) != 0u;
+            if (all_ready) {
+                bool alive = true;
+#pragma unroll
+                for (int j = 0; j < LOOK; ++j) {
+                    excl += alive ? (v[j] & kStMask) : 0u;
+                    alive = alive && (v[j] & ~kStMask) != kStIncl;
+                }
+                done = !alive;
+                continue;
+            }
 #pragma unroll
             for (int j = 0; j < LOOK; ++j) {
                 if (done) break;
                 uint32_t x = v[j];
-                // (bounded: kSpinLimit polls per word.  The pragma matters: a loop with a known trip bound gets unrolled
-                // eightfold, 64 copies of the poll in this walk, which cost the binning stage 15 us at c3)
+                // (bounded: kSpinLimit polls per word; the loop must not be unrolled -- a known trip bound gets it
+                // unrolled eightfold, 64 copies of the poll in this walk)
                 int polls = 0;
 #pragma clang loop unroll(disable)
                 while ((x & ~kStMask) == 0u && polls < kSpinLimit) {
