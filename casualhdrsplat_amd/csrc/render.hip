@@ -808,13 +808,17 @@ __device__ __forceinline__ void step_bwd_pair(PairB& s, bool act0, bool act1, f2
 //   in plane order: bitwise reproducible.
 constexpr int kTailPct = 8;           // share of the tiles handed out by the queue (see the kernel)
 constexpr int kAccF = 12;             // first float of the sums
-// staged entries per batch (<= threads per workgroup).  64: 13 KB of LDS per workgroup, six waves per SIMD; measured at c3
-// with 96 / 128 entries (four / three waves per SIMD): 0.473 / 0.504 ms against 0.468
-constexpr int kBwdKB = 64;
+// staged entries per batch (<= 64: the lists are built from one ballot per group).  52 entries = 10.8 KB of LDS per
+// workgroup, which -- with the kernel held to 72 registers (amdgpu_waves_per_eu 7, no spill in the loop) -- lets seven
+// waves per SIMD stay resident.  Measured at c3 (whole step, ms): 64 entries / six waves 1.197, 52 / seven 1.179, 48 / seven
+// 1.191, 56 / seven 1.213, 40 / eight (64 registers, spills) 1.209; 96 / 128 entries (four / three waves): 0.473 / 0.504 ms
+// for the kernel against 0.468.
+constexpr int kBwdKB = 52;
 
 
 template <bool DEPTH, bool STATS>
-__global__ void __launch_bounds__(kBatch) render_bwd_kernel(RenderBwd p) {
+__global__ void __launch_bounds__(kBatch) __attribute__((amdgpu_waves_per_eu((DEPTH || STATS) ? 1 : 7)))
+render_bwd_kernel(RenderBwd p) {
     constexpr int KB = kBwdKB;              // staged entries per batch (<= threads per workgroup)
     constexpr int NV = DEPTH ? 10 : 9;      // reduced values per (tile, entry): nine published sums (+ d inverse depth)
     constexpr int kEntF = kAccF + 4 * NV;   // floats per LDS entry record: 48 (192 bytes) / 52 (208 bytes)

@@ -1,0 +1,12 @@
+#!/bin/bash
+set -u
+for v in "" k52w7 k52w7t4 k52w7t6 k48w7t4 k56w7t4 k40w8t4 "" k52w7t4; do
+  s=${v:+_$v}
+  HS_LIB_PATH=$PWD/casualhdrsplat_amd/libhdrsplat$s.so timeout 300 python scripts/ab_render.py --iters 30 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['lib'], 'c3 bwd', d['render_bwd_ms'], d['render_bwd_med'], 'fwd', d['render_fwd_ms'], 'step', d['step_ms'], d['step_med'])"
+done
+for v in k52w7t4 k48w7t4; do
+  s=${v:+_$v}
+  for c in c2 c4; do
+  HS_LIB_PATH=$PWD/casualhdrsplat_amd/libhdrsplat$s.so timeout 300 python scripts/ab_render.py --iters 10 --config $c 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['lib'], '$c bwd', d['render_bwd_ms'], 'step', d['step_ms'], d['step_med'])"
+  done
+done
