@@ -1062,12 +1062,13 @@ render_bwd_kernel(RenderBwd p) {
     if constexpr (STATS) {
         ws.flush(p.stats);
         if (p.timeline && threadIdx.x == 0) {
-            p.timeline[3 * blockIdx.x + 0] = t_start;
-            p.timeline[3 * blockIdx.x + 1] = wall_clock64();
+            // one row per TILE SLOT of the launch (bidx: a queue worker serves several slots, or none)
+            p.timeline[3 * bidx + 0] = t_start;
+            p.timeline[3 * bidx + 1] = wall_clock64();
             // HW_REG_XCC_ID (20): bits 3:0 ; HW_REG_HW_ID (4): cu_id bits 11:8, sh_id 12, se_id 15:13
             const uint32_t xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);
             const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
-            p.timeline[3 * blockIdx.x + 2] = ((unsigned long long)xcc << 32) | hw;
+            p.timeline[3 * bidx + 2] = ((unsigned long long)xcc << 32) | hw;
         }
     }
     if ((int)blockIdx.x < n_static) return;
