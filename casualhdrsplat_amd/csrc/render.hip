@@ -404,11 +404,12 @@ __device__ __forceinline__ void write_pixel_fwd(const RenderFwd& p, const PixF& 
 // one (scalar-computed) byte offset addresses all of it.
 constexpr int kFwdEntF = 12;
 
-// The plain instantiation needs 69 vector registers as written, one wave per SIMD short of the eight that 64 allow;
-// asked for eight, the compiler fits it into 64 without a spill (the inverse-depth and diagnostic instantiations
-// would spill: they keep what they get).  Measured: -6 us at c3.
+// Seven waves per SIMD (72 registers).  Round 2's one-list kernel fitted 64 registers / eight waves without a spill (-6 us);
+// with the two lane groups the same request spills eight registers per lane around the batch loop -- 33 MB written and
+// read back per frame, visible as +30 % L2-fabric traffic -- and is no faster (0.248-0.250 ms at c3 against 0.245-0.247 at
+// seven waves; c4 1.648 vs 1.614; six waves: 0.251).  (The inverse-depth and diagnostic instantiations keep what they get.)
 template <bool DEPTH, bool STATS>
-__global__ void __launch_bounds__(kBatch) __attribute__((amdgpu_waves_per_eu((DEPTH || STATS) ? 1 : 8)))
+__global__ void __launch_bounds__(kBatch) __attribute__((amdgpu_waves_per_eu((DEPTH || STATS) ? 1 : 7)))
 render_fwd_kernel(RenderFwd p) {
     constexpr int KB = kBatch;
     constexpr int kEnt = kFwdEntF * 4;          // bytes per staged record
