@@ -31,10 +31,11 @@ constexpr int kInstFloats = 4 * kInstF4;
 // Radix passes (binning.hip): 256 threads per block, ITEMS elements per thread; LOOK = status words a thread requests at
 // once during the decoupled look-back.  Measured at c3 / c4 (binning stage, ms; profiles/README.md): depth sort with
 // 8 / 4 items per thread 0.29 / 0.38 against 0.275 with 16 (c4: 2.09 / 2.41 against 1.85), 16 / 32 words in flight 0.29 /
-// 0.31 -- more, smaller blocks lose to their fixed cost (digit totals, block scans), and deeper look-back over-reads.
+// 0.31 -- more, smaller blocks lose to their fixed cost (digit totals, block scans), and deeper look-back over-reads;
+// pair sort with 12 / 20 / 24 items per thread: 0.226 / 0.232 / 0.249 against 0.225 (three blocks per CU at 24).
 constexpr int kSortBlock = 256;
 constexpr int kDepthSortItems = 16, kDepthSortLook = 8;                                     // instances by depth
-constexpr int kPairSortItems = 16, kPairSortLook = 8;                                       // (tile, instance) pairs by tile
+constexpr int kPairSortItems = 16, kPairSortLook = 8;                                       // (tile, instance) pairs by tile                                       // (tile, instance) pairs by tile
 constexpr int kU64SortItems = 16;                                                           // hs_sort_pairs
 constexpr int kSortTileMin = (kDepthSortItems < 16 ? kDepthSortItems : 16) * kSortBlock;    // smallest radix block in use
 
