@@ -74,7 +74,7 @@ class hs_bwd_args(C.Structure):
 class hs_layout(C.Structure):
     _fields_ = [(n, C.c_int64) for n in (
         "counters", "rec", "depth", "radii", "tiles_touched", "offsets", "cov3D", "clamped", "scan_spine", "binfo",
-        "keys_sorted", "point_list", "pairs_tmp", "ranges", "sort_tmp", "depth_pairs", "inst_sorted", "offs_sorted", "srect",
+        "keys_sorted", "point_list", "pairs_tmp", "ranges", "sort_tmp", "depth_pairs", "inst_sorted", "offs_sorted", "pair_sort_tmp",
         "pair_flags", "pair_act",
         "final_T", "n_contrib", "pose_hdr", "tile_work", "tile_order",
         "pair_grads", "crf_partials", "inst_grads", "pose_partials")]

@@ -24,6 +24,11 @@ bool sort_tickets() {
     return on;
 }
 
+bool scan_in_emission(int64_t I) {
+    static const int forced = [] { const char* e = getenv("HS_SCAN_IN_EMISSION"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+    return forced >= 0 ? forced == 1 : I >= (2 << 20);
+}
+
 void set_error(const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -71,11 +76,11 @@ static int plan(const hs_dims& d, hs_sizes* sz, hs_layout* L) {
     l.point_list = l.keys_sorted + align_up(d.capacity * 4, 256);
     l.pairs_tmp = carve(d.capacity * 8);
     l.ranges = carve(vtiles * 8);
-    l.sort_tmp = carve(sort_tmp_bytes(d.capacity > I ? d.capacity : I));
+    l.sort_tmp = carve(sort_tmp_bytes(I));
     l.depth_pairs = carve(2 * I * 8);
     l.inst_sorted = carve(I * 4);
     l.offs_sorted = carve(I * 4);
-    l.srect = carve(I * 8);
+    l.pair_sort_tmp = carve(emit_scan_words(I) * 4 + sort_tmp_bytes(d.capacity));
     l.pair_flags = carve(d.capacity);  // cleared by the pair emission, set by the render backward
     l.pair_act = carve(d.capacity);    // written by the render forward, read by the render backward
     sz->binning_bytes = o;

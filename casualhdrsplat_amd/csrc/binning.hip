@@ -117,13 +117,15 @@ __global__ void __launch_bounds__(256) scan_apply_kernel(const uint32_t* in, int
     }
 }
 
-// Sums of 256 consecutive values (the pair emission's block size): with scan_spine_kernel, the first two thirds of the
-// scan whose last third runs inside emit_pairs_kernel.
-__global__ void __launch_bounds__(256) scan_reduce256_kernel(const uint32_t* in, int64_t n, uint32_t* block_sums) {
+// Sums of 256 consecutive values (the pair emission's block size): with scan_spine_kernel, the block-exclusive pair
+// offsets of the emission when they are computed ahead of it (frames of fewer than 2^21 instances).
+__global__ void __launch_bounds__(256) scan_reduce256_kernel(const uint2* srect, int64_t n, uint32_t* block_sums) {
     __shared__ uint32_t s_wave[4];
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    uint32_t cnt = 0;
+    if (i < n) { const uint2 rc = srect[i]; cnt = (rc.y & 0xFFFFu) * (rc.y >> 16); }
     uint32_t total;
-    block_incl_scan(i < n ? in[i] : 0u, s_wave, &total);
+    block_incl_scan(cnt, s_wave, &total);
     if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
 }
 
@@ -139,9 +141,10 @@ int scan_u32(const uint32_t* in, int64_t n, uint32_t* spine, uint32_t* out, uint
 // Start of the binning stage: the instance count for the depth sort, and cleared tile ranges (tiles without pairs
 // must read (0,0)).
 __global__ void __launch_bounds__(256) bin_prepare_kernel(hs_counters* c, uint32_t n_inst, uint2* ranges, int64_t ntiles,
-                                                          uint32_t* zero, int64_t n_zero) {
+                                                          uint32_t* zero, int64_t n_zero, uint32_t* zero2, int64_t n_zero2) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    for (int64_t t = i; t < n_zero; t += (int64_t)gridDim.x * 256) zero[t] = 0u;   // scratch of the depth sort
+    for (int64_t t = i; t < n_zero; t += (int64_t)gridDim.x * 256) zero[t] = 0u;     // scratch of the depth sort
+    for (int64_t t = i; t < n_zero2; t += (int64_t)gridDim.x * 256) zero2[t] = 0u;   // emission scan status + pair-sort scratch
     if (i < ntiles) ranges[i] = make_uint2(0u, 0u);
     if (i == 0) { c->overflow = 0u; c->reserved[1] = n_inst; c->reserved[2] = 0u; c->reserved[3] = 0u; }
 }
@@ -465,19 +468,29 @@ __global__ void __launch_bounds__(256) depth_keys_kernel(int64_t I, const float*
     pairs[i] = make_uint2(radii[i] > 0 ? __float_as_uint(depth[i]) : 0xFFFFFFFFu, (uint32_t)i);
 }
 
-// Tile rectangles and pair counts of the instances, gathered into depth order (one 8-byte gather per instance;
-// everything the emission needs afterwards is read coalesced).
+// Tile rectangles of the instances gathered into depth order (one 8-byte gather per instance) ahead of the emission --
+// the path of frames with fewer than 2^21 instances, see emit_pairs_kernel.
 __global__ void __launch_bounds__(256) gather_binfo_kernel(int64_t I, const uint32_t* inst_sorted, const uint2* binfo,
-                                                           uint2* srect, uint32_t* ts, uint32_t* zero, int64_t n_zero,
-                                                           const hs_counters* counters) {
+                                                           uint2* srect, const hs_counters* counters) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    // digit totals, tickets and status words of the tile sort that follows the emission: cleared here
-    for (int64_t t = i; t < n_zero; t += (int64_t)gridDim.x * 256) zero[t] = 0u;
     if (i >= I) return;
-    // a depth sort that gave up (overflow = 2) left no instance list: every instance counts as culled, nothing is emitted
-    const uint2 b = counters->overflow >= 2u ? make_uint2(0u, 0u) : binfo[inst_sorted[i]];
-    srect[i] = b;
-    ts[i] = (b.y & 0xFFFFu) * (b.y >> 16);
+    srect[i] = counters->overflow >= 2u ? make_uint2(0u, 0u) : binfo[inst_sorted[i]];
+}
+
+// ---- chained scan of the emission (one 64-bit status word per 256-instance block: flag << 62 | pairs) ----
+// Two ways to the block-exclusive pair offsets of the emission, chosen by the instance count (measured, binning stage, ms):
+//   * ahead of it: gather_binfo_kernel + scan_reduce256_kernel + scan_spine_kernel (three small launches, no chain) --
+//     c3 (1 M instances) 0.222, c4 (8 M) 1.716, c2 (0.1 M) 0.114;
+//   * inside it: the emission gathers its rectangles itself and learns the earlier blocks' pairs by decoupled look-back
+//     -- c3 0.229 (the chain over 3906 blocks costs more than two tiny kernels), c4 1.581 (three passes over 8 M
+//     instances and 130 MB of intermediate arrays less), c2 0.111.
+// (the switch: scan_in_emission(I), api.hip -- from 2^21 instances on; HS_SCAN_IN_EMISSION=0/1 forces it)
+constexpr uint64_t kScFlag = 3ull << 62, kScAgg = 1ull << 62, kScIncl = 2ull << 62, kScPoison = 3ull << 62;
+__device__ __forceinline__ void sc_publish(uint64_t* p, uint64_t v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint64_t sc_read(const uint64_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // duplicateWithKeys walking the instances in depth order.  A wave owns 64 consecutive instances, whose pair slots
@@ -485,13 +498,19 @@ __global__ void __launch_bounds__(256) gather_binfo_kernel(int64_t I, const uint
 // slot's owner by binary search over the 64 slot starts in LDS and its tile from the owner's rectangle (row-major, the
 // published emission order).  Also records where each instance's slots start (render-backward addresses its
 // gradient records with it; the segmented sum walks them).
-// The inclusive scan of the depth-ordered pair counts (a5 on the order the pairs are laid out in) is finished HERE: the
-// two small kernels before this one leave the exclusive sum of every 256-instance block in `block_excl`, the block adds
-// its own running counts and writes `offs_sorted` (the segmented sum of the backward walks it again).
+// The inclusive scan of the depth-ordered pair counts (a5 on the order the pairs are laid out in) is finished HERE.  Frames
+// of fewer than 2^21 instances: three small kernels ahead of this one leave the gathered rectangles in `srect`
+// and the exclusive sum of every 256-instance block in `block_excl`.  Larger frames (several poses): both are null -- a
+// block gathers the tile rectangles of its 256 instances itself (one 8-byte gather each), scans their pair counts, and
+// learns the pairs of all earlier blocks by decoupled look-back over one 64-bit status word per block (wave 0 reads 64
+// predecessors per step; same progress argument and the same bounded waits as the radix passes).  The LAST block knows num_rendered and publishes
+// the verdict for the later kernels: n_sort = R, or 0 when R exceeds the binning capacity (or a wait gave up) -- then
+// nothing is sorted, the frame renders empty, and the host sees counters.overflow and replays with a larger capacity
+// (blocks that lie below the capacity have emitted their pairs by then: harmless, they are never looked at).
 __global__ void __launch_bounds__(256) emit_pairs_kernel(int64_t I, int P, int gx, int gy, float4* rec,
-                                                         const uint32_t* inst_sorted, const uint32_t* block_excl,
-                                                         uint32_t* offs_sorted,
-                                                         const uint2* srect, uint2* pairs,
+                                                         const uint32_t* inst_sorted, const uint2* binfo, const uint2* srect,
+                                                         const uint32_t* block_excl, uint64_t* scan_status,
+                                                         uint32_t* offs_sorted, uint2* pairs,
                                                          uint8_t* pair_flags, hs_counters* counters, uint64_t capacity,
                                                          uint32_t* ghist, int nbits, int passes) {
     __shared__ uint32_t s_hist[4 * 256];   // digit totals of the tile sort's passes (<= 4), this block's pairs
@@ -499,33 +518,70 @@ __global__ void __launch_bounds__(256) emit_pairs_kernel(int64_t I, int P, int g
     __shared__ uint2 s_rect[4][64];
     __shared__ uint32_t s_inst[4][64];
     __shared__ uint32_t s_wsum[4];
-    // num_rendered (total of the depth-ordered scan just before this launch) against the binning capacity: an
-    // overflowing call emits nothing, sorts nothing (n_sort = 0) and renders empty; the host sees counters.overflow
-    // and replays with a larger capacity.  One thread publishes the verdict for the later kernels.  (overflow = 2, a
-    // depth sort that gave up, stays: gather_binfo_kernel then made every pair count zero.)
-    const bool overflow = (uint64_t)counters->num_rendered > capacity;
+    __shared__ uint64_t s_excl;            // pairs of all earlier blocks; kScPoison in the flag bits: a wait gave up
     for (int t = threadIdx.x; t < passes * 256; t += 256) s_hist[t] = 0;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (overflow) counters->overflow = 1u;
-        counters->reserved[0] = overflow ? 0u : counters->num_rendered;
-    }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    uint32_t beg = 0, end = 0, inst = 0;
+    const int blk = blockIdx.x;
+    const int64_t i = (int64_t)blk * 256 + threadIdx.x;
+    uint32_t inst = 0;
     uint2 rc = make_uint2(0u, 0u);
-    if (i < I) rc = srect[i];
-    {   // inclusive scan of the block's pair counts on top of the block's exclusive sum
-        const uint32_t cnt = (rc.y & 0xFFFFu) * (rc.y >> 16);
-        uint32_t total;
-        end = block_excl[blockIdx.x] + block_incl_scan(cnt, s_wsum, &total);
-        beg = end - cnt;
-        if (i < I) offs_sorted[i] = end;   // written even on overflow: the segmented sum then finds nothing flagged
-    }
-    if (overflow) return;
-    if (i < I) {
+    // (a depth sort that gave up -- overflow = 2 -- left no instance list: every instance counts as culled)
+    if (i < I && counters->overflow < 2u) {
         inst = inst_sorted[i];
-        if (end > beg) reinterpret_cast<float*>(rec + kRecF4 * (int64_t)inst + 2)[3] = __uint_as_float(beg);
+        rc = srect ? srect[i] : binfo[inst];   // (srect: the rectangles gathered into depth order by a kernel of their own)
     }
+    const uint32_t cnt = (rc.y & 0xFFFFu) * (rc.y >> 16);
+    uint32_t block_total;
+    const uint32_t incl = block_incl_scan(cnt, s_wsum, &block_total);
+    if (block_excl) {          // offsets computed ahead of this launch (srect given as well)
+        if (threadIdx.x == 0) s_excl = block_excl[blk];
+    } else if (wave == 0) {
+        if (lane == 0) sc_publish(scan_status + blk, (blk == 0 ? kScIncl : kScAgg) | (uint64_t)block_total);
+        uint64_t excl = 0;
+        bool poison = false;
+        for (int base = blk - 1; base >= 0; base -= 64) {
+            const int idx = base - lane;
+            uint64_t x = idx >= 0 ? sc_read(scan_status + idx) : kScIncl;
+            int polls = 0;
+#pragma clang loop unroll(disable)
+            while ((x & kScFlag) == 0ull && polls < kSpinLimit) {
+                ++polls;
+                __builtin_amdgcn_s_sleep(1);
+                x = sc_read(scan_status + idx);
+            }
+            const uint64_t flag = x & kScFlag;
+            poison = poison || __ballot(flag == 0ull || flag == kScPoison) != 0ull;
+            // the nearest inclusive prefix of this window (lowest lane) ends the walk: everything in front of it counts
+            const uint64_t incl_mask = __ballot(flag == kScIncl || flag == kScPoison || flag == 0ull);
+            const int first = incl_mask ? (int)__builtin_ctzll(incl_mask) : 64;
+            uint64_t v = lane <= first ? (x & ~kScFlag) : 0ull;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) v += (uint64_t)__shfl_xor((long long)v, d);
+            excl += v;
+            if (incl_mask) break;
+        }
+        if (lane == 0) {
+            if (blk != 0) sc_publish(scan_status + blk, (poison ? kScPoison : kScIncl) | ((excl + block_total) & ~kScFlag));
+            s_excl = poison ? kScPoison : excl;
+        }
+    }
+    __syncthreads();
+    const bool poison = (s_excl & kScFlag) != 0ull;
+    const uint64_t bexcl = s_excl & ~kScFlag;
+    const uint64_t bend = bexcl + block_total;
+    if (blk == (int)gridDim.x - 1 && threadIdx.x == 0) {   // the last block knows R: the verdict for the later kernels
+        const bool over = bend > capacity;
+        counters->num_rendered = bend > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)bend;
+        if (poison) counters->overflow = 2u;
+        else if (over && counters->overflow < 2u) counters->overflow = 1u;
+        counters->reserved[0] = (poison || over || counters->overflow != 0u) ? 0u : (uint32_t)bend;
+    }
+    uint32_t beg = 0, end = 0;
+    end = (uint32_t)bexcl + incl;   // (32 bits: exact whenever the block lies below the capacity < 2^30)
+    beg = end - cnt;
+    if (i < I) offs_sorted[i] = end;   // written even on overflow: the segmented sum then finds nothing flagged
+    if (poison || bend > capacity) return;
+    if (i < I && end > beg) reinterpret_cast<float*>(rec + kRecF4 * (int64_t)inst + 2)[3] = __uint_as_float(beg);
     // lanes past the end of the array inherit the running end so the range stays monotone
     const uint32_t last_end = __shfl(end, 63 - __builtin_clzll(__ballot(i < I) | 1ull));
     if (i >= I) beg = end = last_end;
@@ -663,13 +719,19 @@ int launch_binning(const hs_fwd_args& a, const hs_layout& L, hipStream_t s) {
     uint32_t* n_sort = &counters->reserved[0];
     const uint32_t* n_inst = &counters->reserved[1];
     uint2* ranges = (uint2*)(bin + L.ranges);
-    // when preprocess ran in this same call it already wrote the depth keys, the instance count and cleared ranges
+    // when preprocess ran in this same call it already wrote the depth keys, the instance count, cleared the ranges and
+    // both scratch regions
     const bool prepared = (a.stages & HS_STAGE_PREPROCESS) != 0;
-    void* tmp = bin + L.sort_tmp;
-    constexpr int kDepthTile = kDepthSortItems * kSortBlock, kPairTile = kPairSortItems * kSortBlock;
+    void* tmp = bin + L.sort_tmp;                         // scratch of the depth sort
+    uint64_t* scan_status = (uint64_t*)(bin + L.pair_sort_tmp);   // one word per emission block, then the pair sort's scratch
+    void* tmp2 = (char*)scan_status + emit_scan_words(I) * 4;
+    const int tbits = tile_bits((uint32_t)ntiles);
+    const int passes = sort_passes(tbits);
+    constexpr int kDepthTile = kDepthSortItems * kSortBlock;
     if (!prepared)
         bin_prepare_kernel<<<ceil_div(ntiles, 256), 256, 0, s>>>(counters, (uint32_t)I, ranges, ntiles, (uint32_t*)tmp,
-                                                                 sort_scratch_words(I, 4, kDepthTile));
+                                                                 sort_scratch_words(I, 4, kDepthTile), (uint32_t*)scan_status,
+                                                                 pair_scratch_words(I, d.capacity, passes));
 
     // 1. instances by depth (stable, 32-bit keys -> 4 passes over (key, instance) elements; the last one leaves only
     //    the instance list)
@@ -682,36 +744,35 @@ int launch_binning(const hs_fwd_args& a, const hs_layout& L, hipStream_t s) {
                                                                &counters->overflow, nullptr, s, /*zeroed=*/true,
                                                                /*ghist_ready=*/false);   // cleared by preprocess / bin_prepare
     if (rc != HS_OK) return rc;
-    // 2. pair offsets in depth order, then emission
-    uint32_t* ts = (uint32_t*)dp0;   // tiles touched in depth order (the depth sort's buffers are free again)
-    uint32_t* offs = (uint32_t*)(bin + L.offs_sorted);   // inclusive scan of ts; the backward's segmented sum walks it
-    uint2* srect = (uint2*)(bin + L.srect);
-    // the tile sort below runs single-sweep passes: its digit totals are counted by the emission, its scratch (totals +
-    // tickets + status words) is cleared by this gather
-    const int tbits = tile_bits((uint32_t)ntiles);
-    const int passes = sort_passes(tbits);
-    const int64_t n_zero = sort_scratch_words(d.capacity, passes, kPairTile);
-    gather_binfo_kernel<<<ceil_div(I, 256), 256, 0, s>>>(I, inst_sorted, (const uint2*)(geom + L.binfo), srect, ts,
-                                                         (uint32_t*)tmp, n_zero, counters);
-    // pair offsets in depth order: block sums + their exclusive scan here, the rest inside the emission
-    uint32_t* spine = (uint32_t*)(geom + L.scan_spine);
-    const int eblk = ceil_div(I, 256);
-    scan_reduce256_kernel<<<eblk, 256, 0, s>>>(ts, I, spine);
-    scan_spine_kernel<<<1, 256, 0, s>>>(spine, eblk, &counters->num_rendered);  // total = R
-    // the last pass writes (keys_sorted, point_list), which overlay packed buffer A: it must read buffer B, so the
-    // emission starts in A when the pass count is even
+    // 2. pair emission in depth order, with the scan of the pair counts inside (emit_pairs_kernel); it also counts the
+    //    digit totals of the tile sort below.  The last pass of that sort writes (keys_sorted, point_list), which overlay
+    //    packed buffer A: it must read buffer B, so the emission starts in A when the pass count is even
+    uint32_t* offs = (uint32_t*)(bin + L.offs_sorted);   // inclusive pair offsets in depth order (the backward's segmented sum walks them)
     uint2* pA = (uint2*)(bin + L.keys_sorted);
     uint2* pB = (uint2*)(bin + L.pairs_tmp);
     uint2* p0 = (passes % 2 == 0) ? pA : pB;
     uint2* p1 = (passes % 2 == 0) ? pB : pA;
-    emit_pairs_kernel<<<eblk, 256, 0, s>>>(I, d.P, gx, gy, (float4*)(geom + L.rec), inst_sorted, spine, offs, srect,
-                                           p0, (uint8_t*)(bin + L.pair_flags), counters, (uint64_t)d.capacity,
-                                           (uint32_t*)tmp, tbits, passes);
+    // (the depth sort's two buffers are free again: they hold the gathered rectangles and their block sums when the
+    // offsets are computed ahead of the emission)
+    const int eblk = ceil_div(I, 256);
+    uint2* srect = nullptr;
+    uint32_t* block_excl = nullptr;
+    if (!scan_in_emission(I)) {
+        srect = dp0;
+        block_excl = (uint32_t*)dp1;
+        gather_binfo_kernel<<<eblk, 256, 0, s>>>(I, inst_sorted, (const uint2*)(geom + L.binfo), srect, counters);
+        scan_reduce256_kernel<<<eblk, 256, 0, s>>>(srect, I, block_excl);
+        scan_spine_kernel<<<1, 256, 0, s>>>(block_excl, eblk, nullptr);
+    }
+    emit_pairs_kernel<<<eblk, 256, 0, s>>>(I, d.P, gx, gy, (float4*)(geom + L.rec), inst_sorted,
+                                           (const uint2*)(geom + L.binfo), srect, block_excl, scan_status, offs, p0,
+                                           (uint8_t*)(bin + L.pair_flags), counters, (uint64_t)d.capacity,
+                                           (uint32_t*)tmp2, tbits, passes);
     HS_LAUNCH_CHECK();
     // 3. stable sort by tile id only
     uint32_t* keys_sorted = (uint32_t*)(bin + L.keys_sorted);
     rc = radix_sort_packed<kPairSortItems, kPairSortLook>(p0, p1, keys_sorted, (uint32_t*)(bin + L.point_list), n_sort,
-                                                         d.capacity, tbits, tmp, &counters->overflow, n_sort, s,
+                                                         d.capacity, tbits, tmp2, &counters->overflow, n_sort, s,
                                                          /*zeroed=*/true, /*ghist_ready=*/true);
     if (rc != HS_OK) return rc;
     if (d.capacity > 0) {

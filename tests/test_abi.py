@@ -56,7 +56,7 @@ def test_struct_sizes_match_c(lib, tmp_path):
 
 def test_version_and_plan(lib):
     L = lib.load()
-    assert L.hs_version() == 300
+    assert L.hs_version() == 301
     d, sz, lay = lib.plan(1_000_000, 16, 3, 1920, 1080, 1, 7_000_000)
     assert sz.geom_bytes > 1_000_000 * 48 and sz.binning_bytes > 7_000_000 * 16
     assert sz.image_bytes >= 1920 * 1080 * (8 + 12) and sz.bwd_bytes >= 7_000_000 * 48
@@ -64,7 +64,7 @@ def test_version_and_plan(lib):
             lay.scan_spine]
     assert geom == sorted(geom) and all(o % 256 == 0 for o in geom) and len(set(geom)) == len(geom)
     binning = [lay.keys_sorted, lay.point_list, lay.pairs_tmp, lay.ranges, lay.sort_tmp, lay.depth_pairs, lay.inst_sorted,
-               lay.offs_sorted, lay.srect]
+               lay.offs_sorted, lay.pair_sort_tmp]
     assert binning == sorted(binning) and all(o % 256 == 0 for o in binning)
     # N poses scale the per-instance arrays
     _, sz8, _ = lib.plan(1_000_000, 16, 3, 1920, 1080, 8, 7_000_000)

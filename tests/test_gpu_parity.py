@@ -598,9 +598,11 @@ def test_softplus_gradient_of_dark_gaussians_vs_oracle(oracle):
     assert np.percentile(rel, 99) < 1e-3 and rel.max() < 5e-2, (float(np.percentile(rel, 99)), float(rel.max()))
 
 
-def test_ticketed_radix_passes_give_the_same_frame():
+def test_ticketed_radix_passes_and_both_emission_scans_give_the_same_frame():
     """HS_SORT_TICKETS=1 (chain positions of the radix passes from a per-pass ticket counter instead of blockIdx: the
-    fallback should a dispatcher ever start workgroups out of order) sorts exactly as the default."""
+    fallback should a dispatcher ever start workgroups out of order) sorts exactly as the default; and the pair emission
+    lays the same pairs out whether its block offsets come from the kernels ahead of it (small frames) or from its own
+    chained scan (HS_SCAN_IN_EMISSION=1: the path of frames with several million instances)."""
     import subprocess
     import sys
     code = r"""
@@ -617,12 +619,13 @@ print("FRAME", R, h.hexdigest())
 """
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
-    for tickets in ("0", "1"):
+    for env in (dict(HS_SORT_TICKETS="0", HS_SCAN_IN_EMISSION="0"), dict(HS_SORT_TICKETS="1", HS_SCAN_IN_EMISSION="0"),
+                dict(HS_SORT_TICKETS="0", HS_SCAN_IN_EMISSION="1")):
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
-                           env=dict(os.environ, HS_ROOT=root, HS_SORT_TICKETS=tickets))
+                           env=dict(os.environ, HS_ROOT=root, **env))
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
         outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("FRAME")][0])
-    assert outs[0] == outs[1] and int(outs[0].split()[1]) > 100000, outs
+    assert outs[0] == outs[1] == outs[2] and int(outs[0].split()[1]) > 100000, outs
 
 
 def test_full_size_properties_c3():
