@@ -477,9 +477,12 @@ render_fwd_kernel(RenderFwd p) {
     // group 1).  The lists hold LDS byte offsets, so the loop spends no vector instruction on address arithmetic; the
     // contributor number is kept scaled the same way (`last` = (index + 1) * 48, divided once at the end).
     auto walk = [&](int i0, int i1, int base48) -> uint32_t {
-        uint32_t act = 0u;
-        for (int i = i0; i < i1; ++i) {
-            const int jb = (int)my_list[i];                 // one address per lane group
+        uint32_t act_lo = 0u, act_hi = 0u;                  // lane i - i0: the `took` mask of position i (two halves = two groups)
+        uint32_t pos = 0u;                                  // i - i0, a scalar register by construction (asm below)
+        const uint32_t npos = (uint32_t)(i1 - i0);
+        const uint16_t* lp = my_list + i0;
+        auto trip = [&]() {
+            const int jb = (int)*lp++;                      // one address per lane group
             const char* e = ent + jb;
             const float4 a = *reinterpret_cast<const float4*>(e);
             const float4 b = *reinterpret_cast<const float4*>(e + 16);
@@ -495,20 +498,25 @@ render_fwd_kernel(RenderFwd p) {
             const uint64_t took = blend_fwd_pair<DEPTH>(ps, done0, done1, pw, f2{al0, al1}, b.z, b.w, c.x, DEPTH ? c.y : 0.f, idx48,
                                                         STATS ? &n_pix : nullptr);
             if constexpr (STATS) ws.v[kStFwdActivePix] += n_pix;
-            // gb = (lanes 0-31 took ? 1 : 0) | (lanes 32-63 took ? 4 : 0), written to lane i - i0 of `act` -- all in
-            // scalar registers plus one v_writelane (the plain expression costs the compiler five vector instructions:
-            // it materialises the uniform conditions through VGPRs)
-            uint32_t lo = (uint32_t)took, hi = (uint32_t)(took >> 32), gb;
-            asm("s_min_u32 %1, %1, 1\n\t"
-                "s_min_u32 %2, %2, 1\n\t"
-                "s_lshl2_add_u32 %0, %2, %1\n\t"
-                "s_mov_b32 m0, %4\n\t"
-                "v_writelane_b32 %3, %0, m0"   // (m0: reserved, never live across instructions in compiler-generated code)
-                : "=&s"(gb), "+s"(lo), "+s"(hi), "+v"(act) : "s"(i - i0) : "scc");
-            if constexpr (STATS) { ws.v[kStFwdTrips] += 1; ws.v[kStFwdEmpty] += gb == 0u; }
-            if ((done0 & done1) == ~0ull) break;
+            // the two halves of `took` go to lane i - i0 of act_lo / act_hi as they are (one scalar + two vector
+            // instructions; whether a half is non-zero -- its lane group took the entry -- is asked once per walk)
+            asm("s_mov_b32 m0, %2\n\t"
+                "v_writelane_b32 %0, %3, m0\n\t"   // (m0: reserved, never live across instructions in compiler-generated code)
+                "v_writelane_b32 %1, %4, m0\n\t"
+                "s_add_u32 %2, %2, 1"
+                : "+v"(act_lo), "+v"(act_hi), "+s"(pos) : "s"((uint32_t)took), "s"((uint32_t)(took >> 32)) : "scc");
+            if constexpr (STATS) { ws.v[kStFwdTrips] += 1; ws.v[kStFwdEmpty] += took == 0ull; }
+        };
+        // two trips per test of "every pixel of the wave is finished" (a trip after that changes nothing and records
+        // nothing); an odd last position on its own
+        if (npos >= 2u) {
+            do {
+                trip();
+                trip();
+            } while (pos + 2u <= npos && (done0 & done1) != ~0ull);
         }
-        return act;
+        if (pos + 1u == npos && (done0 & done1) != ~0ull) trip();
+        return (act_lo != 0u ? 1u : 0u) | (act_hi != 0u ? 4u : 0u);
     };
     s_taken[0][0][threadIdx.x] = 0; s_taken[0][1][threadIdx.x] = 0; s_taken[1][0][threadIdx.x] = 0; s_taken[1][1][threadIdx.x] = 0;
     uint32_t n_taken = 0;

@@ -7,7 +7,8 @@ Compiles casualhdrsplat_amd/csrc/render.hip to device assembly with the flags of
 render_fwd_kernel<false,false> and render_bwd_kernel<false,false> the innermost loop that contains v_exp_f32 (the
 per-(wave, entry) trip of the front-to-back / back-to-front replay), and counts its instructions by kind.  Where the
 loop has an early `continue` (the backward skips the replay of an entry no lane is active for) the count is given for
-both paths.  Issue cycles weight each vector instruction by its measured wave64 issue cost on MI355X
+both paths.  A loop body that holds several trips (the forward's holds two: two pairs of v_exp_f32) is divided by
+that number; `full_trip` keeps the counts of the whole body.  Issue cycles weight each vector instruction by its measured wave64 issue cost on MI355X
 (profiles/r01b_valu_rate.txt): 4 cycles, 8 for transcendentals and v_permlane*_swap.
 
 Writes profiles/isa_loop_counts.json with the SHA-256 of the source it was made from; bench.py multiplies these
@@ -153,8 +154,11 @@ def analyse(items, marker):
     full_rng, empty_rng = hot_loops(items, marker)
     loop = items[full_rng[0]:full_rng[1] + 1]
     full = count(loop)
-    res = {"valu_per_trip": full["valu"], "valu_cycles_per_trip": full["valu_issue_cycles"], "full_trip": full,
-           "loop_instructions": sum(1 for x in loop if x[0] == "ins")}
+    # a trip evaluates two exponentials (one per pixel of the lane); the forward's loop body holds two trips
+    tpi = max(1, sum(1 for x in loop if x[0] == "ins" and x[1].startswith("v_exp_f32")) // 2)
+    res = {"trips_per_iteration": tpi, "valu_per_trip": full["valu"] / tpi,
+           "valu_cycles_per_trip": full["valu_issue_cycles"] / tpi, "salu_per_trip": full["salu"] / tpi,
+           "full_trip": full, "loop_instructions": sum(1 for x in loop if x[0] == "ins")}
     if empty_rng is not None:
         short = count(items[empty_rng[0]:empty_rng[1] + 1])
         res.update({"valu_per_empty_trip": short["valu"], "valu_cycles_per_empty_trip": short["valu_issue_cycles"],
