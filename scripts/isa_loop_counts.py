@@ -177,7 +177,7 @@ def main():
         cands = [n for n in fns if kern in n and "ILb0ELb0E" in n]
         if len(cands) != 1:
             raise SystemExit(f"{kern}: expected one <false,false> instantiation, found {cands}")
-        res, loop = analyse(parse(fns[cands[0]]), "v_exp_f32" if kern == "render_fwd_kernel" else "v_permlane16_swap")
+        res, loop = analyse(parse(fns[cands[0]]), "v_exp_f32" if kern == "render_fwd_kernel" else "v_rcp_f32")
         res["symbol"] = cands[0]
         out[kern] = res
         if "--show" in sys.argv:

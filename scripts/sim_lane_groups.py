@@ -17,7 +17,7 @@ cam = Hh.oracle_camera(O, sc)
 f = O.forward(cam, sc.means3D.numpy(), sc.opacities.numpy(), shs=sc.shs.numpy(), scales=sc.scales.numpy(), rotations=sc.rotations.numpy())
 xy, co, pl, rg = f["xy"], f["conic_opacity"], f["point_list"], f["ranges"]
 gx, gy = (W + 15) // 16, (H + 15) // 16
-KBS = (64, 96, 128)
+KBS = (32, 48, 64, 128)
 res = {}
 def add(k, v): res[k] = res.get(k, 0) + v
 partitions = {"8x4": (8, 4), "16x2": (16, 2), "4x8": (4, 8), "4x4": (4, 4), "8x8": (8, 8), "16x4": (16, 4), "8x2": (8,2)}
