@@ -49,8 +49,9 @@ static int plan(const hs_dims& d, hs_sizes* sz, hs_layout* L) {
     const int64_t gx = (d.W + kTile - 1) / kTile, gy = (d.H + kTile - 1) / kTile;
     const int64_t vtiles = gx * gy * d.n_poses;
     // 2^30: a status word of the radix passes carries a 30-bit count next to its 2-bit flag (binning.hip)
-    if (I >= (1ll << 30) || vtiles >= (1ll << 31) || d.capacity >= (1ll << 30)) {
-        set_error("hs_plan: problem too large (instances and binning capacity must stay below 2^30)");
+    // 2^22 tiles per pose (a 32768 x 32768 frame): the emission's slot -> tile arithmetic (binning.hip)
+    if (I >= (1ll << 30) || vtiles >= (1ll << 31) || d.capacity >= (1ll << 30) || gx * gy >= (1ll << 22)) {
+        set_error("hs_plan: problem too large (instances and binning capacity must stay below 2^30, tiles per pose below 2^22)");
         return HS_EINVAL;
     }
     const int64_t HW = (int64_t)d.W * d.H;

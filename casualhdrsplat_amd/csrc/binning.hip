@@ -515,8 +515,7 @@ __global__ void __launch_bounds__(256) emit_pairs_kernel(int64_t I, int P, int g
                                                          uint32_t* ghist, int nbits, int passes) {
     __shared__ uint32_t s_hist[4 * 256];   // digit totals of the tile sort's passes (<= 4), this block's pairs
     __shared__ uint32_t s_beg[4][64];
-    __shared__ uint2 s_rect[4][64];
-    __shared__ uint32_t s_inst[4][64];
+    __shared__ uint4 s_own[4][64];         // per instance: key of its first tile, rectangle width, 1 / width (float), instance
     __shared__ uint32_t s_wsum[4];
     __shared__ uint64_t s_excl;            // pairs of all earlier blocks; kScPoison in the flag bits: a wait gave up
     for (int t = threadIdx.x; t < passes * 256; t += 256) s_hist[t] = 0;
@@ -585,39 +584,60 @@ __global__ void __launch_bounds__(256) emit_pairs_kernel(int64_t I, int P, int g
     // lanes past the end of the array inherit the running end so the range stays monotone
     const uint32_t last_end = __shfl(end, 63 - __builtin_clzll(__ballot(i < I) | 1ull));
     if (i >= I) beg = end = last_end;
-    s_beg[wave][lane] = beg;
-    s_rect[wave][lane] = rc;
-    s_inst[wave][lane] = inst;
+    // what a slot needs from its owner, once per instance instead of once per pair: the key of the rectangle's first tile
+    // (pose * tiles + row * gx + column), the rectangle's width and its reciprocal.  slot -> (row, column) inside the
+    // rectangle: row = floor(t / w) as (uint)((t + 0.5) * fl(1 / w)) -- exact for t < 2^22 (the product is off by at most
+    // (t + 0.5) / w * 2^-23, the quotient's fraction stays 0.5 / w away from an integer; hs_plan keeps a frame below 2^22
+    // tiles), four instructions instead of the thirty of an integer division.
+    {
+        const uint32_t w = rc.y & 0xFFFFu;
+        const uint32_t pose = I > (int64_t)P ? inst / (uint32_t)P : 0u;
+        const uint32_t key0 = pose * (uint32_t)(gx * gy) + (rc.x >> 16) * (uint32_t)gx + (rc.x & 0xFFFFu);
+        s_beg[wave][lane] = beg;
+        s_own[wave][lane] = make_uint4(key0, w, __float_as_uint(1.0f / (float)w), inst);
+    }
+    // digit layout of the tile sort's passes (same as radix_sort_packed), once
+    int sh[4] = {0, 0, 0, 0}, wd[4] = {0, 0, 0, 0};
+    {
+        int shift = 0;
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            if (pass < passes) {
+                const int w = (nbits - shift + (passes - pass) - 1) / (passes - pass);
+                sh[pass] = shift; wd[pass] = w;
+                shift += w;
+            }
+        }
+    }
     const uint32_t first = __shfl(beg, 0);
     const uint32_t total = last_end - first;
     // same wave wrote and reads these LDS rows: no workgroup barrier needed (wave-private rows)
     for (uint32_t p = lane; p < total; p += 64) {
         const uint32_t pos = first + p;
-        int k = 0;
+        uint32_t k = 0;
 #pragma unroll
-        for (int step = 32; step >= 1; step >>= 1)
-            if (s_beg[wave][k + step] <= pos) k += step;  // largest k with beg[k] <= pos (k + step <= 63)
-        const uint2 r = s_rect[wave][k];
+        for (uint32_t step = 32; step >= 1; step >>= 1)   // largest k with beg[k] <= pos (k + step <= 63); slots < 2^30
+            k |= (uint32_t)((int32_t)(s_beg[wave][k + step] - pos - 1u) >> 31) & step;
+        const uint4 o = s_own[wave][k];
         const uint32_t t = pos - s_beg[wave][k];
-        const uint32_t w = r.y & 0xFFFFu;
-        const uint32_t ty = t / w, tx = t - ty * w;
-        const uint32_t idx = s_inst[wave][k];
-        const uint32_t tile_base = (idx / (uint32_t)P) * (uint32_t)(gx * gy);
-        const uint32_t key = tile_base + ((r.x >> 16) + ty) * (uint32_t)gx + (r.x & 0xFFFFu) + tx;
-        pairs[pos] = make_uint2(key, idx);
+        const uint32_t ty = (uint32_t)(((float)t + 0.5f) * __uint_as_float(o.z));
+        const uint32_t tx = t - ty * o.y;
+        const uint32_t key = o.x + ty * (uint32_t)gx + tx;
+        pairs[pos] = make_uint2(key, o.w);
         pair_flags[pos] = 0;  // "gradient record written" flag of this slot, set by the render backward
-        // digit totals for the single-sweep tile sort (same digit layout as radix_sort_packed).  The lanes of a wave hold
-        // neighbouring tiles of a few Gaussians: when they all agree on a digit, one lane adds the count
-        int pass = 0;
-        for (int shift = 0, w = 0; shift < nbits; shift += w, ++pass) {
-            w = (nbits - shift + (passes - pass) - 1) / (passes - pass);
-            const uint32_t dgt = (key >> shift) & ((1u << w) - 1u);
-            const uint32_t d0 = __builtin_amdgcn_readfirstlane(dgt);
-            const uint64_t act = __ballot(true);
-            if (__ballot(dgt != d0) == 0ull) {
-                if (lane == (int)__builtin_ctzll(act)) atomicAdd(&s_hist[pass * 256 + d0], (uint32_t)__popcll(act));
-            } else {
-                atomicAdd(&s_hist[pass * 256 + dgt], 1u);
+        // digit totals for the single-sweep tile sort.  The lanes of a wave hold neighbouring tiles of a few Gaussians:
+        // when they all agree on a digit, one lane adds the count
+        const uint64_t act = __ballot(true);
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            if (pass < passes) {
+                const uint32_t dgt = (key >> sh[pass]) & ((1u << wd[pass]) - 1u);
+                const uint32_t d0 = __builtin_amdgcn_readfirstlane(dgt);
+                if (__ballot(dgt != d0) == 0ull) {
+                    if (lane == (int)__builtin_ctzll(act)) atomicAdd(&s_hist[pass * 256 + d0], (uint32_t)__popcll(act));
+                } else {
+                    atomicAdd(&s_hist[pass * 256 + dgt], 1u);
+                }
             }
         }
     }

@@ -230,6 +230,8 @@ typedef struct hs_layout {
 
 HS_API int hs_version(void);
 HS_API const char* hs_last_error(void);
+/* Limits (HS_EINVAL beyond them): P * n_poses < 2^30 instances, capacity < 2^30 pairs, fewer than 2^22 tiles per pose
+ * (a 32768 x 32768 frame), n_poses <= 21845, crf_K <= 4096. */
 HS_API int hs_plan(const hs_dims* dims, hs_sizes* sizes, hs_layout* layout /* may be NULL */);
 HS_API int hs_forward(const hs_fwd_args* args, void* hip_stream);
 HS_API int hs_backward(const hs_bwd_args* args, void* hip_stream);

@@ -85,6 +85,11 @@ def test_plan_rejects_bad_dims(lib):
     assert L.hs_plan(C.byref(d), C.byref(sz), None) == lib.HS_EINVAL and b"2^30" in L.hs_last_error()
     d = lib.hs_dims(1000, 0, 0, 64, 64, 1, (1 << 30) - 1)
     assert L.hs_plan(C.byref(d), C.byref(sz), None) == lib.HS_OK
+    # the pair emission turns a slot into (row, column) of its rectangle with arithmetic that is exact below 2^22 tiles
+    d = lib.hs_dims(1000, 0, 0, 32768, 32768, 1, 1000)
+    assert L.hs_plan(C.byref(d), C.byref(sz), None) == lib.HS_EINVAL and b"2^22" in L.hs_last_error()
+    d = lib.hs_dims(1000, 0, 0, 32768, 32752, 1, 1000)
+    assert L.hs_plan(C.byref(d), C.byref(sz), None) == lib.HS_OK
 
 
 def test_forward_backward_validate_before_touching_the_gpu(lib):
