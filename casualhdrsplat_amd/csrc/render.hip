@@ -16,14 +16,14 @@
 //    its own entry (ds_read_b128, two addresses per wave) -- one trip serves up to two different entries;
 //  * workgroups map to tiles through an XCD strip permutation (two-tile-row strips dealt round-robin to the XCDs) so
 //    that the tiles one XCD works on are neighbours and share its L2;
-//  * the forward records which staged entries each half tile actually took (one byte per sorted pair) and how many
-//    trips each tile cost; the backward replays exactly those entries, walked as set bits of scalar masks;
-//  * backward: no global atomics.  Per (wave, Gaussian) nine partial sums are formed in-lane over the pixel
-//    pair, reduced across the 64 lanes by halving steps ordered by price (bank-masked DPP adds first, then
-//    v_permlane32_swap / v_permlane16_swap: 21 instructions for all ten values), added to the entry's LDS record
-//    (two addends per word: order-independent) and written as ONE record (a 64-byte sector) per (tile, instance)
-//    pair at the pair's duplicateWithKeys slot; preprocess-backward then sums each instance's contiguous slots.
-//    Gradients are bitwise reproducible run to run;
+//  * the forward records which staged entries each lane group of each wave actually took (one byte per sorted pair) and
+//    how many trips each tile cost; the backward's lane groups replay exactly those entries, each from its own list;
+//  * backward: no global atomics.  Per (lane group, Gaussian) nine partial sums are formed in-lane over the pixel
+//    pair, reduced across the 32 lanes of the group by halving steps ordered by price (bank-masked DPP adds first, one
+//    v_permlane16_swap / ds_bpermute step, quad steps last), STORED into the group's own plane of the entry's LDS
+//    record (a (wave, group) visits an entry once: no LDS atomics), the planes added in a fixed order and written as
+//    ONE record (a 64-byte sector) per (tile, instance) pair at the pair's duplicateWithKeys slot; preprocess-backward
+//    then sums each instance's contiguous slots.  Gradients are bitwise reproducible run to run;
 //  * the backward's launch ends on light tiles taken from a queue: each XCD keeps its strip-ordered tiles except its
 //    lightest 8 % (order_tiles_kernel, from the forward's trip counts), which the last workgroups of the launch take
 //    one after the other -- faster XCDs take more, and the tail is one short tile long.
@@ -86,17 +86,12 @@ __device__ __forceinline__ float wave_sum_hi(float v) {
     v += dpp<0x143, 0xC>(v);  // row_bcast:31 -> rows 2,3
     return v;
 }
-// ---- the 9 (10) value wave reduction of the backward replay ----
+// ---- the 9 (10) value reduction of the backward replay (over the 32 lanes of a lane group) ----
 // Every halving step sums TWO registers over one lane bit into ONE register (x's partial sums land in the lanes
-// whose bit is 0, y's in the lanes whose bit is 1), so the register count shrinks 10 -> 5 -> 3 -> 2 -> 1.  The steps
-// differ in price -- a bank-masked v_add_f32_dpp issues in 4 cycles, a v_permlane{32,16}_swap in 8 (plus its add) -- so
-// the cheap in-row steps (lane bits 3 and 2) run FIRST, while there are many registers, and the swaps (bits 5 and 4)
-// last, on the few that remain: 21 vector instructions / 92 issue cycles for all ten values (the earlier order, swaps
-// first, cost 27 / 130).
-__device__ __forceinline__ float halve32(float x, float y) {  // lane bit 5
-    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
+// whose bit is 0, y's in the lanes whose bit is 1), so the register count shrinks 10 -> 5 -> 3 -> 2.  The steps
+// differ in price -- a bank-masked v_add_f32_dpp issues in 4 cycles, a v_permlane16_swap in 8 (plus its add) -- so
+// the cheap in-row steps (lane bits 3 and 2) run FIRST, while there are many registers, and the swap (bit 4) last,
+// on the few that remain.
 __device__ __forceinline__ float halve16(float x, float y) {  // lane bit 4 (x -> even rows, y -> odd rows)
     auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
@@ -105,7 +100,7 @@ __device__ __forceinline__ float halve16(float x, float y) {  // lane bit 4 (x -
 // out).  pair8(x, y): lanes with (lane & 8) == 0 get x[l] + x[l+8], the others y[l] + y[l-8]; pair4 likewise on lane
 // bit 2.  A VALU write followed by a DPP read of the same register needs two wait states (hipcc pads nothing inside
 // asm): the ten inputs are written by ordinary code just before, hence the leading s_nop; inside the block every
-// register is read at least two instructions after it was written.  The trailing s_nop covers the v_permlane32_swap
+// register is read at least two instructions after it was written.  The trailing s_nop covers the v_permlane16_swap
 // the compiler places behind the block.
 // Out: w0 = {g0, g2, g1, g3} by quad, w1 = {g4, g6, g5, g7} by quad, w2 = {g8, g8, g9, g9} by quad -- each the sum over
 // lane bits 3 and 2, i.e. over the four quads of the row.
@@ -165,24 +160,10 @@ __device__ __forceinline__ float reduce_in_quads(float t) {
     return t;
 }
 
-// Reduces g[0..8] (and g9 when TEN) over the wave.  `xor32_addr` = ((lane ^ 32) << 2), the ds_bpermute address of the
-// lane's partner in the other half: the odd register of the bit-5 step is summed through the LDS crossbar (an LDS-pipe
-// instruction plus ONE vector add) instead of a copy + swap + add -- the loop is bound by vector issue, the LDS pipe
-// is not.  Result: ONE register in which lane 16*r + 4*k (all four lanes of that quad) holds the wave total of
-//     r = 0: g0, g2, g1, g3 (k = 0..3)     r = 2: g4, g6, g5, g7     r = 1 (and 3): g8, g8, g9, g9.
-template <bool TEN>
-__device__ __forceinline__ float wave_reduce(const float* g, float g9, int xor32_addr) {
-    float w0, w1, w2;
-    reduce_in_rows<TEN>(g, g9, w0, w1, w2);
-    const float u0 = halve32(w0, w1);  // lanes 0-31: w0 over bit 5, lanes 32-63: w1 over bit 5
-    const float u1 = w2 + __int_as_float(__builtin_amdgcn_ds_bpermute(xor32_addr, __float_as_int(w2)));
-    const float t = halve16(u0, u1);   // rows 0, 2: u0 over bit 4 ; rows 1, 3: u1 over bit 4
-    return reduce_in_quads(t);
-}
-
-// The same nine (ten) values reduced over each 32-lane half of the wave separately (the lane groups of the render
-// backward): the in-row steps, then ONE swap step over lane bit 4 for two of the three registers, the third through the
-// LDS crossbar (`xor16_addr` = ((lane ^ 16) << 2)), then the quad steps on both results -- lane bit 5 is never crossed.
+// Nine (ten) values reduced over each 32-lane half of the wave separately (the lane groups of the render backward): the
+// in-row steps, then ONE swap step over lane bit 4 for two of the three registers, the third through the LDS crossbar
+// (`xor16_addr` = ((lane ^ 16) << 2): an LDS-pipe instruction plus one vector add instead of copy + swap + add -- the loop
+// is bound by vector issue, the LDS pipe is not), then the quad steps on both results -- lane bit 5 is never crossed.
 // Out, per group (rows 2g and 2g + 1 of the wave), all four lanes of a quad alike:
 //   t0: row 2g, quads 0..3 = g0, g2, g1, g3 ; row 2g + 1, quads 0..3 = g4, g6, g5, g7      t1: every row, quads = g8, g8, g9, g9.
 template <bool TEN>
