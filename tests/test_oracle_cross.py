@@ -50,6 +50,41 @@ def test_c_oracle_matches_fp64_autograd(oracle, P, W, H, deg, seed):
         assert l2 < 2e-5, (k, l2)
 
 
+@pytest.mark.parametrize("P,W,H,deg,seed,max_flips", [(3000, 160, 112, 3, 6, 0), (20000, 320, 240, 2, 7, 16)])
+def test_c_oracle_matches_fp64_autograd_at_scale(oracle, P, W, H, deg, seed, max_flips):
+    """The same pinning beyond toy size (the independent twin used to meet the oracle at <= 500
+    Gaussians only): thousands of Gaussians, tile lists hundreds of entries long.  Integer structure identical; on a frame
+    this size float64 and float32 decide a handful of thresholds differently (pixels inside the oracle's guard band) -- the
+    Gaussians on those pixels' tile lists are then left out of the comparison, every other row is held to the bar."""
+    sc = S.make_scene(P, W, H, deg, seed=seed)
+    f, b = Hh.run_oracle(oracle, sc)
+    color, st, g = torch_run(sc, torch.float64)
+    assert np.array_equal(st["point_list"].numpy(), f["point_list"].astype(np.int64))
+    assert np.array_equal(st["ranges"].numpy(), f["ranges"].astype(np.int64))
+    assert np.array_equal(st["pre"]["radii"].numpy(), f["radii"])
+    # a differing decision shows as another contributor count, or (a skipped entry in the middle of the list) as a final
+    # transmittance off by >= 1/255 relative; identical decisions leave it within ~1e-6 here
+    Tf = st["final_T"].detach().numpy()
+    differ = (st["n_contrib"].numpy() != f["n_contrib"]) | (np.abs(f["final_T"] - Tf) > 2e-3 * np.maximum(Tf, 1e-4))
+    assert differ.sum() <= max_flips, int(differ.sum())
+    # ... and only where the fp32 oracle itself calls the decision fragile (float64 against float32: a wider band than the
+    # 1e-5 the HIP tests use between two fp32 implementations)
+    pix_risk, _ = Hh.oracle_risk(oracle, sc, [f], guard_alpha=1e-4, guard_T=5e-4)
+    assert not (differ & ~pix_risk[0]).any(), int((differ & ~pix_risk[0]).sum())
+    rows = ~oracle.pixel_reach(Hh.oracle_camera(oracle, sc), f, differ, whole_list=True) if differ.any() else np.ones(P, bool)
+    assert rows.mean() > 0.9, rows.mean()
+    err = np.abs(f["color"] - color.numpy()) / np.maximum(np.abs(color.numpy()), 1e-2)
+    assert err[:, ~differ].max() < 1e-4   # (fp32 accumulation over lists of hundreds of entries; 3.7e-5 measured)
+    for k, ok in [("means3D", "dL_dmeans3D"), ("means2D", "dL_dmeans2D"), ("opacities", "dL_dopacity"),
+                  ("shs", "dL_dshs"), ("scales", "dL_dscales"), ("rotations", "dL_drots")]:
+        ref = g[k].reshape(b[ok].shape)[rows]
+        got = b[ok][rows]
+        mx, frac = Hh.rel_err(got, ref, Hh.grad_floor(ref))
+        assert frac < 2e-2 and mx < 5e-2, (k, mx, frac)
+        l2 = np.linalg.norm(got.astype(np.float64) - ref) / max(np.linalg.norm(ref), 1e-30)
+        assert l2 < 2e-5, (k, l2)
+
+
 def test_torch_rasterizer_gradcheck_fp64():
     """Finite differences on a tiny scene (5 Gaussians, 16x16).  Skip/termination decisions are piecewise
     constant, so the scene keeps every alpha well inside (1/255, 0.99) and T above 1e-4."""
