@@ -417,7 +417,8 @@ def choose_exchange(step, state, barrier, dev, rank, world, backend, cfg):
         exchange (HS_BENCH_PROBE_CAP_X; or raises, or -- the 1-hop forms -- does not reproduce dist.all_reduce on a test
         vector) is dropped on all ranks before it can cost more.  (Over gloo on a shared GPU -- the plumbing check -- a
         236 MB exchange takes 50-330 ms and the cap drops everything but the fallback; over xGMI it is 1-3 ms);
-      * HS_BENCH_PROBE=safe restricts the probe to the library-only strategies.
+      * the probe covers the library-collective strategies only (all-reduce, all-reduce + all-gather); the 1-hop
+        all-to-all forms, which no multi-GPU node has run yet, join it with HS_BENCH_PROBE=all.
     "allreduce" = all-reduce of the flat per-Gaussian gradient buffer; "views" = all-reduce of the non-SH part +
     all-gather of per-view colour gradients, SH gradient rebuilt locally; "views_overlap" = the same with the all-gather
     started inside the backward, under its per-Gaussian half; "rccl" / "direct" = library ring vs 1-hop all-to-all."""
@@ -452,7 +453,7 @@ def choose_exchange(step, state, barrier, dev, rank, world, backend, cfg):
     step()
     base_ms = agree([timed_steps(2)])[0]
     cap_ms = float(os.environ.get("HS_BENCH_PROBE_CAP_X", "20")) * base_ms
-    candidates = [e for e in EXCHANGES if e[1] == "rccl"] if os.environ.get("HS_BENCH_PROBE") == "safe" else list(EXCHANGES)
+    candidates = list(EXCHANGES) if os.environ.get("HS_BENCH_PROBE") == "all" else [e for e in EXCHANGES if e[1] == "rccl"]
     direct_ok = None
     times, dropped = {}, {}
     for mode, algo in candidates:
