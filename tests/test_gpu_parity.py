@@ -896,6 +896,9 @@ def test_bench_bare_multi_gpu_invocation_launches_its_own_ranks():
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     if torch.cuda.device_count() < 2:
         env["HS_BENCH_BACKEND"] = "gloo"
+        # (over gloo on a shared GPU an exchange costs 50-300 ms against a 0.6 ms step: with the default cap of 20 x only
+        # the fallback would survive the probe; the plumbing check wants to see several strategies timed)
+        env["HS_BENCH_PROBE_CAP_X"] = "100000"
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", "c2", "--steps", "2",
                         "--warmup", "1", "--no-cpu-baseline", "--kernel-iters", "2"],
                        capture_output=True, text=True, timeout=900, env=env)
