@@ -7,8 +7,8 @@ include/hdrsplat.h; importing the package does not load the library, calling it 
 missing library is a hard error (no CPU fallback).
 """
 from .rasterizer import (BinningOverflow, DensifyStats, GaussianRasterizationSettings, GaussianRasterizer,
-                         inspect_state, rasterize_gaussians)
+                         SortChainStalled, inspect_state, rasterize_gaussians)
 
-__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "DensifyStats", "BinningOverflow",
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "DensifyStats", "BinningOverflow", "SortChainStalled",
            "rasterize_gaussians", "inspect_state"]
 __version__ = "0.1.0"

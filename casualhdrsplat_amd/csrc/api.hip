@@ -4,6 +4,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
 
 #include "hs_common.h"
 
@@ -14,14 +15,23 @@ static thread_local char g_err[512] = "";
 int fault_injection() {
     static const int mode = [] {
         const char* e = getenv("HS_FAULT_INJECT");
-        return (e && !strcmp(e, "sort_ticket")) ? 1 : 0;
+        return (e && !strcmp(e, "sort_ticket")) ? 1 : (e && !strcmp(e, "stalled_chain")) ? 2 : 0;
     }();
     return mode;
 }
 
+// Chain positions of the radix passes: blockIdx (default) or start-order tickets.  Process-wide, switchable at run time
+// (hs_sort_tickets): the host turns tickets on when a pass reports a stalled chain (hs_counters.overflow = 2).
+static std::atomic<int> g_sort_tickets{-1};
 bool sort_tickets() {
-    static const bool on = [] { const char* e = getenv("HS_SORT_TICKETS"); return e && e[0] == '1'; }();
-    return on;
+    int v = g_sort_tickets.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char* e = getenv("HS_SORT_TICKETS");
+        v = (e && e[0] == '1') ? 1 : 0;
+        int expected = -1;
+        if (!g_sort_tickets.compare_exchange_strong(expected, v)) v = expected;
+    }
+    return v != 0;
 }
 
 bool scan_in_emission(int64_t I) {
@@ -275,6 +285,11 @@ int hs_backward(const hs_bwd_args* a, void* hip_stream) {
         if ((rc = debug_sync(a->flags, s, "preprocess backward"))) return rc;
     }
     return HS_OK;
+}
+
+int hs_sort_tickets(int enable) {
+    if (enable >= 0) { (void)hs::sort_tickets(); hs::g_sort_tickets.store(enable ? 1 : 0, std::memory_order_relaxed); }
+    return hs::sort_tickets() ? 1 : 0;
 }
 
 int hs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, uint8_t* visible, void* hip_stream) {

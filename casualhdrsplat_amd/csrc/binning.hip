@@ -170,7 +170,11 @@ __device__ __forceinline__ uint32_t digit_of(K k, int shift, uint32_t mask) {
 //   * every wait is bounded (st_wait: kSpinLimit polls, about a second): a predecessor that never publishes -- a broken
 //     assumption, or a status array some stray write damaged -- ends in `fail_word` = 2 (hs_counters.overflow for the
 //     pipeline: the frame renders empty and the host raises) instead of a hung GPU;
-//   * HS_SORT_TICKETS=1 in the environment selects the TICKET instantiation, in which a block's chain position is a
+//     This does happen: TWO PROCESSES running these passes on one GPU at the same time.  Each XCD hands out its share in
+//     order but the XCDs advance independently, so A's resident blocks may wait for an A-block whose XCD is full of B's
+//     blocks, which wait the same way for a B-block behind A's -- both kernels give up after their bound.  The host then
+//     switches the process to ticket order (hs_sort_tickets) and repeats the step;
+//   * HS_SORT_TICKETS=1 in the environment (or hs_sort_tickets(1)) selects the TICKET instantiation, in which a block's chain position is a
 //     ticket drawn from a per-pass counter when it STARTS (one atomic per block): position p < b then means block p is
 //     already running, whatever the dispatch order.  Measured at c3: +30 us per frame (six passes of one same-address
 //     atomic per block), which is why it is the fallback and not the default.
@@ -753,6 +757,8 @@ int launch_binning(const hs_fwd_args& a, const hs_layout& L, hipStream_t s) {
                                                                  sort_scratch_words(I, 4, kDepthTile), (uint32_t*)scan_status,
                                                                  pair_scratch_words(I, d.capacity, passes));
 
+    if (fault_injection() == 2 && !sort_tickets())   // tests only (HS_FAULT_INJECT=stalled_chain): the verdict of a stalled chain
+        HS_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)&counters->overflow, 2, 1, s));
     // 1. instances by depth (stable, 32-bit keys -> 4 passes over (key, instance) elements; the last one leaves only
     //    the instance list)
     uint2* dp0 = (uint2*)(bin + L.depth_pairs);

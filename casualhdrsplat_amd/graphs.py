@@ -75,6 +75,13 @@ class GraphedStep:
                 continue
             n, over = int(p.host[0]) & 0xFFFFFFFF, int(p.host[1])
             if over >= 2:
+                # (the captured graph holds the blockIdx-ordered passes: ticket order needs a new capture)
+                from . import _lib as L
+                if L.load().hs_sort_tickets(-1) == 0:
+                    L.load().hs_sort_tickets(1)
+                    raise RuntimeError("libhdrsplat: a radix pass of the binning stage gave up waiting (hs_counters.overflow "
+                                       "= 2; another process on this GPU?) and the frame was rendered empty; the library "
+                                       "now uses ticket-ordered passes -- rebuild the GraphedStep and repeat the step")
                 raise RuntimeError("libhdrsplat: a radix pass of the binning stage gave up (hs_counters.overflow = 2)")
             if over:
                 raise BinningOverflow(n, p.capacity, f"; rebuild the GraphedStep with capacity >= {grown_capacity(n)}")

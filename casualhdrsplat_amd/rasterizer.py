@@ -28,6 +28,8 @@ from __future__ import annotations
 import ctypes as C
 from typing import NamedTuple, Optional
 
+import warnings
+
 import torch
 import torch.nn as nn
 
@@ -142,6 +144,22 @@ class BinningOverflow(RuntimeError):
             "re-run with a larger `capacity` (or capacity=None for the synchronous mode)")
 
 
+class SortChainStalled(BinningOverflow):
+    """A radix pass of the binning stage gave up waiting for an earlier block of its own launch (hs_counters.overflow = 2)
+    and the frame was rendered empty.  Seen when several processes run these kernels on ONE GPU: two blockIdx-ordered
+    passes can keep each other's blocks out (include/hdrsplat.h, hs_sort_tickets).  The library has switched to
+    ticket-ordered passes for the rest of the process by the time this is raised, so -- like BinningOverflow, whose
+    handlers therefore cover it -- repeating the step succeeds; forwards without a backward are repeated by the
+    rasterizer itself."""
+    def __init__(self):
+        RuntimeError.__init__(
+            self, "libhdrsplat: a radix pass of the binning stage gave up waiting for a predecessor's status word "
+                  "(hs_counters.overflow = 2) and the frame was rendered empty -- is another process running the same "
+                  "kernels on this GPU?  Switched to ticket-ordered passes (hs_sort_tickets(1), as HS_SORT_TICKETS=1 "
+                  "would from the start); repeat the step")
+        self.num_rendered, self.capacity = 0, 0
+
+
 def grown_capacity(num_rendered: int) -> int:
     """Capacity to retry with after an overflow: 1.5 x the pair count the device reported."""
     return int(num_rendered * 1.5) + 4096
@@ -153,6 +171,7 @@ class _Pending:
     until someone asks."""
     def __init__(self, host, event, capacity):
         self.host, self.event, self.capacity = host, event, capacity
+        self.reported = False   # this frame's stalled chain has been turned into SortChainStalled once already
 
     def resolve(self):
         """(num_rendered, overflowed) -- waits for the forward's counter copy on first use."""
@@ -162,8 +181,20 @@ class _Pending:
             _PINNED_POOL.append(self.host)
             self.host = None
         if self.overflow >= 2:
+            lib = L.load()
+            if not self.reported and lib.hs_sort_tickets(-1) == 0:
+                # blockIdx-ordered passes met a dispatch order they cannot live with (another process on the GPU):
+                # ticket order from here on, and the caller repeats the step
+                self.reported = True
+                lib.hs_sort_tickets(1)
+                warnings.warn("casualhdrsplat_amd: a radix pass gave up waiting (GPU shared with another process?); "
+                              "using ticket-ordered passes from now on", RuntimeWarning, stacklevel=3)
+                raise SortChainStalled()
+            if self.reported:
+                raise SortChainStalled()
             raise RuntimeError("libhdrsplat: a radix pass of the binning stage gave up waiting for a predecessor's status "
-                               "word (hs_counters.overflow = 2: damaged sort scratch); the frame was rendered empty")
+                               "word although the passes were ticket-ordered (hs_counters.overflow = 2: damaged sort "
+                               "scratch?); the frame was rendered empty")
         return self.n, self.overflow != 0
 
     def check(self, where: str = ""):
@@ -258,7 +289,7 @@ def _run_forward(settings: GaussianRasterizationSettings, means3D, opacities, sh
     image = torch.empty(max(int(sizes.image_bytes), 256), dtype=torch.uint8, device=dev)
     a.binning, a.image = binning.data_ptr(), image.data_ptr()
     L.check(lib.hs_forward(C.byref(a), stream), "hs_forward")
-    if not sync_mode:
+    if True:   # (the synchronous mode too: its sorts can report a stalled chain -- overflow = 2 -- like any other)
         if not _PINNED_POOL and torch.cuda.is_current_stream_capturing():
             raise RuntimeError("GaussianRasterizer inside a graph capture needs one eager step first (graphs.GraphedStep "
                                "does that): page-locked memory cannot be allocated while a stream is capturing")
@@ -266,7 +297,7 @@ def _run_forward(settings: GaussianRasterizationSettings, means3D, opacities, sh
         host.copy_(geom[:8].view(torch.int32), non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        st.pending = _Pending(host, ev, int(capacity))
+        st.pending = _Pending(host, ev, R if sync_mode else int(capacity))
 
     st.dims, st.layout, st.geom, st.binning, st.image = dims, layout, geom, binning, image
     st.num_rendered, st.flags, st.views, st.projs, st.camposes, st.bg = R, flags, views, projs, campos, bg
@@ -660,7 +691,11 @@ class GaussianRasterizer(nn.Module):
             pend = aux.get("pending")
             if pend is None or backward_possible:
                 return outs  # synchronous mode, or a training step (its backward looks at the counters)
-            n, over = pend.resolve()
+            try:
+                n, over = pend.resolve()
+            except SortChainStalled:
+                self.overflow_replays += 1   # ticket-ordered passes are on now: render the frame again
+                continue
             if not over:
                 return outs
             # nobody else would ever look: grow and render the frame again, transparently

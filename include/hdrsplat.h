@@ -35,7 +35,7 @@ extern "C" {
 /* libhdrsplat.so is built with -fvisibility=hidden: the hs_* entry points below are its only exported symbols */
 #define HS_API __attribute__((visibility("default")))
 
-#define HS_VERSION 301
+#define HS_VERSION 302
 
 #define HS_OK 0
 #define HS_EINVAL (-1)    /* bad argument (null pointer, bad shape, unsupported degree ...) */
@@ -259,6 +259,15 @@ HS_API int hs_render_stats(const hs_fwd_args* fwd /* or NULL */, const hs_bwd_ar
                     uint64_t* bwd_timeline /* or NULL: per workgroup of the backward launch (tiles x poses of them)
                                               {start, end} on the 100 MHz device clock and (XCC id << 32 | HW_ID) */,
                     void* hip_stream);
+
+/* Chain positions of the radix passes of HS_STAGE_BIN, process-wide: 0 = blockIdx (default: relies on every XCD handing
+ * its share of a grid out in increasing order), 1 = tickets drawn when a block STARTS (+3 % per step at c3; correct under
+ * any dispatch order, and the setting to use when SEVERAL PROCESSES run this library on one GPU: two blockIdx-ordered
+ * passes of different processes can fill the GPU with blocks that wait for blocks of their own kernel which the other
+ * process' waiting blocks keep out -- both then give up after about a second, hs_counters.overflow = 2, empty frame).
+ * enable < 0 only queries.  Returns the setting in force.  Initial value: HS_SORT_TICKETS=1 in the environment, else 0.
+ * The Python host switches to 1 by itself the first time a frame reports overflow = 2 and asks for the step again. */
+HS_API int hs_sort_tickets(int enable);
 
 /* Bench/test only: stable LSD radix sort of (u64 key, u32 value) pairs on bits [0, nbits), n < 2^30, using the
  * same pass kernel as HS_STAGE_BIN.  tmp must hold hs_sort_tmp_bytes(n).  Result in keys_out/vals_out.  The u32 at

@@ -1,0 +1,4 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -30
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1

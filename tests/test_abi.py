@@ -56,7 +56,7 @@ def test_struct_sizes_match_c(lib, tmp_path):
 
 def test_version_and_plan(lib):
     L = lib.load()
-    assert L.hs_version() == 301
+    assert L.hs_version() == 302
     d, sz, lay = lib.plan(1_000_000, 16, 3, 1920, 1080, 1, 7_000_000)
     assert sz.geom_bytes > 1_000_000 * 48 and sz.binning_bytes > 7_000_000 * 16
     assert sz.image_bytes >= 1920 * 1080 * (8 + 12) and sz.bwd_bytes >= 7_000_000 * 48
@@ -90,6 +90,17 @@ def test_plan_rejects_bad_dims(lib):
     assert L.hs_plan(C.byref(d), C.byref(sz), None) == lib.HS_EINVAL and b"2^22" in L.hs_last_error()
     d = lib.hs_dims(1000, 0, 0, 32768, 32752, 1, 1000)
     assert L.hs_plan(C.byref(d), C.byref(sz), None) == lib.HS_OK
+
+
+def test_sort_ticket_switch_is_process_wide_and_queryable(lib):
+    """hs_sort_tickets: the chain-position mode of the radix passes can be read and changed at run time (the Python host
+    turns tickets on after a stalled chain); no GPU involved."""
+    L = lib.load()
+    before = L.hs_sort_tickets(-1)
+    assert before in (0, 1)
+    assert L.hs_sort_tickets(1) == 1 and L.hs_sort_tickets(-1) == 1
+    assert L.hs_sort_tickets(0) == 0 and L.hs_sort_tickets(-1) == 0
+    L.hs_sort_tickets(before)
 
 
 def test_forward_backward_validate_before_touching_the_gpu(lib):

@@ -562,6 +562,62 @@ print("FAIL-WORD", int(tmp[:8].view(torch.int32)[1]), "SECONDS %.1f" % (time.tim
         assert f"FAIL-WORD {want} " in r.stdout, r.stdout[-500:]
 
 
+def test_stalled_sort_chain_switches_to_ticket_order_and_the_step_is_repeated():
+    """What two processes sharing a GPU can do to the blockIdx-ordered radix passes (each keeps the other's waited-for
+    blocks out until both give up: hs_counters.overflow = 2, empty frame) -- provoked by HS_FAULT_INJECT=stalled_chain,
+    which plants that verdict while the passes are blockIdx-ordered.  The host must switch the library to ticket order
+    and (a) repeat a forward nobody differentiates by itself, (b) raise SortChainStalled -- a BinningOverflow, so existing
+    handlers repeat the step -- from a training step's backward, in the synchronous mode as in the sync-free one."""
+    import subprocess
+    import sys
+    code = r"""
+import os, sys, warnings, torch
+sys.path.insert(0, os.environ["HS_ROOT"]); sys.path.insert(0, os.path.join(os.environ["HS_ROOT"], "tests"))
+import helpers as Hh
+from casualhdrsplat_amd import synthetic as S, _lib as L, BinningOverflow, SortChainStalled, GaussianRasterizer
+sc = S.make_scene(5000, 200, 136, 1, seed=3)
+lib = L.load()
+rs, _, _ = Hh.settings_from_scene(sc, "cuda")
+leaf = {k: getattr(sc, k).cuda() for k in ("means3D", "opacities", "shs", "scales", "rotations")}
+def call(rast, grad):
+    for v in leaf.values(): v.requires_grad_(grad)
+    return rast(leaf["means3D"], torch.zeros(5000, 3, device="cuda"), leaf["opacities"], shs=leaf["shs"],
+                scales=leaf["scales"], rotations=leaf["rotations"])
+for capacity in (None, 200000):
+    lib.hs_sort_tickets(0)
+    rast = GaussianRasterizer(rs, capacity=capacity)
+    # (b) training step: the backward reports, the repeated step succeeds
+    out = call(rast, True)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        try:
+            out[0].sum().backward()
+            print("NO-RAISE")
+        except SortChainStalled as e:
+            assert isinstance(e, BinningOverflow)
+            print("RAISED", len(w))
+    assert lib.hs_sort_tickets(-1) == 1
+    out = call(rast, True)
+    out[0].sum().backward()
+    good = out[0].detach().clone()
+    assert float(good.abs().sum()) > 0 and rast.last_num_rendered > 0
+    # (a) a forward without a backward: repeated transparently
+    lib.hs_sort_tickets(0)
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        img = call(rast, False)[0]
+    assert torch.equal(img, good), float((img - good).abs().max())
+    assert lib.hs_sort_tickets(-1) == 1 and rast.overflow_replays >= 1
+    print("OK", capacity)
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HS_ROOT=root, HS_FAULT_INJECT="stalled_chain")
+    env.pop("HS_SORT_TICKETS", None)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert r.stdout.count("RAISED 1") == 2 and "OK None" in r.stdout and "OK 200000" in r.stdout, r.stdout[-1000:]
+
+
 def test_overflow_found_by_a_backward_reaches_the_rasterizer_after_other_forwards():
     """The capacity request of an overflowed training step lives in the rasterizer, not in the bookkeeping of its latest
     forward: a second forward (an eval render, another view) between the overflowing forward and its backward must not
