@@ -257,19 +257,34 @@ __global__ void __launch_bounds__(kSortBlock) radix_sweep_kernel(const void* in_
     __shared__ K s_keys[TILE];
     __shared__ uint32_t s_vals[TILE];
     __shared__ uint32_t s_wave[4];
-    __shared__ uint32_t s_ticket, s_fail;
+    __shared__ uint32_t s_ticket, s_fail, s_n;
 
-    if (threadIdx.x == 0) { s_ticket = TICKET ? atomicAdd(ticket, 1u) : blockIdx.x; s_fail = 0u; }
+    if (threadIdx.x == 0) {
+        s_ticket = TICKET ? atomicAdd(ticket, 1u) : blockIdx.x;
+        // (one lane asks for the element count and the verdict of the passes so far -- both loads in flight together, and
+        // the whole block takes the same way out)
+        const uint32_t n0 = *n_dev;
+        const uint32_t f0 = __hip_atomic_load(fail_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_n = n0;
+        s_fail = f0 >= 2u ? 1u : 0u;
+    }
 #pragma unroll
     for (int w = 0; w < 4; ++w) s_cnt[w][threadIdx.x] = 0;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     __syncthreads();
-    const int64_t n = *n_dev;
+    const int64_t n = s_n;
     const int bid = (int)s_ticket;         // this block's place in the look-back chain (see above)
     const int64_t base = (int64_t)bid * TILE;
     if (base >= n) return;
     const int cnt_block = (int)min((int64_t)TILE, n - base);
     uint32_t* const my_status = status + (int64_t)bid * 256 + threadIdx.x;
+    // A pass that gave up left its output incomplete: the digit totals no longer describe what the later passes would read,
+    // and a scatter by them could leave the buffer.  Blocks that start after the verdict (the rest of that pass, every
+    // block of the passes behind it) only release their successors and go.
+    if (s_fail) {
+        st_publish(my_status, kStIncl);
+        return;
+    }
 
     uint32_t digit_base;   // keys of the whole array with a smaller digit
     {

@@ -368,13 +368,14 @@ __global__ void __launch_bounds__(256) pair_segsum_kernel(int64_t I, const uint3
         r[k] += __shfl_xor(r[k], 2);
     }
     if (i < I && q == 0) {
-        float4* o = inst_grads + kInstF4 * (int64_t)inst_sorted[i];
+        // (a depth sort that gave up -- overflow = 2 -- left no instance list: zeros go to row i, any bijection will do)
+        const int64_t inst = counters->overflow >= 2u ? i : (int64_t)inst_sorted[i];
+        float4* o = inst_grads + kInstF4 * inst;
         o[0] = make_float4(r[0], r[1], r[2], r[3]);
         o[1] = make_float4(r[4], r[5], r[6], r[7]);
         o[2] = make_float4(r[8], r[9], 0.f, 0.f);
         if constexpr (kInstF4 == 4) o[3] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (view_colors) {  // colour gradient of the instance after the SH clamp mask (hs_sh_backward_views input)
-            const int64_t inst = inst_sorted[i];
             const uint8_t cl = clamped[inst];
             const bool on = radii_inst[inst] > 0;
             float col[3] = {0.f, 0.f, 0.f};
