@@ -36,7 +36,10 @@ bool sort_tickets() {
 
 bool scan_in_emission(int64_t I) {
     static const int forced = [] { const char* e = getenv("HS_SCAN_IN_EMISSION"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
-    return forced >= 0 ? forced == 1 : I >= (2 << 20);
+    // (the scan inside the emission is a blockIdx-ordered look-back chain like the radix passes': once the process has gone
+    // to ticket order -- a chain stalled, several processes share the GPU -- the offsets come from the three kernels ahead
+    // of the emission, which wait for nobody)
+    return forced >= 0 ? forced == 1 : (I >= (2 << 20) && !sort_tickets());
 }
 
 void set_error(const char* fmt, ...) {

@@ -265,6 +265,7 @@ HS_API int hs_render_stats(const hs_fwd_args* fwd /* or NULL */, const hs_bwd_ar
  * any dispatch order, and the setting to use when SEVERAL PROCESSES run this library on one GPU: two blockIdx-ordered
  * passes of different processes can fill the GPU with blocks that wait for blocks of their own kernel which the other
  * process' waiting blocks keep out -- both then give up after about a second, hs_counters.overflow = 2, empty frame).
+ * With 1 the pair emission also takes its slot offsets from kernels of their own instead of its in-launch chain.
  * enable < 0 only queries.  Returns the setting in force.  Initial value: HS_SORT_TICKETS=1 in the environment, else 0.
  * The Python host switches to 1 by itself the first time a frame reports overflow = 2 and asks for the step again. */
 HS_API int hs_sort_tickets(int enable);
