@@ -167,7 +167,7 @@ __device__ __forceinline__ uint32_t digit_of(K k, int shift, uint32_t mask) {
 // so the chain advances as long as the lowest unfinished position belongs to a running block.  Chain position = blockIdx:
 // every XCD's dispatcher hands out its share of a 1-D grid in increasing blockIdx order, so the globally lowest
 // unfinished block cannot be queued behind higher ones.  HIP does not PROMISE that order, hence two safety nets:
-//   * every wait is bounded (st_wait: kSpinLimit polls, about a second): a predecessor that never publishes -- a broken
+//   * every wait is bounded (kSpinLimit / kSpinLimitBlockIdx polls): a predecessor that never publishes -- a broken
 //     assumption, or a status array some stray write damaged -- ends in `fail_word` = 2 (hs_counters.overflow for the
 //     pipeline: the frame renders empty and the host raises) instead of a hung GPU;
 //     This does happen: TWO PROCESSES running these passes on one GPU at the same time.  Each XCD hands out its share in
@@ -182,7 +182,12 @@ __device__ __forceinline__ uint32_t digit_of(K k, int shift, uint32_t mask) {
 // with 16 / 32 in flight 48 / 55; group sums (one word per 32 blocks and digit, filled by returning atomics, plus a
 // member counter) instead of inclusive prefixes 85.
 constexpr uint32_t kStAgg = 1u << 30, kStIncl = 2u << 30, kStMask = (1u << 30) - 1u;
-constexpr int kSpinLimit = 1 << 20;
+// Polls per awaited word (each ~1-2 us: a sleep and an uncached load).  Ticket order: a predecessor has started and only
+// ever waits for earlier starters, so a second without its word means damage -- 2^20.  blockIdx order: the awaited block may
+// not even be resident (another process' blocks in its place), the cure is ticket order and the host applies it at once,
+// so giving up early costs one repeated step instead of a second of spinning -- 2^14 (~20 ms; a false alarm merely moves
+// the process to ticket order).
+constexpr int kSpinLimit = 1 << 20, kSpinLimitBlockIdx = 1 << 14;
 
 __device__ __forceinline__ void st_publish(uint32_t* p, uint32_t v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -388,11 +393,11 @@ __global__ void __launch_bounds__(kSortBlock) radix_sweep_kernel(const void* in_
             for (int j = 0; j < LOOK; ++j) {
                 if (done) break;
                 uint32_t x = v[j];
-                // (bounded: kSpinLimit polls per word; the loop must not be unrolled -- a known trip bound gets it
+                // (bounded: see kSpinLimit; the loop must not be unrolled -- a known trip bound gets it
                 // unrolled eightfold, 64 copies of the poll in this walk)
                 int polls = 0;
 #pragma clang loop unroll(disable)
-                while ((x & ~kStMask) == 0u && polls < kSpinLimit) {
+                while ((x & ~kStMask) == 0u && polls < (TICKET ? kSpinLimit : kSpinLimitBlockIdx)) {
                     ++polls;
                     __builtin_amdgcn_s_sleep(1);
                     x = st_read(status + (int64_t)(p - j) * 256 + threadIdx.x);
@@ -562,7 +567,7 @@ __global__ void __launch_bounds__(256) emit_pairs_kernel(int64_t I, int P, int g
             uint64_t x = idx >= 0 ? sc_read(scan_status + idx) : kScIncl;
             int polls = 0;
 #pragma clang loop unroll(disable)
-            while ((x & kScFlag) == 0ull && polls < kSpinLimit) {
+            while ((x & kScFlag) == 0ull && polls < kSpinLimitBlockIdx) {   // (a blockIdx-ordered chain: see kSpinLimit)
                 ++polls;
                 __builtin_amdgcn_s_sleep(1);
                 x = sc_read(scan_status + idx);
