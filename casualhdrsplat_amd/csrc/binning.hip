@@ -146,10 +146,15 @@ __global__ void __launch_bounds__(256) bin_prepare_kernel(hs_counters* c, uint32
     for (int64_t t = i; t < n_zero; t += (int64_t)gridDim.x * 256) zero[t] = 0u;     // scratch of the depth sort
     for (int64_t t = i; t < n_zero2; t += (int64_t)gridDim.x * 256) zero2[t] = 0u;   // emission scan status + pair-sort scratch
     if (i < ntiles) ranges[i] = make_uint2(0u, 0u);
-    if (i == 0) { c->overflow = 0u; c->reserved[1] = n_inst; c->reserved[2] = 0u; c->reserved[3] = 0u; }
+    if (i == 0) { c->overflow = 0u; c->reserved[1] = n_inst; c->reserved[2] = 0u; c->reserved[3] = 0u; c->reserved[4] = 0u; }
 }
 
 // ---------------------------------------------------------------- radix sort passes (a7)
+// number of set bits of `m` below `lane`
+__device__ __forceinline__ int mask_rank(uint64_t m, int lane) {
+    return (int)__popcll(m & ((1ull << lane) - 1ull));
+}
+
 template <typename K>
 __device__ __forceinline__ uint32_t digit_of(K k, int shift, uint32_t mask) {
     return (uint32_t)(k >> shift) & mask;
@@ -365,10 +370,38 @@ __global__ void __launch_bounds__(kSortBlock) radix_sweep_kernel(const void* in_
     }
     {   // look-back: keys with this thread's digit in earlier blocks (LOOK words requested at once: the walk is bound
         // by the latency of these uncached loads -- with hundreds of blocks ranking at the same time the nearest
-        // inclusive prefix is far behind)
+        // inclusive prefix is far behind).
+        // HELPING (blockIdx order): a block whose words are not there after kHelpAfter polls may simply not have STARTED
+        // -- another process' blocks in its place, which may in turn wait for blocks of theirs that OUR waiting blocks keep
+        // out.  Waiting cannot resolve that; but the silent block's digit counts are a function of the pass' input alone,
+        // so the lanes still waiting for it count them themselves (one read of that block's 4096 keys, shared among
+        // however many lanes of the wave are still here), offer them to everybody (compare-and-swap into the empty
+        // words) and walk on.  No wait depends on an unstarted block any more: the chain advances under any dispatch
+        // order, alone or next to other processes.
         uint32_t excl = 0;
         bool done = threadIdx.x > mask;   // a digit no key of this pass can have: nothing to look up
         bool failed = false;
+        constexpr int kHelpAfter = 128;
+        // (called by the lanes of the wave that are still polling block q -- all at the same poll count, so together)
+        auto help = [&](int q) {
+            const uint64_t here = __ballot(true);
+            const int n_here = __popcll(here), my = mask_rank(here, lane);
+            uint32_t* tab = s_cnt[wave];                       // (free since the reorder above; wave-private row)
+            for (int i = my; i < 64; i += n_here) tab[i] = 0u;
+            const int64_t qbase = (int64_t)q * TILE;           // a full tile: q < bid
+            for (int i = my; i < TILE; i += n_here) {
+                K k;
+                if constexpr (PACKED_IN) k = (K) reinterpret_cast<const uint2*>(in_keys)[qbase + i].x;
+                else k = reinterpret_cast<const K*>(in_keys)[qbase + i];
+                const uint32_t d = digit_of<K>(k, shift, mask);
+                if ((int)(d >> 6) == wave) atomicAdd(&tab[d & 63u], 1u);
+            }
+            const uint32_t c = tab[lane];                      // (same wave: LDS operations complete in order)
+            atomicCAS(status + (int64_t)q * 256 + threadIdx.x, 0u, kStAgg | c);
+            // tell the host (hs_counters.reserved[4], four words behind `overflow`): help was needed, i.e. the GPU is shared
+            // with kernels that keep our blocks out -- ticket order, where nobody waits for an unstarted block, is the faster mode then
+            if (my == 0) atomicAdd(fail_word + 5, 1u);
+        };
         for (int p = bid - 1; p >= 0 && !done; p -= LOOK) {
             uint32_t v[LOOK];
 #pragma unroll
@@ -399,6 +432,7 @@ __global__ void __launch_bounds__(kSortBlock) radix_sweep_kernel(const void* in_
 #pragma clang loop unroll(disable)
                 while ((x & ~kStMask) == 0u && polls < (TICKET ? kSpinLimit : kSpinLimitBlockIdx)) {
                     ++polls;
+                    if constexpr (!TICKET) { if (polls == kHelpAfter) help(p - j); }
                     __builtin_amdgcn_s_sleep(1);
                     x = st_read(status + (int64_t)(p - j) * 256 + threadIdx.x);
                 }
@@ -567,10 +601,34 @@ __global__ void __launch_bounds__(256) emit_pairs_kernel(int64_t I, int P, int g
             uint64_t x = idx >= 0 ? sc_read(scan_status + idx) : kScIncl;
             int polls = 0;
 #pragma clang loop unroll(disable)
-            while ((x & kScFlag) == 0ull && polls < kSpinLimitBlockIdx) {   // (a blockIdx-ordered chain: see kSpinLimit)
+            while (__ballot((x & kScFlag) == 0ull) != 0ull && polls < kSpinLimitBlockIdx) {   // (wave-uniform: see the radix passes)
                 ++polls;
+                if (polls == 128) {
+                    // helping, as in the radix passes: a silent predecessor may not have started; its pair count depends on
+                    // the sorted instance list alone, so this wave adds it up itself (256 rectangles), offers it, walks on
+                    uint64_t missing = __ballot((x & kScFlag) == 0ull);
+                    while (missing) {
+                        const int l = (int)__builtin_ctzll(missing);
+                        missing &= missing - 1ull;
+                        const int q = base - l;
+                        uint32_t tot = 0;
+                        for (int r = 0; r < 4; ++r) {
+                            const int64_t ii = (int64_t)q * 256 + r * 64 + lane;
+                            if (ii < I && counters->overflow < 2u) {
+                                const uint2 rq = binfo[inst_sorted[ii]];
+                                tot += (rq.y & 0xFFFFu) * (rq.y >> 16);
+                            }
+                        }
+#pragma unroll
+                        for (int d = 32; d >= 1; d >>= 1) tot += (uint32_t)__shfl_xor((int)tot, d);
+                        if (lane == 0) {
+                            atomicCAS(reinterpret_cast<unsigned long long*>(scan_status + q), 0ull, (unsigned long long)(kScAgg | (uint64_t)tot));
+                            atomicAdd(&counters->reserved[4], 1u);
+                        }
+                    }
+                }
                 __builtin_amdgcn_s_sleep(1);
-                x = sc_read(scan_status + idx);
+                if ((x & kScFlag) == 0ull) x = sc_read(scan_status + idx);
             }
             const uint64_t flag = x & kScFlag;
             poison = poison || __ballot(flag == 0ull || flag == kScPoison) != 0ull;

@@ -302,6 +302,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreFwd p) {
             p.counters->overflow = 0u;
             p.counters->reserved[1] = (uint32_t)((int64_t)p.P * p.N);
             p.counters->reserved[2] = 0u; p.counters->reserved[3] = 0u;   // tile-queue counters of the render kernels
+            p.counters->reserved[4] = 0u;                                 // look-back helps of this frame's binning
         }
     }
 }

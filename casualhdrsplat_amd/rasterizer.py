@@ -131,7 +131,8 @@ class DensifyStats:
         self.grad_accum.zero_(); self.denom.zero_(); self.max_radii.zero_()
 
 
-_PINNED_POOL: list = []  # recycled page-locked int32[2] buffers (hipHostMalloc per step is slow)
+_HELPED_FRAMES = [0]      # frames of this process whose binning stage reported look-back helps (hs_counters.reserved[4])
+_PINNED_POOL: list = []  # recycled page-locked int32[8] buffers (one hs_counters each) (hipHostMalloc per step is slow)
 
 
 class BinningOverflow(RuntimeError):
@@ -178,8 +179,20 @@ class _Pending:
         if self.host is not None:  # first call: wait for the copy, recycle the pinned buffer, remember the verdict
             self.event.synchronize()
             self.n, self.overflow = int(self.host[0]) & 0xFFFFFFFF, int(self.host[1])
+            helps = int(self.host[6])   # hs_counters.reserved[4]
             _PINNED_POOL.append(self.host)
             self.host = None
+            if helps:
+                _HELPED_FRAMES[0] += 1
+            # (the second such frame decides: one late block on a cold start is not a shared GPU)
+            if helps and _HELPED_FRAMES[0] >= 2 and L.load().hs_sort_tickets(-1) == 0:
+                # waiting workgroups of the binning stage had to do silent predecessors' counting for them: other kernels
+                # (another process on this GPU) keep blocks of ours out.  The frame is right; ticket order, in which nobody
+                # waits for a block that has not started, is the faster mode under those conditions
+                L.load().hs_sort_tickets(1)
+                warnings.warn("casualhdrsplat_amd: the GPU is shared with other kernels (the radix passes had to help "
+                              f"{helps} silent predecessors); using ticket-ordered passes from now on", RuntimeWarning,
+                              stacklevel=3)
         if self.overflow >= 2:
             lib = L.load()
             if not self.reported and lib.hs_sort_tickets(-1) == 0:
@@ -293,8 +306,8 @@ def _run_forward(settings: GaussianRasterizationSettings, means3D, opacities, sh
         if not _PINNED_POOL and torch.cuda.is_current_stream_capturing():
             raise RuntimeError("GaussianRasterizer inside a graph capture needs one eager step first (graphs.GraphedStep "
                                "does that): page-locked memory cannot be allocated while a stream is capturing")
-        host = _PINNED_POOL.pop() if _PINNED_POOL else torch.empty(2, dtype=torch.int32).pin_memory()
-        host.copy_(geom[:8].view(torch.int32), non_blocking=True)
+        host = _PINNED_POOL.pop() if _PINNED_POOL else torch.empty(8, dtype=torch.int32).pin_memory()
+        host.copy_(geom[:32].view(torch.int32), non_blocking=True)   # the whole hs_counters struct
         ev = torch.cuda.Event()
         ev.record()
         st.pending = _Pending(host, ev, R if sync_mode else int(capacity))

@@ -102,7 +102,9 @@ typedef struct hs_counters {
     uint32_t overflow;     /* HS_STAGE_BIN: 1 = R > capacity; 2 = a radix pass gave up waiting for a predecessor's status
                               word (damaged scratch).  Either way the frame is rendered empty */
     uint32_t reserved[6];  /* [0] = pairs actually binned (R, or 0 on overflow); [1] = instance count of the depth sort;
-                              [3] = tile-queue counter of the render backward (zero between launches); others unused */
+                              [3] = tile-queue counter of the render backward (zero between launches); [4] = times a
+                              waiting workgroup of HS_STAGE_BIN had to compute a silent predecessor's counts itself
+                              (non-zero: other kernels kept its blocks off the GPU -- see hs_sort_tickets); others unused */
 } hs_counters;
 
 typedef struct hs_fwd_args {
@@ -262,12 +264,14 @@ HS_API int hs_render_stats(const hs_fwd_args* fwd /* or NULL */, const hs_bwd_ar
 
 /* Chain positions of the radix passes of HS_STAGE_BIN, process-wide: 0 = blockIdx (default: relies on every XCD handing
  * its share of a grid out in increasing order), 1 = tickets drawn when a block STARTS (+3 % per step at c3; correct under
- * any dispatch order, and the setting to use when SEVERAL PROCESSES run this library on one GPU: two blockIdx-ordered
+ * any dispatch order, and the faster setting when SEVERAL PROCESSES run this library on one GPU: two blockIdx-ordered
  * passes of different processes can fill the GPU with blocks that wait for blocks of their own kernel which the other
- * process' waiting blocks keep out -- both then give up after about a second, hs_counters.overflow = 2, empty frame).
+ * process' waiting blocks keep out; a waiting block then computes the silent predecessor's counts itself -- correct,
+ * counted in hs_counters.reserved[4], but slower than never having to).
  * With 1 the pair emission also takes its slot offsets from kernels of their own instead of its in-launch chain.
  * enable < 0 only queries.  Returns the setting in force.  Initial value: HS_SORT_TICKETS=1 in the environment, else 0.
- * The Python host switches to 1 by itself the first time a frame reports overflow = 2 and asks for the step again. */
+ * The Python host switches to 1 by itself once frames report helps (or, should a pass ever give up: overflow = 2, after
+ * which it asks for the step again). */
 HS_API int hs_sort_tickets(int enable);
 
 /* Bench/test only: stable LSD radix sort of (u64 key, u32 value) pairs on bits [0, nbits), n < 2^30, using the

@@ -1,6 +1,7 @@
-"""Two (or more) processes running the c3 training step on ONE GPU at the same time: how often does a radix pass give up
-(hs_counters.overflow = 2 -> SortChainStalled), with blockIdx-ordered passes (which the library leaves after the first
-such event) and with ticket-ordered ones (HS_SORT_TICKETS=1: never expected).
+"""Two (or more) processes running the c3 training step on ONE GPU at the same time: how often does the host move a process
+to ticket order -- because waiting blocks of a radix pass had to help silent predecessors (hs_counters.reserved[4]), or,
+before helping existed, because a pass gave up (hs_counters.overflow = 2 -> SortChainStalled) -- and what a step costs in
+each mode; ticket order from the start (HS_SORT_TICKETS=1) for comparison.
 usage: python scripts/shared_gpu_soak.py [--procs 2] [--steps 300] [--config c3]"""
 import argparse, json, os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -30,7 +31,7 @@ for i in range(n):
         if keep:
             lib.hs_sort_tickets(0)   # keep provoking: back to blockIdx order
 torch.cuda.synchronize()
-print(json.dumps({"pid": os.getpid(), "steps": n, "stalls": stalls, "tickets_at_end": lib.hs_sort_tickets(-1),
+print(json.dumps({"pid": os.getpid(), "steps": n, "switches_to_ticket_order": stalls, "tickets_at_end": lib.hs_sort_tickets(-1),
                   "ms_per_step": (time.time() - t0) / n * 1e3}))
 """
 
