@@ -15,7 +15,7 @@ static thread_local char g_err[512] = "";
 int fault_injection() {
     static const int mode = [] {
         const char* e = getenv("HS_FAULT_INJECT");
-        return (e && !strcmp(e, "sort_ticket")) ? 1 : (e && !strcmp(e, "stalled_chain")) ? 2 : 0;
+        return (e && !strcmp(e, "sort_ticket")) ? 1 : (e && !strcmp(e, "stalled_chain")) ? 2 : (e && !strcmp(e, "late_block")) ? 3 : 0;
     }();
     return mode;
 }

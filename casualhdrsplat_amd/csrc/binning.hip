@@ -168,21 +168,22 @@ __device__ __forceinline__ uint32_t digit_of(K k, int shift, uint32_t mask) {
 // one 32-bit word (2 + 30 bits: hs_plan rejects sorts of 2^30 or more elements), written and read with agent-scope
 // atomics, so no ordering between separate words is needed (and no fence: a __threadfence() writes back the XCD's
 // whole L2).
-// Progress.  A block waits only for words that blocks with a lower chain position publish before they themselves wait,
-// so the chain advances as long as the lowest unfinished position belongs to a running block.  Chain position = blockIdx:
-// every XCD's dispatcher hands out its share of a 1-D grid in increasing blockIdx order, so the globally lowest
-// unfinished block cannot be queued behind higher ones.  HIP does not PROMISE that order, hence two safety nets:
-//   * every wait is bounded (kSpinLimit / kSpinLimitBlockIdx polls): a predecessor that never publishes -- a broken
-//     assumption, or a status array some stray write damaged -- ends in `fail_word` = 2 (hs_counters.overflow for the
-//     pipeline: the frame renders empty and the host raises) instead of a hung GPU;
-//     This does happen: TWO PROCESSES running these passes on one GPU at the same time.  Each XCD hands out its share in
-//     order but the XCDs advance independently, so A's resident blocks may wait for an A-block whose XCD is full of B's
-//     blocks, which wait the same way for a B-block behind A's -- both kernels give up after their bound.  The host then
-//     switches the process to ticket order (hs_sort_tickets) and repeats the step;
-//   * HS_SORT_TICKETS=1 in the environment (or hs_sort_tickets(1)) selects the TICKET instantiation, in which a block's chain position is a
-//     ticket drawn from a per-pass counter when it STARTS (one atomic per block): position p < b then means block p is
-//     already running, whatever the dispatch order.  Measured at c3: +30 us per frame (six passes of one same-address
-//     atomic per block), which is why it is the fallback and not the default.
+// Progress.  Chain position = blockIdx.  Alone on the GPU that is safe: every XCD's dispatcher hands out its share of a
+// 1-D grid in increasing blockIdx order, so the lowest unfinished block is always running.  It is NOT safe next to other
+// kernels (seen with several processes on one GPU): the XCDs advance independently, so A's resident blocks may wait for an
+// A-block whose XCD is full of B's blocks, which wait the same way for a B-block behind A's.  Hence:
+//   * HELPING: a wave still waiting for a predecessor's words after kHelpAfter polls counts that block's digits itself
+//     (they depend on the pass' input alone), publishes them by compare-and-swap and walks on (see the look-back): no wait
+//     depends on a block that has not started, the chain advances under any dispatch order.  Helps are counted in
+//     fail_word[5] (hs_counters.reserved[4]); the host takes them as the sign of a shared GPU and moves to ticket order;
+//   * HS_SORT_TICKETS=1 in the environment (or hs_sort_tickets(1)) selects the TICKET instantiation, in which a block's
+//     chain position is a ticket drawn from a per-pass counter when it STARTS (one atomic per block): position p < b then
+//     means block p is already running, nobody ever waits for an unstarted block, nothing needs help -- the faster mode on
+//     a shared GPU.  Alone it costs +30 us per frame at c3 (six passes of one same-address atomic per block), which is
+//     why it is not the default;
+//   * every wait is bounded all the same (kSpinLimit / kSpinLimitBlockIdx polls): status words some stray write damaged
+//     end in `fail_word` = 2 (hs_counters.overflow for the pipeline: the frame renders empty, the blocks that start after
+//     the verdict only release their successors, the host raises) instead of a hung GPU.
 // Measured alternatives (c3 tile sort, us per pass; the three-kernel pass: 76): this walk with 8 words in flight 42,
 // with 16 / 32 in flight 48 / 55; group sums (one word per 32 blocks and digit, filled by returning atomics, plus a
 // member counter) instead of inclusive prefixes 85.
@@ -269,6 +270,13 @@ __global__ void __launch_bounds__(kSortBlock) radix_sweep_kernel(const void* in_
     __shared__ uint32_t s_wave[4];
     __shared__ uint32_t s_ticket, s_fail, s_n;
 
+    // tests only (HS_FAULT_INJECT=late_block sets bit 31 of `mask`): block 1 starts ~3 ms late, as if its XCD had no room
+    // for it -- the blocks behind it must help themselves (see the look-back below)
+    if ((mask >> 31) != 0u) {
+        mask &= 0x7FFFFFFFu;
+        if (!TICKET && blockIdx.x == 1)
+            for (int i = 0; i < 1000; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     if (threadIdx.x == 0) {
         s_ticket = TICKET ? atomicAdd(ticket, 1u) : blockIdx.x;
         // (one lane asks for the element count and the verdict of the passes so far -- both loads in flight together, and
@@ -501,7 +509,7 @@ int radix_sort_packed(uint2* p0, uint2* p1, uint32_t* keys_out, uint32_t* vals_o
     for (int shift = 0, w = 0; shift < nbits; shift += w, ++pass) {
         w = (nbits - shift + (passes - pass) - 1) / (passes - pass);
         uint32_t* st = sc.status + (int64_t)pass * sc.pass_words;
-        const uint32_t mask = (1u << w) - 1u;
+        const uint32_t mask = ((1u << w) - 1u) | (fault_injection() == 3 ? 0x80000000u : 0u);
         const uint32_t* gh = sc.ghist + 256 * pass;
         uint32_t* tk = sc.tickets + pass;
         const bool last = pass == passes - 1;

@@ -562,6 +562,36 @@ print("FAIL-WORD", int(tmp[:8].view(torch.int32)[1]), "SECONDS %.1f" % (time.tim
         assert f"FAIL-WORD {want} " in r.stdout, r.stdout[-500:]
 
 
+def test_blocks_behind_a_late_block_help_themselves_and_the_frame_is_unchanged():
+    """HS_FAULT_INJECT=late_block: block 1 of every blockIdx-ordered radix pass starts ~3 ms late, as when other kernels
+    leave its XCD no room.  The blocks behind it must not just wait: they count the late block's digits themselves, publish
+    them and go on (hs_counters.reserved[4] > 0) -- and the frame (sorted lists, image, gradients) is the one of a normal
+    run, bit for bit."""
+    import subprocess
+    import sys
+    code = r"""
+import os, sys, hashlib, numpy as np
+sys.path.insert(0, os.environ["HS_ROOT"]); sys.path.insert(0, os.path.join(os.environ["HS_ROOT"], "tests"))
+import helpers as Hh
+from casualhdrsplat_amd import synthetic as S
+g = Hh.run_hip(S.make_scene(60000, 640, 400, 1, seed=3), capacity=900000)
+st = g["state"]; R = st["num_rendered"]
+h = hashlib.sha256()
+for a in (st["point_list"][:R], st["ranges"], g["color"], g["d_means3D"], g["d_shs"]):
+    h.update(np.ascontiguousarray(a).tobytes())
+print("FRAME", R, h.hexdigest(), "HELPS", st["look_back_helps"])
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for inject in ("", "late_block"):
+        env = dict(os.environ, HS_ROOT=root, HS_FAULT_INJECT=inject, HS_SORT_TICKETS="0")
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        outs[inject] = [ln for ln in r.stdout.splitlines() if ln.startswith("FRAME")][0].split()
+    assert outs[""][1:3] == outs["late_block"][1:3] and int(outs[""][1]) > 100000, outs
+    assert int(outs[""][4]) == 0 and int(outs["late_block"][4]) > 0, outs
+
+
 def test_stalled_sort_chain_switches_to_ticket_order_and_the_step_is_repeated():
     """What two processes sharing a GPU can do to the blockIdx-ordered radix passes (each keeps the other's waited-for
     blocks out until both give up: hs_counters.overflow = 2, empty frame) -- provoked by HS_FAULT_INJECT=stalled_chain,
