@@ -188,11 +188,10 @@ __device__ __forceinline__ uint32_t digit_of(K k, int shift, uint32_t mask) {
 // with 16 / 32 in flight 48 / 55; group sums (one word per 32 blocks and digit, filled by returning atomics, plus a
 // member counter) instead of inclusive prefixes 85.
 constexpr uint32_t kStAgg = 1u << 30, kStIncl = 2u << 30, kStMask = (1u << 30) - 1u;
-// Polls per awaited word (each ~1-2 us: a sleep and an uncached load).  Ticket order: a predecessor has started and only
-// ever waits for earlier starters, so a second without its word means damage -- 2^20.  blockIdx order: the awaited block may
-// not even be resident (another process' blocks in its place), the cure is ticket order and the host applies it at once,
-// so giving up early costs one repeated step instead of a second of spinning -- 2^14 (~20 ms; a false alarm merely moves
-// the process to ticket order).
+// Polls per awaited word (each ~1-2 us: a sleep and an uncached load) before a wait gives up.  After kHelpAfter polls a
+// waiting wave of a blockIdx-ordered pass has published the awaited words itself, and in ticket order a predecessor is
+// running by construction: running into these bounds means damaged status words, not a slow neighbour.  The blockIdx
+// bound is the shorter one because the cure the host applies (ticket order, step repeated) makes waiting longer pointless.
 constexpr int kSpinLimit = 1 << 20, kSpinLimitBlockIdx = 1 << 14;
 
 __device__ __forceinline__ void st_publish(uint32_t* p, uint32_t v) {
