@@ -14,7 +14,8 @@ resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
 
 Workload = BASELINE.json configs[2] ("c3": 1M Gaussians, 1920x1080, SH degree 3, HDR linear radiance + learned CRF
 tone-map), the configuration the metric is quoted on; at N>1 each rank renders its own view of the same cloud
-(configs[4]).  Synthetic scene: SURVEY.md 8(d), seed 0 for the headline, seeds {0,1,2} in `seeds_ms_per_step`.
+(configs[4]).  Synthetic scene: SURVEY.md 8(d); seeds {0,1,2} are each timed the same way (W warm-up + K steps, fresh scene
+and rasterizers) and the headline `value` / `ms_per_step` is their MEDIAN (`seeds_ms_per_step` has all three).
 
 Extra objects on the line (all measured in this run unless marked `from_profiles`):
   roofline      -- the dominant kernel (render_bwd_kernel): algorithmic bytes per launch (76*R' + 20*W*H) /
@@ -242,8 +243,8 @@ def cpu_baseline(sc, cfg, n_tiles_sample=96, with_c2=False):
     section 3 (oracle/torch_rasterizer.py) on the box's host cores, on a bounded sample of the same frame (full preprocess
     + binning, then forward+backward of every k-th tile, extrapolated to images/s of the whole frame);
     `c_oracle_single_thread` = the C oracle (one thread) on the WHOLE frame (_c_oracle_frame), no sampling; c1 in full
-    with the PyTorch rasterizer (median of 5); c2 in full only with --cpu-c2 (it takes 2.5 minutes on the 128 host cores
-    of the MI355X box -- profiles/ holds that run -- and the default run must stay short)."""
+    with the PyTorch rasterizer (median of 5); c2 in full as well ("config 2 if it completes in < 10 min" --
+    2.5 minutes on the 128 host cores of the MI355X box) unless --no-cpu-c2."""
     import torch
     from oracle import torch_rasterizer as TR
     P, W, H, deg, hdr, n_poses = cfg
@@ -275,7 +276,7 @@ def cpu_baseline(sc, cfg, n_tiles_sample=96, with_c2=False):
         t = _cpu_full_frame(CONFIGS["c2"])
         out["c2_full"] = {"images_per_s": 1.0 / t, "seconds": t, "workload": "100k Gaussians, 800x800, SH 0, LDR, fwd+bwd, whole frame"}
     else:
-        out["c2_full"] = {"skipped": "run with --cpu-c2 (about 150 s of CPU time); last measured: profiles/r02_cpu_baseline_c2.json"}
+        out["c2_full"] = {"skipped": "--no-cpu-c2 given (about 150 s of CPU time); last measured: profiles/r02_cpu_baseline_c2.json"}
     torch_port = {
         "value": 1.0 / t_full, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
         "sample": (f"pure-PyTorch fp32 autograd rasterizer (oracle/torch_rasterizer.py): full preprocess+binning of "
@@ -523,8 +524,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="c3", choices=sorted(c for c in CONFIGS if c != "c1"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-c2", action="store_true", help="also time BASELINE config c2 in full on the CPU (~2.5 min)")
-    ap.add_argument("--no-extras", action="store_true", help="skip the per-seed and per-stage legs (profiling runs)")
+    ap.add_argument("--no-cpu-c2", action="store_true",
+                    help="skip BASELINE config c2 in full on the CPU (BASELINE.md 3: 'config 2 if it completes in < 10 min'; "
+                         "it takes ~2.5 min on the 128 host cores of the MI355X box and is part of the default run)")
+    ap.add_argument("--cpu-c2", action="store_true", help="(kept for older command lines: c2 in full is the default now)")
+    ap.add_argument("--no-extras", action="store_true", help="profiling runs: one seed only, no CPU baseline")
+    ap.add_argument("--one-seed", action="store_true", help="time seed 0 only (the headline is then NOT the median of seeds)")
     ap.add_argument("--kernel-iters", type=int, default=10)
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
                     help="replay the whole step as one HIP graph (single GPU).  auto = only where the host can pace the "
@@ -555,80 +560,113 @@ def main():
     cfg = CONFIGS[args.config]
     P, W, H, deg, hdr, n_poses = cfg
 
-    step, state, make_rasterizer, sc, dL, plist = build_step(cfg, rank, world, dev)
-    # first step in the upstream-compatible synchronous mode learns num_rendered; the timed steps use the
-    # sync-free mode with a fixed binning capacity (25 % headroom), overflow checked lazily every step.
-    out = step()
-    torch.cuda.synchronize()
-    R, Rp, E, vtiles = derived_counts(out, W, H, n_poses)
-    state["rast"] = make_rasterizer(int(R * 1.25) + 4096)
-
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    allreduce_info = None
-    if world > 1:
-        allreduce_info = choose_exchange(step, state, barrier, dev, rank, world, backend, cfg)
+    exchange = {"info": None, "choice": None}   # the gradient exchange is chosen once (first seed) and reused
 
-    # One launch per step: the sync-free step (fixed binning capacity: no host read in forward or backward) is captured in
-    # a HIP graph and replayed -- the same kernels on the same buffers, minus ~40 launches of host work per step (at c2 the
-    # host, not the GPU, paces the eager step).  Used only if the replay reproduces the eager step bit for bit.
-    launch, run_step, gstep = "eager (one enqueue per kernel)", step, None
-    want_graph = args.graph == "on"
-    if world == 1 and args.graph == "auto":
-        for _ in range(3):
-            step()
+    def prepare_seed(seed):
+        """Everything ahead of the timed region, identical for every seed: scene, one synchronous step (learns num_rendered,
+        as the published API does), rasterizers in the sync-free mode with a fixed binning capacity (25 % headroom; overflow
+        checked lazily every step), the exchange strategy (N > 1) and the launch form (eager or one HIP graph)."""
+        step, state, make_rasterizer, sc, dL, plist = build_step(cfg, rank, world, dev, seed=seed)
+        out = step()
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(10):
-            step()
-        torch.cuda.synchronize()
-        want_graph = (time.perf_counter() - t0) / 10 < 0.6e-3   # a step this short is at the mercy of the box's CPU
-    if world == 1 and want_graph:
-        try:
-            from casualhdrsplat_amd.graphs import GraphedStep
-            step()
+        counts = derived_counts(out, W, H, n_poses)
+        del out
+        state["out"] = None
+        state["rast"] = make_rasterizer(int(counts[0] * 1.25) + 4096)
+        if world > 1:
+            if exchange["choice"] is None:
+                exchange["info"] = choose_exchange(step, state, barrier, dev, rank, world, backend, cfg)
+                exchange["choice"] = state["exchange"]
+            state["exchange"] = exchange["choice"]
+        # One launch per step: the sync-free step (fixed binning capacity: no host read in forward or backward) is captured
+        # in a HIP graph and replayed -- the same kernels on the same buffers, minus ~40 launches of host work per step (at
+        # c2 the host, not the GPU, paces the eager step).  Used only if the replay reproduces the eager step bit for bit.
+        launch, run_step, gstep = "eager (one enqueue per kernel)", step, None
+        want_graph = args.graph == "on"
+        if world == 1 and args.graph == "auto":
+            for _ in range(3):
+                step()
             torch.cuda.synchronize()
-            want = [state["out"][0].detach().clone()] + [p_.grad.detach().clone() for p_ in plist]
-            # no autograd graph of an earlier (default-stream) step may be alive when the capture starts: its
-            # AccumulateGrad nodes would run on the default stream and break the capture
-            out = None
-            state["out"] = None
-            for p_ in plist:
-                p_.grad = None
-            gstep = GraphedStep(step, [state["rast"]["allreduce"]])
-            gstep.step()
-            gstep.check_overflow()
-            got = [state["out"][0].detach()] + [p_.grad.detach() for p_ in plist]
-            if not all(torch.equal(a_, b_) for a_, b_ in zip(want, got)):
-                raise RuntimeError("graph replay differs from the eager step")
-            launch, run_step = "hip_graph (whole step captured once, replayed)", gstep.step
-        except Exception as e:  # noqa: BLE001 -- any capture problem: the eager step is always there
-            if args.graph == "on":
-                raise
-            print(f"[bench] HIP-graph step unavailable ({type(e).__name__}: {str(e)[:200]}); timing the eager step",
-                  file=sys.stderr)
-            gstep, run_step = None, step
-            for p_ in plist:
-                p_.grad = None
-    for _ in range(args.warmup):
-        run_step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run_step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if gstep is not None:
-        gstep.check_overflow()   # the timed frames all fitted their binning capacity
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    ms_per_step = elapsed / args.steps * 1e3
-    images_per_s = world * args.steps / elapsed
+            t0 = time.perf_counter()
+            for _ in range(10):
+                step()
+            torch.cuda.synchronize()
+            want_graph = (time.perf_counter() - t0) / 10 < 0.6e-3   # a step this short is at the mercy of the box's CPU
+        if world == 1 and want_graph:
+            try:
+                from casualhdrsplat_amd.graphs import GraphedStep
+                step()
+                torch.cuda.synchronize()
+                want = [state["out"][0].detach().clone()] + [p_.grad.detach().clone() for p_ in plist]
+                # no autograd graph of an earlier (default-stream) step may be alive when the capture starts: its
+                # AccumulateGrad nodes would run on the default stream and break the capture
+                state["out"] = None
+                for p_ in plist:
+                    p_.grad = None
+                gstep = GraphedStep(step, [state["rast"]["allreduce"]])
+                gstep.step()
+                gstep.check_overflow()
+                got = [state["out"][0].detach()] + [p_.grad.detach() for p_ in plist]
+                if not all(torch.equal(a_, b_) for a_, b_ in zip(want, got)):
+                    raise RuntimeError("graph replay differs from the eager step")
+                launch, run_step = "hip_graph (whole step captured once, replayed)", gstep.step
+            except Exception as e:  # noqa: BLE001 -- any capture problem: the eager step is always there
+                if args.graph == "on":
+                    raise
+                print(f"[bench] HIP-graph step unavailable ({type(e).__name__}: {str(e)[:200]}); timing the eager step",
+                      file=sys.stderr)
+                gstep, run_step = None, step
+                for p_ in plist:
+                    p_.grad = None
+        return dict(step=step, state=state, sc=sc, dL=dL, plist=plist, counts=counts, launch=launch, run_step=run_step,
+                    gstep=gstep, seed=seed)
+
+    def time_seed(seed):
+        """W untimed warm-up steps, then EXACTLY K timed steps between barrier + synchronize, MAX over ranks: the same
+        procedure for every seed of SURVEY.md 8(d); returns (context, ms per step)."""
+        ctx = prepare_seed(seed)
+        for _ in range(args.warmup):
+            ctx["run_step"]()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            ctx["run_step"]()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if ctx["gstep"] is not None:
+            ctx["gstep"].check_overflow()   # the timed frames all fitted their binning capacity
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return ctx, elapsed / args.steps * 1e3
+
+    # SURVEY.md 8(d): "seeds {0,1,2}, report median".  Every seed is timed by the same function -- same warm-up, same K
+    # steps, a fresh scene, fresh rasterizers, an emptied allocator cache -- and the headline is the MEDIAN seed; the
+    # per-stage / roofline legs below then run on that seed's scene.
+    seeds = [0] if (args.one_seed or args.no_extras) else [0, 1, 2]
+    per_seed, ctx = {}, None
+    for seed in seeds:
+        ctx = None                       # (the previous seed's scene and state buffers go before the next is built)
+        torch.cuda.empty_cache()
+        ctx, ms = time_seed(seed)
+        per_seed[seed] = {"ms_per_step": ms, "R": ctx["counts"][0], "R_prime": ctx["counts"][1]}
+    order = sorted(seeds, key=lambda s_: per_seed[s_]["ms_per_step"])
+    med_seed = order[len(order) // 2]
+    ms_per_step = per_seed[med_seed]["ms_per_step"]
+    if ctx["seed"] != med_seed and rank == 0 and world == 1:
+        ctx = None
+        torch.cuda.empty_cache()
+        ctx = prepare_seed(med_seed)     # the median seed's scene for the per-stage legs (not timed again)
+    step, state, sc, dL, plist, launch = ctx["step"], ctx["state"], ctx["sc"], ctx["dL"], ctx["plist"], ctx["launch"]
+    R, Rp, E, vtiles = ctx["counts"]
+    allreduce_info = exchange["info"]
+    images_per_s = world * 1e3 / ms_per_step
 
     line = {
         "metric": "train-step images/sec (fwd+bwd raster) @ 1M Gaussians 1080p",
@@ -638,9 +676,18 @@ def main():
         "config": {"workload": f"{args.config}: {P} Gaussians, {W}x{H}, SH degree {deg}, "
                                f"{'HDR radiance + CRF tone-map' if hdr else 'LDR'}, {n_poses} pose(s)/view, "
                                f"{world} view(s)/step (one per GPU)" + (", gradients summed over views (config.gradient_exchange)" if world > 1 else ""),
-                   "num_rendered_R": R, "R_prime": Rp, "pixel_pair_evals_E": E, "seed": 0,
+                   "num_rendered_R": R, "R_prime": Rp, "pixel_pair_evals_E": E,
+                   "seed": ctx["seed"],
+                   "seeds": f"value / ms_per_step = the median of seeds {seeds}, each timed alike ({args.warmup} warm-up + "
+                            f"{args.steps} steps); roofline / stages / counts belong to seed {ctx['seed']}",
                    "binning": "sync-free fixed capacity 1.25*R", "launch": launch},
-        "mpix_per_s": world * args.steps * W * H * n_poses / elapsed / 1e6,
+        "mpix_per_s": world * W * H * n_poses / ms_per_step / 1e3,
+        "seeds_ms_per_step": {**{str(k): v["ms_per_step"] for k, v in per_seed.items()},
+                              **{f"R_{k}": v["R"] for k, v in per_seed.items()},
+                              **{f"R_prime_{k}": v["R_prime"] for k, v in per_seed.items()},
+                              "median": ms_per_step, "median_seed": med_seed, "median_images_per_s": images_per_s,
+                              "spread": (max(v["ms_per_step"] for v in per_seed.values()) /
+                                         min(v["ms_per_step"] for v in per_seed.values()) - 1.0)},
     }
     if allreduce_info is not None:
         line["config"]["gradient_exchange"] = allreduce_info
@@ -705,33 +752,8 @@ def main():
                                                     "(separate --pmc passes, gfx950 FETCH_SIZE correction), same render.hip")
         line["stages_ms"] = {k: round(v, 4) for k, v in stages.items()}
         line["render_stats"] = stats
-        if world == 1 and not args.no_extras:
-            # the headline is seed 0; the other two seeds of SURVEY.md 8(d) are timed the same way (fewer steps)
-            per_seed = {"0": ms_per_step}
-            del out
-            for seed in (1, 2):
-                step_s, state_s, mk_s, _, _, _ = build_step(cfg, rank, world, dev, seed=seed)
-                o = step_s()
-                torch.cuda.synchronize()
-                Rs = derived_counts(o, W, H, n_poses)
-                per_seed[f"R_{seed}"] = Rs[0]
-                state_s["rast"] = mk_s(int(Rs[0] * 1.25) + 4096)
-                del o
-                for _ in range(3):
-                    step_s()
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                n_s = max(5, args.steps // 2)
-                for _ in range(n_s):
-                    step_s()
-                torch.cuda.synchronize()
-                per_seed[str(seed)] = (time.perf_counter() - t0) / n_s * 1e3
-                del step_s, state_s, mk_s
-                torch.cuda.empty_cache()
-            med = sorted(per_seed[k] for k in ("0", "1", "2"))[1]
-            line["seeds_ms_per_step"] = {**per_seed, "median": med, "median_images_per_s": 1e3 / med}
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(sc, cfg, with_c2=args.cpu_c2)
+        if world == 1 and not (args.no_cpu_baseline or args.no_extras):
+            line["cpu_baseline"] = cpu_baseline(sc, cfg, with_c2=not args.no_cpu_c2)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

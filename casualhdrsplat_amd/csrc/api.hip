@@ -12,6 +12,9 @@ namespace hs {
 
 static thread_local char g_err[512] = "";
 
+#ifdef HS_TESTING
+// libhdrsplat_test.so only (make test_lib; -DHS_TESTING): the fault injection of tests/test_gpu_parity.py.  The product
+// library is built without it: no environment variable can plant a fault in it (hs_common.h: fault_injection() == 0).
 int fault_injection() {
     static const int mode = [] {
         const char* e = getenv("HS_FAULT_INJECT");
@@ -19,6 +22,7 @@ int fault_injection() {
     }();
     return mode;
 }
+#endif
 
 // Chain positions of the radix passes: blockIdx (default) or start-order tickets.  Process-wide, switchable at run time
 // (hs_sort_tickets): the host turns tickets on when a pass reports a stalled chain (hs_counters.overflow = 2).

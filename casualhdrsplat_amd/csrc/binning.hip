@@ -269,13 +269,15 @@ __global__ void __launch_bounds__(kSortBlock) radix_sweep_kernel(const void* in_
     __shared__ uint32_t s_wave[4];
     __shared__ uint32_t s_ticket, s_fail, s_n;
 
-    // tests only (HS_FAULT_INJECT=late_block sets bit 31 of `mask`): block 1 starts ~3 ms late, as if its XCD had no room
-    // for it -- the blocks behind it must help themselves (see the look-back below)
+#ifdef HS_TESTING
+    // libhdrsplat_test.so only (HS_FAULT_INJECT=late_block sets bit 31 of `mask`): block 1 starts ~3 ms late, as if its XCD
+    // had no room for it -- the blocks behind it must help themselves (see the look-back below)
     if ((mask >> 31) != 0u) {
         mask &= 0x7FFFFFFFu;
         if (!TICKET && blockIdx.x == 1)
             for (int i = 0; i < 1000; ++i) __builtin_amdgcn_s_sleep(127);
     }
+#endif
     if (threadIdx.x == 0) {
         s_ticket = TICKET ? atomicAdd(ticket, 1u) : blockIdx.x;
         // (one lane asks for the element count and the verdict of the passes so far -- both loads in flight together, and

@@ -35,9 +35,11 @@ constexpr int kInstFloats = 4 * kInstF4;
 // pair sort with 12 / 20 / 24 items per thread: 0.226 / 0.232 / 0.249 against 0.225 (three blocks per CU at 24).
 constexpr int kSortBlock = 256;
 constexpr int kDepthSortItems = 16, kDepthSortLook = 8;                                     // instances by depth
-constexpr int kPairSortItems = 16, kPairSortLook = 8;                                       // (tile, instance) pairs by tile                                       // (tile, instance) pairs by tile
+constexpr int kPairSortItems = 16, kPairSortLook = 8;                                       // (tile, instance) pairs by tile
 constexpr int kU64SortItems = 16;                                                           // hs_sort_pairs
-constexpr int kSortTileMin = (kDepthSortItems < 16 ? kDepthSortItems : 16) * kSortBlock;    // smallest radix block in use
+constexpr int kMinSortItems = kDepthSortItems < kPairSortItems ? (kDepthSortItems < kU64SortItems ? kDepthSortItems : kU64SortItems)
+                                                               : (kPairSortItems < kU64SortItems ? kPairSortItems : kU64SortItems);
+constexpr int kSortTileMin = kMinSortItems * kSortBlock;    // smallest radix block in use: sizes the status words of every sort
 
 static inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
@@ -79,7 +81,7 @@ int64_t sort_tmp_bytes(int64_t n);
 // (as u32 words), then the pair sort's scratch.  pair_scratch_words = what must be cleared before the emission runs.
 static inline int64_t emit_scan_words(int64_t I) { return 2 * ((I + 255) / 256 + 2) / 64 * 64 + 64; }
 static inline int64_t pair_scratch_words(int64_t I, int64_t capacity, int passes) {
-    return emit_scan_words(I) + sort_scratch_words(capacity, passes, 16 * kSortBlock);
+    return emit_scan_words(I) + sort_scratch_words(capacity, passes, kPairSortItems * kSortBlock);
 }
 // Stable LSD radix sort of (u64 key, u32 value) pairs on bits [0,nbits) (hs_sort_pairs; the forward sorts packed
 // (u32 key, u32 value) elements with the same pass kernel).  Ping-pongs between (k0,v0) and (k1,v1); the result lands
@@ -87,9 +89,16 @@ static inline int64_t pair_scratch_words(int64_t I, int64_t capacity, int passes
 // (<= n_launch); `tmp` must hold sort_tmp_bytes(n_launch); *fail_word reads 2 afterwards if a look-back gave up.
 int launch_radix_sort(uint64_t* k0, uint32_t* v0, uint64_t* k1, uint32_t* v1, const uint32_t* n_dev,
                       int64_t n_launch, int nbits, void* tmp, uint32_t* fail_word, hipStream_t s);
-// Test hook (HS_FAULT_INJECT in the environment, read once): 0 = none, 1 = "sort_ticket": hs_sort_pairs starts its first
-// pass with ticket 1, so chain position 0 never publishes and the bounded look-back must give up.
+// Test hook, compiled into libhdrsplat_test.so only (-DHS_TESTING; `make test_lib`): HS_FAULT_INJECT in the environment,
+// read once.  0 = none; 1 = "sort_ticket": hs_sort_pairs starts its first pass with ticket 1, so chain position 0 never
+// publishes and the bounded look-back must give up; 2 = "stalled_chain": the binning stage starts with the verdict of a
+// stalled chain (hs_counters.overflow = 2) while the passes are blockIdx-ordered; 3 = "late_block": block 1 of every
+// blockIdx-ordered radix pass starts ~3 ms late.  The product library has none of it.
+#ifdef HS_TESTING
 int fault_injection();
+#else
+constexpr int fault_injection() { return 0; }
+#endif
 // HS_SORT_TICKETS=1 in the environment (read once): the pipeline's radix passes take their chain positions from tickets
 // instead of blockIdx (binning.hip, "Progress").
 bool sort_tickets();

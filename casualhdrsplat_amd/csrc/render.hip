@@ -481,11 +481,18 @@ render_fwd_kernel(RenderFwd p) {
             if constexpr (STATS) ws.v[kStFwdActivePix] += n_pix;
             // the two halves of `took` go to lane i - i0 of act_lo / act_hi as they are (one scalar + two vector
             // instructions; whether a half is non-zero -- its lane group took the entry -- is asked once per walk)
+            // m0 carries the lane number: a gfx9 VALU instruction reads one SGPR, m0 not counted, and this clang has no
+            // writelane builtin.  m0 is on the clobber list, so the compiler keeps no value of its own in it across the
+            // statement (it re-initialises m0 before each of its own uses anyway; the diagnostic about a reserved register on
+            // a clobber list is switched off for this one statement).
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
             asm("s_mov_b32 m0, %2\n\t"
-                "v_writelane_b32 %0, %3, m0\n\t"   // (m0: reserved, never live across instructions in compiler-generated code)
+                "v_writelane_b32 %0, %3, m0\n\t"
                 "v_writelane_b32 %1, %4, m0\n\t"
                 "s_add_u32 %2, %2, 1"
-                : "+v"(act_lo), "+v"(act_hi), "+s"(pos) : "s"((uint32_t)took), "s"((uint32_t)(took >> 32)) : "scc");
+                : "+v"(act_lo), "+v"(act_hi), "+s"(pos) : "s"((uint32_t)took), "s"((uint32_t)(took >> 32)) : "scc", "m0");
+#pragma clang diagnostic pop
             if constexpr (STATS) { ws.v[kStFwdTrips] += 1; ws.v[kStFwdEmpty] += took == 0ull; }
         };
         // two trips per test of "every pixel of the wave is finished" (a trip after that changes nothing and records

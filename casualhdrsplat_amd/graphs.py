@@ -50,11 +50,18 @@ class GraphedStep:
         torch.cuda.synchronize()
         for r in self.rasterizers:   # an overflow during warm-up: fail before capturing a graph that renders empty frames
             r.check_overflow()
+        for r in self.rasterizers:
+            r._cell["captured"] = []     # every forward a rasterizer enqueues while the stream captures lands here
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.outputs = fn()
-        # the forwards captured above left their counter copies pending (nobody may wait inside a capture)
-        self._pending = [r._last.get("pending") for r in self.rasterizers]
+        # the forwards captured above left their counter copies pending (nobody may wait inside a capture): ALL of them
+        # -- `fn` may call one rasterizer several times (several views, an eval render in between), and a frame that
+        # overflowed renders empty whichever call it was
+        self._pending = [(r, p) for r in self.rasterizers for p in r._cell.pop("captured", []) if p is not None]
+        if len({id(r) for r, _ in self._pending}) != len(self.rasterizers):
+            raise ValueError("GraphedStep: a rasterizer listed in `rasterizers` was not called by `fn` during the capture")
+        self._warned_helps = False
         # `params`: the leaves whose gradients the step produces -- `grads` are the static tensors every replay rewrites
         self.grads = [p.grad for p in params]
 
@@ -66,14 +73,17 @@ class GraphedStep:
     __call__ = step
 
     def check_overflow(self) -> list:
-        """Wait for the latest replay and return num_rendered per rasterizer; raises BinningOverflow if one overflowed."""
+        """Wait for the latest replay and return num_rendered of every captured forward (in call order per rasterizer, the
+        rasterizers in the order given); raises BinningOverflow if ANY of them overflowed."""
         torch.cuda.current_stream().synchronize()
         counts = []
-        for r, p in zip(self.rasterizers, self._pending):
-            if p is None or p.host is None:
+        helps = 0
+        for r, p in self._pending:
+            if p.host is None:
                 counts.append(None)
                 continue
             n, over = int(p.host[0]) & 0xFFFFFFFF, int(p.host[1])
+            helps += int(p.host[6])   # hs_counters.reserved[4]: waiting workgroups did silent predecessors' counting
             if over >= 2:
                 # (the captured graph holds the blockIdx-ordered passes: ticket order needs a new capture)
                 from . import _lib as L
@@ -86,4 +96,12 @@ class GraphedStep:
             if over:
                 raise BinningOverflow(n, p.capacity, f"; rebuild the GraphedStep with capacity >= {grown_capacity(n)}")
             counts.append(n)
+        if helps and not self._warned_helps:
+            # the frames are right (helping keeps the look-back chains moving), but the GPU is shared with other kernels and
+            # the captured graph holds the blockIdx-ordered passes: ticket order is the faster mode there, and needs a new capture
+            import warnings
+            self._warned_helps = True
+            warnings.warn(f"casualhdrsplat_amd: the captured step's radix passes had to help {helps} silent predecessors "
+                          "(GPU shared with other kernels?); call _lib.load().hs_sort_tickets(1) and rebuild the GraphedStep "
+                          "for ticket-ordered passes", RuntimeWarning, stacklevel=2)
         return counts

@@ -170,9 +170,9 @@ class _Pending:
     """Deferred overflow check for the sync-free (fixed capacity) mode: the forward copies the device counters
     {num_rendered, overflow} into a pinned buffer behind its kernels and records an event; nothing waits for it
     until someone asks."""
-    def __init__(self, host, event, capacity):
+    def __init__(self, host, event, capacity, ticket_order=0):
         self.host, self.event, self.capacity = host, event, capacity
-        self.reported = False   # this frame's stalled chain has been turned into SortChainStalled once already
+        self.ticket_order = ticket_order   # chain-position mode the frame was ENQUEUED under (hs_sort_tickets(-1) then)
 
     def resolve(self):
         """(num_rendered, overflowed) -- waits for the forward's counter copy on first use."""
@@ -194,16 +194,17 @@ class _Pending:
                               f"{helps} silent predecessors); using ticket-ordered passes from now on", RuntimeWarning,
                               stacklevel=3)
         if self.overflow >= 2:
-            lib = L.load()
-            if not self.reported and lib.hs_sort_tickets(-1) == 0:
+            # judged by the mode THIS frame was enqueued under, not the process-wide mode of the moment: with several
+            # forwards in flight the first stalled frame switches the library to tickets, and the others that stalled in
+            # blockIdx order are the same retryable event, not damaged scratch
+            if not self.ticket_order:
                 # blockIdx-ordered passes met a dispatch order they cannot live with (another process on the GPU):
                 # ticket order from here on, and the caller repeats the step
-                self.reported = True
-                lib.hs_sort_tickets(1)
-                warnings.warn("casualhdrsplat_amd: a radix pass gave up waiting (GPU shared with another process?); "
-                              "using ticket-ordered passes from now on", RuntimeWarning, stacklevel=3)
-                raise SortChainStalled()
-            if self.reported:
+                lib = L.load()
+                if lib.hs_sort_tickets(-1) == 0:
+                    lib.hs_sort_tickets(1)
+                    warnings.warn("casualhdrsplat_amd: a radix pass gave up waiting (GPU shared with another process?); "
+                                  "using ticket-ordered passes from now on", RuntimeWarning, stacklevel=3)
                 raise SortChainStalled()
             raise RuntimeError("libhdrsplat: a radix pass of the binning stage gave up waiting for a predecessor's status "
                                "word although the passes were ticket-ordered (hs_counters.overflow = 2: damaged sort "
@@ -287,6 +288,7 @@ def _run_forward(settings: GaussianRasterizationSettings, means3D, opacities, sh
     st = _State()
     st.pending = None
     stream = _stream()
+    ticket_order = lib.hs_sort_tickets(-1)   # the chain-position mode this frame's passes are enqueued under
     if sync_mode:
         # upstream semantics: one host read of num_rendered between the scan and the binning
         a.stages = L.HS_STAGE_PREPROCESS
@@ -310,7 +312,7 @@ def _run_forward(settings: GaussianRasterizationSettings, means3D, opacities, sh
         host.copy_(geom[:32].view(torch.int32), non_blocking=True)   # the whole hs_counters struct
         ev = torch.cuda.Event()
         ev.record()
-        st.pending = _Pending(host, ev, R if sync_mode else int(capacity))
+        st.pending = _Pending(host, ev, R if sync_mode else int(capacity), ticket_order)
 
     st.dims, st.layout, st.geom, st.binning, st.image = dims, layout, geom, binning, image
     st.num_rendered, st.flags, st.views, st.projs, st.camposes, st.bg = R, flags, views, projs, campos, bg
@@ -702,6 +704,8 @@ class GaussianRasterizer(nn.Module):
                                        self.return_invdepth, self.densify_stats, aux)
             self._last = aux
             pend = aux.get("pending")
+            if "captured" in self._cell and torch.cuda.is_current_stream_capturing():
+                self._cell["captured"].append(pend)   # graphs.GraphedStep checks EVERY forward of the captured step
             if pend is None or backward_possible:
                 return outs  # synchronous mode, or a training step (its backward looks at the counters)
             try:

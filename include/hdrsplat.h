@@ -215,9 +215,10 @@ typedef struct hs_layout {
     /* pair_flags (binning workspace): u8 per pair slot, cleared by the forward's pair emission, set to 1 by the
      * render backward for the records it wrote */
     int64_t pair_flags;
-    /* pair_act (binning workspace): u8 per SORTED pair, written by the render forward for every entry it staged: bit w
-     * = some pixel of half tile w (rows 8w .. 8w+7 of the tile) took the entry.  The render backward walks exactly
-     * those entries per half tile */
+    /* pair_act (binning workspace): u8 per SORTED pair, written by the render forward for every entry it staged: bit
+     * 2g + w = some pixel of lane group g (the 8 x 8 block of columns 8g .. 8g+7) of half tile w (rows 8w .. 8w+7 of the
+     * tile) took the entry -- four bits, one per 8 x 8 block of the 16 x 16 tile.  The render backward walks exactly
+     * those entries, one list per block */
     int64_t pair_act;
     /* image workspace */
     int64_t final_T, n_contrib, pose_hdr;
@@ -276,8 +277,8 @@ HS_API int hs_sort_tickets(int enable);
 
 /* Bench/test only: stable LSD radix sort of (u64 key, u32 value) pairs on bits [0, nbits), n < 2^30, using the
  * same pass kernel as HS_STAGE_BIN.  tmp must hold hs_sort_tmp_bytes(n).  Result in keys_out/vals_out.  The u32 at
- * byte 4 of tmp reads 2 afterwards if a pass gave up waiting (results invalid), else 0.  HS_FAULT_INJECT=sort_ticket
- * in the environment (tests) provokes exactly that. */
+ * byte 4 of tmp reads 2 afterwards if a pass gave up waiting (results invalid), else 0.  (The tests provoke exactly
+ * that with HS_FAULT_INJECT=sort_ticket, which only libhdrsplat_test.so -- built with -DHS_TESTING -- reads.) */
 HS_API int64_t hs_sort_tmp_bytes(int64_t n);
 HS_API int hs_sort_pairs(const uint64_t* keys_in, const uint32_t* vals_in, uint64_t* keys_out, uint32_t* vals_out,
                   int64_t n, int32_t nbits, void* tmp, void* hip_stream);

@@ -166,13 +166,62 @@ def analyse(items, marker):
     return res, loop
 
 
+def _vregs(tok):
+    """Register numbers named by one operand token: v12 -> {12}, v[4:7] -> {4,5,6,7}, anything else -> {}."""
+    tok = tok.strip().rstrip(",")
+    m = re.fullmatch(r"v(\d+)", tok)
+    if m:
+        return {int(m.group(1))}
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    return set()
+
+
+def check_dpp_hazards(fns):
+    """The hand-placed wait states of render.hip's inline-asm DPP blocks (reduce_in_rows / reduce_in_quads), checked in
+    the ISA the compiler actually emitted around them: gfx9 needs TWO wait states between a VALU write of a VGPR and a
+    DPP read of it as the permuted source (src0), and the hazard recogniser does not look inside inline asm.  Every DPP
+    instruction of every function is checked against the instructions laid out before it (one wait state each, `s_nop k`
+    = k + 1; layout order, which is what a fall-through sees -- the asm blocks open with their own s_nop for every
+    other way in).  Returns (number of DPP instructions, violations)."""
+    n_dpp, bad = 0, []
+    for name, body in fns.items():
+        items = [it for it in parse(body) if it[0] == "ins"]
+        for i, it in enumerate(items):
+            m, ops = it[1], it[2]
+            if not (m.startswith("v_") and ("_dpp" in m or "row_" in ops or "quad_perm" in ops or "wave_" in ops)):
+                continue
+            n_dpp += 1
+            toks = ops.split(",")
+            src0 = _vregs(toks[1].split()[0]) if len(toks) > 1 else set()
+            waited, j = 0, i - 1
+            while j >= 0 and waited < 2:
+                pm, pops = items[j][1], items[j][2]
+                if pm == "s_nop":
+                    waited += int(pops.strip() or 0) + 1
+                else:
+                    if pm.startswith("v_") and not pm.startswith(("v_cmp", "v_cmpx")):
+                        if _vregs(pops.split(",")[0]) & src0:
+                            bad.append(f"{name}: `{m} {ops}` reads v{sorted(src0)} {waited} wait state(s) after `{pm} {pops}`")
+                    waited += 1
+                j -= 1
+    return n_dpp, bad
+
+
 def main():
     asm = device_asm()
     fns = functions(asm)
+    n_dpp, bad = check_dpp_hazards(fns)
+    if bad:
+        raise SystemExit("DPP read-after-VALU-write hazard (2 wait states needed):\n  " + "\n  ".join(bad[:20]))
     out = {"source": "scripts/isa_loop_counts.py (hipcc -O3 -ffp-contract=fast -S --cuda-device-only, gfx950)",
            "render_hip_sha256": kernel_source_hash(SRC),
            "issue_cycle_model": "4 cycles per wave64 vector instruction, 8 for transcendental and v_permlane*_swap "
-                                "(profiles/r01b_valu_rate.txt)"}
+                                "(profiles/r01b_valu_rate.txt)",
+           "dpp_hazard_check": {"dpp_instructions_checked": n_dpp, "violations": 0,
+                                "rule": "VALU write of a VGPR -> DPP read of it as src0: >= 2 wait states, over every "
+                                        "function of the emitted ISA (the inline-asm blocks carry their own s_nop)"}}
     for kern in ("render_fwd_kernel", "render_bwd_kernel"):
         cands = [n for n in fns if kern in n and "ILb0ELb0E" in n]
         if len(cands) != 1:

@@ -195,18 +195,30 @@ def grad_floor(ref):
     return max(1e-3 * rms, 1e-30)
 
 
+def _pose_map(fn, items, workers):
+    """fn over the poses, in order; `workers` > 1: on that many threads (the C oracle holds no global state and ctypes
+    releases the interpreter lock for the duration of a call -- full-size frames, 12 s per pose and direction)."""
+    items = list(items)
+    if workers <= 1 or len(items) <= 1:
+        return [fn(x) for x in items]
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(workers, len(items))) as ex:
+        return list(ex.map(fn, items))
+
+
 def run_oracle_hdr(O, sc: S.Scene, cameras=None, blur_domain="ldr", dL_ldr=None, dL_hdr=None,
-                   radiance_activation="relu_shift"):
+                   radiance_activation="relu_shift", workers=1):
     """HDR image formation with the C oracle: per pose H_k (a4..a9), tone-map (a15), average over poses;
-    backward chains tonemap_bwd into the rasterizer backward per pose and sums.  Returns dict of outputs
-    and gradients (numpy)."""
+    backward chains tonemap_bwd into the rasterizer backward per pose and sums (in pose order, whatever `workers`).
+    Returns dict of outputs and gradients (numpy)."""
     cams = cameras or [sc.camera]
     N = len(cams)
     dL_ldr = sc.dL_dimage.numpy() if dL_ldr is None else dL_ldr
     dt = float(sc.exposure)
     tab = sc.crf_table.numpy()
     umin, umax = sc.crf_range
-    fs = [run_oracle(O, sc, cam=c, backward=False, radiance_activation=radiance_activation)[0] for c in cams]
+    fs = _pose_map(lambda c: run_oracle(O, sc, cam=c, backward=False, radiance_activation=radiance_activation)[0], cams,
+                   workers)
     Hs = [f["color"] for f in fs]
     Hm = np.mean(np.stack(Hs), axis=0, dtype=np.float64).astype(np.float32)
     if blur_domain == "ldr":
@@ -219,19 +231,24 @@ def run_oracle_hdr(O, sc: S.Scene, cameras=None, blur_domain="ldr", dL_ldr=None,
         dHm, dtab, dexp = O.tonemap_bwd(Hm, dt, tab, umin, umax, dL_ldr)
         dtab_sum += dtab
         dexp_sum += dexp
-    for k, c in enumerate(cams):
+    keys = ["dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dshs", "dL_dscales", "dL_drots"]
+
+    def pose_backward(k):
         if blur_domain == "ldr":
             dH, dtab, dexp = O.tonemap_bwd(Hs[k], dt, tab, umin, umax, dL_ldr / N)
-            dtab_sum += dtab
-            dexp_sum += dexp
         else:
-            dH = dHm / N
+            dH, dtab, dexp = dHm / N, None, 0.0
         if dL_hdr is not None:
             dH = dH + dL_hdr / N
-        ocam = oracle_camera(O, sc, c, radiance_activation)
+        ocam = oracle_camera(O, sc, cams[k], radiance_activation)
         b = O.backward(ocam, fs[k], dH.astype(np.float32), sc.means3D.numpy(), shs=sc.shs.numpy(),
                        scales=sc.scales.numpy(), rotations=sc.rotations.numpy())
-        keys = ["dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dshs", "dL_dscales", "dL_drots"]
+        return {q: b[q] for q in keys}, dtab, dexp
+
+    for b, dtab, dexp in _pose_map(pose_backward, range(N), workers):
+        if dtab is not None:
+            dtab_sum += dtab
+            dexp_sum += dexp
         if gsum is None:
             gsum = {q: b[q].astype(np.float64) for q in keys}
         else:
@@ -294,13 +311,18 @@ def assert_grads_close(got: dict, ref: dict, keys=GRAD_KEYS, frac_tol=None, max_
                 continue
             mx, frac = rel_err(gg, rr, floor)
             d2 = ((gg.astype(np.float64) - rr) ** 2).reshape(rr.shape[0], -1).sum(axis=1)
-            # one isolated row may carry the L2: a Gaussian that covers the whole frame sums thousands of random-sign
-            # pixel terms, and an fp32 sum of n such terms is off by ~1e-7 sqrt(n) of their magnitude -- 1e-4 of the
-            # row, which then IS the tensor's L2 error when the row is also its largest (sweep seed 24 case 9: radius
-            # 2738 px, 1.2e-4 on that row, with the one-list and the two-group kernel alike).  When a single row holds
-            # more than half of the squared error it is left to the per-element bar (max_tol) and the L2 bar judges the rest
+            # The L2 bar judges the FULL tensor.  One exception, narrowly: a Gaussian that covers the whole frame sums
+            # thousands of random-sign pixel terms, and an fp32 sum of n such terms is off by ~1e-7 sqrt(n) of their
+            # magnitude -- 1e-4 of the row, which then IS the tensor's L2 error when the row is also its largest (sweep seed
+            # 24 case 9: radius 2738 px, 1.2e-4 on that row, one-list and two-group kernel alike).  Only THAT case is
+            # excused: the row holding more than half of the squared error must be the largest row of the reference and
+            # must itself be within 3e-4 of its own norm (a wrong slot or plane for one entry is a per-cent error of the
+            # row, not 1e-4) -- then the L2 bar judges the rest; any other single-row error stays in the L2.
             if d2.size > 1 and d2.max() > 0.5 * d2.sum():
-                d2 = np.delete(d2, int(d2.argmax()))
+                k = int(d2.argmax())
+                n2 = (rr.astype(np.float64) ** 2).reshape(rr.shape[0], -1).sum(axis=1)
+                if k == int(n2.argmax()) and d2[k] <= (3e-4 ** 2) * n2[k]:
+                    d2 = np.delete(d2, k)
             l2 = float(np.sqrt(d2.sum()) / max(np.linalg.norm(r.astype(np.float64)), 1e-30))
             report[gk + tag] = (mx, frac, l2)
             # the fraction bound always admits two elements (tensors of a few dozen entries: P down to 1 in the sweep)
@@ -350,20 +372,20 @@ def crf_interval_risk(sc: S.Scene, hdr_got, hdr_ref, ulps=4):
     return ((crf_region(sc, ug) != crf_region(sc, ur)) | ambiguous(ug) | ambiguous(ur)).any(axis=0)
 
 
-def oracle_risk(O, sc: S.Scene, fwds, cams=None, guard_alpha=1e-5, guard_T=5e-5):
+def oracle_risk(O, sc: S.Scene, fwds, cams=None, guard_alpha=1e-5, guard_T=5e-5, workers=1):
     """Union over the poses of oracle.threshold_risk: (pix_risk [N,H,W], gauss_risk [P]) -- the guard band of the frame:
     where another fp32 implementation MAY decide differently.  Which rows actually leave the strict gradient bar is
     decided by decision_masks (where it DID)."""
     cams = cams or [sc.camera]
     pix, gs = [], None
-    for cam, f in zip(cams, fwds):
-        r = O.threshold_risk(oracle_camera(O, sc, cam), f, guard_alpha, guard_T)
+    for r in _pose_map(lambda cf: O.threshold_risk(oracle_camera(O, sc, cf[0]), cf[1], guard_alpha, guard_T),
+                       zip(cams, fwds), workers):
         pix.append(r["pix_risk"])
         gs = r["gauss_risk"] if gs is None else (gs | r["gauss_risk"])
     return np.stack(pix), gs
 
 
-def decision_masks(O, sc: S.Scene, fwds, st, cams=None, crf_got=None, crf_ref=None, what=""):
+def decision_masks(O, sc: S.Scene, fwds, st, cams=None, crf_got=None, crf_ref=None, what="", workers=1):
     """Where the HIP path (`st`: inspect_state as numpy) and the oracle (`fwds`: one forward dict per pose) took
     different decisions, and which gradient rows that excuses.
       differs [N,H,W]  pixels whose contributor count differs or whose final transmittance is off by more than 2e-3
@@ -376,7 +398,7 @@ def decision_masks(O, sc: S.Scene, fwds, st, cams=None, crf_got=None, crf_ref=No
                        whose CRF interval is not provably the same (crf_interval_risk).
     Everything else is held to the STRICT gradient bar."""
     cams = cams or [sc.camera]
-    pix_risk, _ = oracle_risk(O, sc, fwds, cams)
+    pix_risk, _ = oracle_risk(O, sc, fwds, cams, workers=workers)
     P = fwds[0]["radii"].shape[0]
     rows = np.zeros(P, bool)
     differs = np.zeros_like(pix_risk)
@@ -398,6 +420,25 @@ def decision_masks(O, sc: S.Scene, fwds, st, cams=None, crf_got=None, crf_ref=No
             if m.any():
                 rows |= O.pixel_reach(oracle_camera(O, sc, cam), f, m)
     return dict(pix_risk=pix_risk, differs=differs, rows=rows, n_differ=int(differs.sum()), n_knot_pixels=n_knot)
+
+
+def crf_grads_given_decisions(O, sc: S.Scene, masks, ref_imgs, got_imgs, dL_ldr=None):
+    """Oracle d(crf_table), d(exposure) of the 'ldr' blur domain (or a single pose) GIVEN the decisions the HIP path took:
+    the oracle's tone-map backward run on its own radiance images, except on the pixels where a compositing decision
+    demonstrably differed (masks["differs"], already confined to the guard band), where the HIP path's radiance stands
+    in.  One flipped contribution moves a pixel's log-exposure by up to a third of a knot interval and with it ~|dL| of
+    weight between two table entries -- 1e-2 of a knot's sum at full size, where 8000 pixels meet in a knot -- which is a
+    property of the decision, not of the table-gradient kernel this comparison is about."""
+    N = len(ref_imgs)
+    dL = (sc.dL_dimage.numpy() if dL_ldr is None else dL_ldr) / N
+    dt, tab, (umin, umax) = float(sc.exposure), sc.crf_table.numpy(), sc.crf_range
+    dtab, dexp = np.zeros_like(tab, dtype=np.float64), 0.0
+    for k in range(N):
+        h = np.where(masks["differs"][k][None], np.asarray(got_imgs[k], np.float32), np.asarray(ref_imgs[k], np.float32))
+        _, t, e = O.tonemap_bwd(np.ascontiguousarray(h), dt, tab, umin, umax, dL)
+        dtab += t
+        dexp += e
+    return dtab.astype(np.float32), float(dexp)
 
 
 def guarded_scene(O, P, W, H, deg, seed=0, hdr=False, cams_fn=None, tries=2000, **kw):

@@ -40,6 +40,20 @@ def test_header_symbols_exported(lib):
     assert others == [], others
 
 
+def test_fault_injection_exists_only_in_the_test_library(lib):
+    """HS_FAULT_INJECT (a stalled chain, a late block, a missing ticket: tests/test_gpu_parity.py) is compiled into
+    libhdrsplat_test.so alone (-DHS_TESTING); the product library does not read that variable -- no environment can plant a
+    fault in it -- and exports the same C ABI."""
+    prod = open(lib.LIB_PATH, "rb").read()
+    assert b"HS_FAULT_INJECT" not in prod and b"late_block" not in prod and b"stalled_chain" not in prod
+    test_path = os.path.join(os.path.dirname(lib.LIB_PATH), "libhdrsplat_test.so")
+    test = open(test_path, "rb").read()
+    assert b"HS_FAULT_INJECT" in test and b"late_block" in test
+    out = subprocess.check_output(["nm", "-D", "--defined-only", test_path]).decode()
+    for n in header_functions():
+        assert re.search(rf"\bT {n}\b", out), n
+
+
 def test_struct_sizes_match_c(lib, tmp_path):
     """ctypes mirrors must have the layout the C compiler gives include/hdrsplat.h."""
     src = tmp_path / "sz.c"

@@ -29,6 +29,8 @@ from casualhdrsplat_amd import synthetic as S
 pytestmark = pytest.mark.gpu
 
 GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+# libhdrsplat_test.so = the product sources + -DHS_TESTING: the only build that reads HS_FAULT_INJECT (csrc/Makefile)
+_TEST_LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "casualhdrsplat_amd", "libhdrsplat_test.so")
 
 
 def u32(a):
@@ -556,7 +558,7 @@ print("FAIL-WORD", int(tmp[:8].view(torch.int32)[1]), "SECONDS %.1f" % (time.tim
 """
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for inject, want in (("sort_ticket", 2), ("", 0)):
-        env = dict(os.environ, HS_ROOT=root, HS_FAULT_INJECT=inject)
+        env = dict(os.environ, HS_ROOT=root, HS_FAULT_INJECT=inject, HS_LIB_PATH=_TEST_LIB)   # (the only build with the hooks)
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
         assert f"FAIL-WORD {want} " in r.stdout, r.stdout[-500:]
@@ -584,7 +586,7 @@ print("FRAME", R, h.hexdigest(), "HELPS", st["look_back_helps"])
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = {}
     for inject in ("", "late_block"):
-        env = dict(os.environ, HS_ROOT=root, HS_FAULT_INJECT=inject, HS_SORT_TICKETS="0")
+        env = dict(os.environ, HS_ROOT=root, HS_FAULT_INJECT=inject, HS_SORT_TICKETS="0", HS_LIB_PATH=_TEST_LIB)
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
         outs[inject] = [ln for ln in r.stdout.splitlines() if ln.startswith("FRAME")][0].split()
@@ -641,7 +643,7 @@ for capacity in (None, 200000):
     print("OK", capacity)
 """
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, HS_ROOT=root, HS_FAULT_INJECT="stalled_chain")
+    env = dict(os.environ, HS_ROOT=root, HS_FAULT_INJECT="stalled_chain", HS_LIB_PATH=_TEST_LIB)
     env.pop("HS_SORT_TICKETS", None)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
@@ -1336,6 +1338,111 @@ def test_full_size_properties_c4_eight_poses():
     torch.cuda.empty_cache()
     same, _, _ = render([cams[0]] * N)
     assert Hh.rel_err(same[0].detach().cpu().numpy(), out1[0].detach().cpu().numpy(), 1e-3)[0] <= 1e-5
+
+
+def _parity_row(name, sc, m, g, r, extra=None):
+    """HS_PARITY_JSON=<file>: append this full-size frame's row (profiles/r04_parity_table.json: differing pixels, share
+    of rows on the strict bar, per-tensor error of the HIP gradients against the C oracle's on those rows)."""
+    path = os.environ.get("HS_PARITY_JSON")
+    if not path:
+        return
+    import json
+    rows = ~m["rows"]
+    row = {"case": name, "P": int(rows.size), "guard_band_pixels": int(m["pix_risk"].sum()), "n_differ": m["n_differ"],
+           "n_knot_pixels": m["n_knot_pixels"], "strict_share": float(rows.mean()), "tensors": {}}
+    for gk, rk in Hh.GRAD_KEYS:
+        ref = np.asarray(r[rk], np.float64)
+        got = np.asarray(g["d_" + gk], np.float64).reshape(ref.shape)
+        floor = Hh.grad_floor(ref)
+        e = np.abs(got[rows] - ref[rows]) / np.maximum(np.abs(ref[rows]), floor)
+        row["tensors"][gk] = {"max": float(e.max()), "p999": float(np.percentile(e, 99.9)),
+                              "frac_gt_1e-4": float((e > 1e-4).mean()),
+                              "l2": float(np.linalg.norm(got[rows] - ref[rows]) / max(np.linalg.norm(ref), 1e-30))}
+    row.update(extra or {})
+    old = json.load(open(path)) if os.path.exists(path) else {"cases": []}
+    old["cases"] = [c for c in old["cases"] if c["case"] != name] + [row]
+    json.dump(old, open(path, "w"), indent=1)
+
+
+def test_c3_full_size_vs_oracle(oracle):
+    """BASELINE c3 itself -- the frame bench.py times: 1M Gaussians, 1920 x 1080, SH degree 3, HDR radiance + CRF, seed 0
+    -- against the C oracle (25 s of one host core): depths / screen positions / conics / radii / tile counts and the whole
+    sorted list (6.78 M pairs: point_list, ranges, the rebuilt 64-bit keys) bit for bit, decisions confined to the
+    oracle's guard band, radiance and LDR images within 1e-4 off the pixels where a decision differs, every gradient on
+    the STRICT bar for >= 95 % of the Gaussians, d_crf_table / d_exposure as in the golden test.  Paths only this size
+    reaches: a depth sort of 245 blocks, 8160 tiles through the ordered list + the tail queue of the backward."""
+    P, W, H = 1_000_000, 1920, 1080
+    sc = S.make_scene(P, W, H, 3, seed=0, hdr=True)
+    r = Hh.run_oracle_hdr(oracle, sc)
+    g = Hh.run_hip(sc, hdr=True)
+    st, f = g["state"], r["fwd"][0]
+    R = f["R"]
+    assert st["num_rendered"] == R and R > 6_000_000
+    check_structure(st, f)
+    assert np.array_equal(u32(st["offsets"]), u32(f["offsets"]))
+    assert np.array_equal(st["keys_sorted"].view(np.uint64)[:R], f["keys_sorted"])
+    assert np.array_equal(u32(st["point_list"][:R]), u32(f["point_list"]))
+    assert np.array_equal(u32(st["ranges"]), u32(f["ranges"]))
+    assert np.array_equal(g["radii"], f["radii"])
+    m = Hh.decision_masks(oracle, sc, [f], st, crf_got=[g["hdr"]], crf_ref=[r["hdr"]], what="c3")
+    check_image(g["hdr"], r["hdr"], m, "c3 radiance")
+    check_image(st["final_T"][0], f["final_T"], m, "c3 final_T")
+    check_image(g["color"], r["ldr"], m, "c3 ldr")
+    rep = Hh.assert_grads_close(g, r, what="c3", at_risk=m["rows"], min_strict=0.95)
+    # table / exposure gradients: against the oracle's tone-map backward given the same decisions (on the handful of
+    # differing pixels the radiance the HIP path composited stands in), and loosely against the oracle's own
+    tab, dexp = Hh.crf_grads_given_decisions(oracle, sc, m, [r["hdr"]], [g["hdr"]])
+    assert Hh.rel_err(g["d_crf_table"], tab, 1e3 * Hh.grad_floor(tab))[0] <= 2e-4
+    assert float(g["d_exposure"]) == pytest.approx(dexp, rel=2e-4, abs=1e-3)
+    assert Hh.rel_err(g["d_crf_table"], r["dL_dcrf_table"], 1e3 * Hh.grad_floor(tab))[0] <= 2e-2
+    _parity_row("c3 (1M Gaussians, 1920x1080, SH3, HDR + CRF, seed 0): HIP vs fp32 C oracle, rows off the differing pixels",
+                sc, m, g, r, {"R": int(R), "report": {k: v for k, v in rep.items()}})
+
+
+def test_c4_eight_poses_full_size_vs_oracle(oracle):
+    """BASELINE c4 itself: the c3 cloud seen from 8 virtual poses in ONE frame (8 M instances: the pair emission's
+    in-launch chained scan, depth-sort passes of 1954 blocks, 65 280 virtual tiles in strip order + queue) against the C
+    oracle run per pose (eight host threads): per-pose structure and the sorted list of all ~54 M pairs bit for bit,
+    every pose's radiance image off the differing pixels, the blurred LDR / mean radiance, all gradients (sums over the
+    eight poses) on the STRICT bar for >= 90 % of the Gaussians, CRF-table and exposure gradients."""
+    P, W, H, N = 1_000_000, 1920, 1080, 8
+    sc = S.make_scene(P, W, H, 3, seed=0, hdr=True)
+    cams = S.blur_poses(W, H, N)
+    workers = min(N, os.cpu_count() or 1)
+    r = Hh.run_oracle_hdr(oracle, sc, cams, "ldr", workers=workers)
+    g = Hh.run_hip(sc, cameras=cams, hdr=True, blur_domain="ldr")
+    st = g["state"]
+    Rs = [f["R"] for f in r["fwd"]]
+    R = sum(Rs)
+    assert st["num_rendered"] == R
+    tiles = 120 * 68
+    base = 0
+    for k, f in enumerate(r["fwd"]):
+        check_structure(st, f, pose=k, P=P)
+        assert np.array_equal(u32(st["point_list"][base:base + Rs[k]]), u32(f["point_list"]) + k * P), k
+        rg = u32(st["ranges"][k * tiles:(k + 1) * tiles])
+        ref = u32(f["ranges"])
+        full = ref[:, 1] > ref[:, 0]
+        assert np.array_equal(rg[full], ref[full] + base), k
+        assert np.array_equal(rg[~full, 0], rg[~full, 1]), k
+        base += Rs[k]
+    assert np.array_equal(g["radii"], np.max(np.stack([f["radii"] for f in r["fwd"]]), axis=0))
+    m = Hh.decision_masks(oracle, sc, r["fwd"], st, cams, crf_got=list(st["pose_hdr"][:N]),
+                          crf_ref=[f["color"] for f in r["fwd"]], what="c4", workers=workers)
+    for k, f in enumerate(r["fwd"]):
+        check_image(st["pose_hdr"][k], f["color"], m, f"c4 pose {k}", pose=k)
+        check_image(st["final_T"][k], f["final_T"], m, f"c4 final_T {k}", pose=k)
+    any_differs = m["differs"].any(axis=0)
+    for name, got, ref in (("ldr", g["color"], r["ldr"]), ("hdr", g["hdr"], r["hdr"])):
+        e = np.abs(np.asarray(got, np.float64) - ref) / np.maximum(np.abs(ref), 1e-2)
+        assert not ((e > 1e-4).any(axis=0) & ~any_differs).any(), ("c4 " + name, float(e.max()))
+    rep = Hh.assert_grads_close(g, r, what="c4", at_risk=m["rows"], min_strict=0.90)
+    tab, dexp = Hh.crf_grads_given_decisions(oracle, sc, m, [f["color"] for f in r["fwd"]], list(st["pose_hdr"][:N]))
+    assert Hh.rel_err(g["d_crf_table"], tab, 1e3 * Hh.grad_floor(tab))[0] <= 2e-4
+    assert float(g["d_exposure"]) == pytest.approx(dexp, rel=2e-4, abs=1e-3)
+    assert Hh.rel_err(g["d_crf_table"], r["dL_dcrf_table"], 1e3 * Hh.grad_floor(tab))[0] <= 2e-2
+    _parity_row("c4 (c3's cloud, 8 poses per frame): HIP vs fp32 C oracle, rows off the differing pixels",
+                sc, m, g, r, {"R": int(R), "report": {k: v for k, v in rep.items()}})
 
 
 def test_debug_flag_gives_identical_results():

@@ -152,6 +152,32 @@ def test_bench_offline_counters_are_tied_to_the_kernel_source(tmp_path, monkeypa
     assert bench.offline_profile("c3")["same_kernel_source"] is False
 
 
+def test_isa_script_checks_the_wait_states_in_front_of_dpp_reads():
+    """scripts/isa_loop_counts.py asserts, on the ISA the compiler emitted for render.hip, the wait states the hand-written
+    DPP blocks assume (VALU write -> DPP read of the same VGPR as src0: two).  The checker itself: a planted hazard is
+    found, the padded form passes, and the committed counts were made with zero violations."""
+    import importlib.util
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("isa_loop_counts", os.path.join(root, "scripts", "isa_loop_counts.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    bad = {"f": ["\tv_mul_f32_e32 v3, v1, v2", "\ts_nop 0",
+                 "\tv_add_f32_dpp v5, v3, v3 row_shr:8 row_mask:0xf bank_mask:0xc"]}
+    n, v = mod.check_dpp_hazards(bad)
+    assert n == 1 and len(v) == 1 and "v_mul_f32_e32" in v[0]
+    ok = {"f": ["\tv_mul_f32_e32 v3, v1, v2", "\ts_nop 1",
+                "\tv_add_f32_dpp v5, v3, v3 row_shr:8 row_mask:0xf bank_mask:0xc",
+                "\tv_mov_b32_e32 v9, v3", "\tv_mov_b32_e32 v8, v3",
+                "\tv_add_f32_dpp v6, v5, v5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"]}
+    assert mod.check_dpp_hazards(ok) == (2, [])
+    rng = {"f": ["\tv_pk_mul_f32 v[2:3], v[0:1], v[0:1]", "\tv_add_f32_dpp v5, v3, v3 row_shr:4 row_mask:0xf bank_mask:0xa"]}
+    assert len(mod.check_dpp_hazards(rng)[1]) == 1
+    d = json.load(open(os.path.join(root, "profiles", "isa_loop_counts.json")))
+    assert d["dpp_hazard_check"]["violations"] == 0 and d["dpp_hazard_check"]["dpp_instructions_checked"] >= 50
+
+
 def test_bench_exchange_bytes_and_probe_order():
     """config c5 bookkeeping: the probe tries the library-only strategies first (allreduce/rccl first of all: it is also the
     fallback), and the bytes a rank sends per step follow from the tensor sizes (P x 59 fp32 = 236 MB
