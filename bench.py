@@ -136,6 +136,7 @@ def build_step(cfg, rank, world, dev, seed=0):
     def make_rasterizer(capacity):
         # front ends over the same kernels: plain, and with the SH gradient deferred to the view exchange
         return {"allreduce": GaussianRasterizer(rs, capacity=capacity),
+                "allreduce_overlap": GaussianRasterizer(rs, capacity=capacity, reduce_group=True, reduce_chunks=4),
                 "views": GaussianRasterizer(rs, capacity=capacity, defer_sh_grad=True),
                 "views_overlap": GaussianRasterizer(rs, capacity=capacity, defer_sh_grad=True, gather_group=True)}
 
@@ -158,12 +159,14 @@ def build_step(cfg, rank, world, dev, seed=0):
                 # ranks sharing one GPU (the gloo plumbing check) can stall each other's blockIdx-ordered radix passes; the
                 # library has switched to ticket order: repeat the step -- unless this backward already started a
                 # collective of its own (the other ranks run it once)
-                if attempt or (world > 1 and mode == "views_overlap"):
+                if attempt or (world > 1 and mode in ("views_overlap", "allreduce_overlap")):
                     raise
                 for p in plist:
                     p.grad = None
         if world > 1 and mode != "none":   # ("none": the probe's yardstick, a step without the exchange)
-            if mode != "allreduce":
+            if mode == "allreduce_overlap":
+                rast.finish_reduce()      # the backward itself issued the chunked all-reduce, under its per-Gaussian half
+            elif mode != "allreduce":
                 exchange_view_gradients(non_sh, params["shs"], rast.deferred, algo=algo)
             else:
                 all_reduce_gradients(reduced, algo=algo)
@@ -401,8 +404,24 @@ def offline_profile(cfg_name):
         return None
 
 
-EXCHANGES = [("allreduce", "rccl"), ("views", "rccl"), ("views_overlap", "rccl"),       # library collectives only ...
+FALLBACK = ("allreduce", "rccl")   # the plain library all-reduce of the flat gradient buffer: never dropped unless it raises
+EXCHANGES = [("allreduce", "rccl"), ("allreduce_overlap", "rccl"), ("views", "rccl"), ("views_overlap", "rccl"),  # library collectives only ...
              ("allreduce", "direct"), ("views", "direct"), ("views_overlap", "direct")]  # ... then the 1-hop all-to-all forms
+# xGMI of an 8 x MI355X node (MI355X_MICROARCH.md / SURVEY.md 5): a full mesh, 7 links of ~153 GB/s per GPU
+XGMI_LINKS, XGMI_LINK_GBS = 7, 153.0
+
+
+def probe_order(sh_degree: int, everything: bool = False) -> list:
+    """Order in which choose_exchange tries the strategies.  With SH colours (degree >= 1) the view forms go first -- they
+    put 5x fewer bytes on the wire (exchange_bytes) and are the only ones whose model reaches 6x at 8 GPUs
+    (exchange_model) -- then the plain all-reduce with its chunked overlap, the plain all-reduce last: it is the fallback
+    whatever it costs.  Degree 0: the SH row IS the colour gradient, nothing to gain from the view form."""
+    lib = [e for e in EXCHANGES if e[1] == "rccl"]
+    if sh_degree >= 1:
+        lib = [("views_overlap", "rccl"), ("views", "rccl"), ("allreduce_overlap", "rccl"), FALLBACK]
+    else:
+        lib = [("allreduce_overlap", "rccl"), FALLBACK, ("views", "rccl"), ("views_overlap", "rccl")]
+    return lib + ([e for e in EXCHANGES if e[1] == "direct"] if everything else [])
 
 
 def exchange_bytes(mode, world, cfg, crf_K=256):
@@ -420,6 +439,42 @@ def exchange_bytes(mode, world, cfg, crf_K=256):
     return {**payload, "sent_per_rank_bytes": int(sent)}
 
 
+def exchange_model(mode, world, cfg, base_ms=None, crf_K=256):
+    """Analytic cost of one gradient exchange on the xGMI mesh, so the measured probe can be checked against it (and so the
+    scaling a strategy can reach is known before any 8-GPU run).  Per rank: an all-reduce of B bytes moves 2 (w-1)/w B, an
+    all-gather of b bytes per rank (w-1) b.  Two bounds per collective: `ring` = one ring over ONE link per hop
+    (2 (w-1)/w B / link for the all-reduce, (w-1) b / link for the all-gather) and `one_hop` = every peer over its own
+    link at once (2 (B / w) / link; b / link) -- the library lands between them.  `hidden_under_ms`: kernel time of the same
+    step the collective travels beside (the per-Gaussian backward, 0.13 ms per 1M Gaussians and pose at SH degree 3, for
+    what starts after the record sums; the SH rebuild, 0.06 ms per 1M Gaussians and view, for the all-reduce of the view
+    forms) -- r03 stage timings scaled by P.  exposed = what is left; `extra_kernel_ms` = the SH rebuild of the view forms
+    minus the SH rows their backward no longer writes; expected scaling = w x base / (base + exposed + extra)."""
+    P, W, H, deg, hdr, n_poses = cfg
+    b = exchange_bytes("views" if mode.startswith("views") else "allreduce", world, cfg, crf_K)
+    link = XGMI_LINK_GBS * 1e9
+    w = max(world, 2)
+    ar, ag = b["all_reduced_bytes"], b["all_gathered_bytes_per_rank"]
+    t = {"all_reduce_ring_ms": 2 * (w - 1) / w * ar / link * 1e3, "all_reduce_one_hop_ms": 2 * (ar / w) / link * 1e3,
+         "all_gather_ring_ms": (w - 1) * ag / link * 1e3, "all_gather_one_hop_ms": ag / link * 1e3}
+    project_ms = 0.13 * P / 1e6 * n_poses * (0.4 + 0.6 * (3 * (deg + 1) ** 2) / 48.0)
+    # hs_sh_backward_views over V = world x poses views: (12 V + 12 M) bytes per Gaussian at ~4.6 TB/s plus V basis evaluations
+    rebuild_ms = (0.045 + 0.008 * world * n_poses) * P / 1e6 * ((deg + 1) ** 2 / 16.0) if deg >= 1 else 0.0
+    saved_ms = 0.04 * P / 1e6 * ((deg + 1) ** 2 / 16.0) if deg >= 1 else 0.0   # the backward no longer writes the SH rows
+    hide = {"allreduce": (0.0, 0.0), "allreduce_overlap": (project_ms * 0.75, 0.0),   # (under it: all-reduce, all-gather)
+            "views": (rebuild_ms, 0.0), "views_overlap": (rebuild_ms, project_ms)}[mode]
+    out = {**t, "hidden_under_ms": {"all_reduce": hide[0], "all_gather": hide[1]},
+           "extra_kernel_ms": (rebuild_ms - saved_ms) if mode.startswith("views") else 0.0,
+           "note": "bounds for 7 x 153 GB/s xGMI links per GPU: `ring` = one link per hop, `one_hop` = all peers at once; "
+                   "UNMEASURED on hardware until an 8-GPU node runs this"}
+    for algo in ("ring", "one_hop"):
+        exposed = max(0.0, t[f"all_reduce_{algo}_ms"] - hide[0]) + max(0.0, t[f"all_gather_{algo}_ms"] - hide[1])
+        # the view forms run the SH rebuild kernel instead of writing the SH rows in the backward (about the same bytes)
+        out[f"exposed_{algo}_ms"] = exposed
+        if base_ms:
+            out[f"expected_scaling_{algo}"] = world * base_ms / (base_ms + exposed + out["extra_kernel_ms"])
+    return out
+
+
 def choose_exchange(step, state, barrier, dev, rank, world, backend, cfg):
     """Which gradient exchange the timed steps use (config c5).  HS_BENCH_EXCHANGE=<mode>/<algo> pins one and skips the
     probe.  Otherwise: measure, don't guess -- a few whole steps with each strategy on this node's links, safest first
@@ -432,7 +487,8 @@ def choose_exchange(step, state, barrier, dev, rank, world, backend, cfg):
         236 MB exchange takes 50-330 ms and the cap drops everything but the fallback; over xGMI it is 1-3 ms);
       * the probe covers the library-collective strategies only (all-reduce, all-reduce + all-gather); the 1-hop
         all-to-all forms, which no multi-GPU node has run yet, join it with HS_BENCH_PROBE=all.
-    "allreduce" = all-reduce of the flat per-Gaussian gradient buffer; "views" = all-reduce of the non-SH part +
+    "allreduce" = all-reduce of the flat per-Gaussian gradient buffer; "allreduce_overlap" = the same bytes, issued chunk by
+    chunk from inside the backward while its per-Gaussian half computes the next chunk; "views" = all-reduce of the non-SH part +
     all-gather of per-view colour gradients, SH gradient rebuilt locally; "views_overlap" = the same with the all-gather
     started inside the backward, under its per-Gaussian half; "rccl" / "direct" = library ring vs 1-hop all-to-all."""
     import torch
@@ -452,7 +508,10 @@ def choose_exchange(step, state, barrier, dev, rank, world, backend, cfg):
         barrier()
         return (time.perf_counter() - t0) / n * 1e3
 
-    info = {"backend": backend, "bytes": {f"{m}/{a}": exchange_bytes(m, world, cfg) for m, a in EXCHANGES if a == "rccl"}}
+    info = {"backend": backend,
+            "bytes": {f"{m}/{a}": exchange_bytes("views" if m.startswith("views") else "allreduce", world, cfg)
+                      for m, a in EXCHANGES if a == "rccl"},
+            "model_ms": {m: exchange_model(m, world, cfg) for m, a in EXCHANGES if a == "rccl"}}
     pinned = os.environ.get("HS_BENCH_EXCHANGE", "").strip()
     if pinned:
         mode, _, algo = pinned.partition("/")
@@ -466,7 +525,8 @@ def choose_exchange(step, state, barrier, dev, rank, world, backend, cfg):
     step()
     base_ms = agree([timed_steps(2)])[0]
     cap_ms = float(os.environ.get("HS_BENCH_PROBE_CAP_X", "20")) * base_ms
-    candidates = list(EXCHANGES) if os.environ.get("HS_BENCH_PROBE") == "all" else [e for e in EXCHANGES if e[1] == "rccl"]
+    info["model_ms"] = {m: exchange_model(m, world, cfg, base_ms) for m, a in EXCHANGES if a == "rccl"}
+    candidates = probe_order(cfg[3], os.environ.get("HS_BENCH_PROBE") == "all")
     direct_ok = None
     times, dropped = {}, {}
     for mode, algo in candidates:
@@ -484,7 +544,7 @@ def choose_exchange(step, state, barrier, dev, rank, world, backend, cfg):
             ok, err = 0.0, str(e)[:200]
         first_ms, bad = agree([first_ms, 1.0 - ok])
         # (the plain library all-reduce is the fallback whatever it costs: only a failure removes it)
-        over = first_ms > cap_ms and (mode, algo) != EXCHANGES[0]
+        over = first_ms > cap_ms and (mode, algo) != FALLBACK
         if over and not bad and first_ms <= 50.0 * cap_ms:
             # the first use of a collective pays one-time costs (RCCL sets its channels up lazily): one second chance,
             # decided on the agreed MAX like everything else, so every rank takes the same branch

@@ -68,6 +68,7 @@ class hs_bwd_args(C.Structure):
         ("dL_dviewmatrices", _fp), ("dL_dprojmatrices", _fp), ("dL_dcamposes", _fp),
         ("dL_dview_colors", _fp), ("dL_dout_invdepth", _fp),
         ("densify_grad_accum", _fp), ("densify_denom", _fp), ("densify_max_radii", _fp),
+        ("g_begin", C.c_int32), ("g_end", C.c_int32),
     ]
 
 

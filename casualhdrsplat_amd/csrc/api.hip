@@ -274,6 +274,14 @@ int hs_backward(const hs_bwd_args* a, void* hip_stream) {
         set_error("hs_backward: densification statistics need grad_accum, denom and max_radii together");
         return HS_EINVAL;
     }
+    if (a->g_begin != 0 || a->g_end != 0) {
+        if (a->g_begin < 0 || a->g_end < a->g_begin || a->g_end > a->dims.P || (a->g_begin & 127) ||
+            (a->stages & ~HS_BWD_PROJECT)) {
+            set_error("hs_backward: [g_begin, g_end) = [%d, %d) needs 0 <= g_begin <= g_end <= P, g_begin a multiple of 128, "
+                      "and stages == HS_BWD_PROJECT", a->g_begin, a->g_end);
+            return HS_EINVAL;
+        }
+    }
     if (a->dims.P == 0) return HS_OK;
     if (a->stages & HS_BWD_RENDER) {
         rc = launch_render_bwd(*a, L, s);

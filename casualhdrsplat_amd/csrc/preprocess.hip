@@ -405,6 +405,7 @@ struct PreBwd {
     float* d_rots; float* d_cov;
     float* dens_grad; float* dens_denom; int* dens_radii;  // densification statistics, updated in place, or null
     float* pose_partials;  // [blocks][N][kPoseVals] or null
+    int blk0;              // first block of this launch (hs_bwd_args.g_begin / kPreBwdBlock: a chunk of the Gaussians)
 };
 
 // Camera-pose gradient terms per pose: 12 view-matrix entries (flat 4j+i, i<3), 12 projection entries (rows 0,1,3),
@@ -455,7 +456,8 @@ __global__ void __launch_bounds__(kPreBwdBlock) preprocess_bwd_kernel(PreBwd p) 
     extern __shared__ float s_sh[];  // [kPreBwdBlock][M*3 + 1]
     __shared__ float s_pose[kPreBwdBlock / 64][kPoseVals];
     constexpr int NC = (DEG + 1) * (DEG + 1);
-    const int g0 = blockIdx.x * kPreBwdBlock;
+    const int blk = (int)blockIdx.x + p.blk0;
+    const int g0 = blk * kPreBwdBlock;
     const int g = g0 + threadIdx.x;
     const int M3 = p.M * 3, ld = M3 + 1;
     const int rows = min(kPreBwdBlock, p.P - g0);
@@ -651,7 +653,7 @@ __global__ void __launch_bounds__(kPreBwdBlock) preprocess_bwd_kernel(PreBwd p) 
             }
             __syncthreads();
             if (threadIdx.x < kPoseVals - 1)
-                p.pose_partials[((int64_t)blockIdx.x * p.N + pose) * kPoseVals + threadIdx.x] =
+                p.pose_partials[((int64_t)blk * p.N + pose) * kPoseVals + threadIdx.x] =
                     s_pose[0][threadIdx.x] + s_pose[1][threadIdx.x];
         }
     }
@@ -901,7 +903,13 @@ int launch_preprocess_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t 
     p.d_cov = a.dL_dcov3D_precomp;
     p.dens_grad = a.densify_grad_accum; p.dens_denom = a.densify_denom; p.dens_radii = a.densify_max_radii;
     const bool shg = p.d_shs != nullptr;
-    const int grid = ceil_div(d.P, kPreBwdBlock);
+    // hs_bwd_args.g_begin / g_end: this launch covers the Gaussians [g_lo, g_hi) (all of them by default); a step that
+    // exchanges gradients chunk by chunk enqueues the chunks in ascending order
+    const bool ranged = a.g_begin != 0 || a.g_end != 0;
+    const int g_lo = ranged ? a.g_begin : 0, g_hi = ranged ? a.g_end : d.P;
+    const int nblk_all = ceil_div(d.P, kPreBwdBlock);
+    const int grid = ceil_div(g_hi - g_lo, kPreBwdBlock);
+    p.blk0 = g_lo / kPreBwdBlock;
     const int deg = a.colors_precomp ? 0 : d.sh_degree;
     const size_t lds = (size_t)kPreBwdBlock * (d.M * 3 + 1) * sizeof(float);
     float* pose_partials = a.dL_dviewmatrices ? (float*)((char*)a.bwd + L.pose_partials) : nullptr;
@@ -911,7 +919,7 @@ int launch_preprocess_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t 
     else if (pose_partials) preprocess_bwd_kernel<DEG_, true, false><<<grid, kPreBwdBlock, lds, s>>>(p);        \
     else if (shg) preprocess_bwd_kernel<DEG_, false, true><<<grid, kPreBwdBlock, lds, s>>>(p);                  \
     else preprocess_bwd_kernel<DEG_, false, false><<<grid, kPreBwdBlock, lds, s>>>(p)
-    switch (deg) {
+    if (grid > 0) switch (deg) {
         case 0: HS_LAUNCH_PRE_BWD(0); break;
         case 1: HS_LAUNCH_PRE_BWD(1); break;
         case 2: HS_LAUNCH_PRE_BWD(2); break;
@@ -919,7 +927,8 @@ int launch_preprocess_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t 
     }
 #undef HS_LAUNCH_PRE_BWD
     HS_LAUNCH_CHECK();
-    if (pose_partials) {
+    if (pose_partials && g_hi >= d.P) {   // (the last chunk: every block's partial row is written by now)
+        const int grid = nblk_all;
         const int cols = d.n_poses * kPoseVals;
         float* stage = pose_partials + (int64_t)grid * cols;
         // unused matrix entries (row 3 of the view matrix, row 2 of the projection) stay zero

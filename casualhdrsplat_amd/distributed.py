@@ -201,6 +201,57 @@ def all_reduce_gradients(params: Iterable[torch.Tensor], group=None, average: bo
     return packed.numel()
 
 
+def chunk_bounds(P: int, chunks: int, align: int = 128) -> list:
+    """[(g0, g1)] covering [0, P) in at most `chunks` ascending pieces whose starts are multiples of `align` (the
+    workgroup size of the per-Gaussian backward: hs_bwd_args.g_begin)."""
+    if P <= 0:
+        return []
+    chunks = max(1, int(chunks))
+    per = max(align, ((P + chunks - 1) // chunks + align - 1) // align * align)
+    return [(g0, min(P, g0 + per)) for g0 in range(0, P, per)]
+
+
+def chunked_all_reduce(rows: Sequence[torch.Tensor], P: int, chunks: int, compute_chunk, tail: Sequence[torch.Tensor] = (),
+                       group=None) -> list:
+    """The plain gradient exchange, overlapped with the kernels that produce the gradients (BASELINE.json configs[4]).
+
+    rows           per-Gaussian gradient tensors [P, ...] (contiguous; in the rasterizer: views of its flat buffer);
+    compute_chunk  callable (g0, g1): enqueue the computation of rows [g0, g1) of every tensor in `rows` on the current
+                   stream (the rasterizer: hs_backward(HS_BWD_PROJECT, g_begin, g_end));
+    tail           gradients that are complete before the first chunk (exposure, CRF table): reduced with the first one.
+    For each ascending chunk: compute it, then issue the asynchronous all-reduce of exactly those rows of every tensor --
+    on RCCL the collective waits (on its own stream) for what the current stream holds at that moment, i.e. for the
+    chunk just enqueued, and travels while the next chunk computes.  Returns the list of completion callables
+    (finish_pending waits for them); [] when not distributed (the chunks are still computed).  Element for element
+    the result is that of one all-reduce of the whole buffer: every element is summed over the ranks exactly once."""
+    distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    pending: list = []
+    first = True
+    for g0, g1 in chunk_bounds(P, chunks):
+        compute_chunk(g0, g1)
+        if not distributed:
+            continue
+        pieces = [t[g0:g1] for t in rows] + (list(tail) if first else [])
+        first = False
+        for t in pieces:
+            if t.numel() == 0:
+                continue
+            if not t.is_contiguous():
+                raise ValueError("chunked_all_reduce: gradient rows must be contiguous")
+            work = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True)
+            pending.append(work.wait)
+    return pending
+
+
+def finish_pending(pending) -> int:
+    """Wait for the collectives chunked_all_reduce / all_reduce_gradients(pending=...) left in flight."""
+    n = 0
+    for fin in pending or ():
+        fin()
+        n += 1
+    return n
+
+
 def _gather_rows(out: torch.Tensor, inp: torch.Tensor, group, direct: bool, async_op: bool = False):
     """out[r * n : (r + 1) * n] = rank r's `inp` (n = inp.shape[0]).  direct: every rank sends its block straight to
     every peer (a list all-to-all = grouped point-to-point sends over all seven xGMI links at once) instead of the

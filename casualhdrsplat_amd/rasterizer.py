@@ -389,7 +389,11 @@ class _RasterizeGaussians(torch.autograd.Function):
             g = _launch_backward(st, saved, gcol, ghdr, L.HS_BWD_ALL, want_pose, galpha,
                                  defer_sh=ctx.deferred is not None, ginvd=ginvd, densify=ctx.densify,
                                  gather_group=None if ctx.deferred is None else ctx.deferred.get("gather_group"),
-                                 gather_direct=bool(ctx.deferred.get("gather_direct")) if ctx.deferred else False)
+                                 gather_direct=bool(ctx.deferred.get("gather_direct")) if ctx.deferred else False,
+                                 reduce_group=None if ctx.aux is None else ctx.aux.get("reduce_group"),
+                                 reduce_chunks=0 if ctx.aux is None else int(ctx.aux.get("reduce_chunks") or 0))
+        if ctx.aux is not None and g.get("_reduce_pending") is not None:
+            ctx.aux["cell"]["reduce_pending"] = g["_reduce_pending"]   # GaussianRasterizer.finish_reduce() waits for these
         if ctx.deferred is not None:
             # view-parallel exchange: hand the per-view colour gradients to distributed.exchange_view_gradients
             ctx.deferred.update(view_colors=g["view_colors"], camposes=st.camposes, means3D=saved[0],
@@ -424,10 +428,10 @@ class _RasterizeGaussians(torch.autograd.Function):
 
 def _launch_backward(st: "_State", saved, gcol, ghdr, stages: int, want_pose: bool = False, galpha=None,
                      defer_sh: bool = False, ginvd=None, densify=None, gather_group=None, stats=None,
-                     timeline=None, gather_direct: bool = False) -> dict:
+                     timeline=None, gather_direct: bool = False, reduce_group=None, reduce_chunks: int = 0) -> dict:
     """Enqueue hs_backward.  All per-Gaussian gradients are carved out of ONE flat fp32 buffer (the
-    layout casualhdrsplat_amd.distributed all-reduces in a single RCCL call): [means3D | opacities | sh | colors |
-    scales | rotations | cov3D | exposure | crf_table | means2D | pose gradients].  means2D -- the screen-space
+    layout casualhdrsplat_amd.distributed all-reduces in a single RCCL call): [means3D | opacities | colors | scales |
+    rotations | cov3D | exposure | crf_table | sh | means2D | pose gradients].  means2D -- the screen-space
     gradient of THIS view, a densification statistic and not a parameter gradient -- comes after everything a
     view-parallel step sums over the ranks, so the summed set is one contiguous span without it."""
     lib = L.load()
@@ -437,10 +441,12 @@ def _launch_backward(st: "_State", saved, gcol, ghdr, stages: int, want_pose: bo
     _, sizes, _ = L.plan(P, M, st.dims.sh_degree, st.W, st.H, st.dims.n_poses, st.dims.capacity, st.dims.crf_K)
     bwd = torch.empty(max(int(sizes.bwd_bytes), 256), dtype=torch.uint8, device=dev)
     hdr = bool(st.flags & L.HS_FLAG_HDR)
-    spec = [("means3D", (P, 3), True), ("opacities", (P, 1), True),
-            ("shs", (P, M, 3), shs is not None and not defer_sh), ("colors_precomp", (P, 3), cp is not None),
+    # (the SH rows -- four fifths of the bytes at degree 3 -- come last of the summed span, so a chunked exchange moves the
+    # other per-Gaussian rows as a few short slices and the SH rows of a chunk as ONE long one)
+    spec = [("means3D", (P, 3), True), ("opacities", (P, 1), True), ("colors_precomp", (P, 3), cp is not None),
             ("scales", (P, 3), sc is not None), ("rotations", (P, 4), ro is not None),
             ("cov3D_precomp", (P, 6), cv is not None), ("exposure", (1,), hdr), ("crf_table", (3, st.crf_K), hdr),
+            ("shs", (P, M, 3), shs is not None and not defer_sh),
             ("means2D", (P, 3), True),
             ("viewmatrices", (st.dims.n_poses, 16), want_pose), ("projmatrices", (st.dims.n_poses, 16), want_pose),
             ("camposes", (st.dims.n_poses, 3), want_pose)]
@@ -503,6 +509,25 @@ def _launch_backward(st: "_State", saved, gcol, ghdr, stages: int, want_pose: bo
         a.stages = L.HS_BWD_PROJECT
         L.check(lib.hs_backward(C.byref(a), _stream()), "hs_backward[project]")
         a.stages = stages
+    elif reduce_group is not None and reduce_chunks > 0 and stages == L.HS_BWD_ALL:
+        # view-parallel step with the plain (all-reduce) exchange: the per-Gaussian half runs in ascending chunks of the
+        # Gaussians and the all-reduce of a chunk's gradient rows starts while the next chunk computes
+        # (distributed.chunked_all_reduce; the caller waits with distributed.finish_pending before reading a gradient)
+        from . import distributed as D
+        a.stages = L.HS_BWD_RENDER | L.HS_BWD_CRF | L.HS_BWD_SEGSUM
+        L.check(lib.hs_backward(C.byref(a), _stream()), "hs_backward[render+segsum]")
+        a.stages = L.HS_BWD_PROJECT
+
+        def project(g0, g1):
+            a.g_begin, a.g_end = int(g0), int(g1)
+            L.check(lib.hs_backward(C.byref(a), _stream()), "hs_backward[project chunk]")
+
+        rows = [g[k] for k in ("means3D", "opacities", "colors_precomp", "scales", "rotations", "cov3D_precomp", "shs")
+                if g[k] is not None]
+        tail = [g[k] for k in ("exposure", "crf_table") if g[k] is not None]
+        g["_reduce_pending"] = D.chunked_all_reduce(rows, P, reduce_chunks, project, tail=tail,
+                                                    group=None if reduce_group is True else reduce_group)
+        a.g_begin, a.g_end, a.stages = 0, 0, stages
     else:
         L.check(lib.hs_backward(C.byref(a), _stream()), "hs_backward")
     return g
@@ -621,8 +646,15 @@ class GaussianRasterizer(nn.Module):
 
     def __init__(self, raster_settings: GaussianRasterizationSettings, capacity: Optional[int] = None,
                  return_alpha: bool = False, defer_sh_grad: bool = False, return_invdepth: bool = False,
-                 densify_stats: Optional[DensifyStats] = None, gather_group=None, keep_state: bool = False):
+                 densify_stats: Optional[DensifyStats] = None, gather_group=None, keep_state: bool = False,
+                 reduce_group=None, reduce_chunks: int = 4):
         super().__init__()
+        # view-parallel training with the plain exchange (every rank renders its own view; the per-Gaussian gradients
+        # are summed over the ranks): a torch.distributed process group (or True for the default group) makes the
+        # backward run its per-Gaussian half in `reduce_chunks` ascending chunks and start the all-reduce of each
+        # chunk's gradient rows while the next chunk computes; call finish_reduce() before reading any gradient
+        self.reduce_group = reduce_group
+        self.reduce_chunks = int(reduce_chunks)
         # with defer_sh_grad: a torch.distributed process group (or True for the default group) makes the backward
         # start the all-gather of the view colour gradients itself, overlapped with its per-Gaussian half
         self.gather_group = gather_group
@@ -662,6 +694,12 @@ class GaussianRasterizer(nn.Module):
             raise BinningOverflow(n, pend.capacity)
         return n
 
+    def finish_reduce(self) -> int:
+        """Wait for the chunked all-reduce the latest backward started (reduce_group=...); returns the number of
+        collectives waited for (0: nothing was pending, e.g. a single-rank run)."""
+        from .distributed import finish_pending
+        return finish_pending(self._cell.pop("reduce_pending", None))
+
     def markVisible(self, positions: torch.Tensor) -> torch.Tensor:
         lib = L.load()
         with torch.no_grad():
@@ -699,6 +737,8 @@ class GaussianRasterizer(nn.Module):
                 self.deferred["gather_group"] = self.gather_group
                 self.deferred["gather_direct"] = bool(self.gather_direct)
             aux = {"keep_state": self.keep_state, "cell": self._cell}
+            if self.reduce_group is not None and not self.defer_sh_grad:
+                aux["reduce_group"], aux["reduce_chunks"] = self.reduce_group, self.reduce_chunks
             outs = rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
                                        cov3D_precomp, rs, self.capacity, self.return_alpha, self.deferred,
                                        self.return_invdepth, self.densify_stats, aux)

@@ -35,7 +35,7 @@ extern "C" {
 /* libhdrsplat.so is built with -fvisibility=hidden: the hs_* entry points below are its only exported symbols */
 #define HS_API __attribute__((visibility("default")))
 
-#define HS_VERSION 302
+#define HS_VERSION 303
 
 #define HS_OK 0
 #define HS_EINVAL (-1)    /* bad argument (null pointer, bad shape, unsupported degree ...) */
@@ -197,6 +197,12 @@ typedef struct hs_bwd_args {
     float* densify_grad_accum;    /* [P] */
     float* densify_denom;         /* [P] */
     int32_t* densify_max_radii;   /* [P] */
+    /* HS_BWD_PROJECT over the Gaussians [g_begin, g_end) only (both 0: all of them).  The per-Gaussian half of the
+     * backward is one thread per Gaussian, so a view-parallel step may run it in ascending chunks and start the
+     * exchange of a chunk's gradient rows while the next chunk computes (casualhdrsplat_amd.distributed.
+     * chunked_all_reduce; BASELINE.json configs[4]).  g_begin must be a multiple of 128; the chunks of one backward
+     * must be enqueued in ascending order, the last one ending at P (it also finishes the pose-gradient reduction). */
+    int32_t g_begin, g_end;
 } hs_bwd_args;
 
 /* Byte offsets of the arrays carved out of the three state workspaces, for tests, profilers and

@@ -29,13 +29,14 @@ def main():
     sc = S.make_scene(3000, W, Hh, 3, seed=7)
     names = ("means3D", "means2D", "opacities", "shs", "scales", "rotations")
 
-    def backward(view_rank, defer, overlap=False):
+    def backward(view_rank, defer, overlap=False, chunked=False):
         sc.camera = S.yaw_camera(W, Hh, -5.0 + 10.0 * view_rank / max(world - 1, 1))
         rs, _, _ = H.settings_from_scene(sc, dev)
         leaf = {k: t.clone().to(dev).requires_grad_(True) for k, t in
                 dict(means3D=sc.means3D, means2D=torch.zeros_like(sc.means3D), opacities=sc.opacities, shs=sc.shs,
                      scales=sc.scales, rotations=sc.rotations).items()}
-        rast = GaussianRasterizer(rs, defer_sh_grad=defer, gather_group=True if overlap else None)
+        rast = GaussianRasterizer(rs, defer_sh_grad=defer, gather_group=True if overlap else None,
+                                  reduce_group=True if chunked else None, reduce_chunks=3)
         out = rast(leaf["means3D"], leaf["means2D"], leaf["opacities"], shs=leaf["shs"], scales=leaf["scales"],
                    rotations=leaf["rotations"])
         (out[0] * sc.dL_dimage.to(dev)).sum().backward()
@@ -47,12 +48,20 @@ def main():
         g = {k: leaf[k].grad.clone() for k in names}
         want = g if want is None else {k: want[k] + g[k] for k in names}
 
-    for mode in ("allreduce", "views", "views_overlap"):
+    for mode in ("allreduce", "allreduce_overlap", "views", "views_overlap"):
         for algo in ("rccl", "direct"):
-            leaf, rast = backward(rank, mode != "allreduce", overlap=mode == "views_overlap")
+            if mode == "allreduce_overlap" and algo == "direct":
+                continue
+            leaf, rast = backward(rank, mode.startswith("views"), overlap=mode == "views_overlap",
+                                  chunked=mode == "allreduce_overlap")
             if mode == "views_overlap":
                 assert rast.deferred["gather"] is not None
-            if mode != "allreduce":
+            if mode == "allreduce_overlap":
+                # the backward ran its per-Gaussian half in 3 chunks and started each chunk's all-reduce itself; means2D (this
+                # view's screen-space gradient) is not part of it
+                assert rast.finish_reduce() > 0
+                all_reduce_gradients([leaf["means2D"]], algo=algo)
+            elif mode != "allreduce":
                 n = exchange_view_gradients([leaf[k] for k in names if k != "shs"], leaf["shs"], rast.deferred, algo=algo)
                 assert n["all_gathered"] == world * (3000 * 3 + 3), n
             else:

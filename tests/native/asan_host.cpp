@@ -73,6 +73,15 @@ static int run() {
     CHECK(hs_backward(&b, nullptr) == HS_EINVAL);
     b.means3D = b.viewmatrices = b.projmatrices = b.camposes = b.bg = b.shs = b.scales = b.rotations = fake;
     CHECK(hs_backward(&b, nullptr) == HS_EINVAL && std::strstr(hs_last_error(), "null workspace"));
+    // a Gaussian range is for HS_BWD_PROJECT alone, starts on a workgroup boundary and lies inside [0, P]
+    b.geom = b.binning = b.image = b.bwd = fake; b.dL_dout_color = fake;
+    b.stages = HS_BWD_PROJECT; b.g_begin = 64; b.g_end = b.dims.P;
+    CHECK(hs_backward(&b, nullptr) == HS_EINVAL && std::strstr(hs_last_error(), "g_begin"));
+    b.g_begin = 0; b.g_end = b.dims.P + 1;
+    CHECK(hs_backward(&b, nullptr) == HS_EINVAL && std::strstr(hs_last_error(), "g_begin"));
+    b.g_end = b.dims.P; b.stages = HS_BWD_ALL;
+    CHECK(hs_backward(&b, nullptr) == HS_EINVAL && std::strstr(hs_last_error(), "HS_BWD_PROJECT"));
+    b.g_begin = b.g_end = 0; b.geom = b.binning = b.image = b.bwd = nullptr; b.dL_dout_color = nullptr;
     CHECK(hs_mark_visible(-1, nullptr, nullptr, nullptr, nullptr) == HS_EINVAL);
     CHECK(hs_mark_visible(0, nullptr, nullptr, nullptr, nullptr) == HS_OK);
     CHECK(hs_sort_pairs(nullptr, nullptr, nullptr, nullptr, 5, 40, nullptr, nullptr) == HS_EINVAL);

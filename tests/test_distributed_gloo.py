@@ -145,6 +145,101 @@ def test_allreduce_equals_sum_of_single_view_gradients(oracle, shared_flat, algo
     assert np.abs(want[0]).max() > 0
 
 
+def _worker_chunked(rank, world, port, q):
+    """The rasterizer's flat gradient buffer (rasterizer._launch_backward: [means3D | opacities | scales | rotations |
+    exposure | crf_table | sh | means2D]) filled chunk by chunk the way hs_backward(HS_BWD_PROJECT, g_begin, g_end) fills
+    it, each chunk's rows all-reduced as soon as they exist (distributed.chunked_all_reduce), against ONE all-reduce of the
+    whole span afterwards (all_reduce_gradients): bit for bit the same sums.  Rows a chunk has not computed yet hold NaN: a
+    collective that ran ahead of its chunk would poison the result."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from casualhdrsplat_amd.distributed import (all_reduce_gradients, chunk_bounds, chunked_all_reduce, finish_pending,
+                                                init_from_env)
+    init_from_env("gloo")
+    src = [torch.from_numpy(g.copy()) for g in _view_grads(rank, world)]   # means3D, means2D, opacity, sh, scales, rots
+    P, K = src[0].shape[0], 5
+    order = [0, 2, 4, 5, 3]                                                 # summed span: means3D, opacity, scales, rots | sh
+    tail_src = [torch.full((1,), 10.0 + rank), torch.arange(3 * K, dtype=torch.float32).reshape(3, K) * (rank + 1)]
+
+    def carve(fill):
+        sizes = [src[i].numel() for i in order[:-1]] + [t.numel() for t in tail_src] + [src[3].numel(), src[1].numel()]
+        flat = torch.full((sum((n + 3) // 4 * 4 for n in sizes),), fill)
+        views, o = [], 0
+        shapes = [src[i].shape for i in order[:-1]] + [t.shape for t in tail_src] + [src[3].shape, src[1].shape]
+        for n, sh in zip(sizes, shapes):
+            views.append(flat[o:o + n].view(sh))
+            o += (n + 3) // 4 * 4
+        return flat, views
+
+    # chunked: rows appear chunk by chunk
+    flat_c, v = carve(float("nan"))
+    rows_c, tail_c, m2d_c = v[:4] + [v[6]], v[4:6], v[7]
+    for t, s_ in zip(tail_c, tail_src):
+        t.copy_(s_)
+    m2d_c.copy_(src[1])
+    calls = []
+
+    def compute(g0, g1):
+        calls.append((g0, g1))
+        for t, i in zip(rows_c, order):
+            t[g0:g1] = src[i][g0:g1]
+
+    pending = chunked_all_reduce(rows_c, P, 3, compute, tail=tail_c)
+    assert calls == chunk_bounds(P, 3) and calls[0][0] == 0 and calls[-1][1] == P and all(a % 128 == 0 for a, _ in calls)
+    assert finish_pending(pending) == len(calls) * len(rows_c) + len(tail_c)
+    # unchunked: the whole span in one collective
+    flat_u, v = carve(0.0)
+    views_u = v
+    params = []
+    for t, s_ in zip(v[:4] + v[4:6] + [v[6]], [src[i] for i in order[:-1]] + tail_src + [src[3]]):
+        t.copy_(s_)
+        p = torch.zeros(t.shape, requires_grad=True)
+        p.grad = t
+        params.append(p)
+    v[7].copy_(src[1])
+    all_reduce_gradients(params)
+    _, views_c = flat_c, rows_c[:4] + tail_c + [rows_c[4], m2d_c]
+    same = all(torch.equal(a.contiguous().view(torch.int32), b.contiguous().view(torch.int32))
+               for a, b in zip(views_c, views_u))   # (the 16-byte pads between the slices belong to nobody)
+    m2d_local = torch.equal(m2d_c, src[1])   # the screen-space gradient of THIS view stays on its rank
+    if rank == 0:
+        q.put((same, m2d_local, [t.numpy().copy() for t in rows_c]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_chunked_exchange_equals_one_all_reduce_bit_for_bit(oracle):
+    """the per-Gaussian backward in K ascending chunks, each chunk's gradient rows all-reduced while the
+    next computes == the sum of the single-view gradients, bit for bit the unchunked exchange."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_chunked, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    same, m2d_local, rows = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert same and m2d_local
+    views = [_view_grads(r, world) for r in range(world)]
+    for got, i in zip(rows, [0, 2, 4, 5, 3]):
+        want = views[0][i] + views[1][i]
+        assert np.array_equal(got, want) and np.abs(want).max() > 0
+
+
+def test_chunk_bounds_cover_the_cloud_in_aligned_ascending_pieces():
+    from casualhdrsplat_amd.distributed import chunk_bounds
+    for P, K in ((1, 4), (127, 4), (128, 4), (129, 2), (1000, 3), (1_000_000, 4), (1_000_000, 1), (5, 0)):
+        b = chunk_bounds(P, K)
+        assert b[0][0] == 0 and b[-1][1] == P and len(b) <= max(1, K)
+        assert all(g0 % 128 == 0 and g1 > g0 for g0, g1 in b) and all(x[1] == y[0] for x, y in zip(b, b[1:]))
+    assert chunk_bounds(0, 4) == []
+
+
 def test_single_process_is_a_noop():
     from casualhdrsplat_amd.distributed import all_reduce_gradients
     p = torch.zeros(3, requires_grad=True)

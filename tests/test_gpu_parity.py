@@ -952,6 +952,36 @@ def test_view_parallel_step_two_ranks_on_one_gpu():
     assert r.stdout.count("VIEW-EXCHANGE-OK") == 2, r.stdout[-2000:]
 
 
+def test_backward_in_gaussian_chunks_is_bit_identical_to_the_whole_backward():
+    """hs_bwd_args.g_begin / g_end (the chunked exchange of a view-parallel step, distributed.chunked_all_reduce): the
+    per-Gaussian half of the backward run in ascending chunks of the Gaussians writes bit for bit the gradients of the
+    single launch -- per-Gaussian rows, the camera-pose gradients (whose per-workgroup partial rows are reduced after the
+    last chunk) and the densification statistics.  Single rank: no collective runs, the chunks do."""
+    from casualhdrsplat_amd import DensifyStats, GaussianRasterizer
+    dev = "cuda"
+    sc = S.make_scene(5000, 224, 144, 3, seed=17, hdr=True)
+    cams = S.blur_poses(224, 144, 3, step=0.02)
+    res = []
+    for chunks in (0, 1, 3, 64):
+        rs, expo, crf = Hh.settings_from_scene(sc, dev, cams, hdr=True, requires_grad=True)
+        rs = rs._replace(viewmatrices=rs.viewmatrices.clone().requires_grad_(True),
+                         projmatrices=rs.projmatrices.clone().requires_grad_(True),
+                         camposes=rs.camposes.clone().requires_grad_(True))
+        leaf = [t.clone().to(dev).requires_grad_(True) for t in (sc.means3D, torch.zeros_like(sc.means3D), sc.opacities,
+                                                                  sc.shs, sc.scales, sc.rotations)]
+        dens = DensifyStats(5000, dev)
+        rast = GaussianRasterizer(rs, densify_stats=dens, reduce_group=True if chunks else None, reduce_chunks=chunks)
+        out = rast(leaf[0], leaf[1], leaf[2], shs=leaf[3], scales=leaf[4], rotations=leaf[5])
+        (out[0] * sc.dL_dimage.to(dev)).sum().backward()
+        assert rast.finish_reduce() == 0   # one rank: nothing on the wire
+        res.append([t.grad.clone() for t in leaf + [expo, crf, rs.viewmatrices, rs.projmatrices, rs.camposes]] +
+                   [dens.grad_accum.clone(), dens.denom.clone(), dens.max_radii.clone()])
+    assert float(res[0][3].abs().sum()) > 0 and float(res[0][8].abs().sum()) > 0
+    for other in res[1:]:
+        for a, b in zip(res[0], other):
+            assert torch.equal(a, b)
+
+
 def test_view_parallel_step_two_ranks_over_rccl():
     """The same check over backend "nccl" (= RCCL), one GPU per rank -- runs wherever the box has two GPUs."""
     import socket
@@ -997,6 +1027,9 @@ def test_bench_bare_multi_gpu_invocation_launches_its_own_ranks():
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
     ex = d["config"]["gradient_exchange"]
     assert ex["choice"] in ex["step_ms"] and len(ex["step_ms"]) >= 2, ex
+    # the analytic cost of every library strategy rides along, so the measured probe can be read against it
+    assert set(ex["model_ms"]) >= {"allreduce", "allreduce_overlap", "views", "views_overlap"}
+    assert ex["model_ms"]["allreduce"]["all_reduce_ring_ms"] > ex["model_ms"]["views"]["all_reduce_ring_ms"] > 0
     # every strategy that was kept stayed under the probe's cap; the dropped ones say why
     assert all(t <= ex["first_step_cap_ms"] for t in ex["step_ms"].values()) and isinstance(ex["dropped"], dict), ex
     assert ex["bytes"]["allreduce/rccl"]["sent_per_rank_bytes"] == 100_000 * 14 * 4   # c2, SH degree 0, two ranks: 2 * 1/2 * payload

@@ -179,11 +179,24 @@ def test_isa_script_checks_the_wait_states_in_front_of_dpp_reads():
 
 
 def test_bench_exchange_bytes_and_probe_order():
-    """config c5 bookkeeping: the probe tries the library-only strategies first (allreduce/rccl first of all: it is also the
-    fallback), and the bytes a rank sends per step follow from the tensor sizes (P x 59 fp32 = 236 MB
-    all-reduced at c3; the view form all-reduces P x 11 fp32 and all-gathers 12 B per Gaussian and view)."""
+    """config c5 bookkeeping: with SH colours the probe tries the view forms first (5x fewer bytes, the only ones whose model
+    reaches 6x), the plain library all-reduce LAST -- it is the fallback and is never dropped for being slow; the 1-hop
+    all-to-all forms join only on request.  The bytes a rank sends per step follow from the tensor sizes (SURVEY.md 2.4:
+    P x 59 fp32 = 236 MB all-reduced at c3; the view form all-reduces P x 11 fp32 and all-gathers 12 B per Gaussian and
+    view), and the analytic model prices them on 7 x 153 GB/s links."""
     import bench
-    assert bench.EXCHANGES[0] == ("allreduce", "rccl") and [a for _, a in bench.EXCHANGES[:3]] == ["rccl"] * 3
+    assert bench.FALLBACK == ("allreduce", "rccl") and bench.FALLBACK in bench.EXCHANGES
+    o3 = bench.probe_order(3)
+    assert o3[0][0].startswith("views") and o3[-1] == bench.FALLBACK and all(a == "rccl" for _, a in o3)
+    assert ("allreduce_overlap", "rccl") in o3
+    assert bench.probe_order(0)[0][0].startswith("allreduce") and bench.FALLBACK in bench.probe_order(0)
+    assert [e for e in bench.probe_order(3, everything=True) if e[1] == "direct"] and len(set(bench.probe_order(3, True))) == len(bench.EXCHANGES)
+    m = bench.exchange_model("allreduce", 8, bench.CONFIGS["c3"], base_ms=1.18)
+    assert 2.6 < m["all_reduce_ring_ms"] < 2.8 and 0.37 < m["all_reduce_one_hop_ms"] < 0.41   # SURVEY.md 5: 2.7 / 0.39 ms
+    assert m["expected_scaling_one_hop"] < 6.1 and m["expected_scaling_ring"] < 3.0
+    mv = bench.exchange_model("views_overlap", 8, bench.CONFIGS["c3"], base_ms=1.18)
+    assert mv["expected_scaling_one_hop"] > 7.0 and mv["exposed_one_hop_ms"] < 0.1
+    assert mv["all_reduce_ring_ms"] < 0.25 * m["all_reduce_ring_ms"]
     b = bench.exchange_bytes("allreduce", 8, bench.CONFIGS["c3"])
     assert b["all_reduced_bytes"] == 4 * (1_000_000 * 59 + 1 + 3 * 256) and b["all_gathered_bytes_per_rank"] == 0
     assert b["sent_per_rank_bytes"] == int(2 * 7 / 8 * b["all_reduced_bytes"])
