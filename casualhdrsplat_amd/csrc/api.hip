@@ -46,6 +46,15 @@ bool scan_in_emission(int64_t I) {
     return forced >= 0 ? forced == 1 : (I >= (2 << 20) && !sort_tickets());
 }
 
+// Stamp of a single-enqueue forward (hs_common.h, kDepthBitsAt): never 0, never the same for two calls of a process that
+// could meet in the same memory (2^32 - 1 calls apart).  The only thing the library counts.
+static std::atomic<uint32_t> g_frame_tag{0};
+static uint32_t next_frame_tag() {
+    uint32_t t;
+    do { t = g_frame_tag.fetch_add(1u, std::memory_order_relaxed) + 1u; } while (t == 0u);
+    return t;
+}
+
 void set_error(const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -213,8 +222,9 @@ int hs_forward(const hs_fwd_args* a, void* hip_stream) {
         // nothing to rasterize: clear counters so the host sees R = 0, and paint the background
         if (a->stages & HS_STAGE_PREPROCESS) HS_HIP_CHECK(hipMemsetAsync(a->geom, 0, sizeof(hs_counters), s));
     }
+    const uint32_t frame_tag = ((a->stages & HS_STAGE_PREPROCESS) && (a->stages & HS_STAGE_BIN) && a->binning) ? next_frame_tag() : 0u;
     if ((a->stages & HS_STAGE_PREPROCESS) && a->dims.P > 0) {
-        rc = launch_preprocess_fwd(*a, L, s);
+        rc = launch_preprocess_fwd(*a, L, s, frame_tag);
         if (rc) return rc;
         if ((rc = debug_sync(a->flags, s, "preprocess"))) return rc;
         if (!(a->stages & HS_STAGE_BIN)) {  // upstream-style call: the host reads num_rendered before binning
@@ -225,7 +235,7 @@ int hs_forward(const hs_fwd_args* a, void* hip_stream) {
     if (a->stages & HS_STAGE_BIN) {
         if (!a->binning) { set_error("hs_forward: null binning workspace"); return HS_EINVAL; }
         if (a->dims.P > 0) {
-            rc = launch_binning(*a, L, s);
+            rc = launch_binning(*a, L, s, frame_tag);
             if (rc) return rc;
             if ((rc = debug_sync(a->flags, s, "binning"))) return rc;
         } else {

@@ -41,18 +41,22 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
     return v;
 }
 
-// Block-wide inclusive scan of one value per thread (256 threads); returns the inclusive prefix and
+// Block-wide inclusive scan of one value per thread (NW waves: 256 threads by default); returns the inclusive prefix and
 // the block total through *total.
-__device__ __forceinline__ uint32_t block_incl_scan(uint32_t v, uint32_t* s_wave /*[4]*/, uint32_t* total) {
+template <int NW = 4>
+__device__ __forceinline__ uint32_t block_incl_scan(uint32_t v, uint32_t* s_wave /*[NW]*/, uint32_t* total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t incl = wave_incl_scan(v, lane);
     if (lane == 63) s_wave[wave] = incl;
     __syncthreads();
-    uint32_t add = 0;
+    uint32_t add = 0, tot = 0;
 #pragma unroll
-    for (int w = 0; w < 4; ++w)
-        if (w < wave) add += s_wave[w];
-    *total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    for (int w = 0; w < NW; ++w) {
+        const uint32_t c = s_wave[w];
+        if (w < wave) add += c;
+        tot += c;
+    }
+    *total = tot;
     __syncthreads();
     return incl + add;
 }
@@ -248,26 +252,118 @@ __global__ void __launch_bounds__(kHistThreads) radix_ghist_kernel(const void* k
     }
 }
 
+// ---- depth sort over the VARYING bits only (the instances' 32-bit depth keys) ----
+// Depths of a scene span a few octaves: z in [2, 10) gives 25 varying bits (23 of mantissa, 2 of exponent), so four 8-bit
+// passes over all 32 bits sort seven bits that are the same in every key.  Whoever writes the depth keys (preprocess_fwd in
+// a single-enqueue forward, depth_keys_kernel otherwise) ORs every visible key and its complement into kDepthBitsCopies
+// copies of two words; a bit varies iff it is set in both.  The passes then sort bits [lo, hi) only, in ceil((hi - lo) / 9)
+// digits of at most NINE bits (512-thread blocks, one bin per thread): three passes for any scene spanning up to 2^4 in
+// depth, read from device memory by every kernel (the host never knows); four kernels are always enqueued, a pass with no
+// digit left returns at once, and the last pass that has one writes the instance list.  Culled instances carry the
+// all-ones key, are left out of the OR, and sort behind (or, when a visible key is all ones inside the window, among)
+// the largest visible keys -- they have no pairs, so their place changes nothing downstream.
+// (no arrays indexed by a run-time pass number: those would live in scratch memory)
+struct DepthLayout {
+    int npasses, lo, base, rem;   // digit p: width base + (p < rem), starting at lo + p * base + min(p, rem)
+    __device__ __forceinline__ int width(int p) const { return base + (p < rem ? 1 : 0); }
+    __device__ __forceinline__ int shift(int p) const { return lo + p * base + min(p, rem); }
+};
+__device__ __forceinline__ DepthLayout depth_layout_from(uint32_t o, uint32_t nz) {
+    const uint32_t varying = o & nz;                       // some key has the bit set, some key has it clear
+    DepthLayout L;
+    L.lo = varying ? (int)__builtin_ctz(varying) : 0;
+    const int hi = varying ? 32 - (int)__builtin_clz(varying) : 1;
+    const int nbits = hi - L.lo;
+    L.npasses = (nbits + kDepthDigitBits - 1) / kDepthDigitBits;
+    L.base = nbits / L.npasses;
+    L.rem = nbits - L.base * L.npasses;
+    return L;
+}
+__device__ __forceinline__ DepthLayout depth_layout(const unsigned long long* bits, uint32_t tag) {
+    uint32_t o = 0u, nz = 0u;
+#pragma unroll
+    for (int c = 0; c < kDepthBitsCopies; ++c) {   // (words of another frame -- another tag -- count as empty)
+        const unsigned long long a = bits[2 * c], b = bits[2 * c + 1];
+        o |= (uint32_t)(a >> 32) == tag ? (uint32_t)a : 0u;
+        nz |= (uint32_t)(b >> 32) == tag ? (uint32_t)b : 0u;
+    }
+    return depth_layout_from(o, nz);
+}
+
+// Digit totals of the depth sort's passes (<= 4 digits of <= 9 bits, layout read from the device): ghist[pass * 512 + digit]
+__global__ void __launch_bounds__(1024) depth_ghist_kernel(const uint2* pairs, const uint32_t* n_dev,
+                                                           const unsigned long long* bits, uint32_t tag, uint32_t* ghist) {
+    __shared__ uint32_t s_hist[4 * kDepthBins];
+    const int64_t n = *n_dev;
+    const int64_t base = (int64_t)blockIdx.x * 4096;
+    if (base >= n) return;
+    const DepthLayout L = depth_layout(bits, tag);
+    for (int i = threadIdx.x; i < L.npasses * kDepthBins; i += 1024) s_hist[i] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t k = base + i * 1024 + threadIdx.x;
+        const bool valid = k < n;
+        const uint32_t key = valid ? pairs[k].x : 0u;
+        const uint64_t vm = __ballot(valid);
+        for (int pass = 0; pass < L.npasses; ++pass) {
+            const uint32_t d = (key >> L.shift(pass)) & ((1u << L.width(pass)) - 1u);
+            // the top digit is nearly constant (a few exponent values): when the whole wave agrees, one lane adds the count
+            const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
+            if (__ballot(valid && d != d0) == 0ull) {
+                if ((threadIdx.x & 63) == 0 && vm) atomicAdd(&s_hist[pass * kDepthBins + d0], (uint32_t)__popcll(vm));
+            } else if (valid) {
+                atomicAdd(&s_hist[pass * kDepthBins + d], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t* mine = ghist + (blockIdx.x % kGhistCopies) * (8 * 256);
+    for (int i = threadIdx.x; i < L.npasses * kDepthBins; i += 1024) {
+        const uint32_t c = s_hist[i];
+        if (c) atomicAdd(&mine[i], c);
+    }
+}
+
 // One pass: rank the block's keys (stable: wave w owns ITEMS * 64 consecutive keys of the block, ITEMS rounds of 64
 // consecutive keys), publish / look back, reorder through LDS, write each digit's run contiguously.
 //   PACKED_IN : `in_keys` holds (key, value) uint2 elements (K = uint32_t), else K keys with the values in `in_vals`;
 //   PACKED_OUT: `out_keys` receives uint2 elements, else keys go to `out_keys` (skipped when null) and values to
 //               `out_vals`.
 //   LOOK      : status words a thread requests at once during the look-back.
-template <typename K, int ITEMS, int LOOK, bool PACKED_IN, bool PACKED_OUT, bool TICKET>
-__global__ void __launch_bounds__(kSortBlock) radix_sweep_kernel(const void* in_keys, const uint32_t* in_vals,
-                                                                 void* out_keys, uint32_t* out_vals, const uint32_t* n_dev,
-                                                                 int shift, uint32_t mask, uint32_t* status,
-                                                                 const uint32_t* ghist, uint32_t* ticket,
-                                                                 uint32_t* fail_word, uint32_t* kill_word) {
-    constexpr int TILE = ITEMS * kSortBlock;
-    __shared__ uint32_t s_cnt[4][256];    // per-wave digit counters -> per-wave exclusive offsets
-    __shared__ uint32_t s_dstart[256];    // block-local start of each digit's run
-    __shared__ uint32_t s_gbase[256];     // global start of this block's run of each digit
+//   BLOCK     : threads = bins per block (256: digits of <= 8 bits; 512: <= 9 bits, the depth sort);
+//   DYN       : the depth sort's dynamic form -- `dyn_bits` gives the digit layout (depth_layout), `dyn_pass` this launch's
+//               pass; `in_keys` / `out_keys` are the two ping-pong buffers (pass p reads the first when p is even), the
+//               last pass that has a digit writes the values to `out_vals`, a pass without one returns at once.
+template <typename K, int ITEMS, int LOOK, bool PACKED_IN, bool PACKED_OUT, bool TICKET, int BLOCK = kSortBlock, bool DYN = false>
+__global__ void __launch_bounds__(BLOCK) radix_sweep_kernel(const void* in_keys, const uint32_t* in_vals,
+                                                            void* out_keys, uint32_t* out_vals, const uint32_t* n_dev,
+                                                            int shift, uint32_t mask, uint32_t* status,
+                                                            const uint32_t* ghist, uint32_t* ticket,
+                                                            uint32_t* fail_word, uint32_t* kill_word,
+                                                            const unsigned long long* dyn_bits = nullptr, int dyn_pass = 0,
+                                                            uint32_t dyn_tag = 0u) {
+    constexpr int TILE = ITEMS * BLOCK;
+    constexpr int NW = BLOCK / 64;                 // waves per block
+    constexpr int DBITS = BLOCK == 512 ? 9 : 8;   // bits of the widest digit
+    static_assert(BLOCK == 256 || BLOCK == 512, "one bin per thread: 256 or 512 bins");
+    __shared__ uint32_t s_cnt[NW][BLOCK];   // per-wave digit counters -> per-wave exclusive offsets
+    __shared__ uint32_t s_dstart[BLOCK];    // block-local start of each digit's run
+    __shared__ uint32_t s_gbase[BLOCK];     // global start of this block's run of each digit
     __shared__ K s_keys[TILE];
     __shared__ uint32_t s_vals[TILE];
-    __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_wave[NW];
     __shared__ uint32_t s_ticket, s_fail, s_n;
+    bool dyn_last = false;
+    if constexpr (DYN) {
+        const DepthLayout L = depth_layout(dyn_bits, dyn_tag);
+        if (dyn_pass >= L.npasses) return;          // nothing left to sort: the previous pass wrote the final list
+        shift = L.shift(dyn_pass);
+        mask = (mask & 0x80000000u) | ((1u << L.width(dyn_pass)) - 1u);
+        dyn_last = dyn_pass == L.npasses - 1;
+        if (dyn_pass & 1) { const void* t = in_keys; in_keys = out_keys; out_keys = const_cast<void*>(t); }
+        ghist += dyn_pass * BLOCK;
+    }
 
 #ifdef HS_TESTING
     // libhdrsplat_test.so only (HS_FAULT_INJECT=late_block sets bit 31 of `mask`): block 1 starts ~3 ms late, as if its XCD
@@ -288,7 +384,7 @@ __global__ void __launch_bounds__(kSortBlock) radix_sweep_kernel(const void* in_
         s_fail = f0 >= 2u ? 1u : 0u;
     }
 #pragma unroll
-    for (int w = 0; w < 4; ++w) s_cnt[w][threadIdx.x] = 0;
+    for (int w = 0; w < NW; ++w) s_cnt[w][threadIdx.x] = 0;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     __syncthreads();
     const int64_t n = s_n;
@@ -296,7 +392,7 @@ __global__ void __launch_bounds__(kSortBlock) radix_sweep_kernel(const void* in_
     const int64_t base = (int64_t)bid * TILE;
     if (base >= n) return;
     const int cnt_block = (int)min((int64_t)TILE, n - base);
-    uint32_t* const my_status = status + (int64_t)bid * 256 + threadIdx.x;
+    uint32_t* const my_status = status + (int64_t)bid * BLOCK + threadIdx.x;
     // A pass that gave up left its output incomplete: the digit totals no longer describe what the later passes would read,
     // and a scatter by them could leave the buffer.  Blocks that start after the verdict (the rest of that pass, every
     // block of the passes behind it) only release their successors and go.
@@ -311,14 +407,14 @@ __global__ void __launch_bounds__(kSortBlock) radix_sweep_kernel(const void* in_
 #pragma unroll
         for (int c = 0; c < kGhistCopies; ++c) tot += ghist[c * (8 * 256) + threadIdx.x];
         uint32_t all;
-        digit_base = block_incl_scan(tot, s_wave, &all) - tot;
+        digit_base = block_incl_scan<NW>(tot, s_wave, &all) - tot;
     }
 
     K key[ITEMS];
     uint32_t val[ITEMS];
     uint16_t rank[ITEMS];
     const uint64_t lt_mask = (1ull << lane) - 1ull;
-    const int wbase = wave * (TILE / 4);
+    const int wbase = wave * (TILE / NW);
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
         const int loc = wbase + i * 64 + lane;
@@ -342,7 +438,7 @@ __global__ void __launch_bounds__(kSortBlock) radix_sweep_kernel(const void* in_
         const uint32_t d = digit_of<K>(key[i], shift, mask);
         uint64_t peers = __ballot(valid);   // match-any: lanes holding the same digit
 #pragma unroll
-        for (int b = 0; b < 8; ++b) {
+        for (int b = 0; b < DBITS; ++b) {
             const uint64_t m = __ballot((d >> b) & 1u);
             peers &= ((d >> b) & 1u) ? m : ~m;
         }
@@ -355,14 +451,16 @@ __global__ void __launch_bounds__(kSortBlock) radix_sweep_kernel(const void* in_
     __syncthreads();
     uint32_t my_tot;
     {   // per digit: the block's count goes out first, then the offsets over waves and the block-local run starts
-        const uint32_t c0 = s_cnt[0][threadIdx.x], c1 = s_cnt[1][threadIdx.x], c2 = s_cnt[2][threadIdx.x],
-                       c3 = s_cnt[3][threadIdx.x];
-        my_tot = c0 + c1 + c2 + c3;
+        uint32_t c[NW];
+        my_tot = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { c[w] = s_cnt[w][threadIdx.x]; my_tot += c[w]; }
         st_publish(my_status, (bid == 0 ? kStIncl : kStAgg) | my_tot);
-        s_cnt[0][threadIdx.x] = 0; s_cnt[1][threadIdx.x] = c0; s_cnt[2][threadIdx.x] = c0 + c1;
-        s_cnt[3][threadIdx.x] = c0 + c1 + c2;
+        uint32_t run = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { s_cnt[w][threadIdx.x] = run; run += c[w]; }
         uint32_t total;
-        const uint32_t incl = block_incl_scan(my_tot, s_wave, &total);
+        const uint32_t incl = block_incl_scan<NW>(my_tot, s_wave, &total);
         s_dstart[threadIdx.x] = incl - my_tot;
     }
     __syncthreads();
@@ -388,7 +486,7 @@ __global__ void __launch_bounds__(kSortBlock) radix_sweep_kernel(const void* in_
         // words) and walk on.  No wait depends on an unstarted block any more: the chain advances under any dispatch
         // order, alone or next to other processes.
         uint32_t excl = 0;
-        bool done = threadIdx.x > mask;   // a digit no key of this pass can have: nothing to look up
+        bool done = threadIdx.x > (mask & 0x7FFFFFFFu);   // a digit no key of this pass can have: nothing to look up
         bool failed = false;
         constexpr int kHelpAfter = 128;
         // (called by the lanes of the wave that are still polling block q -- all at the same poll count, so together)
@@ -406,7 +504,7 @@ __global__ void __launch_bounds__(kSortBlock) radix_sweep_kernel(const void* in_
                 if ((int)(d >> 6) == wave) atomicAdd(&tab[d & 63u], 1u);
             }
             const uint32_t c = tab[lane];                      // (same wave: LDS operations complete in order)
-            atomicCAS(status + (int64_t)q * 256 + threadIdx.x, 0u, kStAgg | c);
+            atomicCAS(status + (int64_t)q * BLOCK + threadIdx.x, 0u, kStAgg | c);
             // tell the host (hs_counters.reserved[4], four words behind `overflow`): help was needed, i.e. the GPU is shared
             // with kernels that keep our blocks out -- ticket order, where nobody waits for an unstarted block, is the faster mode then
             if (my == 0) atomicAdd(fail_word + 5, 1u);
@@ -415,7 +513,7 @@ __global__ void __launch_bounds__(kSortBlock) radix_sweep_kernel(const void* in_
             uint32_t v[LOOK];
 #pragma unroll
             for (int j = 0; j < LOOK; ++j)
-                v[j] = p - j >= 0 ? st_read(status + (int64_t)(p - j) * 256 + threadIdx.x) : kStIncl;
+                v[j] = p - j >= 0 ? st_read(status + (int64_t)(p - j) * BLOCK + threadIdx.x) : kStIncl;
             // fast path: all LOOK words are published already (the usual case once the chain is moving) -- no loop, no
             // branch per word: add counts up to and including the first inclusive prefix
             bool all_ready = true;
@@ -443,7 +541,7 @@ __global__ void __launch_bounds__(kSortBlock) radix_sweep_kernel(const void* in_
                     ++polls;
                     if constexpr (!TICKET) { if (polls == kHelpAfter) help(p - j); }
                     __builtin_amdgcn_s_sleep(1);
-                    x = st_read(status + (int64_t)(p - j) * 256 + threadIdx.x);
+                    x = st_read(status + (int64_t)(p - j) * BLOCK + threadIdx.x);
                 }
                 if ((x & ~kStMask) == 0u) { failed = true; done = true; break; }
                 excl += x & kStMask;
@@ -462,12 +560,15 @@ __global__ void __launch_bounds__(kSortBlock) radix_sweep_kernel(const void* in_
     if (s_fail) return;
 #pragma unroll 4
     for (int i = 0; i < ITEMS; ++i) {
-        const int pos = i * kSortBlock + threadIdx.x;
+        const int pos = i * BLOCK + threadIdx.x;
         if (pos < cnt_block) {
             const K k = s_keys[pos];
             const uint32_t d = digit_of<K>(k, shift, mask);
             const int64_t dst = (int64_t)s_gbase[d] + (pos - s_dstart[d]);
-            if constexpr (PACKED_OUT) {
+            if constexpr (DYN) {   // the depth sort: packed elements between the passes, the bare instance list at the end
+                if (dyn_last) out_vals[dst] = s_vals[pos];
+                else reinterpret_cast<uint2*>(out_keys)[dst] = make_uint2((uint32_t)k, s_vals[pos]);
+            } else if constexpr (PACKED_OUT) {
                 reinterpret_cast<uint2*>(out_keys)[dst] = make_uint2((uint32_t)k, s_vals[pos]);
             } else {
                 if (out_keys) reinterpret_cast<K*>(out_keys)[dst] = k;
@@ -480,11 +581,11 @@ __global__ void __launch_bounds__(kSortBlock) radix_sweep_kernel(const void* in_
 // Scratch of a sort (`tmp`: sort_tmp_bytes(n_launch)): digit totals, one ticket counter per pass, status words.
 struct SortScratch {
     uint32_t* ghist; uint32_t* tickets; uint32_t* status; int64_t pass_words;
-    SortScratch(void* tmp, int64_t n_launch, int tile) {
+    SortScratch(void* tmp, int64_t n_launch, int tile, int bins = 256) {
         ghist = (uint32_t*)tmp;                       // [kGhistCopies][8][256]
-        tickets = ghist + kGhistWords;                // [8] (+ padding)
-        status = tickets + kTicketWords;              // [passes][sweep_pass_words(nblk)]
-        pass_words = sweep_pass_words((n_launch + tile - 1) / tile);
+        tickets = ghist + kGhistWords;                // [8] (+ the depth-bits words: hs_common.h)
+        status = tickets + kTicketWords;              // [passes][sweep_pass_words(nblk, bins)]
+        pass_words = sweep_pass_words((n_launch + tile - 1) / tile, bins);
     }
 };
 
@@ -529,10 +630,16 @@ int radix_sort_packed(uint2* p0, uint2* p1, uint32_t* keys_out, uint32_t* vals_o
 
 // ---------------------------------------------------------------- split tile sort (a6 + a7)
 // Depth keys of the instances as (key, instance) elements: culled instances get the largest key so they sort to the end.
-__global__ void __launch_bounds__(256) depth_keys_kernel(int64_t I, const float* depth, const int* radii, uint2* pairs) {
+__global__ void __launch_bounds__(256) depth_keys_kernel(int64_t I, const float* depth, const int* radii, uint2* pairs,
+                                                         unsigned long long* bits) {
+    __shared__ uint32_t s_two[2];
+    if (threadIdx.x < 2) s_two[threadIdx.x] = 0u;
+    __syncthreads();
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= I) return;
-    pairs[i] = make_uint2(radii[i] > 0 ? __float_as_uint(depth[i]) : 0xFFFFFFFFu, (uint32_t)i);
+    const bool visible = i < I && radii[i] > 0;
+    const uint32_t key = visible ? __float_as_uint(depth[i]) : 0xFFFFFFFFu;
+    if (i < I) pairs[i] = make_uint2(key, (uint32_t)i);
+    depth_bits_accumulate(key, visible, bits, 0u, s_two);   // which bits vary (tag 0: bin_prepare_kernel zeroed the words)
 }
 
 // Tile rectangles of the instances gathered into depth order (one 8-byte gather per instance) ahead of the emission --
@@ -579,13 +686,17 @@ __global__ void __launch_bounds__(256) emit_pairs_kernel(int64_t I, int P, int g
                                                          const uint32_t* block_excl, uint64_t* scan_status,
                                                          uint32_t* offs_sorted, uint2* pairs,
                                                          uint8_t* pair_flags, hs_counters* counters, uint64_t capacity,
-                                                         uint32_t* ghist, int nbits, int passes) {
+                                                         uint32_t* ghist, int nbits, int passes,
+                                                         unsigned long long* depth_bits) {
     __shared__ uint32_t s_hist[4 * 256];   // digit totals of the tile sort's passes (<= 4), this block's pairs
     __shared__ uint32_t s_beg[4][64];
     __shared__ uint4 s_own[4][64];         // per instance: key of its first tile, rectangle width, 1 / width (float), instance
     __shared__ uint32_t s_wsum[4];
     __shared__ uint64_t s_excl;            // pairs of all earlier blocks; kScPoison in the flag bits: a wait gave up
     for (int t = threadIdx.x; t < passes * 256; t += 256) s_hist[t] = 0;
+    // the depth sort is over: its tagged depth-bits words go back to empty, so a replayed graph (same tag every frame)
+    // starts each frame's OR from nothing instead of from every earlier frame's bits
+    if (blockIdx.x == 0 && threadIdx.x < 2 * kDepthBitsCopies) depth_bits[threadIdx.x] = 0ull;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int blk = blockIdx.x;
     const int64_t i = (int64_t)blk * 256 + threadIdx.x;
@@ -772,7 +883,9 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(const uint32_t* tiles,
 }  // namespace
 
 int64_t sort_tmp_bytes(int64_t n) {
-    // sized for the smallest radix block any of the sorts uses (most blocks, hence most status words)
+    // every sort uses the same tile; 8 passes of 256-bin status words (hs_sort_pairs on 64-bit keys) is also what the depth
+    // sort's 4 passes of 512-bin words need
+    static_assert(8 * 256 >= 4 * kDepthBins && kDepthTile >= kSortTileMin, "sort_tmp_bytes covers the depth sort's status words");
     return align_up(sort_scratch_words(n > 0 ? n : 1, 8, kSortTileMin) * 4, 256);
 }
 
@@ -819,7 +932,7 @@ int launch_scan(const hs_fwd_args& a, const hs_layout& L, hipStream_t s) {
                     (uint32_t*)(geom + L.offsets), &counters->num_rendered, s);
 }
 
-int launch_binning(const hs_fwd_args& a, const hs_layout& L, hipStream_t s) {
+int launch_binning(const hs_fwd_args& a, const hs_layout& L, hipStream_t s, uint32_t frame_tag) {
     const hs_dims& d = a.dims;
     char* geom = (char*)a.geom;
     char* bin = (char*)a.binning;
@@ -838,25 +951,45 @@ int launch_binning(const hs_fwd_args& a, const hs_layout& L, hipStream_t s) {
     void* tmp2 = (char*)scan_status + emit_scan_words(I) * 4;
     const int tbits = tile_bits((uint32_t)ntiles);
     const int passes = sort_passes(tbits);
-    constexpr int kDepthTile = kDepthSortItems * kSortBlock;
-    if (!prepared)
-        bin_prepare_kernel<<<ceil_div(ntiles, 256), 256, 0, s>>>(counters, (uint32_t)I, ranges, ntiles, (uint32_t*)tmp,
-                                                                 sort_scratch_words(I, 4, kDepthTile), (uint32_t*)scan_status,
-                                                                 pair_scratch_words(I, d.capacity, passes));
+    const SortScratch dsc(tmp, I, kDepthTile, kDepthBins);
+    unsigned long long* depth_bits = reinterpret_cast<unsigned long long*>(dsc.tickets + kDepthBitsAt);
+    const uint32_t dtag = prepared ? frame_tag : 0u;   // (not prepared: bin_prepare_kernel zeroes the words, tag 0)
+    if (!prepared) {
+        // (a grid wide enough for the scratch it clears: a few MB of status words at several million instances)
+        const int64_t nz = depth_scratch_words(I) + pair_scratch_words(I, d.capacity, passes);
+        const int grid = (int)max((int64_t)ceil_div(ntiles, 256), min((int64_t)4096, (nz + 4 * 256 - 1) / (4 * 256)));
+        bin_prepare_kernel<<<grid, 256, 0, s>>>(counters, (uint32_t)I, ranges, ntiles, (uint32_t*)tmp, depth_scratch_words(I),
+                                                (uint32_t*)scan_status, pair_scratch_words(I, d.capacity, passes));
+    }
 
     if (fault_injection() == 2 && !sort_tickets())   // tests only (HS_FAULT_INJECT=stalled_chain): the verdict of a stalled chain
         HS_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)&counters->overflow, 2, 1, s));
-    // 1. instances by depth (stable, 32-bit keys -> 4 passes over (key, instance) elements; the last one leaves only
-    //    the instance list)
+    // 1. instances by depth: stable, over the bits of the depth keys that VARY, in digits of up to nine bits (three passes
+    //    for a scene spanning up to 2^4 in depth; the layout lives on the device, so four passes are enqueued and those
+    //    without a digit return at once); (key, instance) elements, the last pass leaves only the instance list
     uint2* dp0 = (uint2*)(bin + L.depth_pairs);
     uint2* dp1 = dp0 + I;
     uint32_t* inst_sorted = (uint32_t*)(bin + L.inst_sorted);
     if (!prepared)
-        depth_keys_kernel<<<ceil_div(I, 256), 256, 0, s>>>(I, (const float*)(geom + L.depth), (const int*)(geom + L.radii), dp0);
-    int rc = radix_sort_packed<kDepthSortItems, kDepthSortLook>(dp0, dp1, nullptr, inst_sorted, n_inst, I, 32, tmp,
-                                                               &counters->overflow, nullptr, s, /*zeroed=*/true,
-                                                               /*ghist_ready=*/false);   // cleared by preprocess / bin_prepare
-    if (rc != HS_OK) return rc;
+        depth_keys_kernel<<<ceil_div(I, 256), 256, 0, s>>>(I, (const float*)(geom + L.depth), (const int*)(geom + L.radii), dp0,
+                                                           depth_bits);
+    {
+        const int nblk = ceil_div(I, kDepthTile);
+        depth_ghist_kernel<<<ceil_div(I, 4096), 1024, 0, s>>>(dp0, n_inst, depth_bits, dtag, dsc.ghist);
+        const uint32_t late = fault_injection() == 3 ? 0x80000000u : 0u;
+        for (int pass = 0; pass < 4; ++pass) {
+            uint32_t* st = dsc.status + (int64_t)pass * dsc.pass_words;
+            if (sort_tickets())
+                radix_sweep_kernel<uint32_t, kDepthSortItems, kDepthSortLook, true, true, true, kDepthBins, true>
+                    <<<nblk, kDepthBins, 0, s>>>(dp0, nullptr, dp1, inst_sorted, n_inst, 0, late, st, dsc.ghist, dsc.tickets + pass,
+                                                 &counters->overflow, nullptr, depth_bits, pass, dtag);
+            else
+                radix_sweep_kernel<uint32_t, kDepthSortItems, kDepthSortLook, true, true, false, kDepthBins, true>
+                    <<<nblk, kDepthBins, 0, s>>>(dp0, nullptr, dp1, inst_sorted, n_inst, 0, late, st, dsc.ghist, dsc.tickets + pass,
+                                                 &counters->overflow, nullptr, depth_bits, pass, dtag);
+        }
+        HS_LAUNCH_CHECK();
+    }
     // 2. pair emission in depth order, with the scan of the pair counts inside (emit_pairs_kernel); it also counts the
     //    digit totals of the tile sort below.  The last pass of that sort writes (keys_sorted, point_list), which overlay
     //    packed buffer A: it must read buffer B, so the emission starts in A when the pass count is even
@@ -880,11 +1013,11 @@ int launch_binning(const hs_fwd_args& a, const hs_layout& L, hipStream_t s) {
     emit_pairs_kernel<<<eblk, 256, 0, s>>>(I, d.P, gx, gy, (float4*)(geom + L.rec), inst_sorted,
                                            (const uint2*)(geom + L.binfo), srect, block_excl, scan_status, offs, p0,
                                            (uint8_t*)(bin + L.pair_flags), counters, (uint64_t)d.capacity,
-                                           (uint32_t*)tmp2, tbits, passes);
+                                           (uint32_t*)tmp2, tbits, passes, depth_bits);
     HS_LAUNCH_CHECK();
     // 3. stable sort by tile id only
     uint32_t* keys_sorted = (uint32_t*)(bin + L.keys_sorted);
-    rc = radix_sort_packed<kPairSortItems, kPairSortLook>(p0, p1, keys_sorted, (uint32_t*)(bin + L.point_list), n_sort,
+    int rc = radix_sort_packed<kPairSortItems, kPairSortLook>(p0, p1, keys_sorted, (uint32_t*)(bin + L.point_list), n_sort,
                                                          d.capacity, tbits, tmp2, &counters->overflow, n_sort, s,
                                                          /*zeroed=*/true, /*ghist_ready=*/true);
     if (rc != HS_OK) return rc;

@@ -34,12 +34,18 @@ constexpr int kInstFloats = 4 * kInstF4;
 // 0.31 -- more, smaller blocks lose to their fixed cost (digit totals, block scans), and deeper look-back over-reads;
 // pair sort with 12 / 20 / 24 items per thread: 0.226 / 0.232 / 0.249 against 0.225 (three blocks per CU at 24).
 constexpr int kSortBlock = 256;
-constexpr int kDepthSortItems = 16, kDepthSortLook = 8;                                     // instances by depth
+// depth sort (instances by depth, binning.hip "depth sort over the VARYING bits"): 512-thread blocks = 512 bins = digits of
+// up to nine bits, eight items per thread -- the same 4096-element tile as the other sorts
+constexpr int kDepthBins = 512, kDepthDigitBits = 9;
+#ifndef HS_TUNE_DEPTH_ITEMS
+#define HS_TUNE_DEPTH_ITEMS 8
+#endif
+constexpr int kDepthSortItems = HS_TUNE_DEPTH_ITEMS, kDepthSortLook = 8;
 constexpr int kPairSortItems = 16, kPairSortLook = 8;                                       // (tile, instance) pairs by tile
 constexpr int kU64SortItems = 16;                                                           // hs_sort_pairs
-constexpr int kMinSortItems = kDepthSortItems < kPairSortItems ? (kDepthSortItems < kU64SortItems ? kDepthSortItems : kU64SortItems)
-                                                               : (kPairSortItems < kU64SortItems ? kPairSortItems : kU64SortItems);
-constexpr int kSortTileMin = kMinSortItems * kSortBlock;    // smallest radix block in use: sizes the status words of every sort
+constexpr int kDepthTile = kDepthSortItems * kDepthBins, kPairTile = kPairSortItems * kSortBlock, kU64Tile = kU64SortItems * kSortBlock;
+static_assert(kPairTile == kU64Tile && kDepthTile >= kPairTile, "the scratch of every sort is sized for the smallest tile");
+constexpr int kSortTileMin = kPairTile;                     // smallest radix tile (elements per block) in use
 
 static inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
@@ -52,9 +58,11 @@ static inline int tile_bits(uint32_t n) {
 }
 
 // ---- launchers (each enqueues on `s`, returns HS_OK / HS_EHIP) ----
-int launch_preprocess_fwd(const hs_fwd_args& a, const hs_layout& L, hipStream_t s);
+// `frame_tag`: stamp of this hs_forward call when preprocess and binning run in the same call (else 0: the binning stage
+// then clears its own scratch): see kDepthBitsAt
+int launch_preprocess_fwd(const hs_fwd_args& a, const hs_layout& L, hipStream_t s, uint32_t frame_tag);
 int launch_scan(const hs_fwd_args& a, const hs_layout& L, hipStream_t s);
-int launch_binning(const hs_fwd_args& a, const hs_layout& L, hipStream_t s);
+int launch_binning(const hs_fwd_args& a, const hs_layout& L, hipStream_t s, uint32_t frame_tag);
 // `stats` (device, render_stats_count() u64 counters, or null) selects the diagnostic instantiation of the kernel
 int launch_render_fwd(const hs_fwd_args& a, const hs_layout& L, hipStream_t s, unsigned long long* stats = nullptr);
 int launch_render_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s, unsigned long long* stats = nullptr,
@@ -70,12 +78,22 @@ int launch_sh_backward_views(int P, int M, int deg, int V, const float* means3D,
 // ticket counter per pass (a block's place in the look-back chain), then one status word per (pass, block, digit).
 // sort_scratch_words(n, passes, tile) = the words a sort of n elements in blocks of `tile` needs cleared.
 constexpr int kGhistCopies = 16;
-constexpr int kGhistWords = kGhistCopies * 8 * 256;
-constexpr int kTicketWords = 64;
-__host__ __device__ inline int64_t sweep_pass_words(int64_t nblk) { return nblk * 256; }
-static inline int64_t sort_scratch_words(int64_t n, int passes, int tile) {
-    return n > 0 ? kGhistWords + kTicketWords + (int64_t)passes * sweep_pass_words((n + tile - 1) / tile) : 0;
+constexpr int kGhistWords = kGhistCopies * 8 * 256;      // (8 passes x 256 bins, or the depth sort's 4 x 512)
+// the ticket row: words [0, 8) one ticket counter per pass; words [kDepthBitsAt, kDepthBitsAt + kDepthBitsWords): OR of the
+// visible depth keys and of their complements (the depth sort's digit layout, binning.hip), in kDepthBitsCopies copies of
+// two 64-bit words {frame tag << 32 | bits}.  The tag makes the words self-initialising: the forward's first kernel cannot
+// count on zeroed memory (it IS the kernel that zeroes the scratch, and a memset node ahead of it costs 4 us), so a
+// word whose tag is not this frame's is taken as empty -- by the workgroup that ORs into it (compare-and-swap) and by the
+// readers alike.  Stale or garbage bits under a matching tag could only ADD varying bits, i.e. sort a constant bit too:
+// never a wrong order.
+constexpr int kTicketWords = 128, kDepthBitsAt = 32, kDepthBitsCopies = 16, kDepthBitsWords = 4 * kDepthBitsCopies;
+static_assert(kDepthBitsAt >= 8 && kDepthBitsAt % 2 == 0 && kDepthBitsAt + kDepthBitsWords <= kTicketWords, "depth bits live in the ticket row");
+__host__ __device__ inline int64_t sweep_pass_words(int64_t nblk, int bins = 256) { return nblk * bins; }
+static inline int64_t sort_scratch_words(int64_t n, int passes, int tile, int bins = 256) {
+    return n > 0 ? kGhistWords + kTicketWords + (int64_t)passes * sweep_pass_words((n + tile - 1) / tile, bins) : 0;
 }
+// words the forward's first kernel clears for the depth sort of I instances (4 passes of 512-bin status words)
+static inline int64_t depth_scratch_words(int64_t I) { return sort_scratch_words(I, 4, kDepthTile, kDepthBins); }
 int64_t sort_tmp_bytes(int64_t n);
 // Scratch behind hs_layout.pair_sort_tmp: one 64-bit status word per 256-instance block of the pair emission's chained scan
 // (as u32 words), then the pair sort's scratch.  pair_scratch_words = what must be cleared before the emission runs.
@@ -108,6 +126,30 @@ bool scan_in_emission(int64_t I);
 static inline int sort_passes(int nbits) { return (nbits + 7) / 8; }
 
 // ---- small device helpers ----
+// OR `bits` into a tagged word (see kDepthBitsAt): a word carrying another tag counts as empty
+__device__ __forceinline__ void tagged_or(unsigned long long* p, uint32_t tag, uint32_t bits) {
+    unsigned long long old = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (;;) {
+        const unsigned long long cur = (uint32_t)(old >> 32) == tag ? old : ((unsigned long long)tag << 32);
+        const unsigned long long nw = cur | bits;
+        if (nw == old) return;
+        const unsigned long long prev = atomicCAS(p, old, nw);
+        if (prev == old) return;
+        old = prev;
+    }
+}
+// OR of the visible depth keys of a workgroup and of their complements into one of the copies of the depth-bits words (two
+// atomics per workgroup; binning.hip derives the depth sort's digit layout from them).  Every thread of the block calls it.
+__device__ __forceinline__ void depth_bits_accumulate(uint32_t key, bool visible, unsigned long long* bits, uint32_t tag,
+                                                      uint32_t* s_two /*LDS[2], zeroed*/) {
+    // (`s_two` was zeroed before the workgroup's last barrier.  Every lane ORs into the two LDS words directly: 64 lanes on
+    // one address retire in a few hundred cycles with nothing waiting on them, where a shuffle tree is a chain of twelve
+    // dependent LDS-crossbar round trips at the very end of a long kernel)
+    if (visible) { atomicOr(&s_two[0], key); atomicOr(&s_two[1], ~key); }
+    __syncthreads();
+    if (threadIdx.x < 2 && s_two[threadIdx.x])
+        tagged_or(bits + 2 * (blockIdx.x % kDepthBitsCopies) + threadIdx.x, tag, s_two[threadIdx.x]);
+}
 __device__ __forceinline__ float xform_row(const float* m, int i, float x, float y, float z) {
     return ((m[i] * x + m[4 + i] * y) + m[8 + i] * z) + m[12 + i];
 }

@@ -146,7 +146,9 @@ struct PreFwd {
     // single-enqueue forward (binning workspace already there): the start of the binning stage rides along --
     // depth-sort keys/values of the instances, the instance count word, cleared tile ranges; else null
     uint2* depth_pairs; hs_counters* counters; uint2* ranges; int64_t n_vtiles;
-    uint32_t* sort_zero; int64_t n_sort_zero;   // scratch of the depth sort that follows (binning.hip), cleared here
+    uint32_t* sort_zero; int64_t n_sort_zero;   // scratch of the depth sort that follows (binning.hip), cleared here ...
+    int64_t bits_at;                            // ... except the depth-bits words [bits_at, bits_at + kDepthBitsWords): this
+    uint32_t frame_tag;                         // kernel ORs the depth keys into them, stamped with the frame's tag
     uint32_t* pair_zero; int64_t n_pair_zero;   // ... and of the pair emission's scan + the tile sort
     bool antialias;
     int act;  // radiance activation: 0 relu_shift, 1 exp, 2 softplus
@@ -162,6 +164,12 @@ __device__ __forceinline__ float radiance_dact(int act, float col, bool was_clam
 // a4.  instance = pose * P + g.
 template <int DEG>
 __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreFwd p) {
+    __shared__ uint32_t s_two[2];       // OR of the workgroup's visible depth keys / of their complements
+    if (p.depth_pairs) {                // (uniform)
+        if (threadIdx.x < 2) s_two[threadIdx.x] = 0u;
+        __syncthreads();
+    }
+    uint32_t depth_key = 0xFFFFFFFFu;   // this thread's key of the depth sort (all ones: culled, or no instance)
     // Block -> (chunk of 256 Gaussians, pose): workgroups are dealt to the 8 XCDs round-robin by blockIdx, so XCD x runs
     // its blocks x, x + 8, x + 16, ... in order; those are made the N poses of chunk x, then of chunk x + 8, ... -- the
     // poses of a chunk follow each other on ONE XCD and read the chunk's SH rows, scales and rotations (236 bytes
@@ -291,12 +299,18 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreFwd p) {
     p.clamped[idx] = clampbits;
     if (p.N == 1) p.radii_out[g] = my_radius;
     else if (my_radius > 0) atomicMax(p.radii_out + g, my_radius);
-    if (p.depth_pairs)   // (depth bits, instance) for the depth sort; culled instances get the largest key: they sort to the end
-        p.depth_pairs[idx] = make_uint2(my_radius > 0 ? __float_as_uint(depth) : 0xFFFFFFFFu, (uint32_t)idx);
+    if (p.depth_pairs) {  // (depth bits, instance) for the depth sort; culled instances get the largest key: they sort to the end
+        if (my_radius > 0) depth_key = __float_as_uint(depth);
+        p.depth_pairs[idx] = make_uint2(depth_key, (uint32_t)idx);
+    }
     }  // g < P
     if (p.depth_pairs) {
+        // which bits of the visible depth keys vary (the depth sort sorts only those: binning.hip)
+        depth_bits_accumulate(depth_key, depth_key != 0xFFFFFFFFu,
+                              reinterpret_cast<unsigned long long*>(p.sort_zero + p.bits_at), p.frame_tag, s_two);
         for (int64_t t = lin; t < p.n_vtiles; t += (int64_t)gridDim.x * 256) p.ranges[t] = make_uint2(0u, 0u);
-        for (int64_t t = lin; t < p.n_sort_zero; t += (int64_t)gridDim.x * 256) p.sort_zero[t] = 0u;
+        for (int64_t t = lin; t < p.n_sort_zero; t += (int64_t)gridDim.x * 256)
+            if (t < p.bits_at || t >= p.bits_at + kDepthBitsWords) p.sort_zero[t] = 0u;
         for (int64_t t = lin; t < p.n_pair_zero; t += (int64_t)gridDim.x * 256) p.pair_zero[t] = 0u;
         if (lin == 0) {
             p.counters->overflow = 0u;
@@ -827,7 +841,7 @@ __global__ void __launch_bounds__(256) pose_reduce2_kernel(const float* stage, i
 
 }  // namespace
 
-int launch_preprocess_fwd(const hs_fwd_args& a, const hs_layout& L, hipStream_t s) {
+int launch_preprocess_fwd(const hs_fwd_args& a, const hs_layout& L, hipStream_t s, uint32_t frame_tag) {
     const hs_dims& d = a.dims;
     char* geom = (char*)a.geom;
     PreFwd p;
@@ -843,7 +857,7 @@ int launch_preprocess_fwd(const hs_fwd_args& a, const hs_layout& L, hipStream_t 
     p.antialias = (a.flags & HS_FLAG_ANTIALIAS) != 0;
     p.act = (a.flags & HS_FLAG_RADIANCE_EXP) ? 1 : (a.flags & HS_FLAG_RADIANCE_SOFTPLUS) ? 2 : 0;
     p.depth_pairs = nullptr; p.counters = nullptr; p.ranges = nullptr; p.n_vtiles = 0;
-    p.sort_zero = nullptr; p.n_sort_zero = 0;
+    p.sort_zero = nullptr; p.n_sort_zero = 0; p.bits_at = 0; p.frame_tag = 0u;
     p.pair_zero = nullptr; p.n_pair_zero = 0;
     if ((a.stages & HS_STAGE_BIN) && a.binning) {
         char* bin = (char*)a.binning;
@@ -851,7 +865,9 @@ int launch_preprocess_fwd(const hs_fwd_args& a, const hs_layout& L, hipStream_t 
         p.counters = (hs_counters*)(geom + L.counters); p.ranges = (uint2*)(bin + L.ranges);
         p.n_vtiles = (int64_t)((d.W + kTile - 1) / kTile) * ((d.H + kTile - 1) / kTile) * d.n_poses;
         p.sort_zero = (uint32_t*)(bin + L.sort_tmp);
-        p.n_sort_zero = sort_scratch_words((int64_t)d.P * d.n_poses, 4, kDepthSortItems * kSortBlock);
+        p.n_sort_zero = depth_scratch_words((int64_t)d.P * d.n_poses);
+        p.bits_at = kGhistWords + kDepthBitsAt;   // (tagged words: no memset ahead of the frame's first kernel)
+        p.frame_tag = frame_tag;
         p.pair_zero = (uint32_t*)(bin + L.pair_sort_tmp);
         p.n_pair_zero = pair_scratch_words((int64_t)d.P * d.n_poses, d.capacity,
                                            sort_passes(tile_bits((uint32_t)p.n_vtiles)));
