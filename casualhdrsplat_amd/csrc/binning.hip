@@ -24,6 +24,14 @@
 // capacity).  (The older three-kernel passes -- histogram, row scan, scatter -- are profiles/r02_sort_three_kernel_passes.patch.)
 #include "hs_common.h"
 
+// Non-temporal hints of the large-frame pair emission (emit_pairs_kernel<true>), measured one by one at c4 on one box
+// (preprocess + binning, ms; none: 2.005): 1 = the 8-byte rectangle gather 2.156 (worse: the gathers then miss the
+// neighbours another lane just brought in), 2 = the 4-byte slot-start scatter into the render records 1.934, 4 = the
+// streaming store of the pairs 1.953.  The two stores it is.
+#ifndef HS_EMIT_NT_MASK
+#define HS_EMIT_NT_MASK 6
+#endif
+
 namespace hs {
 
 namespace {
@@ -681,6 +689,7 @@ __device__ __forceinline__ uint64_t sc_read(const uint64_t* p) {
 // the verdict for the later kernels: n_sort = R, or 0 when R exceeds the binning capacity (or a wait gave up) -- then
 // nothing is sorted, the frame renders empty, and the host sees counters.overflow and replays with a larger capacity
 // (blocks that lie below the capacity have emitted their pairs by then: harmless, they are never looked at).
+template <bool BIG>   // BIG: the large-frame path (srect / block_excl null, non-temporal hints: see the rectangle gather below)
 __global__ void __launch_bounds__(256) emit_pairs_kernel(int64_t I, int P, int gx, int gy, float4* rec,
                                                          const uint32_t* inst_sorted, const uint2* binfo, const uint2* srect,
                                                          const uint32_t* block_excl, uint64_t* scan_status,
@@ -705,12 +714,19 @@ __global__ void __launch_bounds__(256) emit_pairs_kernel(int64_t I, int P, int g
     // (a depth sort that gave up -- overflow = 2 -- left no instance list: every instance counts as culled)
     if (i < I && counters->overflow < 2u) {
         inst = inst_sorted[i];
-        rc = srect ? srect[i] : binfo[inst];   // (srect: the rectangles gathered into depth order by a kernel of their own)
+        // (srect: the rectangles gathered into depth order by a kernel of their own; else -- frames of millions of instances
+        // -- one 8-byte gather each.  That path marks its scattered slot-start store and its streaming pair store
+        // non-temporal (HS_EMIT_NT_MASK): at that size neither line is touched again before it would be evicted anyway, and
+        // keeping them out of the L2 takes ~120 us off c4's 590 us emission; at c3, where the records stay cached for the
+        // render forward, the same hint on the slot start COSTS 10 us)
+        if constexpr (BIG && (HS_EMIT_NT_MASK & 1)) rc = make_uint2(__builtin_nontemporal_load(&binfo[inst].x), __builtin_nontemporal_load(&binfo[inst].y));
+        else if constexpr (BIG) rc = binfo[inst];
+        else rc = srect[i];
     }
     const uint32_t cnt = (rc.y & 0xFFFFu) * (rc.y >> 16);
     uint32_t block_total;
     const uint32_t incl = block_incl_scan(cnt, s_wsum, &block_total);
-    if (block_excl) {          // offsets computed ahead of this launch (srect given as well)
+    if constexpr (!BIG) {      // offsets computed ahead of this launch (srect given as well)
         if (threadIdx.x == 0) s_excl = block_excl[blk];
     } else if (wave == 0) {
         if (lane == 0) sc_publish(scan_status + blk, (blk == 0 ? kScIncl : kScAgg) | (uint64_t)block_total);
@@ -782,7 +798,11 @@ __global__ void __launch_bounds__(256) emit_pairs_kernel(int64_t I, int P, int g
     beg = end - cnt;
     if (i < I) offs_sorted[i] = end;   // written even on overflow: the segmented sum then finds nothing flagged
     if (poison || bend > capacity) return;
-    if (i < I && end > beg) reinterpret_cast<float*>(rec + kRecF4 * (int64_t)inst + 2)[3] = __uint_as_float(beg);
+    if (i < I && end > beg) {
+        float* slot_start = &reinterpret_cast<float*>(rec + kRecF4 * (int64_t)inst + 2)[3];
+        if constexpr (BIG && (HS_EMIT_NT_MASK & 2)) __builtin_nontemporal_store(__uint_as_float(beg), slot_start);
+        else *slot_start = __uint_as_float(beg);
+    }
     // lanes past the end of the array inherit the running end so the range stays monotone
     const uint32_t last_end = __shfl(end, 63 - __builtin_clzll(__ballot(i < I) | 1ull));
     if (i >= I) beg = end = last_end;
@@ -825,7 +845,8 @@ __global__ void __launch_bounds__(256) emit_pairs_kernel(int64_t I, int P, int g
         const uint32_t ty = (uint32_t)(((float)t + 0.5f) * __uint_as_float(o.z));
         const uint32_t tx = t - ty * o.y;
         const uint32_t key = o.x + ty * (uint32_t)gx + tx;
-        pairs[pos] = make_uint2(key, o.w);
+        if constexpr (BIG && (HS_EMIT_NT_MASK & 4)) { __builtin_nontemporal_store(key, &pairs[pos].x); __builtin_nontemporal_store(o.w, &pairs[pos].y); }
+        else pairs[pos] = make_uint2(key, o.w);
         pair_flags[pos] = 0;  // "gradient record written" flag of this slot, set by the render backward
         // digit totals for the single-sweep tile sort.  The lanes of a wave hold neighbouring tiles of a few Gaussians:
         // when they all agree on a digit, one lane adds the count
@@ -1010,10 +1031,12 @@ int launch_binning(const hs_fwd_args& a, const hs_layout& L, hipStream_t s, uint
         scan_reduce256_kernel<<<eblk, 256, 0, s>>>(srect, I, block_excl);
         scan_spine_kernel<<<1, 256, 0, s>>>(block_excl, eblk, nullptr);
     }
-    emit_pairs_kernel<<<eblk, 256, 0, s>>>(I, d.P, gx, gy, (float4*)(geom + L.rec), inst_sorted,
-                                           (const uint2*)(geom + L.binfo), srect, block_excl, scan_status, offs, p0,
-                                           (uint8_t*)(bin + L.pair_flags), counters, (uint64_t)d.capacity,
-                                           (uint32_t*)tmp2, tbits, passes, depth_bits);
+#define HS_EMIT_ARGS I, d.P, gx, gy, (float4*)(geom + L.rec), inst_sorted, (const uint2*)(geom + L.binfo), srect, block_excl,       \
+                     scan_status, offs, p0, (uint8_t*)(bin + L.pair_flags), counters, (uint64_t)d.capacity, (uint32_t*)tmp2, tbits, \
+                     passes, depth_bits
+    if (srect) emit_pairs_kernel<false><<<eblk, 256, 0, s>>>(HS_EMIT_ARGS);
+    else emit_pairs_kernel<true><<<eblk, 256, 0, s>>>(HS_EMIT_ARGS);
+#undef HS_EMIT_ARGS
     HS_LAUNCH_CHECK();
     // 3. stable sort by tile id only
     uint32_t* keys_sorted = (uint32_t*)(bin + L.keys_sorted);
