@@ -10,6 +10,7 @@
 // read/write), so loads are issued as wide as the [P,*] layouts allow.
 #include "hs_common.h"
 
+
 namespace hs {
 
 namespace {
@@ -453,7 +454,11 @@ __device__ __forceinline__ void stage_rows_out(float* dst, const float* s_rows, 
         for (int i = threadIdx.x; i < rows * q; i += kPreBwdBlock) {
             const int r = i / q;
             const float* sr = s_rows + r * ld + ((i - r * q) << 2);
-            dst4[i] = make_float4(sr[0], sr[1], sr[2], sr[3]);
+            // non-temporal: the gradient rows are this library's last word on them (the optimiser reads them much later),
+            // and keeping 192 MB of them out of the L2 leaves it to the rows being READ: stage -9 us at c3 (same-box A/B;
+            // the same hint on the render backward's pair records or on the segmented sum's reads of them costs time)
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            __builtin_nontemporal_store(v4f{sr[0], sr[1], sr[2], sr[3]}, reinterpret_cast<v4f*>(dst4) + i);
         }
     } else {
         for (int i = threadIdx.x; i < rows * M3; i += kPreBwdBlock) dst[i] = s_rows[(i / M3) * ld + (i % M3)];
