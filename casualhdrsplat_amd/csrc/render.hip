@@ -226,6 +226,24 @@ constexpr float kLog2e = 1.4426950408889634f;
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
+// acc + splat(pair.y) * w and splat(pair.y) * w as ONE packed instruction (op_sel picks the pair's upper half for both
+// result lanes): the compiler broadcasts a LOWER half this way by itself but copies an upper half into a fresh register
+// first -- one v_mov per trip of both compositing loops (the green channel sits in the upper half of its LDS pair).
+#ifndef HS_NO_OPSEL_ASM
+__device__ __forceinline__ f2 pk_fma_hi(f2 pair, f2 w, f2 acc) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(pair), "v"(w));
+    return acc;
+}
+__device__ __forceinline__ f2 pk_mul_hi(f2 pair, f2 w) {
+    f2 r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(r) : "v"(pair), "v"(w));
+    return r;
+}
+#else
+__device__ __forceinline__ f2 pk_fma_hi(f2 pair, f2 w, f2 acc) { return acc + f2{pair.y, pair.y} * w; }
+__device__ __forceinline__ f2 pk_mul_hi(f2 pair, f2 w) { return f2{pair.y, pair.y} * w; }
+#endif
+
 // Staged entry as the inner loops want it: a = {x, y, A2, B2}, b = {C2, opacity, r, g} with the conic
 // pre-scaled so that log2(G) = dx*(A2*dx + B2*dy) + C2*dy*dy :  A2 = -0.5*A*log2e, B2 = -B*log2e, C2 = -0.5*C*log2e.
 __device__ __forceinline__ void scale_entry(float4& a, float4& b) {
@@ -327,8 +345,10 @@ constexpr int kFcmpOGE = 3, kFcmpOLE = 5;
 // DEPTH: also accumulate the expected inverse depth sum alpha T / z.
 struct PairF {
     f2 T, C0, C1, C2, D;
-    uint32_t last0, last1;
+    uint32_t last0, last1;   // last contributor so far, as (index + 1) * 48, up to the previous batch
+    uint32_t rel0, rel1;     // ... inside the current batch: LDS byte offset of its staged record, kNoRel = none yet
 };
+constexpr uint32_t kNoRel = 0xFFFFFFFFu;
 // Returns the lane mask of the lanes in which at least one of the two pixels took the entry.
 template <bool DEPTH>
 __device__ __forceinline__ uint64_t blend_fwd_pair(PairF& s, uint64_t& done0, uint64_t& done1, f2 pw, f2 alpha, float r,
@@ -346,12 +366,12 @@ __device__ __forceinline__ uint64_t blend_fwd_pair(PairF& s, uint64_t& done0, ui
     const bool upd0 = __builtin_amdgcn_inverse_ballot_w64(cont0), upd1 = __builtin_amdgcn_inverse_ballot_w64(cont1);
     const f2 aT = alpha * s.T;
     const f2 w = {upd0 ? aT.x : 0.f, upd1 ? aT.y : 0.f};
-    const f2 rr = {r, r}, gg = {g, g}, bb = {b, b};
-    s.C0 += rr * w; s.C1 += gg * w; s.C2 += bb * w;
+    const f2 rr = {r, r}, bb = {b, b};
+    s.C0 += rr * w; s.C1 = pk_fma_hi(f2{r, g}, w, s.C1); s.C2 += bb * w;
     if constexpr (DEPTH) { const f2 dd = {invd, invd}; s.D += dd * w; }
     s.T = f2{upd0 ? test_T.x : s.T.x, upd1 ? test_T.y : s.T.y};
-    s.last0 = upd0 ? idx1 : s.last0;
-    s.last1 = upd1 ? idx1 : s.last1;
+    s.rel0 = upd0 ? idx1 : s.rel0;   // (idx1: the entry's LDS byte offset as the list holds it -- no per-trip add; the
+    s.rel1 = upd1 ? idx1 : s.rel1;   // batch's base goes on once per batch: fold_last)
     if (n_pixels) *n_pixels = __popcll(cont0) + __popcll(cont1);
     return cont0 | cont1;
 }
@@ -425,6 +445,7 @@ render_fwd_kernel(RenderFwd p) {
     ps.T = f2{1.f, 1.f};
     ps.C0 = ps.C1 = ps.C2 = ps.D = f2{0.f, 0.f};
     ps.last0 = ps.last1 = 0;
+    ps.rel0 = ps.rel1 = kNoRel;
     // lane masks of finished pixels (all 64 lanes of both waves run the whole kernel: exec is full)
     uint64_t done0 = __builtin_amdgcn_ballot_w64(!in0), done1 = __builtin_amdgcn_ballot_w64(!in1);
 
@@ -474,9 +495,8 @@ render_fwd_kernel(RenderFwd p) {
             const f2 pw = dy * (b.x * dy + u) + t;          // log2 of the Gaussian falloff at the two pixels
             const float al0 = fminf(kAlphaMax, b.y * hs_exp2(pw.x));
             const float al1 = fminf(kAlphaMax, b.y * hs_exp2(pw.y));
-            const uint32_t idx48 = (uint32_t)(base48 + jb + kEnt);
             int n_pix = 0;
-            const uint64_t took = blend_fwd_pair<DEPTH>(ps, done0, done1, pw, f2{al0, al1}, b.z, b.w, c.x, DEPTH ? c.y : 0.f, idx48,
+            const uint64_t took = blend_fwd_pair<DEPTH>(ps, done0, done1, pw, f2{al0, al1}, b.z, b.w, c.x, DEPTH ? c.y : 0.f, (uint32_t)jb,
                                                         STATS ? &n_pix : nullptr);
             if constexpr (STATS) ws.v[kStFwdActivePix] += n_pix;
             // the two halves of `took` go to lane i - i0 of act_lo / act_hi as they are (one scalar + two vector
@@ -565,6 +585,10 @@ render_fwd_kernel(RenderFwd p) {
             // lane per position marks the entries
             const uint32_t t0 = walk(0, min(n_t, 64), base * kEnt);
             const uint32_t t1 = ((done0 & done1) != ~0ull && n_t > 64) ? walk(64, n_t, base * kEnt) : 0u;
+            // the batch's last contributors, from LDS offsets to (index + 1) * 48 -- once per batch instead of once per trip
+            ps.last0 = ps.rel0 != kNoRel ? (uint32_t)(base * kEnt + kEnt) + ps.rel0 : ps.last0;
+            ps.last1 = ps.rel1 != kNoRel ? (uint32_t)(base * kEnt + kEnt) + ps.rel1 : ps.last1;
+            ps.rel0 = ps.rel1 = kNoRel;
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
                 const uint32_t bit = 1u << (2 * g);
@@ -804,7 +828,7 @@ __device__ __forceinline__ void step_bwd_pair(PairB& s, bool act0, bool act1, f2
     const f2 rcp = {__builtin_amdgcn_rcpf(one_m.x), __builtin_amdgcn_rcpf(one_m.y)};
     s.T *= rcp;  // T_i = T_{i+1} / (1 - alpha_i)
     dch = ae * s.T;
-    f2 cd = (splat(r) * s.dL0 + splat(g) * s.dL1) + splat(b) * s.dL2;  // c_i . dL
+    f2 cd = (splat(r) * s.dL0 + pk_mul_hi(f2{r, g}, s.dL1)) + splat(b) * s.dL2;  // c_i . dL
     if constexpr (DEPTH) cd += splat(invd) * s.dLd;                     // the inverse-depth image: a fourth channel
     const f2 diff = cd - s.q;
     const f2 gd = G * (diff * s.T);
@@ -842,6 +866,7 @@ render_bwd_kernel(RenderBwd p) {
     constexpr int kSentinel = KB * kEntB;   // byte offset of the record no pixel takes (opacity 0)
     constexpr int kListLen = KB + 8;        // the read-ahead of the slot behind the last one stays inside the array
     __shared__ __attribute__((aligned(16))) float s_ent[(KB + 1) * kEntF];   // record KB: the sentinel
+    static_assert(KB * kEntF >= 2 * 7 * 128, "the pixel-state re-deal of the prologue borrows the staging area below the sentinel");
     __shared__ uint16_t s_list[2][2][kListLen];   // [wave][lane group]: byte offsets of the group's takers, back to front
     __shared__ uint8_t s_actb[kBatch];      // activity byte of each staged entry (bit 2g + w: group g of wave w took it)
     __shared__ uint32_t s_max[2];
@@ -880,7 +905,6 @@ render_bwd_kernel(RenderBwd p) {
     int px, py0;
     lane_pixels(lane, sx, sy, px, py0);
     const int py1 = py0 + 1;
-    const bool in0 = px < p.W && py0 < p.H, in1 = px < p.W && py1 < p.H;
     const float pxf = (float)px;
     const f2 pyf = {(float)py0, (float)py1};
 
@@ -888,9 +912,33 @@ render_bwd_kernel(RenderBwd p) {
     if constexpr (STATS) t_start = wall_clock64();
     const uint2 range = p.ranges[vt];
 
+    // The pixel state is LOADED row-major (lane = column + 16 x row pair: every 16-lane quarter of a load instruction reads
+    // one whole 64-byte row segment) and re-dealt through LDS to the 8 x 8-block mapping of the replay -- the mirror image of
+    // the forward's store path; loaded in the block mapping, each row segment is fetched in two 32-byte pieces by two
+    // different quarters.  The staging area is free here: the previous tile of a queue worker ended behind a barrier, and
+    // the first batch below starts behind one.  Seven planes of 128 pixels per wave, wave-private (LDS accesses of a wave
+    // complete in order: no barrier).
     PixB s0, s1;
-    load_pixel_bwd(p, s0, in0, pose, px, py0);
-    load_pixel_bwd(p, s1, in1, pose, px, py1);
+    {
+        const int qx = sx + (lane & 15), qy0 = sy + 2 * (lane >> 4);
+        PixB t0, t1;
+        load_pixel_bwd(p, t0, qx < p.W && qy0 < p.H, pose, qx, qy0);
+        load_pixel_bwd(p, t1, qx < p.W && qy0 + 1 < p.H, pose, qx, qy0 + 1);
+        float* const o = s_ent + wave * (7 * 128);
+        const int r0 = (qy0 - sy) * 16 + (lane & 15), r1 = r0 + 16;
+        o[r0] = t0.T; o[r1] = t1.T;
+        o[128 + r0] = t0.dL0; o[128 + r1] = t1.dL0;
+        o[256 + r0] = t0.dL1; o[256 + r1] = t1.dL1;
+        o[384 + r0] = t0.dL2; o[384 + r1] = t1.dL2;
+        o[512 + r0] = t0.q; o[512 + r1] = t1.q;
+        o[640 + r0] = t0.dLd; o[640 + r1] = t1.dLd;
+        o[768 + r0] = __uint_as_float(t0.last); o[768 + r1] = __uint_as_float(t1.last);
+        const int p0 = (py0 - sy) * 16 + (px - sx), p1 = p0 + 16;
+        s0.T = o[p0]; s0.dL0 = o[128 + p0]; s0.dL1 = o[256 + p0]; s0.dL2 = o[384 + p0]; s0.q = o[512 + p0];
+        s0.dLd = o[640 + p0]; s0.last = __float_as_uint(o[768 + p0]);
+        s1.T = o[p1]; s1.dL0 = o[128 + p1]; s1.dL1 = o[256 + p1]; s1.dL2 = o[384 + p1]; s1.q = o[512 + p1];
+        s1.dLd = o[640 + p1]; s1.last = __float_as_uint(o[768 + p1]);
+    }
     PairB ps = pack_pair(s0, s1);
 
     const uint32_t wave_max = wave_max_u32(max(s0.last, s1.last));
@@ -986,7 +1034,11 @@ render_bwd_kernel(RenderBwd p) {
             const int lim0 = ((int)s0.last - base) * kEntB, lim1 = ((int)s1.last - base) * kEntB;
             int jb = (int)my_list[0];
             for (int ti = 0; ti < maxn; ++ti) {
-                const int jn = (int)my_list[ti + 1];       // next trip's entry, read a trip ahead
+                // next trip's entry, read a trip ahead -- and made a full register: carried as 16 bits it is masked again every
+                // trip.  (Two trips per loop body, to drop the copy that hands it on: the compiler rolls them back into one
+                // body with seven more scalar instructions per trip -- 75 + 15 against 76 + 8 -- so the copy stays.)
+                int jn = (int)my_list[ti + 1];
+                asm("" : "+v"(jn));
                 const float4 a = *reinterpret_cast<const float4*>(ent + jb);   // (two addresses per wave: one per group)
                 const float4 b = *reinterpret_cast<const float4*>(ent + jb + 16);
                 const float2 c = *reinterpret_cast<const float2*>(ent + jb + 32);
