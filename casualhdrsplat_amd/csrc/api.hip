@@ -246,6 +246,7 @@ int hs_forward(const hs_fwd_args* a, void* hip_stream) {
     if ((a->stages & HS_STAGE_OFFSETS) && a->dims.P > 0) {
         rc = launch_scan(*a, L, s);  // inspection only: a5 in instance order
         if (rc) return rc;
+        if ((rc = launch_cov3d(*a, L, s))) return rc;   // ... and the 3-D covariances, which the pipeline does not keep
     }
     if (a->stages & HS_STAGE_RENDER) {
         if (!a->binning || !a->image || !a->out_color) { set_error("hs_forward: null binning/image/out_color"); return HS_EINVAL; }

@@ -62,6 +62,7 @@ static inline int tile_bits(uint32_t n) {
 // then clears its own scratch): see kDepthBitsAt
 int launch_preprocess_fwd(const hs_fwd_args& a, const hs_layout& L, hipStream_t s, uint32_t frame_tag);
 int launch_scan(const hs_fwd_args& a, const hs_layout& L, hipStream_t s);
+int launch_cov3d(const hs_fwd_args& a, const hs_layout& L, hipStream_t s);   // inspection: fills hs_layout.cov3D
 int launch_binning(const hs_fwd_args& a, const hs_layout& L, hipStream_t s, uint32_t frame_tag);
 // `stats` (device, render_stats_count() u64 counters, or null) selects the diagnostic instantiation of the kernel
 int launch_render_fwd(const hs_fwd_args& a, const hs_layout& L, hipStream_t s, unsigned long long* stats = nullptr);

@@ -206,10 +206,8 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreFwd p) {
             float q[4] = {q4.x, q4.y, q4.z, q4.w};
             cov3d_from_scale_rot(sc, p.mod, q, s6);
         }
-        if (pose == 0) {
-#pragma unroll
-            for (int k = 0; k < 6; ++k) p.cov3D[6 * (int64_t)g + k] = s6[k];
-        }
+        // (the 3-D covariance is NOT kept: the backward recomputes it from the scale and the rotation it loads anyway -- 24
+        // bytes per Gaussian less to write here and to read there; HS_STAGE_OFFSETS fills the array for inspection)
     }
 
     if (pvz > 0.2f) {
@@ -322,6 +320,25 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreFwd p) {
     }
 }
 
+// Inspection only (HS_STAGE_OFFSETS): the 3-D covariances as the forward computed them, into the geometry workspace
+__global__ void __launch_bounds__(256) cov3d_kernel(int P, float mod, const float* scales, const float* rots, const float* cov_pre,
+                                                    float* cov3D) {
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= P) return;
+    float s6[6];
+    if (cov_pre) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) s6[k] = cov_pre[6 * (int64_t)g + k];
+    } else {
+        float sc[3] = {scales[3 * g], scales[3 * g + 1], scales[3 * g + 2]};
+        const float4 q4 = reinterpret_cast<const float4*>(rots)[g];
+        float q[4] = {q4.x, q4.y, q4.z, q4.w};
+        cov3d_from_scale_rot(sc, mod, q, s6);
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) cov3D[6 * (int64_t)g + k] = s6[k];
+}
+
 __global__ void mark_visible_kernel(int P, const float* means, const float* V, uint8_t* vis) {
     int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
@@ -413,7 +430,7 @@ struct PreBwd {
     const float* means; const float* shs; const float* scales; const float* rots; const float* opac;
     bool has_colors_precomp, has_cov_pre, antialias;
     int act;  // radiance activation: 0 relu_shift, 1 exp, 2 softplus
-    const float4* rec; const int* radii_inst; const uint32_t* tiles; const uint32_t* offsets; const float* cov3D;
+    const float4* rec; const int* radii_inst; const uint32_t* tiles; const uint32_t* offsets; const float* cov_pre;
     const uint8_t* clamped;
     const float4* inst_grads;
     float* d_means3D; float* d_means2D; float* d_opac; float* d_shs; float* d_colors; float* d_scales;
@@ -494,9 +511,18 @@ __global__ void __launch_bounds__(kPreBwdBlock) preprocess_bwd_kernel(PreBwd p) 
     float gop = 0.f;
     float gcol_pre[3] = {0.f, 0.f, 0.f};
 
-    float s6[6];
+    float s6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (valid) {   // the forward's 3-D covariance, bit for bit: the same function of the same inputs (or the input itself)
+        if (p.cov_pre) {
 #pragma unroll
-    for (int k = 0; k < 6; ++k) s6[k] = valid ? p.cov3D[6 * (int64_t)g + k] : 0.f;
+            for (int k = 0; k < 6; ++k) s6[k] = p.cov_pre[6 * (int64_t)g + k];
+        } else {
+            float sc[3] = {p.scales[3 * g], p.scales[3 * g + 1], p.scales[3 * g + 2]};
+            const float4 q4 = reinterpret_cast<const float4*>(p.rots)[g];
+            float q[4] = {q4.x, q4.y, q4.z, q4.w};
+            cov3d_from_scale_rot(sc, p.mod, q, s6);
+        }
+    }
 
     int max_radius = 0;  // over poses
     for (int pose = 0; pose < p.N; ++pose) {
@@ -904,7 +930,7 @@ int launch_preprocess_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t 
     p.has_colors_precomp = a.colors_precomp != nullptr; p.has_cov_pre = a.cov3D_precomp != nullptr;
     p.rec = (const float4*)(geom + L.rec); p.radii_inst = (const int*)(geom + L.radii);
     p.tiles = (const uint32_t*)(geom + L.tiles_touched); p.offsets = (const uint32_t*)(geom + L.offsets);
-    p.cov3D = (const float*)(geom + L.cov3D); p.clamped = (const uint8_t*)(geom + L.clamped);
+    p.cov_pre = a.cov3D_precomp; p.clamped = (const uint8_t*)(geom + L.clamped);
     p.inst_grads = (const float4*)((const char*)a.bwd + L.inst_grads);
     if (segsum) {
         const int64_t I = (int64_t)d.P * d.n_poses;
@@ -977,6 +1003,13 @@ int launch_sh_backward_views(int P, int M, int deg, int V, const float* means3D,
         case 2: sh_views_kernel<2><<<grid, kPreBwdBlock, lds, s>>>(P, M, V, means3D, camposes, view_colors, d_shs); break;
         default: sh_views_kernel<3><<<grid, kPreBwdBlock, lds, s>>>(P, M, V, means3D, camposes, view_colors, d_shs); break;
     }
+    HS_LAUNCH_CHECK();
+    return HS_OK;
+}
+
+int launch_cov3d(const hs_fwd_args& a, const hs_layout& L, hipStream_t s) {
+    cov3d_kernel<<<ceil_div(a.dims.P, 256), 256, 0, s>>>(a.dims.P, a.scale_modifier, a.scales, a.rotations, a.cov3D_precomp,
+                                                        (float*)((char*)a.geom + L.cov3D));
     HS_LAUNCH_CHECK();
     return HS_OK;
 }

@@ -52,7 +52,8 @@ extern "C" {
 #define HS_STAGE_RENDER 4     /* per-tile alpha blend (+ HDR epilogue, + N-pose resolve) */
 #define HS_STAGE_ALL 7
 #define HS_STAGE_OFFSETS 8    /* inspection only: inclusive scan of tiles_touched in instance order into the geom
-                                 workspace (`offsets`); the pipeline itself scans the depth-ordered counts */
+                                 workspace (`offsets`; the pipeline itself scans the depth-ordered counts) and the 3-D
+                                 covariances (`cov3D`; the pipeline recomputes them in the backward instead of storing) */
 
 /* hs_bwd_args.stages */
 #define HS_BWD_RENDER 1      /* per-pixel backward -> one gradient record per (tile, instance) pair */
