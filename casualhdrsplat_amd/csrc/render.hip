@@ -345,10 +345,8 @@ constexpr int kFcmpOGE = 3, kFcmpOLE = 5;
 // DEPTH: also accumulate the expected inverse depth sum alpha T / z.
 struct PairF {
     f2 T, C0, C1, C2, D;
-    uint32_t last0, last1;   // last contributor so far, as (index + 1) * 48, up to the previous batch
-    uint32_t rel0, rel1;     // ... inside the current batch: LDS byte offset of its staged record, kNoRel = none yet
+    uint32_t last0, last1;
 };
-constexpr uint32_t kNoRel = 0xFFFFFFFFu;
 // Returns the lane mask of the lanes in which at least one of the two pixels took the entry.
 template <bool DEPTH>
 __device__ __forceinline__ uint64_t blend_fwd_pair(PairF& s, uint64_t& done0, uint64_t& done1, f2 pw, f2 alpha, float r,
@@ -370,8 +368,8 @@ __device__ __forceinline__ uint64_t blend_fwd_pair(PairF& s, uint64_t& done0, ui
     s.C0 += rr * w; s.C1 = pk_fma_hi(f2{r, g}, w, s.C1); s.C2 += bb * w;
     if constexpr (DEPTH) { const f2 dd = {invd, invd}; s.D += dd * w; }
     s.T = f2{upd0 ? test_T.x : s.T.x, upd1 ? test_T.y : s.T.y};
-    s.rel0 = upd0 ? idx1 : s.rel0;   // (idx1: the entry's LDS byte offset as the list holds it -- no per-trip add; the
-    s.rel1 = upd1 ? idx1 : s.rel1;   // batch's base goes on once per batch: fold_last)
+    s.last0 = upd0 ? idx1 : s.last0;
+    s.last1 = upd1 ? idx1 : s.last1;
     if (n_pixels) *n_pixels = __popcll(cont0) + __popcll(cont1);
     return cont0 | cont1;
 }
@@ -445,7 +443,6 @@ render_fwd_kernel(RenderFwd p) {
     ps.T = f2{1.f, 1.f};
     ps.C0 = ps.C1 = ps.C2 = ps.D = f2{0.f, 0.f};
     ps.last0 = ps.last1 = 0;
-    ps.rel0 = ps.rel1 = kNoRel;
     // lane masks of finished pixels (all 64 lanes of both waves run the whole kernel: exec is full)
     uint64_t done0 = __builtin_amdgcn_ballot_w64(!in0), done1 = __builtin_amdgcn_ballot_w64(!in1);
 
@@ -495,8 +492,12 @@ render_fwd_kernel(RenderFwd p) {
             const f2 pw = dy * (b.x * dy + u) + t;          // log2 of the Gaussian falloff at the two pixels
             const float al0 = fminf(kAlphaMax, b.y * hs_exp2(pw.x));
             const float al1 = fminf(kAlphaMax, b.y * hs_exp2(pw.y));
+            // (keeping the index batch-relative and adding the base once per batch saves this add -- 33.5 instead of 34.5
+            // vector instructions per trip -- but its two extra registers spill around the batch loop: +26 MB of scratch
+            // traffic per frame and not a microsecond gained; rejected)
+            const uint32_t idx48 = (uint32_t)(base48 + jb + kEnt);
             int n_pix = 0;
-            const uint64_t took = blend_fwd_pair<DEPTH>(ps, done0, done1, pw, f2{al0, al1}, b.z, b.w, c.x, DEPTH ? c.y : 0.f, (uint32_t)jb,
+            const uint64_t took = blend_fwd_pair<DEPTH>(ps, done0, done1, pw, f2{al0, al1}, b.z, b.w, c.x, DEPTH ? c.y : 0.f, idx48,
                                                         STATS ? &n_pix : nullptr);
             if constexpr (STATS) ws.v[kStFwdActivePix] += n_pix;
             // the two halves of `took` go to lane i - i0 of act_lo / act_hi as they are (one scalar + two vector
@@ -585,10 +586,7 @@ render_fwd_kernel(RenderFwd p) {
             // lane per position marks the entries
             const uint32_t t0 = walk(0, min(n_t, 64), base * kEnt);
             const uint32_t t1 = ((done0 & done1) != ~0ull && n_t > 64) ? walk(64, n_t, base * kEnt) : 0u;
-            // the batch's last contributors, from LDS offsets to (index + 1) * 48 -- once per batch instead of once per trip
-            ps.last0 = ps.rel0 != kNoRel ? (uint32_t)(base * kEnt + kEnt) + ps.rel0 : ps.last0;
-            ps.last1 = ps.rel1 != kNoRel ? (uint32_t)(base * kEnt + kEnt) + ps.rel1 : ps.last1;
-            ps.rel0 = ps.rel1 = kNoRel;
+
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
                 const uint32_t bit = 1u << (2 * g);
