@@ -3,8 +3,10 @@ against the float64 PyTorch-autograd rasterizer on the same inputs -- max, 99.9t
 |x - truth| / max(|truth|, 1e-3 RMS) -- on guard-banded scenes (no decision of any pixel within the guard band of a
 threshold, so all three implementations take identical decisions) and on larger scenes restricted to the rows the
 tests hold to the strict bar: every Gaussian NOT on the tile list of a pixel where HIP and oracle actually decided
-differently (helpers.decision_masks; `strict_share` = their share of all rows).  Runs on the MI355X box; writes
-gpurun_out/r03_parity_table.json (committed as profiles/r03_parity_table.json).
+differently (helpers.decision_masks; `strict_share` = their share of all rows).  The rows of the two FULL-SIZE frames
+(BASELINE c3 and c4: HIP against the fp32 C oracle only -- float64 autograd of a million Gaussians is out of reach) are
+written by the tests themselves (HS_PARITY_JSON=gpurun_out/r04_parity_fullsize.json pytest -k full_size_vs_oracle) and
+appended here.  Runs on the MI355X box; writes gpurun_out/r04_parity_table.json (committed under profiles/).
 usage: python scripts/parity_table.py [--big]"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -76,4 +78,7 @@ for name, P, W, H, deg, guard in cases:
               f" C/fp64 max {t['c_fp32_vs_fp64']['max']:.2e} p999 {t['c_fp32_vs_fp64']['p999']:.2e} l2 {t['c_fp32_vs_fp64']['l2']:.2e} frac {t['c_fp32_vs_fp64']['frac_gt_1e-4']:.1e} |"
               f" hip/C max {t['hip_vs_c_fp32']['max']:.2e} p999 {t['hip_vs_c_fp32']['p999']:.2e} frac {t['hip_vs_c_fp32']['frac_gt_1e-4']:.1e}")
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r03_parity_table.json"), "w"), indent=1)
+full = os.path.join(ROOT, "gpurun_out", "r04_parity_fullsize.json")
+if os.path.exists(full):
+    out["cases"] += json.load(open(full))["cases"]
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r04_parity_table.json"), "w"), indent=1)

@@ -1421,7 +1421,10 @@ def test_c3_full_size_vs_oracle(oracle):
     check_image(g["hdr"], r["hdr"], m, "c3 radiance")
     check_image(st["final_T"][0], f["final_T"], m, "c3 final_T")
     check_image(g["color"], r["ldr"], m, "c3 ldr")
-    rep = Hh.assert_grads_close(g, r, what="c3", at_risk=m["rows"], min_strict=0.95)
+    # at full size the bar is TIGHTER than helpers.STRICT: millions of elements give the fraction and the L2 their meaning.
+    # Measured (profiles/r04_parity_fullsize.json): 12 differing pixels, 98.9 % of the rows strict, and on those <= 3.2e-4 of
+    # the elements beyond 1e-4 relative (99.97 % within north_star's bar), worst element 6.7e-3, relative L2 5.4e-7
+    rep = Hh.assert_grads_close(g, r, what="c3", at_risk=m["rows"], min_strict=0.95, frac_tol=1e-3, max_tol=1e-2, l2_tol=2e-6)
     # table / exposure gradients: against the oracle's tone-map backward given the same decisions (on the handful of
     # differing pixels the radiance the HIP path composited stands in), and loosely against the oracle's own
     tab, dexp = Hh.crf_grads_given_decisions(oracle, sc, m, [r["hdr"]], [g["hdr"]])
@@ -1469,7 +1472,9 @@ def test_c4_eight_poses_full_size_vs_oracle(oracle):
     for name, got, ref in (("ldr", g["color"], r["ldr"]), ("hdr", g["hdr"], r["hdr"])):
         e = np.abs(np.asarray(got, np.float64) - ref) / np.maximum(np.abs(ref), 1e-2)
         assert not ((e > 1e-4).any(axis=0) & ~any_differs).any(), ("c4 " + name, float(e.max()))
-    rep = Hh.assert_grads_close(g, r, what="c4", at_risk=m["rows"], min_strict=0.90)
+    # (measured: 105 differing pixels over the eight poses, 93 % of the rows strict; on those <= 3e-4 of the elements beyond
+    # 1e-4, worst element 9.5e-3 -- a sum over eight poses' worth of pixel terms --, relative L2 4.7e-7)
+    rep = Hh.assert_grads_close(g, r, what="c4", at_risk=m["rows"], min_strict=0.90, frac_tol=1e-3, max_tol=2e-2, l2_tol=2e-6)
     tab, dexp = Hh.crf_grads_given_decisions(oracle, sc, m, [f["color"] for f in r["fwd"]], list(st["pose_hdr"][:N]))
     assert Hh.rel_err(g["d_crf_table"], tab, 1e3 * Hh.grad_floor(tab))[0] <= 2e-4
     assert float(g["d_exposure"]) == pytest.approx(dexp, rel=2e-4, abs=1e-3)
