@@ -35,8 +35,8 @@ fi
 if [ "$what" = bench ] || [ "$what" = all ]; then
   if [ "$CFG" = c3 ]; then
   python3 $ROOT/bench.py --steps 50 --warmup 5 > $O/bench_c3.json 2> $O/bench_c3.err
-  python3 $ROOT/bench.py --config c4 --steps 20 --warmup 3 --no-cpu-baseline --no-extras > $O/bench_c4.json 2> $O/bench_c4.err
-  python3 $ROOT/bench.py --config c2 --steps 50 --warmup 5 --no-cpu-baseline --no-extras > $O/bench_c2.json 2> $O/bench_c2.err
+  python3 $ROOT/bench.py --config c4 --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_c4.json 2> $O/bench_c4.err
+  python3 $ROOT/bench.py --config c2 --steps 50 --warmup 5 --no-cpu-baseline > $O/bench_c2.json 2> $O/bench_c2.err
   fi
   # per-kernel totals of the bench command at this config (the driver's command at c3)
   extra=""; [ "$CFG" = c3 ] || extra="--config $CFG"
