@@ -652,11 +652,20 @@ __global__ void __launch_bounds__(256) depth_keys_kernel(int64_t I, const float*
 
 // Tile rectangles of the instances gathered into depth order (one 8-byte gather per instance) ahead of the emission --
 // the path of frames with fewer than 2^21 instances, see emit_pairs_kernel.
+// ... and the pair count of every 256 of them (the emission's block size), summed in the same launch (round 4: one launch
+// less than gather + scan_reduce256_kernel; -3 us at c3)
 __global__ void __launch_bounds__(256) gather_binfo_kernel(int64_t I, const uint32_t* inst_sorted, const uint2* binfo,
-                                                           uint2* srect, const hs_counters* counters) {
+                                                           uint2* srect, const hs_counters* counters, uint32_t* block_sums) {
+    __shared__ uint32_t s_wave[4];
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= I) return;
-    srect[i] = counters->overflow >= 2u ? make_uint2(0u, 0u) : binfo[inst_sorted[i]];
+    uint2 rc = make_uint2(0u, 0u);
+    if (i < I) {
+        if (counters->overflow < 2u) rc = binfo[inst_sorted[i]];
+        srect[i] = rc;
+    }
+    uint32_t total;
+    block_incl_scan((rc.y & 0xFFFFu) * (rc.y >> 16), s_wave, &total);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
 }
 
 // ---- chained scan of the emission (one 64-bit status word per 256-instance block: flag << 62 | pairs) ----
@@ -696,7 +705,7 @@ __global__ void __launch_bounds__(256) emit_pairs_kernel(int64_t I, int P, int g
                                                          uint32_t* offs_sorted, uint2* pairs,
                                                          uint8_t* pair_flags, hs_counters* counters, uint64_t capacity,
                                                          uint32_t* ghist, int nbits, int passes,
-                                                         unsigned long long* depth_bits) {
+                                                         unsigned long long* depth_bits, int excl_ready) {
     __shared__ uint32_t s_hist[4 * 256];   // digit totals of the tile sort's passes (<= 4), this block's pairs
     __shared__ uint32_t s_beg[4][64];
     __shared__ uint4 s_own[4][64];         // per instance: key of its first tile, rectangle width, 1 / width (float), instance
@@ -726,8 +735,21 @@ __global__ void __launch_bounds__(256) emit_pairs_kernel(int64_t I, int P, int g
     const uint32_t cnt = (rc.y & 0xFFFFu) * (rc.y >> 16);
     uint32_t block_total;
     const uint32_t incl = block_incl_scan(cnt, s_wsum, &block_total);
-    if constexpr (!BIG) {      // offsets computed ahead of this launch (srect given as well)
-        if (threadIdx.x == 0) s_excl = block_excl[blk];
+    if constexpr (!BIG) {
+        // the pair counts of all 256-instance blocks were summed ahead of this launch (gather_binfo_kernel); every block adds
+        // up the ones in front of it itself -- at most 8192 of them below 2^21 instances, 32 coalesced loads per thread --
+        // instead of waiting for a single-workgroup scan kernel in between (round 4: one launch less, -3 us at c3)
+        // (beyond 8192 blocks -- a frame of millions of instances forced onto this path -- a scan kernel has turned the sums
+        // into exclusive prefixes: `excl_ready`)
+        if (excl_ready) {
+            if (threadIdx.x == 0) s_excl = block_excl[blk];
+        } else {
+            uint32_t part = 0;
+            for (int j = threadIdx.x; j < blk; j += 256) part += block_excl[j];
+            uint32_t before;
+            block_incl_scan(part, s_wsum, &before);
+            if (threadIdx.x == 0) s_excl = before;
+        }
     } else if (wave == 0) {
         if (lane == 0) sc_publish(scan_status + blk, (blk == 0 ? kScIncl : kScAgg) | (uint64_t)block_total);
         uint64_t excl = 0;
@@ -1024,16 +1046,17 @@ int launch_binning(const hs_fwd_args& a, const hs_layout& L, hipStream_t s, uint
     const int eblk = ceil_div(I, 256);
     uint2* srect = nullptr;
     uint32_t* block_excl = nullptr;
+    bool excl_ready = false;
     if (!scan_in_emission(I)) {
         srect = dp0;
         block_excl = (uint32_t*)dp1;
-        gather_binfo_kernel<<<eblk, 256, 0, s>>>(I, inst_sorted, (const uint2*)(geom + L.binfo), srect, counters);
-        scan_reduce256_kernel<<<eblk, 256, 0, s>>>(srect, I, block_excl);
-        scan_spine_kernel<<<1, 256, 0, s>>>(block_excl, eblk, nullptr);
+        gather_binfo_kernel<<<eblk, 256, 0, s>>>(I, inst_sorted, (const uint2*)(geom + L.binfo), srect, counters, block_excl);
+        excl_ready = eblk > 8192;
+        if (excl_ready) scan_spine_kernel<<<1, 256, 0, s>>>(block_excl, eblk, nullptr);
     }
 #define HS_EMIT_ARGS I, d.P, gx, gy, (float4*)(geom + L.rec), inst_sorted, (const uint2*)(geom + L.binfo), srect, block_excl,       \
                      scan_status, offs, p0, (uint8_t*)(bin + L.pair_flags), counters, (uint64_t)d.capacity, (uint32_t*)tmp2, tbits, \
-                     passes, depth_bits
+                     passes, depth_bits, (int)excl_ready
     if (srect) emit_pairs_kernel<false><<<eblk, 256, 0, s>>>(HS_EMIT_ARGS);
     else emit_pairs_kernel<true><<<eblk, 256, 0, s>>>(HS_EMIT_ARGS);
 #undef HS_EMIT_ARGS
