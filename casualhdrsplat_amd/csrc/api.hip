@@ -299,14 +299,19 @@ int hs_backward(const hs_bwd_args* a, void* hip_stream) {
         if (rc) return rc;
         if ((rc = debug_sync(a->flags, s, "render backward"))) return rc;
     }
+    // the second stage of the CRF-table gradient (adding the pixel blocks' partial rows up) rides on the segmented sum's
+    // launch when this call goes on to it: one launch less on the critical path
+    CrfReduce crf_reduce{nullptr, 0, 0, 0, nullptr, nullptr, 0};
+    const bool sums_follow = (a->stages & (HS_BWD_PREPROCESS | HS_BWD_SEGSUM)) != 0 && !(a->flags & HS_FLAG_DEBUG);
     if (a->stages & HS_BWD_CRF) {
-        rc = launch_crf_bwd(*a, L, s);
+        rc = launch_crf_bwd(*a, L, s, sums_follow ? &crf_reduce : nullptr);
         if (rc) return rc;
         if ((rc = debug_sync(a->flags, s, "CRF gradient"))) return rc;
     }
     if (a->stages & (HS_BWD_PREPROCESS | HS_BWD_SEGSUM | HS_BWD_PROJECT)) {
         const bool whole = (a->stages & HS_BWD_PREPROCESS) != 0;
-        rc = launch_preprocess_bwd(*a, L, s, whole || (a->stages & HS_BWD_SEGSUM), whole || (a->stages & HS_BWD_PROJECT));
+        rc = launch_preprocess_bwd(*a, L, s, whole || (a->stages & HS_BWD_SEGSUM), whole || (a->stages & HS_BWD_PROJECT),
+                                   crf_reduce.nblocks ? &crf_reduce : nullptr);
         if (rc) return rc;
         if ((rc = debug_sync(a->flags, s, "preprocess backward"))) return rc;
     }

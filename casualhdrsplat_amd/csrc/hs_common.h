@@ -69,8 +69,11 @@ int launch_render_fwd(const hs_fwd_args& a, const hs_layout& L, hipStream_t s, u
 int launch_render_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s, unsigned long long* stats = nullptr,
                       unsigned long long* timeline = nullptr);
 int render_stats_count();
-int launch_crf_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s);
-int launch_preprocess_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s, bool segsum, bool project);
+struct CrfReduce;
+// `defer`: non-null = do not launch the second stage; describe it there for the segmented sum's launch to run
+int launch_crf_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s, CrfReduce* defer);
+int launch_preprocess_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s, bool segsum, bool project,
+                          const CrfReduce* crf_reduce);
 int launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* vis, hipStream_t s);
 int launch_sh_backward_views(int P, int M, int deg, int V, const float* means3D, const float* camposes,
                              const float* view_colors, float* d_shs, hipStream_t s);
@@ -141,6 +144,51 @@ __device__ __forceinline__ void tagged_or(unsigned long long* p, uint32_t tag, u
 }
 // OR of the visible depth keys of a workgroup and of their complements into one of the copies of the depth-bits words (two
 // atomics per workgroup; binning.hip derives the depth sort's digit layout from them).  Every thread of the block calls it.
+// Sum over the 64 lanes of a wave in a fixed DPP tree; the total is valid in lane 63.
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
+__device__ __forceinline__ float wave_sum_hi_f32(float v) {
+    v += dpp_f32<0xB1>(v);        // quad_perm [1,0,3,2]
+    v += dpp_f32<0x4E>(v);        // quad_perm [2,3,0,1]
+    v += dpp_f32<0x141>(v);       // row_half_mirror
+    v += dpp_f32<0x140>(v);       // row_mirror
+    v += dpp_f32<0x142, 0xA>(v);  // row_bcast:15 -> rows 1,3
+    v += dpp_f32<0x143, 0xC>(v);  // row_bcast:31 -> rows 2,3
+    return v;
+}
+
+// Second stage of the CRF-table / exposure gradient (render.hip, crf_grad_kernel): the partial rows of the pixel blocks
+// added in a fixed order, one wave per output element (3K table entries + the exposure): lanes stride over the rows of the
+// blocks that worked on that channel -- every pose, every pixel block --, then a fixed DPP tree: reproducible.  Run either
+// by crf_reduce_kernel or, when the same hs_backward call goes on to the segmented sum, by the first workgroups of
+// pair_segsum_kernel (one launch less on the backward's critical path).
+struct CrfReduce {
+    const float* partials; int bx, planes, K; float* d_table; float* d_exposure;
+    int nblocks;   // 256-thread workgroups the job takes: ceil((3K + 1) / 4); 0 = nothing to do
+};
+__device__ __forceinline__ void crf_reduce_block(const CrfReduce& c, int block) {
+    const int K = c.K;
+    const int i = block * 4 + (threadIdx.x >> 6);  // 0 .. 3K: table entry ch * K + k, or 3K = exposure
+    const int lane = threadIdx.x & 63;
+    if (i > 3 * K) return;
+    const bool expo = i == 3 * K;
+    const int ch = expo ? 0 : i / K, k = expo ? K : i - ch * K;
+    float acc = 0.f;
+    // rows of plane p = [p * bx, (p + 1) * bx); plane p carries channel p % 3
+    const int nrows = expo ? c.planes * c.bx : (c.planes / 3) * c.bx;
+    for (int r = lane; r < nrows; r += 64) {
+        const int row = expo ? r : ((r / c.bx) * 3 + ch) * c.bx + (r % c.bx);
+        acc += c.partials[(int64_t)row * (K + 1) + k];
+    }
+    acc = wave_sum_hi_f32(acc);
+    if (lane == 63) {
+        if (!expo) { if (c.d_table) c.d_table[i] = acc; }
+        else if (c.d_exposure) c.d_exposure[0] = acc;
+    }
+}
+
 // OR over the 64 lanes of a wave, valid in lane 63 (six DPP steps; OR is idempotent, so rows may overlap)
 template <int CTRL, int ROW_MASK = 0xF>
 __device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {

@@ -358,7 +358,10 @@ __global__ void __launch_bounds__(256) pair_segsum_kernel(int64_t I, const uint3
                                                           const float4* pair_grads, const uint8_t* pair_flags,
                                                           float4* inst_grads, const hs_counters* counters,
                                                           const int* radii_inst, const uint8_t* clamped, float* view_colors,
-                                                          const float4* rec, int act) {
+                                                          const float4* rec, int act, CrfReduce crf_reduce) {
+    // (the second stage of the CRF-table gradient rides on this launch's first workgroups when the same call computed the
+    // first: hs_common.h, CrfReduce)
+    for (int b = blockIdx.x; b < crf_reduce.nblocks; b += gridDim.x) crf_reduce_block(crf_reduce, b);
     // four lanes (one DPP quad) per instance: lane q adds records beg+q, beg+q+4, ...; the four partial sums are
     // combined in a fixed butterfly, so the result does not depend on timing.  Quads shorten the longest run in a
     // wave fourfold (run lengths are heavy-tailed) and make neighbouring lanes read neighbouring records.
@@ -917,7 +920,8 @@ int launch_preprocess_fwd(const hs_fwd_args& a, const hs_layout& L, hipStream_t 
     return HS_OK;
 }
 
-int launch_preprocess_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s, bool segsum, bool project) {
+int launch_preprocess_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s, bool segsum, bool project,
+                          const CrfReduce* crf_reduce) {
     const hs_dims& d = a.dims;
     const char* geom = (const char*)a.geom;
     PreBwd p;
@@ -941,7 +945,8 @@ int launch_preprocess_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t 
                                                            (const uint8_t*)bin + L.pair_flags,
                                                            (float4*)((char*)a.bwd + L.inst_grads),
                                                            (const hs_counters*)(geom + L.counters), p.radii_inst, p.clamped,
-                                                           a.colors_precomp ? nullptr : a.dL_dview_colors, p.rec, p.act);
+                                                           a.colors_precomp ? nullptr : a.dL_dview_colors, p.rec, p.act,
+                                                           crf_reduce ? *crf_reduce : CrfReduce{nullptr, 0, 0, 0, nullptr, nullptr, 0});
         HS_LAUNCH_CHECK();
     }
     if (!project) return HS_OK;

@@ -1256,28 +1256,8 @@ __global__ void __launch_bounds__(256) crf_grad_kernel(int64_t HW, int N, int fl
     }
 }
 
-// One wave per output element (3K table entries + the exposure): lanes stride over the partial rows of the blocks that
-// worked on that channel -- every pose, every pixel block -- in a fixed order, then a fixed DPP tree: reproducible.
-__global__ void __launch_bounds__(256) crf_reduce_kernel(const float* partials, int bx, int planes, int K, float* d_table,
-                                                         float* d_exposure) {
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);  // 0 .. 3K: table entry ch * K + k, or 3K = exposure
-    const int lane = threadIdx.x & 63;
-    if (i > 3 * K) return;
-    const bool expo = i == 3 * K;
-    const int ch = expo ? 0 : i / K, k = expo ? K : i - ch * K;
-    float acc = 0.f;
-    // rows of plane p = [p * bx, (p + 1) * bx); plane p carries channel p % 3
-    const int nrows = expo ? planes * bx : (planes / 3) * bx;
-    for (int r = lane; r < nrows; r += 64) {
-        const int row = expo ? r : ((r / bx) * 3 + ch) * bx + (r % bx);
-        acc += partials[(int64_t)row * (K + 1) + k];
-    }
-    acc = wave_sum_hi(acc);
-    if (lane == 63) {
-        if (!expo) { if (d_table) d_table[i] = acc; }
-        else if (d_exposure) d_exposure[0] = acc;
-    }
-}
+// The partial rows added up in a fixed order (hs_common.h, crf_reduce_block): stand-alone launch
+__global__ void __launch_bounds__(256) crf_reduce_kernel(CrfReduce c) { crf_reduce_block(c, (int)blockIdx.x); }
 
 }  // namespace
 
@@ -1328,7 +1308,7 @@ int launch_render_fwd(const hs_fwd_args& a, const hs_layout& L, hipStream_t s, u
     return HS_OK;
 }
 
-int launch_crf_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s) {
+int launch_crf_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s, CrfReduce* defer) {
     const hs_dims& d = a.dims;
     if (!((a.flags & HS_FLAG_HDR) && (a.dL_dcrf_table || a.dL_dexposure))) return HS_OK;
     Crf crf;
@@ -1341,8 +1321,11 @@ int launch_crf_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s) {
     const int bx = ceil_div(HW, kCrfPixPerBlock);
     crf_grad_kernel<<<dim3(bx, planes), 256, (size_t)(a.crf_K - 1) * sizeof(unsigned long long), s>>>(
         HW, d.n_poses, a.flags, pose_hdr, crf, a.exposure, a.dL_dout_color, partials);
-    crf_reduce_kernel<<<ceil_div(3 * a.crf_K + 1, 4), 256, 0, s>>>(partials, bx, planes, a.crf_K, a.dL_dcrf_table,
-                                                                 a.dL_dexposure);
+    CrfReduce cr;
+    cr.partials = partials; cr.bx = bx; cr.planes = planes; cr.K = a.crf_K; cr.d_table = a.dL_dcrf_table;
+    cr.d_exposure = a.dL_dexposure; cr.nblocks = ceil_div(3 * a.crf_K + 1, 4);
+    if (defer) *defer = cr;   // the segmented sum's launch adds the rows up (its first workgroups): one launch less
+    else crf_reduce_kernel<<<cr.nblocks, 256, 0, s>>>(cr);
     HS_LAUNCH_CHECK();
     return HS_OK;
 }
