@@ -640,14 +640,28 @@ int radix_sort_packed(uint2* p0, uint2* p1, uint32_t* keys_out, uint32_t* vals_o
 // Depth keys of the instances as (key, instance) elements: culled instances get the largest key so they sort to the end.
 __global__ void __launch_bounds__(256) depth_keys_kernel(int64_t I, const float* depth, const int* radii, uint2* pairs,
                                                          unsigned long long* bits) {
+    // 1024 instances per workgroup: the OR of the keys ends in two atomics per workgroup on one of 16 copies -- with one
+    // workgroup per 256 instances four thousand of them queued on those words for 17 us (c3)
     __shared__ uint32_t s_two[2];
     if (threadIdx.x < 2) s_two[threadIdx.x] = 0u;
     __syncthreads();
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const bool visible = i < I && radii[i] > 0;
-    const uint32_t key = visible ? __float_as_uint(depth[i]) : 0xFFFFFFFFu;
-    if (i < I) pairs[i] = make_uint2(key, (uint32_t)i);
-    depth_bits_accumulate(key, visible, bits, 0u, s_two);   // which bits vary (tag 0: bin_prepare_kernel zeroed the words)
+    uint32_t o = 0u, nz = 0u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int64_t i = (int64_t)blockIdx.x * 1024 + k * 256 + threadIdx.x;
+        if (i < I) {
+            const bool visible = radii[i] > 0;
+            const uint32_t key = visible ? __float_as_uint(depth[i]) : 0xFFFFFFFFu;
+            pairs[i] = make_uint2(key, (uint32_t)i);
+            if (visible) { o |= key; nz |= ~key; }
+        }
+    }
+    // which bits vary (tag 0: bin_prepare_kernel zeroed the words); o / nz are ORs already: "visible key o, complement nz"
+    o = wave_or_hi(o); nz = wave_or_hi(nz);
+    if ((threadIdx.x & 63) == 63) { if (o) atomicOr(&s_two[0], o); if (nz) atomicOr(&s_two[1], nz); }
+    __syncthreads();
+    if (threadIdx.x < 2 && s_two[threadIdx.x])
+        tagged_or(bits + 2 * (blockIdx.x % kDepthBitsCopies) + threadIdx.x, 0u, s_two[threadIdx.x]);
 }
 
 // Tile rectangles of the instances gathered into depth order (one 8-byte gather per instance) ahead of the emission --
@@ -1014,8 +1028,8 @@ int launch_binning(const hs_fwd_args& a, const hs_layout& L, hipStream_t s, uint
     uint2* dp1 = dp0 + I;
     uint32_t* inst_sorted = (uint32_t*)(bin + L.inst_sorted);
     if (!prepared)
-        depth_keys_kernel<<<ceil_div(I, 256), 256, 0, s>>>(I, (const float*)(geom + L.depth), (const int*)(geom + L.radii), dp0,
-                                                           depth_bits);
+        depth_keys_kernel<<<ceil_div(I, 1024), 256, 0, s>>>(I, (const float*)(geom + L.depth), (const int*)(geom + L.radii), dp0,
+                                                            depth_bits);
     {
         const int nblk = ceil_div(I, kDepthTile);
         depth_ghist_kernel<<<ceil_div(I, 4096), 1024, 0, s>>>(dp0, n_inst, depth_bits, dtag, dsc.ghist);
