@@ -5,7 +5,8 @@
 //
 // The published algorithm sorts R (tile<<32 | depth_bits) keys with one 64-bit radix sort.  The result of that
 // stable sort is reproduced here with ~4x less HBM traffic by splitting it:
-//   1. stable-sort the I = N*P instances by depth bits (32-bit keys, I << R);
+//   1. stable-sort the I = N*P instances by depth bits (32-bit keys, I << R) -- over the bits that VARY only, in digits of
+//      up to nine bits: three passes for a scene spanning up to 2^4 in depth ("depth sort over the VARYING bits" below);
 //   2. emit each instance's (tile, instance) pairs walking the instances in that depth order, so the pair stream
 //      is already depth-ordered (ties in depth keep ascending instance index, exactly the order in which the
 //      published duplicateWithKeys lays equal keys out);

@@ -499,6 +499,64 @@ def test_frame_of_14400_tiles_vs_oracle(oracle):
     Hh.assert_grads_close(g, b, what="14400 tiles", at_risk=m["rows"], min_strict=0.95)
 
 
+def _with_depths(sc, z_new):
+    """The same cloud as seen on screen, moved to the depths `z_new` (means and scales scale with z / z_old)."""
+    z_new = torch.as_tensor(z_new, dtype=torch.float32)
+    k = (z_new / sc.means3D[:, 2])[:, None]
+    sc.means3D = sc.means3D * k
+    sc.scales = sc.scales * k
+    return sc
+
+
+@pytest.mark.parametrize("case", ["all_equal", "two_values", "lowest_bit", "nine_bits", "wide", "half_culled", "one_visible"])
+def test_depth_sort_layouts_vs_oracle(oracle, case):
+    """The depth sort covers the bits of the depth keys that VARY only, in digits of up to nine bits, with the layout derived
+    on the device (binning.hip): every layout it can arrive at -- one pass (all depths equal, a single varying bit, exactly
+    nine bits), two, three and four passes (depths over five orders of magnitude), culled instances among the keys (they carry
+    the all-ones key and stay out of the layout), a single visible instance -- must give the oracle's sorted list bit for bit."""
+    P, W, H = 3000, 192, 128
+    sc = S.make_scene(P, W, H, 1, seed=31)
+    g = torch.Generator().manual_seed(5)
+    z0 = torch.tensor(4.0)
+    bits0 = int(z0.view(torch.int32))
+    if case == "all_equal":
+        z = torch.full((P,), 4.0)
+    elif case == "two_values":
+        z = torch.where(torch.rand(P, generator=g) < 0.5, torch.tensor(4.0), torch.tensor(4.5))
+    elif case == "lowest_bit":       # neighbouring floats: the keys differ in bit 0 only
+        z = (torch.full((P,), bits0, dtype=torch.int32) + torch.randint(0, 2, (P,), generator=g, dtype=torch.int32)).view(torch.float32)
+    elif case == "nine_bits":        # exactly the nine lowest bits vary: one digit
+        z = (torch.full((P,), bits0, dtype=torch.int32) + torch.randint(0, 512, (P,), generator=g, dtype=torch.int32)).view(torch.float32)
+    elif case == "wide":             # 0.25 ... 2.5e4: the exponent field varies in five bits -> 30 varying bits, four passes
+        z = 0.25 * torch.exp(torch.rand(P, generator=g) * 11.5)
+    elif case == "half_culled":      # every other Gaussian behind the 0.2 cull distance
+        z = 2.0 + 8.0 * torch.rand(P, generator=g)
+    else:
+        z = 2.0 + 8.0 * torch.rand(P, generator=g)
+    sc = _with_depths(sc, z)
+    if case == "half_culled":
+        sc.means3D[::2, 2] = 0.1
+    if case == "one_visible":
+        sc.means3D[1:, 2] = -1.0
+    f, _ = Hh.run_oracle(oracle, sc, backward=False)
+    gh = Hh.run_hip(sc)
+    st = gh["state"]
+    R = f["R"]
+    assert st["num_rendered"] == R and (R > 0)
+    check_structure(st, f)
+    assert np.array_equal(st["keys_sorted"].view(np.uint64)[:R], f["keys_sorted"])
+    assert np.array_equal(u32(st["point_list"][:R]), u32(f["point_list"]))
+    assert np.array_equal(u32(st["ranges"]), u32(f["ranges"]))
+    if case == "half_culled":
+        assert int((f["radii"] > 0).sum()) <= P // 2
+    if case == "one_visible":
+        assert int((f["radii"] > 0).sum()) == 1
+    # ... and the sync-free single-enqueue forward (preprocess writes the keys and ORs them) sorts the same list
+    gc = Hh.run_hip(sc, capacity=R + 1000)
+    assert np.array_equal(u32(gc["state"]["point_list"][:R]), u32(f["point_list"]))
+    assert np.array_equal(gh["color"], gc["color"])
+
+
 def test_crf_gradient_blur_domains_run_to_run_and_tiny_gradients():
     """The fixed-point CRF-gradient accumulation scales itself to each block's largest |dL/dLDR|: a loss gradient
     eight orders of magnitude smaller gives the same table gradient up to that factor (no underflow to zero), for
