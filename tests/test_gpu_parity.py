@@ -1153,6 +1153,46 @@ def test_whole_step_as_a_hip_graph_reproduces_the_eager_step():
         GraphedStep(lambda: None, [GaussianRasterizer(rs)])
 
 
+def test_graphed_step_checks_every_forward_of_a_rasterizer_not_only_the_last():
+    """a captured step may call ONE rasterizer several times (several views, an eval render in between).  The
+    overflow counters of every one of those forwards are copied out inside the graph and looked at by check_overflow():
+    a first call that outgrows the capacity (its frame renders empty, its gradients are zero) is reported even though the
+    rasterizer's latest forward fitted."""
+    from casualhdrsplat_amd import BinningOverflow, GaussianRasterizer
+    from casualhdrsplat_amd.graphs import GraphedStep
+    sc = S.make_scene(20000, 320, 200, 1, seed=21)
+    rs, _, _ = Hh.settings_from_scene(sc, "cuda")
+    names = ("means3D", "opacities", "shs", "scales", "rotations")
+    leaf = {k: getattr(sc, k).cuda().requires_grad_(True) for k in names}
+    other_scales = sc.scales.clone().cuda().requires_grad_(True)     # the scales the FIRST call of a step renders with
+    m2 = torch.zeros(20000, 3, device="cuda", requires_grad=True)
+    dL = sc.dL_dimage.cuda()
+    plist = list(leaf.values()) + [m2, other_scales]
+    R = Hh.run_hip(sc)["state"]["num_rendered"]
+    rast = GaussianRasterizer(rs, capacity=R + 5000)
+
+    def step():
+        for p in plist:
+            p.grad = None
+        first = rast(leaf["means3D"], m2, leaf["opacities"], shs=leaf["shs"], scales=other_scales, rotations=leaf["rotations"])
+        second = rast(leaf["means3D"], m2, leaf["opacities"], shs=leaf["shs"], scales=leaf["scales"], rotations=leaf["rotations"])
+        torch.autograd.backward([first[0], second[0]], grad_tensors=[dL, dL])
+        return first[0], second[0]
+
+    g = GraphedStep(step, [rast])
+    imgs = g.step()
+    counts = g.check_overflow()
+    assert len(counts) == 2 and counts[0] == counts[1] == R        # both forwards of the one rasterizer are tracked
+    assert torch.equal(imgs[0].detach(), imgs[1].detach()) and float(imgs[0].detach().abs().sum()) > 0
+    # now the FIRST call outgrows the capacity (nine times the footprint) while the second -- the rasterizer's latest forward -- fits
+    with torch.no_grad():
+        other_scales.mul_(3.0)
+    imgs = g.step()
+    with pytest.raises(BinningOverflow):
+        g.check_overflow()
+    assert float(imgs[0].detach().abs().sum()) == 0 and float(imgs[1].detach().abs().sum()) > 0   # (the empty frame, the one that fitted)
+
+
 def test_steps_do_not_leak_device_memory():
     """The saved state must not reference the outputs (a cycle through the autograd node is invisible to Python's
     collector): device memory after 3 steps equals device memory after 9."""
