@@ -275,7 +275,13 @@ def cpu_baseline(sc, cfg, n_tiles_sample=96, with_c2=False):
     t_pre, t_tiles = t1 - t0, t2 - t1
     per_tile = t_tiles / len(tiles)
     t_full = t_pre + per_tile * ntiles
-    if with_c2:
+    # c2 in full costs ~170 x the c1 frame just timed (151-165 s on the MI355X box's 128 host threads): run it unless that
+    # prediction says the box's CPU would need more than six minutes for it (the default run must finish within minutes)
+    c2_predicted = 170.0 * c1_med
+    if with_c2 and c2_predicted > 360.0:
+        out["c2_full"] = {"skipped": f"predicted {c2_predicted:.0f} s on this host (170 x the c1 frame's {c1_med:.2f} s) > 360 s budget; "
+                                     "last measured: profiles/r04_bench_c3.json"}
+    elif with_c2:
         t = _cpu_full_frame(CONFIGS["c2"])
         out["c2_full"] = {"images_per_s": 1.0 / t, "seconds": t, "workload": "100k Gaussians, 800x800, SH 0, LDR, fwd+bwd, whole frame"}
     else:
