@@ -162,9 +162,17 @@ __device__ __forceinline__ float radiance_dact(int act, float col, bool was_clam
     return was_clamped ? 0.f : 1.f;
 }
 
+#ifndef HS_TUNE_PF_EARLY
+#define HS_TUNE_PF_EARLY 1
+#endif
 // a4.  instance = pose * P + g.
+#ifdef HS_TUNE_PF_WAVES
+#define HS_PF_OCC __attribute__((amdgpu_waves_per_eu(HS_TUNE_PF_WAVES, HS_TUNE_PF_WAVES)))
+#else
+#define HS_PF_OCC
+#endif
 template <int DEG>
-__global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreFwd p) {
+__global__ void __launch_bounds__(256) HS_PF_OCC preprocess_fwd_kernel(PreFwd p) {
     __shared__ uint32_t s_two[2];       // OR of the workgroup's visible depth keys / of their complements
     if (p.depth_pairs) {                // (uniform)
         if (threadIdx.x < 2) s_two[threadIdx.x] = 0u;
@@ -192,28 +200,48 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreFwd p) {
     float depth = 0.f;
     uint8_t clampbits = 0;
 
+    // Loads first (round 5): position, scale, rotation and opacity are requested together, and the SH row of a Gaussian
+    // whose centre projects into (or near) the frame right behind them -- 192 bytes at degree 3 whose latency then runs
+    // under the projection / covariance arithmetic (a few hundred dependent instructions with their IEEE divisions)
+    // instead of after it.  The test is a HINT: a Gaussian that turns out visible without having passed it loads its row
+    // where it always did; one that passed it and is culled after all has read a row for nothing.
     const float x = p.means[3 * g], y = p.means[3 * g + 1], z = p.means[3 * g + 2];
-    const float pvx = xform_row(V, 0, x, y, z), pvy = xform_row(V, 1, x, y, z), pvz = xform_row(V, 2, x, y, z);
-
+    float sc[3] = {0.f, 0.f, 0.f};
+    float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float s6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (pose == 0 || pvz > 0.2f) {
-        if (p.cov_pre) {
+    if (p.cov_pre) {
 #pragma unroll
-            for (int k = 0; k < 6; ++k) s6[k] = p.cov_pre[6 * g + k];
-        } else {
-            float sc[3] = {p.scales[3 * g], p.scales[3 * g + 1], p.scales[3 * g + 2]};
-            float4 q4 = reinterpret_cast<const float4*>(p.rots)[g];
-            float q[4] = {q4.x, q4.y, q4.z, q4.w};
-            cov3d_from_scale_rot(sc, p.mod, q, s6);
-        }
+        for (int k = 0; k < 6; ++k) s6[k] = p.cov_pre[6 * g + k];
+    } else {
+        sc[0] = p.scales[3 * g]; sc[1] = p.scales[3 * g + 1]; sc[2] = p.scales[3 * g + 2];
+        q4 = reinterpret_cast<const float4*>(p.rots)[g];
+    }
+    const float opac_in = p.opac[g];
+    const float pvx = xform_row(V, 0, x, y, z), pvy = xform_row(V, 1, x, y, z), pvz = xform_row(V, 2, x, y, z);
+    const float phx = xform_row(PM, 0, x, y, z), phy = xform_row(PM, 1, x, y, z), phw = xform_row(PM, 3, x, y, z);
+    const float pw = 1.0f / (phw + 0.0000001f);
+    const float ppx = phx * pw, ppy = phy * pw;
+    constexpr int NCF = (DEG + 1) * (DEG + 1);
+    float shr[3 * NCF];
+#pragma unroll
+    for (int k = 0; k < 3 * NCF; ++k) shr[k] = 0.f;
+    bool have_sh = false;
+#if HS_TUNE_PF_EARLY
+    if (!p.colors && pvz > 0.2f && fabsf(ppx) < 1.5f && fabsf(ppy) < 1.5f) {
+        const float* sh = p.shs + (int64_t)g * p.M * 3;
+#pragma unroll
+        for (int k = 0; k < 3 * NCF; ++k) shr[k] = sh[k];
+        have_sh = true;
+    }
+#endif
+    if (!p.cov_pre && (pose == 0 || pvz > 0.2f)) {
+        float q[4] = {q4.x, q4.y, q4.z, q4.w};
+        cov3d_from_scale_rot(sc, p.mod, q, s6);
         // (the 3-D covariance is NOT kept: the backward recomputes it from the scale and the rotation it loads anyway -- 24
         // bytes per Gaussian less to write here and to read there; HS_STAGE_OFFSETS fills the array for inspection)
     }
 
     if (pvz > 0.2f) {
-        const float phx = xform_row(PM, 0, x, y, z), phy = xform_row(PM, 1, x, y, z), phw = xform_row(PM, 3, x, y, z);
-        const float pw = 1.0f / (phw + 0.0000001f);
-        const float ppx = phx * pw, ppy = phy * pw;
 
         Ewa e;
         ewa_setup(V, p.W, p.H, p.tanfovx, p.tanfovy, pvx, pvy, pvz, e);
@@ -250,13 +278,17 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreFwd p) {
                     const float ux = dx / len, uy = dy / len, uz = dz / len;
                     float b[(DEG + 1) * (DEG + 1)];
                     sh_basis<DEG>(ux, uy, uz, b);
-                    const float* sh = p.shs + (int64_t)g * p.M * 3;
-                    float acc[3] = {b[0] * sh[0], b[0] * sh[1], b[0] * sh[2]};
+                    if (!have_sh) {
+                        const float* sh = p.shs + (int64_t)g * p.M * 3;
+#pragma unroll
+                        for (int k = 0; k < 3 * NCF; ++k) shr[k] = sh[k];
+                    }
+                    float acc[3] = {b[0] * shr[0], b[0] * shr[1], b[0] * shr[2]};
 #pragma unroll
                     for (int k = 1; k < (DEG + 1) * (DEG + 1); ++k) {
-                        acc[0] = acc[0] + b[k] * sh[3 * k + 0];
-                        acc[1] = acc[1] + b[k] * sh[3 * k + 1];
-                        acc[2] = acc[2] + b[k] * sh[3 * k + 2];
+                        acc[0] = acc[0] + b[k] * shr[3 * k + 0];
+                        acc[1] = acc[1] + b[k] * shr[3 * k + 1];
+                        acc[2] = acc[2] + b[k] * shr[3 * k + 2];
                     }
 #pragma unroll
                     for (int ch = 0; ch < 3; ++ch) {
@@ -277,7 +309,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreFwd p) {
                                 (uint32_t)(rmaxx - rminx) | ((uint32_t)(rmaxy - rminy) << 16));
                 depth = pvz;
                 ra = make_float4(pix_x, pix_y, conA, conB);
-                float opac = p.opac[g];
+                float opac = opac_in;
                 if (p.antialias) {  // energy compensation of the 0.3-pixel dilation (newer published rasterizer)
                     const float det0 = (ca - 0.3f) * (cc - 0.3f) - cb * cb;
                     opac = opac * sqrtf(fmaxf(0.000025f, det0 / det));
@@ -467,6 +499,30 @@ __device__ __forceinline__ void stage_rows_in(float* s_rows, const float* src, i
         for (int i = threadIdx.x; i < rows * M3; i += kPreBwdBlock) s_rows[(i / M3) * ld + (i % M3)] = src[i];
     }
 }
+// The same for a FULL block whose rows are Q float4 long, Q known at compile time (M = (DEG + 1)^2 with 3M a multiple of
+// four: degree 3 -> Q = 12, degree 1 -> Q = 3): every thread issues its Q loads back to back and only then writes the LDS.
+// The run-time loop above compiles to one load -> wait -> four LDS writes per trip, i.e. ONE 16-byte load in flight per
+// thread: at three waves per SIMD that is 12 KB in flight per CU while the block does nothing else (round 5; same-box A/B
+// in profiles/README.md).
+#ifndef HS_TUNE_PB_UNROLL
+#define HS_TUNE_PB_UNROLL 1
+#endif
+template <int Q>
+__device__ __forceinline__ void stage_rows_issue(float4 (&v)[Q > 0 ? Q : 1], const float* src) {
+    const float4* src4 = reinterpret_cast<const float4*>(src);
+#pragma unroll
+    for (int j = 0; j < Q; ++j) v[j] = src4[j * kPreBwdBlock + threadIdx.x];
+}
+template <int Q>
+__device__ __forceinline__ void stage_rows_commit(float* s_rows, const float4 (&v)[Q > 0 ? Q : 1], int ld) {
+#pragma unroll
+    for (int j = 0; j < Q; ++j) {
+        const int i = j * kPreBwdBlock + threadIdx.x;
+        const int r = i / Q;
+        float* d = s_rows + r * ld + ((i - r * Q) << 2);
+        d[0] = v[j].x; d[1] = v[j].y; d[2] = v[j].z; d[3] = v[j].w;
+    }
+}
 __device__ __forceinline__ void stage_rows_out(float* dst, const float* s_rows, int rows, int M3, int ld) {
     if ((M3 & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
         const int q = M3 >> 2;
@@ -490,8 +546,13 @@ __device__ __forceinline__ void stage_rows_out(float* dst, const float* s_rows, 
 // instruction; instead the block's rows are moved between HBM and LDS with fully coalesced accesses and each thread
 // works on its row in LDS (row stride M*3+1 words: conflict-free).
 // SHG = false: the SH-coefficient gradient is not formed here (view-parallel exchange, hs_sh_backward_views).
+#ifdef HS_TUNE_PB_WAVES
+#define HS_PB_OCC __attribute__((amdgpu_waves_per_eu(HS_TUNE_PB_WAVES, HS_TUNE_PB_WAVES)))
+#else
+#define HS_PB_OCC
+#endif
 template <int DEG, bool POSE, bool SHG>
-__global__ void __launch_bounds__(kPreBwdBlock) preprocess_bwd_kernel(PreBwd p) {
+__global__ void __launch_bounds__(kPreBwdBlock) HS_PB_OCC preprocess_bwd_kernel(PreBwd p) {
     extern __shared__ float s_sh[];  // [kPreBwdBlock][M*3 + 1]
     __shared__ float s_pose[kPreBwdBlock / 64][kPoseVals];
     constexpr int NC = (DEG + 1) * (DEG + 1);
@@ -501,37 +562,62 @@ __global__ void __launch_bounds__(kPreBwdBlock) preprocess_bwd_kernel(PreBwd p) 
     const int M3 = p.M * 3, ld = M3 + 1;
     const int rows = min(kPreBwdBlock, p.P - g0);
     const bool stage_in = !p.has_colors_precomp && DEG >= 1;
-    if (stage_in) {
-        stage_rows_in(s_sh, p.shs + (int64_t)g0 * M3, rows, M3, ld);
-        __syncthreads();
+    // Loads FIRST, all of them (round 5): the block's SH rows (Q float4 per thread, back to back), then this thread's own
+    // inputs -- position, scale, rotation, pose 0's summed pair record -- and only then the LDS writes and the barrier:
+    // every latency of the kernel's head runs at the same time instead of one after the other.
+    constexpr int Q = (3 * NC) % 4 == 0 && HS_TUNE_PB_UNROLL ? 3 * NC / 4 : 0;
+    float4 staged[Q > 0 ? Q : 1];
+    bool fast_stage = false;
+    if constexpr (Q > 0) {
+        const float* src = p.shs + (int64_t)g0 * M3;
+        fast_stage = stage_in && M3 == 3 * NC && rows == kPreBwdBlock && (reinterpret_cast<uintptr_t>(src) & 15) == 0;   // (uniform)
+        if (fast_stage) stage_rows_issue<Q>(staged, src);
     }
     const bool valid = g < p.P;
     const float x = valid ? p.means[3 * g] : 0.f, y = valid ? p.means[3 * g + 1] : 0.f, z = valid ? p.means[3 * g + 2] : 0.f;
-
+    float s6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float4 rot4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float scl[3] = {0.f, 0.f, 0.f};
+    if (valid) {   // the forward's 3-D covariance, bit for bit: the same function of the same inputs (or the input itself)
+        if (p.cov_pre) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) s6[k] = p.cov_pre[6 * (int64_t)g + k];
+        } else {
+            scl[0] = p.scales[3 * g]; scl[1] = p.scales[3 * g + 1]; scl[2] = p.scales[3 * g + 2];
+            rot4 = reinterpret_cast<const float4*>(p.rots)[g];
+        }
+    }
+    const int rad0 = valid ? p.radii_inst[g] : 0;                       // pose 0
+    float4 pre_q0 = make_float4(0.f, 0.f, 0.f, 0.f), pre_q1 = pre_q0;
+    float2 pre_q2 = make_float2(0.f, 0.f);
+    uint8_t pre_cl = 0;
+    if (rad0 > 0) {
+        pre_q0 = p.inst_grads[kInstF4 * (int64_t)g + 0]; pre_q1 = p.inst_grads[kInstF4 * (int64_t)g + 1];
+        pre_q2 = reinterpret_cast<const float2*>(p.inst_grads + kInstF4 * (int64_t)g + 2)[0];
+        if (!p.has_colors_precomp) pre_cl = p.clamped[g];
+    }
+    if (stage_in) {
+        if (fast_stage) { if constexpr (Q > 0) stage_rows_commit<Q>(s_sh, staged, ld); }
+        else stage_rows_in(s_sh, p.shs + (int64_t)g0 * M3, rows, M3, ld);
+        __syncthreads();
+    }
     float gm[3] = {0.f, 0.f, 0.f};
     float gcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float gm2d[2] = {0.f, 0.f};
     float gop = 0.f;
     float gcol_pre[3] = {0.f, 0.f, 0.f};
 
-    float s6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (valid) {   // the forward's 3-D covariance, bit for bit: the same function of the same inputs (or the input itself)
-        if (p.cov_pre) {
-#pragma unroll
-            for (int k = 0; k < 6; ++k) s6[k] = p.cov_pre[6 * (int64_t)g + k];
-        } else {
-            float sc[3] = {p.scales[3 * g], p.scales[3 * g + 1], p.scales[3 * g + 2]};
-            const float4 q4 = reinterpret_cast<const float4*>(p.rots)[g];
-            float q[4] = {q4.x, q4.y, q4.z, q4.w};
-            cov3d_from_scale_rot(sc, p.mod, q, s6);
-        }
+    if (valid && !p.cov_pre) {
+        const float q[4] = {rot4.x, rot4.y, rot4.z, rot4.w};
+        cov3d_from_scale_rot(scl, p.mod, q, s6);
     }
 
     int max_radius = 0;  // over poses
     for (int pose = 0; pose < p.N; ++pose) {
         const int64_t idx = (int64_t)pose * p.P + g;
-        const bool on = valid && p.radii_inst[idx] > 0;
-        if (on) max_radius = max(max_radius, p.radii_inst[idx]);
+        const int rad = pose == 0 ? rad0 : (valid ? p.radii_inst[idx] : 0);
+        const bool on = rad > 0;
+        if (on) max_radius = max(max_radius, rad);
         float pg[POSE ? kPoseVals : 1];
         if constexpr (POSE) {
 #pragma unroll
@@ -540,13 +626,19 @@ __global__ void __launch_bounds__(kPreBwdBlock) preprocess_bwd_kernel(PreBwd p) 
         if (on) {
         // ---- this instance's summed pair records (pair_segsum_kernel) ----
         float r[9];
+        float r9;
         {
-            const float4 q0 = p.inst_grads[kInstF4 * idx + 0], q1 = p.inst_grads[kInstF4 * idx + 1];
+            float4 q0 = pre_q0, q1 = pre_q1;
+            float2 q2 = pre_q2;
+            if (pose != 0) {
+                q0 = p.inst_grads[kInstF4 * idx + 0]; q1 = p.inst_grads[kInstF4 * idx + 1];
+                q2 = reinterpret_cast<const float2*>(p.inst_grads + kInstF4 * idx + 2)[0];
+            }
             r[0] = q0.x; r[1] = q0.y; r[2] = q0.z; r[3] = q0.w; r[4] = q1.x; r[5] = q1.y; r[6] = q1.z; r[7] = q1.w;
-            r[8] = reinterpret_cast<const float*>(p.inst_grads + kInstF4 * idx + 2)[0];
+            r[8] = q2.x;
+            // r = {dmean2D.x, dmean2D.y, dconic A, B, C, dopacity, dcolor r,g,b}; r9 = d(inverse depth)
+            r9 = q2.y;
         }
-        // r = {dmean2D.x, dmean2D.y, dconic A, B, C, dopacity, dcolor r,g,b}; r9 = d(inverse depth)
-        const float r9 = reinterpret_cast<const float*>(p.inst_grads + kInstF4 * idx + 2)[1];
         gm2d[0] += r[0]; gm2d[1] += r[1];
         if (!p.antialias) gop += r[5];
 
@@ -654,7 +746,7 @@ __global__ void __launch_bounds__(kPreBwdBlock) preprocess_bwd_kernel(PreBwd p) 
             const float dx = x - cp[0], dy = y - cp[1], dz = z - cp[2];
             const float len = sqrtf((dx * dx + dy * dy) + dz * dz);
             const float ux = dx / len, uy = dy / len, uz = dz / len;
-            const uint8_t cl = p.clamped[idx];
+            const uint8_t cl = pose == 0 ? pre_cl : p.clamped[idx];
             float gc[3];
             {
                 float col[3] = {0.f, 0.f, 0.f};
@@ -709,12 +801,11 @@ __global__ void __launch_bounds__(kPreBwdBlock) preprocess_bwd_kernel(PreBwd p) 
     // ---- Sigma -> scale / rotation (pose independent, applied once to the pose-summed gradient) ----
     if (valid && !p.has_cov_pre) {
         float R[9], Mx[9], s[3];
-        const float4 q4 = reinterpret_cast<const float4*>(p.rots)[g];
-        const float q[4] = {q4.x, q4.y, q4.z, q4.w};
+        const float q[4] = {rot4.x, rot4.y, rot4.z, rot4.w};
         quat_to_R(q, R);
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            s[k] = p.mod * p.scales[3 * g + k];
+            s[k] = p.mod * scl[k];
 #pragma unroll
             for (int j = 0; j < 3; ++j) Mx[3 * k + j] = s[k] * R[3 * j + k];
         }
@@ -770,10 +861,10 @@ __global__ void __launch_bounds__(kPreBwdBlock) preprocess_bwd_kernel(PreBwd p) 
             if (valid) {
                 for (int pose = 0; pose < p.N; ++pose) {
                     const int64_t idx = (int64_t)pose * p.P + g;
-                    if (p.radii_inst[idx] <= 0) continue;
-                    const float4 q1 = p.inst_grads[kInstF4 * idx + 1];
-                    const float q2 = reinterpret_cast<const float*>(p.inst_grads + kInstF4 * idx + 2)[0];
-                    const uint8_t cl = p.clamped[idx];
+                    if ((pose == 0 ? rad0 : p.radii_inst[idx]) <= 0) continue;
+                    const float4 q1 = pose == 0 ? pre_q1 : p.inst_grads[kInstF4 * idx + 1];
+                    const float q2 = pose == 0 ? pre_q2.x : reinterpret_cast<const float*>(p.inst_grads + kInstF4 * idx + 2)[0];
+                    const uint8_t cl = pose == 0 ? pre_cl : p.clamped[idx];
                     float col[3] = {0.f, 0.f, 0.f};
                     if (p.act != 0) {
                         const float4 rb = p.rec[kRecF4 * idx + 1];

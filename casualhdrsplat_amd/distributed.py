@@ -211,6 +211,36 @@ def chunk_bounds(P: int, chunks: int, align: int = 128) -> list:
     return [(g0, min(P, g0 + per)) for g0 in range(0, P, per)]
 
 
+def _all_reduce_pieces(pieces: Sequence[torch.Tensor], group=None):
+    """ONE asynchronous collective summing several tensors over the ranks (`allreduce_coalesced`: RCCL brackets the
+    per-tensor all-reduces in one ncclGroupStart / End = one launch on the communication stream; gloo flattens them
+    into one buffer).  Returns a completion callable.  Backends without it fall back to one collective per tensor."""
+    pieces = [t for t in pieces if t.numel() > 0]
+    for t in pieces:
+        if not t.is_contiguous():
+            raise ValueError("chunked_all_reduce: gradient rows must be contiguous")
+    if not pieces:
+        return None, 0
+    if len(pieces) == 1:
+        return dist.all_reduce(pieces[0], op=dist.ReduceOp.SUM, group=group, async_op=True).wait, 1
+    pg = group if group is not None else dist.distributed_c10d._get_default_group()
+    try:
+        opts = dist.AllreduceCoalescedOptions()
+        opts.reduceOp = dist.ReduceOp.SUM
+        work = pg.allreduce_coalesced(list(pieces), opts)
+        return work.wait, 1
+    except (AttributeError, RuntimeError, NotImplementedError):
+        works = [dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True) for t in pieces]
+
+        def wait_all(works=works):
+            for w in works:
+                w.wait()
+        return wait_all, len(works)
+
+
+LAST_EXCHANGE = {"collectives": 0}   # collectives the latest chunked_all_reduce of this process issued (bench.py prints it)
+
+
 def chunked_all_reduce(rows: Sequence[torch.Tensor], P: int, chunks: int, compute_chunk, tail: Sequence[torch.Tensor] = (),
                        group=None) -> list:
     """The plain gradient exchange, overlapped with the kernels that produce the gradients (BASELINE.json configs[4]).
@@ -219,27 +249,28 @@ def chunked_all_reduce(rows: Sequence[torch.Tensor], P: int, chunks: int, comput
     compute_chunk  callable (g0, g1): enqueue the computation of rows [g0, g1) of every tensor in `rows` on the current
                    stream (the rasterizer: hs_backward(HS_BWD_PROJECT, g_begin, g_end));
     tail           gradients that are complete before the first chunk (exposure, CRF table): reduced with the first one.
-    For each ascending chunk: compute it, then issue the asynchronous all-reduce of exactly those rows of every tensor --
-    on RCCL the collective waits (on its own stream) for what the current stream holds at that moment, i.e. for the
-    chunk just enqueued, and travels while the next chunk computes.  Returns the list of completion callables
-    (finish_pending waits for them); [] when not distributed (the chunks are still computed).  Element for element
-    the result is that of one all-reduce of the whole buffer: every element is summed over the ranks exactly once."""
+    For each ascending chunk: compute it, then issue ONE asynchronous collective for exactly those rows of every tensor
+    (round 5: `allreduce_coalesced` -- a step puts `chunks` collectives on the wire instead of chunks x tensors small ones,
+    each of which pays RCCL's launch) -- on RCCL the collective waits (on its own stream) for what the current stream holds
+    at that moment, i.e. for the chunk just enqueued, and travels while the next chunk computes.  Returns the list of
+    completion callables (finish_pending waits for them); [] when not distributed (the chunks are still computed).
+    Element for element the result is that of one all-reduce of the whole buffer: every element is summed over the ranks
+    exactly once."""
     distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
     pending: list = []
     first = True
+    n_coll = 0
     for g0, g1 in chunk_bounds(P, chunks):
         compute_chunk(g0, g1)
         if not distributed:
             continue
         pieces = [t[g0:g1] for t in rows] + (list(tail) if first else [])
         first = False
-        for t in pieces:
-            if t.numel() == 0:
-                continue
-            if not t.is_contiguous():
-                raise ValueError("chunked_all_reduce: gradient rows must be contiguous")
-            work = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True)
-            pending.append(work.wait)
+        fin, n = _all_reduce_pieces(pieces, group)
+        if fin is not None:
+            pending.append(fin)
+        n_coll += n
+    LAST_EXCHANGE["collectives"] = n_coll
     return pending
 
 

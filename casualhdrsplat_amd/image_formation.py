@@ -10,9 +10,20 @@ the estimated blurry LDR image B_i that is compared with the captured frame.
 
 Everything here is small host-side PyTorch (SE(3) math on a handful of poses, a tiny MLP); the heavy lifting --
 N renders, tone-map, averaging, and the gradients w.r.t. Gaussians, exposure, CRF table and camera poses -- is
-ONE call into the HIP rasterizer.  Parameterisations the reference does not specify ([DESIGN]): linear
-interpolation in se(3) between the two knots bracketing the exposure window; CRF = monotone MLP on log-exposure
-sampled on K knots.
+ONE call into the HIP rasterizer.
+
+The figure's trajectory is a "Camera motion spline" through FOUR control knots T_j .. T_{j+3}, and the thick arc on it
+is the "Exposure time range" whose length is the learnable exposure time dt_i.  Both are modelled (round 5):
+
+  * `TrajectorySpline(kind="cubic")`: cumulative uniform cubic B-spline in SE(3) over four knots (C2-continuous camera
+    motion); `kind="linear"` keeps the two-knot form (geodesic between the knots bracketing the window).
+  * the virtual poses of frame i are sampled at times t_i + (s_k - 1/2) * dt_i * window_scale, s_k = (k + 1/2) / n, i.e.
+    inside [t_i - w/2, t_i + w/2] with w the exposure time expressed in knot intervals: dt_i sets the blur EXTENT as well
+    as the brightness, and dL/d(dt_i) has a motion-blur term that arrives through the rasterizer's pose gradients
+    (SURVEY.md 8f n1).  `window_from_exposure=False` pins the window to a fixed length (the round-4 behaviour).
+
+Parameterisations the reference does not specify ([DESIGN]): left-multiplied se(3) corrections on SfM knots, uniform
+knot times (knot j at time j), the CRF as a monotone MLP on log-exposure sampled on K knots.
 """
 from __future__ import annotations
 
@@ -54,43 +65,97 @@ def se3_exp(xi: torch.Tensor) -> torch.Tensor:
     return T
 
 
-class TrajectorySpline(nn.Module):
-    """Learnable camera trajectory: one se(3) control knot per captured-frame boundary (T_j in the figure).
-    `poses(i, n)` samples n virtual world-to-camera poses uniformly inside frame i's exposure window, which spans
-    the segment between knots i and i+1 (interpolated in the Lie algebra)."""
+# Cumulative basis of the uniform cubic B-spline (Lovegrove et al., "Spline fusion", 2013): pose(u) =
+# exp(B3 xi3) exp(B2 xi2) exp(B1 xi1) T_j with xi_k = log(T_{j+k} T_{j+k-1}^-1); B(0) = (5/6, 1/6, 0), B(1) = (1, 5/6, 1/6),
+# so neighbouring segments agree in value, velocity and acceleration.
+def _cubic_cumulative_basis(u: torch.Tensor):
+    u2, u3 = u * u, u * u * u
+    return (5.0 + 3.0 * u - 3.0 * u2 + u3) / 6.0, (1.0 + 3.0 * u + 3.0 * u2 - 2.0 * u3) / 6.0, u3 / 6.0
 
-    def __init__(self, init_w2c: torch.Tensor):
+
+class TrajectorySpline(nn.Module):
+    """Learnable camera trajectory over se(3) control knots (T_j in the figure; knot j sits at time j).
+
+    kind="cubic": cumulative uniform cubic B-spline in SE(3) -- the pose at time t in [j + 1, j + 2) is governed by the
+    four knots T_j .. T_{j+3} (the four knots the figure draws around one exposure window); defined for t in
+    [1, J - 2]; C2-continuous; reproduces constant-velocity motion exactly (knots exp(k xi) T_0 give exp(t xi) T_0,
+    so such knots are interpolated), otherwise it approximates its control knots like any B-spline.
+    kind="linear": geodesic between the two knots bracketing t (t in [0, J - 1]).
+    """
+
+    def __init__(self, init_w2c: torch.Tensor, kind: str = "linear"):
         """init_w2c: [J, 4, 4] initial world-to-camera matrices of the knots (e.g. from SfM)."""
         super().__init__()
+        if kind not in ("linear", "cubic"):
+            raise ValueError("kind must be 'linear' or 'cubic'")
+        if kind == "cubic" and init_w2c.shape[0] < 4:
+            raise ValueError("a cubic spline segment needs four control knots")
+        if kind == "linear" and init_w2c.shape[0] < 2:
+            raise ValueError("a trajectory needs at least two control knots")
+        self.kind = kind
         self.register_buffer("base", init_w2c.clone().float())
         self.delta = nn.Parameter(torch.zeros(init_w2c.shape[0], 6))  # left-multiplied se(3) corrections
+
+    @property
+    def t_range(self):
+        """(t_min, t_max): the times the trajectory is defined on."""
+        J = self.base.shape[0]
+        return (1.0, float(J - 2)) if self.kind == "cubic" else (0.0, float(J - 1))
 
     def knot(self, j: int) -> torch.Tensor:
         return se3_exp(self.delta[j]) @ self.base[j]
 
+    def knots(self) -> torch.Tensor:
+        """All corrected control knots [J, 4, 4]."""
+        return se3_exp(self.delta) @ self.base.to(self.delta.dtype)
+
+    def pose_at(self, t: torch.Tensor) -> torch.Tensor:
+        """World-to-camera matrices [n, 4, 4] at times t [n]; differentiable w.r.t. the knots AND w.r.t. t.  Pure tensor
+        code (segment look-up by index_select): no host read of t, so it neither synchronises nor breaks a graph capture."""
+        t = t.reshape(-1)
+        J = self.base.shape[0]
+        Tk = self.knots()
+        inc = se3_log(Tk[1:] @ torch.linalg.inv(Tk[:-1]))        # [J - 1, 6]: knot(j + 1) = exp(inc[j]) knot(j)
+        fl = torch.floor(t.detach()).long()
+        if self.kind == "linear":
+            j = fl.clamp(0, J - 2)
+            u = t - j.to(t.dtype)
+            return se3_exp(u[:, None] * inc.index_select(0, j)) @ Tk.index_select(0, j)
+        j = (fl - 1).clamp(0, J - 4)
+        u = t - (j + 1).to(t.dtype)
+        b1, b2, b3 = _cubic_cumulative_basis(u)
+        x1, x2, x3 = inc.index_select(0, j), inc.index_select(0, j + 1), inc.index_select(0, j + 2)
+        return (se3_exp(b3[:, None] * x3) @ se3_exp(b2[:, None] * x2) @ se3_exp(b1[:, None] * x1)) @ Tk.index_select(0, j)
+
+    def window_times(self, t_mid, width, n: int) -> torch.Tensor:
+        """n sample times uniformly inside [t_mid - width / 2, t_mid + width / 2] (midpoint rule); differentiable
+        w.r.t. both."""
+        p = next(self.parameters())
+        s = (torch.arange(n, dtype=p.dtype, device=p.device) + 0.5) / n - 0.5
+        return torch.as_tensor(t_mid, dtype=p.dtype, device=p.device) + s * torch.as_tensor(width, dtype=p.dtype, device=p.device)
+
     def poses(self, i: int, n: int) -> torch.Tensor:
-        T0, T1 = self.knot(i), self.knot(i + 1)
-        rel = T1 @ torch.linalg.inv(T0)  # motion over the exposure window
-        xi = se3_log(rel)
-        ts = (torch.arange(n, dtype=T0.dtype, device=T0.device) + 0.5) / n
-        return se3_exp(ts[:, None] * xi[None, :]) @ T0
+        """Round-4 form: n virtual poses uniformly over the whole interval between knots i and i + 1 (kind="linear"),
+        or over the segment [i + 1, i + 2) governed by knots i .. i + 3 (kind="cubic")."""
+        t_mid = i + 0.5 if self.kind == "linear" else i + 1.5
+        return self.pose_at(self.window_times(t_mid, 1.0, n))
 
 
 def se3_log(T: torch.Tensor) -> torch.Tensor:
-    """Logarithm SE(3) -> se(3) for rotations well below pi (adjacent video frames)."""
-    R, t = T[:3, :3], T[:3, 3]
-    cos = ((R.diagonal().sum() - 1) / 2).clamp(-1 + 1e-7, 1 - 1e-7)
+    """Logarithm SE(3) -> se(3) for rotations well below pi (adjacent video frames); T [..., 4, 4] -> [..., 6]."""
+    R, t = T[..., :3, :3], T[..., :3, 3]
+    cos = ((R.diagonal(dim1=-2, dim2=-1).sum(-1) - 1) / 2).clamp(-1 + 1e-7, 1 - 1e-7)
     th = torch.acos(cos)
     small = th < 1e-4
     k = torch.where(small, 0.5 + th * th / 12, th / (2 * torch.sin(th) + 1e-20))
-    om = k * torch.stack([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+    om = k[..., None] * torch.stack([R[..., 2, 1] - R[..., 1, 2], R[..., 0, 2] - R[..., 2, 0], R[..., 1, 0] - R[..., 0, 1]], -1)
     K = _hat(om)
     th2 = th * th
     A = torch.where(small, 1 - th2 / 6, torch.sin(th) / (th + 1e-20))
     B = torch.where(small, 0.5 - th2 / 24, (1 - torch.cos(th)) / (th2 + 1e-20))
     coef = torch.where(small, torch.full_like(th, 1.0 / 12), (1 - A / (2 * B)) / (th2 + 1e-20))
-    Vinv = torch.eye(3, dtype=T.dtype, device=T.device) - 0.5 * K + coef * (K @ K)
-    return torch.cat([Vinv @ t, om])
+    Vinv = torch.eye(3, dtype=T.dtype, device=T.device) - 0.5 * K + coef[..., None, None] * (K @ K)
+    return torch.cat([(Vinv @ t[..., None])[..., 0], om], -1)
 
 
 class ImplicitCRF(nn.Module):
@@ -124,7 +189,12 @@ class HDRBlurFormation(nn.Module):
 
     def __init__(self, trajectory: TrajectorySpline, n_frames: int, W: int, H: int, tanfovx: float, tanfovy: float,
                  n_virtual: int = 8, crf: Optional[ImplicitCRF] = None, blur_domain: str = "ldr", sh_degree: int = 3,
-                 rasterizer_factory: Callable = GaussianRasterizer):
+                 rasterizer_factory: Callable = GaussianRasterizer, frame_times: Optional[torch.Tensor] = None,
+                 window_from_exposure: bool = False, window_scale: float = 1.0):
+        """frame_times [n_frames]: mid-exposure time of every captured frame in knot units (default: the middle of
+        the i-th interval the trajectory defines).  window_from_exposure: the exposure window of frame i is
+        dt_i * window_scale knot intervals long (dt_i = exp(log_exposure_i), window_scale = knot intervals per unit of
+        exposure time, i.e. the capture's knot rate); False: one knot interval whatever the exposure."""
         super().__init__()
         self.trajectory = trajectory
         self.crf = crf if crf is not None else ImplicitCRF()
@@ -132,10 +202,22 @@ class HDRBlurFormation(nn.Module):
         self.W, self.H, self.tanfovx, self.tanfovy = W, H, tanfovx, tanfovy
         self.n_virtual, self.blur_domain, self.sh_degree = n_virtual, blur_domain, sh_degree
         self._factory = rasterizer_factory
+        t0 = trajectory.t_range[0]
+        if frame_times is None:
+            frame_times = t0 + 0.5 + torch.arange(n_frames, dtype=torch.float32)
+        self.register_buffer("frame_times", torch.as_tensor(frame_times, dtype=torch.float32).clone())
+        self.window_from_exposure, self.window_scale = bool(window_from_exposure), float(window_scale)
+
+    def window(self, i: int) -> torch.Tensor:
+        """Length of frame i's exposure window in knot intervals (a tensor: it carries dL/d(dt_i)'s blur term)."""
+        if self.window_from_exposure:
+            return torch.exp(self.log_exposure[i]) * self.window_scale
+        return torch.ones((), dtype=self.log_exposure.dtype, device=self.log_exposure.device)
 
     def cameras(self, i: int):
         """(viewmatrices [N,4,4], projmatrices [N,4,4], camposes [N,3]) in the rasterizer's transposed convention."""
-        w2c = self.trajectory.poses(i, self.n_virtual)
+        times = self.trajectory.window_times(self.frame_times[i].to(self.log_exposure.dtype), self.window(i), self.n_virtual)
+        w2c = self.trajectory.pose_at(times)
         proj = projection_matrix(self.tanfovx, self.tanfovy, device=w2c.device).to(w2c.dtype)
         full = proj[None] @ w2c
         campos = -(w2c[:, :3, :3].transpose(1, 2) @ w2c[:, :3, 3:])[..., 0]

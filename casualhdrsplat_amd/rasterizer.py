@@ -343,6 +343,16 @@ class _RasterizeGaussians(torch.autograd.Function):
                                                                      exposure, crf_table, capacity, return_invdepth)
         ctx.st = st
         ctx.aux = aux
+        # May the chunked all-reduce of a view-parallel backward (reduce_group) still be in flight when backward() hands
+        # the gradients to autograd?  Only if autograd then does nothing with them but store them: every differentiable
+        # input a LEAF without a .grad yet (AccumulateGrad keeps the tensor it is given).  A non-leaf input -- the usual
+        # 3DGS wiring: scales = exp(raw), opacity = sigmoid(raw), rotations = normalize(raw), shs = cat(dc, rest) -- makes
+        # autograd run the activation's backward on the compute stream right away, and a leaf with a .grad is added to:
+        # both would read rows RCCL is still summing.  Then backward() waits for the collectives itself.
+        ctx.reduce_may_stay_in_flight = all(
+            (not t.requires_grad) or (t.is_leaf and t.grad is None)
+            for t in (means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, exposure, crf_table)
+            if isinstance(t, torch.Tensor))
         if aux is not None:  # what GaussianRasterizer keeps of the call (never the outputs: see st.keep)
             aux["pending"], aux["num_rendered"] = st.pending, st.num_rendered
             if aux.get("keep_state"):
@@ -393,7 +403,14 @@ class _RasterizeGaussians(torch.autograd.Function):
                                  reduce_group=None if ctx.aux is None else ctx.aux.get("reduce_group"),
                                  reduce_chunks=0 if ctx.aux is None else int(ctx.aux.get("reduce_chunks") or 0))
         if ctx.aux is not None and g.get("_reduce_pending") is not None:
-            ctx.aux["cell"]["reduce_pending"] = g["_reduce_pending"]   # GaussianRasterizer.finish_reduce() waits for these
+            if ctx.reduce_may_stay_in_flight:
+                ctx.aux["cell"]["reduce_pending"] = g["_reduce_pending"]   # GaussianRasterizer.finish_reduce() waits for these
+            else:
+                # (see forward: autograd is about to USE these gradients.  On RCCL waiting = the compute stream waits for
+                # the communication stream, the host does not block; the overlap with this backward's own chunks stays)
+                from .distributed import finish_pending
+                ctx.aux["cell"]["reduce_waited_in_backward"] = finish_pending(g["_reduce_pending"])
+                ctx.aux["cell"]["reduce_pending"] = []
         if ctx.deferred is not None:
             # view-parallel exchange: hand the per-view colour gradients to distributed.exchange_view_gradients
             ctx.deferred.update(view_colors=g["view_colors"], camposes=st.camposes, means3D=saved[0],
@@ -652,7 +669,10 @@ class GaussianRasterizer(nn.Module):
         # view-parallel training with the plain exchange (every rank renders its own view; the per-Gaussian gradients
         # are summed over the ranks): a torch.distributed process group (or True for the default group) makes the
         # backward run its per-Gaussian half in `reduce_chunks` ascending chunks and start the all-reduce of each
-        # chunk's gradient rows while the next chunk computes; call finish_reduce() before reading any gradient
+        # chunk's gradient rows while the next chunk computes; call finish_reduce() before reading any gradient.
+        # The collectives outlive backward() only when every differentiable input is a leaf without a .grad (autograd
+        # then just stores what it is given); with activations between the parameters and the rasterizer, or gradient
+        # accumulation, backward() itself waits for them before autograd touches the rows (finish_reduce() returns 0)
         self.reduce_group = reduce_group
         self.reduce_chunks = int(reduce_chunks)
         # with defer_sh_grad: a torch.distributed process group (or True for the default group) makes the backward

@@ -42,6 +42,100 @@ def test_trajectory_samples_lie_between_knots():
     assert torch.allclose(traj.poses(1, 8), P) and not torch.allclose(traj.poses(2, 8), IF.TrajectorySpline(knots).double().poses(2, 8))
 
 
+def _random_knots(J, seed=0, step=0.05):
+    g = torch.Generator().manual_seed(seed)
+    T = [torch.eye(4, dtype=torch.float64)]
+    for _ in range(J - 1):
+        T.append(IF.se3_exp(step * torch.randn(6, generator=g, dtype=torch.float64)) @ T[-1])
+    return torch.stack(T)
+
+
+def test_cubic_spline_is_c2_continuous_across_segments():
+    """/root/reference/assets/pipeline.png: a camera motion SPLINE through four control knots.  Value, velocity and
+    acceleration of the cumulative cubic B-spline agree on both sides of every segment boundary (autograd derivatives
+    in float64, the two sides evaluated by different knot quadruples)."""
+    traj = IF.TrajectorySpline(_random_knots(7, seed=3), kind="cubic").double()
+    assert traj.t_range == (1.0, 5.0)
+
+    def d012(t0):
+        t = torch.tensor([t0], dtype=torch.float64, requires_grad=True)
+        T = traj.pose_at(t)[0, :3, :].reshape(-1)
+        d1 = torch.stack([torch.autograd.grad(T[k], t, create_graph=True)[0][0] for k in range(12)])
+        d2 = torch.stack([torch.autograd.grad(d1[k], t, retain_graph=True)[0][0] for k in range(12)])
+        return T.detach(), d1.detach(), d2.detach()
+
+    for tb in (2.0, 3.0, 4.0):
+        lo, hi = d012(tb - 1e-9), d012(tb + 1e-9)   # floor() puts the two sides into neighbouring segments
+        assert torch.allclose(lo[0], hi[0], atol=1e-8)
+        assert torch.allclose(lo[1], hi[1], atol=1e-7), (lo[1] - hi[1]).abs().max()
+        assert torch.allclose(lo[2], hi[2], atol=1e-6), (lo[2] - hi[2]).abs().max()
+        assert float(lo[2].abs().max()) > 1e-4      # (a real acceleration, not 0 == 0)
+    # ... whereas the two-knot form is only C0: its velocity jumps at a knot
+    lin = IF.TrajectorySpline(_random_knots(7, seed=3), kind="linear").double()
+    t = torch.tensor([2.0 - 1e-9], dtype=torch.float64, requires_grad=True)
+    v_lo = torch.autograd.grad(lin.pose_at(t)[0, 0, 3], t)[0]
+    t = torch.tensor([2.0 + 1e-9], dtype=torch.float64, requires_grad=True)
+    v_hi = torch.autograd.grad(lin.pose_at(t)[0, 0, 3], t)[0]
+    assert abs(float(v_lo - v_hi)) > 1e-4
+
+
+def test_cubic_spline_interpolates_knots_of_a_constant_velocity_motion_and_stays_in_se3():
+    """Knot interpolation: a uniform B-spline reproduces linear data, so control knots exp(k xi) T_0 (constant body
+    velocity) are passed through exactly, pose(t) = exp(t xi) T_0; rotations stay orthonormal for any knots; a knot
+    correction reaches exactly the four segments that use the knot."""
+    xi = torch.tensor([0.03, -0.01, 0.02, 0.01, 0.02, -0.015], dtype=torch.float64)
+    T0 = IF.se3_exp(torch.tensor([0.2, 0.1, -0.3, 0.05, -0.02, 0.03], dtype=torch.float64))
+    knots = torch.stack([IF.se3_exp(k * xi) @ T0 for k in range(6)])
+    traj = IF.TrajectorySpline(knots, kind="cubic").double()
+    ts = torch.tensor([1.0, 1.37, 2.0, 2.5, 3.0, 3.999, 4.0], dtype=torch.float64)
+    P = traj.pose_at(ts)
+    for k, t in enumerate(ts.tolist()):
+        assert torch.allclose(P[k], IF.se3_exp(t * xi) @ T0, atol=1e-9), t
+    rnd = IF.TrajectorySpline(_random_knots(6, seed=5, step=0.2), kind="cubic").double()
+    Q = rnd.pose_at(torch.linspace(1.0, 4.0, 13, dtype=torch.float64))
+    eye = torch.eye(3, dtype=torch.float64)
+    # (1e-6: the module keeps its SfM knots in float32; the spline itself multiplies exact exponentials onto them)
+    assert torch.allclose(Q[:, :3, :3] @ Q[:, :3, :3].transpose(1, 2), eye.expand(13, 3, 3), atol=1e-6)
+    assert torch.allclose(Q[:, 3], torch.tensor([0.0, 0.0, 0.0, 1.0], dtype=torch.float64).expand(13, 4))
+    before = rnd.pose_at(torch.tensor([1.5, 2.5, 3.5], dtype=torch.float64)).detach()
+    with torch.no_grad():
+        rnd.delta[0, 0] = 0.1      # knot 0 governs t in [1, 2) only
+    after = rnd.pose_at(torch.tensor([1.5, 2.5, 3.5], dtype=torch.float64)).detach()
+    assert not torch.allclose(after[0], before[0]) and torch.allclose(after[1:], before[1:])
+
+
+def test_exposure_time_sets_the_blur_extent():
+    """The figure's "exposure time range" arc: with window_from_exposure the virtual poses of frame i spread over
+    dt_i * window_scale knot intervals around the frame's time stamp, so dt_i reaches the poses (a motion-blur term
+    in dL/d dt_i) -- and does not when the window is pinned."""
+    traj = IF.TrajectorySpline(_random_knots(6, seed=7), kind="cubic").double()
+    m = IF.HDRBlurFormation(traj, 2, 64, 48, 0.5, 0.4, n_virtual=5, crf=IF.ImplicitCRF(K=8),
+                            frame_times=torch.tensor([2.2, 3.1]), window_from_exposure=True, window_scale=0.8).double()
+    with torch.no_grad():
+        m.log_exposure[0] = -0.5
+    w = float(torch.exp(m.log_exposure[0].detach())) * 0.8
+    times = traj.window_times(m.frame_times[0].double(), m.window(0), 5)
+    assert times.min() > 2.2 - w / 2 and times.max() < 2.2 + w / 2
+    assert float(times.mean()) == pytest.approx(2.2, abs=1e-6)
+    assert float(times[-1] - times[0]) == pytest.approx(w * 4 / 5, rel=1e-9)
+    V, PV, C = m.cameras(0)
+    (C[-1] - C[0]).norm().backward()                      # the extent of the camera path during the exposure
+    g = m.log_exposure.grad.clone()
+    assert g[0] > 0 and g[1] == 0                         # a longer exposure = a longer path; frame 1 untouched
+    # the extent is (to first order) proportional to the exposure time
+    with torch.no_grad():
+        m.log_exposure[0] = -0.5 + 1e-4
+    C2 = m.cameras(0)[2]
+    fd = ((C2[-1] - C2[0]).norm() - (C[-1] - C[0]).norm()).item() / 1e-4
+    assert fd == pytest.approx(float(g[0]), rel=1e-3)
+    pinned = IF.HDRBlurFormation(traj, 2, 64, 48, 0.5, 0.4, n_virtual=5, crf=IF.ImplicitCRF(K=8),
+                                 frame_times=torch.tensor([2.2, 3.1])).double()
+    Cp = pinned.cameras(0)[2]
+    m.zero_grad(); pinned.zero_grad()
+    (Cp[-1] - Cp[0]).norm().backward()
+    assert pinned.log_exposure.grad is None or float(pinned.log_exposure.grad.abs().sum()) == 0
+
+
 def test_crf_table_is_monotone_and_normalised():
     crf = IF.ImplicitCRF(K=64)
     tab = crf.table()
@@ -126,27 +220,37 @@ class _OracleRasterizer:
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dom", ["ldr", "hdr"])
-def test_image_formation_matches_the_fp64_oracle_through_the_same_modules(dom):
+@pytest.mark.parametrize("kind", ["linear", "cubic"])
+def test_image_formation_matches_the_fp64_oracle_through_the_same_modules(dom, kind):
     """SURVEY.md 8(f) n2, oracle-backed: HDRBlurFormation on the MI355X (one HIP rasterizer call: N virtual poses,
     exposure, CRF, blur average, pose gradients) against the float64 autograd rasterizer driven by the SAME
     TrajectorySpline / exposure / ImplicitCRF modules -- blurred LDR image, mean radiance, and the gradients that reach
-    the trajectory knots (camera motion), the exposure time and the CRF network's parameters."""
+    the trajectory knots (camera motion), the exposure time and the CRF network's parameters.
+    kind="cubic" (round 5): the figure's model in full -- a cumulative cubic B-spline over FOUR control knots, the virtual
+    poses spread over the exposure window dt_i * window_scale around the frame's time stamp, so dL/d dt_i carries the
+    motion-blur term (through the rasterizer's pose gradients) next to the brightness term."""
     dev = "cuda"
     W, H, P, deg, n_virtual = 112, 80, 1500, 1, 3
     sc = S.make_scene(P, W, H, deg, seed=33, hdr=True)
     cam = sc.camera
-    knots = IF.knots_from_lookat(3, radius=0.04)
+    cubic = kind == "cubic"
+    knots = IF.knots_from_lookat(5 if cubic else 3, radius=0.09 if cubic else 0.04)
     torch.manual_seed(3)
     crf0 = IF.ImplicitCRF(K=48)
 
     def build(dtype, device, factory=None):
         kw = {} if factory is None else dict(rasterizer_factory=factory)
-        m = IF.HDRBlurFormation(IF.TrajectorySpline(knots), 2, W, H, cam.tanfovx, cam.tanfovy, n_virtual=n_virtual,
+        if cubic:   # frame 0 exposed around t = 1.6 (segment of knots 0..3), 0.67 * 1.2 = 0.8 knot intervals long
+            kw.update(frame_times=torch.tensor([1.6, 2.5]), window_from_exposure=True, window_scale=1.2)
+        m = IF.HDRBlurFormation(IF.TrajectorySpline(knots, kind=kind), 2, W, H, cam.tanfovx, cam.tanfovy, n_virtual=n_virtual,
                                 crf=IF.ImplicitCRF(K=48), blur_domain=dom, sh_degree=deg, **kw)
         m.crf.load_state_dict(crf0.state_dict())
         with torch.no_grad():
             m.trajectory.delta[0] = torch.tensor([0.01, -0.004, 0.006, 0.002, -0.003, 0.001])
             m.trajectory.delta[1] = torch.tensor([-0.008, 0.005, 0.0, -0.001, 0.002, 0.004])
+            if cubic:
+                m.trajectory.delta[2] = torch.tensor([0.004, 0.003, -0.005, 0.002, 0.001, -0.002])
+                m.trajectory.delta[3] = torch.tensor([-0.003, -0.006, 0.002, -0.002, 0.003, 0.001])
             m.log_exposure[0] = -0.4
         return m.to(device=device, dtype=dtype)
 
@@ -173,5 +277,19 @@ def test_image_formation_matches_the_fp64_oracle_through_the_same_modules(dom):
         scale = float(b.abs().max())
         assert scale > 0, k
         assert float((a - b).abs().max()) <= 3e-4 * scale, (k, float((a - b).abs().max()) / scale)
-    assert float(g_o["delta"][2].abs().max()) == 0 and float(g_g["delta"][2].abs().max()) == 0   # knot 2 is outside frame 0
+    if cubic:
+        # all four knots of the segment receive a gradient, the fifth none
+        assert all(float(g_g["delta"][j].abs().max()) > 0 for j in range(4))
+        assert float(g_o["delta"][4].abs().max()) == 0 and float(g_g["delta"][4].abs().max()) == 0
+        # dL/d log dt_0 = brightness term + window term: the window term alone (same modules, window pinned to the same
+        # length) is a sizeable part of it, so the comparison above did test it
+        m_pin = build(torch.float64, "cpu", _OracleRasterizer)
+        m_pin.window_from_exposure = False
+        w0 = float(torch.exp(m_pin.log_exposure[0].detach())) * 1.2
+        m_pin.window = lambda i, w0=w0, m=m_pin: torch.full((), w0 if i == 0 else 1.0, dtype=m.log_exposure.dtype)
+        _, _, g_pin = run(m_pin, torch.float64, "cpu")
+        window_term = float(g_o["log_exposure"][0] - g_pin["log_exposure"][0])
+        assert abs(window_term) > 0.02 * abs(float(g_o["log_exposure"][0])), (window_term, float(g_o["log_exposure"][0]))
+    else:
+        assert float(g_o["delta"][2].abs().max()) == 0 and float(g_g["delta"][2].abs().max()) == 0   # knot 2 is outside frame 0
     assert float(g_g["log_exposure"][1]) == 0
