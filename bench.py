@@ -596,6 +596,8 @@ def main():
     ap.add_argument("--cpu-c2", action="store_true", help="(kept for older command lines: c2 in full is the default now)")
     ap.add_argument("--no-extras", action="store_true", help="profiling runs: one seed only, no CPU baseline")
     ap.add_argument("--one-seed", action="store_true", help="time seed 0 only (the headline is then NOT the median of seeds)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="default c3 runs also time BASELINE configs c2 and c4 once each (other_configs, ~10 s): skip that")
     ap.add_argument("--kernel-iters", type=int, default=10)
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
                     help="replay the whole step as one HIP graph (single GPU).  auto = only where the host can pace the "
@@ -623,9 +625,6 @@ def main():
     local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    cfg = CONFIGS[args.config]
-    P, W, H, deg, hdr, n_poses = cfg
-
     def barrier():
         if world > 1:
             dist.barrier()
@@ -633,191 +632,253 @@ def main():
 
     exchange = {"info": None, "choice": None}   # the gradient exchange is chosen once (first seed) and reused
 
-    def prepare_seed(seed):
-        """Everything ahead of the timed region, identical for every seed: scene, one synchronous step (learns num_rendered,
-        as the published API does), rasterizers in the sync-free mode with a fixed binning capacity (25 % headroom; overflow
-        checked lazily every step), the exchange strategy (N > 1) and the launch form (eager or one HIP graph)."""
-        step, state, make_rasterizer, sc, dL, plist = build_step(cfg, rank, world, dev, seed=seed)
-        out = step()
-        torch.cuda.synchronize()
-        counts = derived_counts(out, W, H, n_poses)
-        del out
-        state["out"] = None
-        state["rast"] = make_rasterizer(int(counts[0] * 1.25) + 4096)
-        if world > 1:
-            if exchange["choice"] is None:
-                exchange["info"] = choose_exchange(step, state, barrier, dev, rank, world, backend, cfg)
-                exchange["choice"] = state["exchange"]
-            state["exchange"] = exchange["choice"]
-        # One launch per step: the sync-free step (fixed binning capacity: no host read in forward or backward) is captured
-        # in a HIP graph and replayed -- the same kernels on the same buffers, minus ~40 launches of host work per step (at
-        # c2 the host, not the GPU, paces the eager step).  Used only if the replay reproduces the eager step bit for bit.
-        launch, run_step, gstep = "eager (one enqueue per kernel)", step, None
-        want_graph = args.graph == "on"
-        if world == 1 and args.graph == "auto":
-            for _ in range(3):
-                step()
+    def bench_config(cfg_name, seeds, steps, warmup):
+        """Time one BASELINE config (median over `seeds`, each by the same procedure) and, on rank 0, its per-stage /
+        roofline legs on the median seed's scene.  Returns (line, scene, cfg)."""
+        cfg = CONFIGS[cfg_name]
+        P, W, H, deg, hdr, n_poses = cfg
+
+        def prepare_seed(seed):
+            """Everything ahead of the timed region, identical for every seed: scene, one synchronous step (learns num_rendered,
+            as the published API does), rasterizers in the sync-free mode with a fixed binning capacity (25 % headroom; overflow
+            checked lazily every step), the exchange strategy (N > 1) and the launch form (eager or one HIP graph)."""
+            step, state, make_rasterizer, sc, dL, plist = build_step(cfg, rank, world, dev, seed=seed)
+            out = step()
             torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(10):
-                step()
-            torch.cuda.synchronize()
-            want_graph = (time.perf_counter() - t0) / 10 < 0.6e-3   # a step this short is at the mercy of the box's CPU
-        if world == 1 and want_graph:
-            try:
-                from casualhdrsplat_amd.graphs import GraphedStep
-                step()
+            counts = derived_counts(out, W, H, n_poses)
+            del out
+            state["out"] = None
+            state["rast"] = make_rasterizer(int(counts[0] * 1.25) + 4096)
+            if world > 1:
+                if exchange["choice"] is None:
+                    exchange["info"] = choose_exchange(step, state, barrier, dev, rank, world, backend, cfg)
+                    exchange["choice"] = state["exchange"]
+                state["exchange"] = exchange["choice"]
+            # One launch per step: the sync-free step (fixed binning capacity: no host read in forward or backward) is captured
+            # in a HIP graph and replayed -- the same kernels on the same buffers, minus ~40 launches of host work per step (at
+            # c2 the host, not the GPU, paces the eager step).  Used only if the replay reproduces the eager step bit for bit.
+            launch, run_step, gstep = "eager (one enqueue per kernel)", step, None
+            want_graph = args.graph == "on"
+            if world == 1 and args.graph == "auto":
+                for _ in range(3):
+                    step()
                 torch.cuda.synchronize()
-                want = [state["out"][0].detach().clone()] + [p_.grad.detach().clone() for p_ in plist]
-                # no autograd graph of an earlier (default-stream) step may be alive when the capture starts: its
-                # AccumulateGrad nodes would run on the default stream and break the capture
-                state["out"] = None
-                for p_ in plist:
-                    p_.grad = None
-                gstep = GraphedStep(step, [state["rast"]["allreduce"]])
-                gstep.step()
-                gstep.check_overflow()
-                got = [state["out"][0].detach()] + [p_.grad.detach() for p_ in plist]
-                if not all(torch.equal(a_, b_) for a_, b_ in zip(want, got)):
-                    raise RuntimeError("graph replay differs from the eager step")
-                launch, run_step = "hip_graph (whole step captured once, replayed)", gstep.step
-            except Exception as e:  # noqa: BLE001 -- any capture problem: the eager step is always there
-                if args.graph == "on":
-                    raise
-                print(f"[bench] HIP-graph step unavailable ({type(e).__name__}: {str(e)[:200]}); timing the eager step",
-                      file=sys.stderr)
-                gstep, run_step = None, step
-                for p_ in plist:
-                    p_.grad = None
-        return dict(step=step, state=state, sc=sc, dL=dL, plist=plist, counts=counts, launch=launch, run_step=run_step,
-                    gstep=gstep, seed=seed)
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    step()
+                torch.cuda.synchronize()
+                want_graph = (time.perf_counter() - t0) / 10 < 0.6e-3   # a step this short is at the mercy of the box's CPU
+            if world == 1 and want_graph:
+                try:
+                    from casualhdrsplat_amd.graphs import GraphedStep
+                    step()
+                    torch.cuda.synchronize()
+                    want = [state["out"][0].detach().clone()] + [p_.grad.detach().clone() for p_ in plist]
+                    # no autograd graph of an earlier (default-stream) step may be alive when the capture starts: its
+                    # AccumulateGrad nodes would run on the default stream and break the capture
+                    state["out"] = None
+                    for p_ in plist:
+                        p_.grad = None
+                    gstep = GraphedStep(step, [state["rast"]["allreduce"]])
+                    gstep.step()
+                    gstep.check_overflow()
+                    got = [state["out"][0].detach()] + [p_.grad.detach() for p_ in plist]
+                    if not all(torch.equal(a_, b_) for a_, b_ in zip(want, got)):
+                        raise RuntimeError("graph replay differs from the eager step")
+                    launch, run_step = "hip_graph (whole step captured once, replayed)", gstep.step
+                except Exception as e:  # noqa: BLE001 -- any capture problem: the eager step is always there
+                    if args.graph == "on":
+                        raise
+                    print(f"[bench] HIP-graph step unavailable ({type(e).__name__}: {str(e)[:200]}); timing the eager step",
+                          file=sys.stderr)
+                    gstep, run_step = None, step
+                    for p_ in plist:
+                        p_.grad = None
+            return dict(step=step, state=state, sc=sc, dL=dL, plist=plist, counts=counts, launch=launch, run_step=run_step,
+                        gstep=gstep, seed=seed)
 
-    def time_seed(seed):
-        """W untimed warm-up steps, then EXACTLY K timed steps between barrier + synchronize, MAX over ranks: the same
-        procedure for every seed of SURVEY.md 8(d); returns (context, ms per step)."""
-        ctx = prepare_seed(seed)
-        for _ in range(args.warmup):
-            ctx["run_step"]()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            ctx["run_step"]()
-        barrier()
-        elapsed = time.perf_counter() - t0
-        if ctx["gstep"] is not None:
-            ctx["gstep"].check_overflow()   # the timed frames all fitted their binning capacity
-        if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
-        return ctx, elapsed / args.steps * 1e3
+        def time_seed(seed):
+            """W untimed warm-up steps, then EXACTLY K timed steps between barrier + synchronize, MAX over ranks: the same
+            procedure for every seed of SURVEY.md 8(d); returns (context, ms per step)."""
+            ctx = prepare_seed(seed)
+            for _ in range(warmup):
+                ctx["run_step"]()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                ctx["run_step"]()
+            barrier()
+            elapsed = time.perf_counter() - t0
+            if ctx["gstep"] is not None:
+                ctx["gstep"].check_overflow()   # the timed frames all fitted their binning capacity
+            if world > 1:
+                t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                elapsed = float(t.item())
+            return ctx, elapsed / steps * 1e3
 
-    # SURVEY.md 8(d): "seeds {0,1,2}, report median".  Every seed is timed by the same function -- same warm-up, same K
-    # steps, a fresh scene, fresh rasterizers, an emptied allocator cache -- and the headline is the MEDIAN seed; the
-    # per-stage / roofline legs below then run on that seed's scene.
-    seeds = [0] if (args.one_seed or args.no_extras) else [0, 1, 2]
-    per_seed, ctx = {}, None
-    for seed in seeds:
-        ctx = None                       # (the previous seed's scene and state buffers go before the next is built)
-        torch.cuda.empty_cache()
-        ctx, ms = time_seed(seed)
-        per_seed[seed] = {"ms_per_step": ms, "R": ctx["counts"][0], "R_prime": ctx["counts"][1]}
-    order = sorted(seeds, key=lambda s_: per_seed[s_]["ms_per_step"])
-    med_seed = order[len(order) // 2]
-    ms_per_step = per_seed[med_seed]["ms_per_step"]
-    if ctx["seed"] != med_seed and rank == 0 and world == 1:
-        ctx = None
-        torch.cuda.empty_cache()
-        ctx = prepare_seed(med_seed)     # the median seed's scene for the per-stage legs (not timed again)
-    step, state, sc, dL, plist, launch = ctx["step"], ctx["state"], ctx["sc"], ctx["dL"], ctx["plist"], ctx["launch"]
-    R, Rp, E, vtiles = ctx["counts"]
-    allreduce_info = exchange["info"]
-    images_per_s = world * 1e3 / ms_per_step
+        # SURVEY.md 8(d): "seeds {0,1,2}, report median".  Every seed is timed by the same function -- same warm-up, same K
+        # steps, a fresh scene, fresh rasterizers, an emptied allocator cache -- and the headline is the MEDIAN seed; the
+        # per-stage / roofline legs below then run on that seed's scene.
+        per_seed, ctx = {}, None
+        for seed in seeds:
+            ctx = None                       # (the previous seed's scene and state buffers go before the next is built)
+            torch.cuda.empty_cache()
+            ctx, ms = time_seed(seed)
+            per_seed[seed] = {"ms_per_step": ms, "R": ctx["counts"][0], "R_prime": ctx["counts"][1]}
+        order = sorted(seeds, key=lambda s_: per_seed[s_]["ms_per_step"])
+        med_seed = order[len(order) // 2]
+        ms_per_step = per_seed[med_seed]["ms_per_step"]
+        if ctx["seed"] != med_seed and rank == 0 and world == 1:
+            ctx = None
+            torch.cuda.empty_cache()
+            ctx = prepare_seed(med_seed)     # the median seed's scene for the per-stage legs (not timed again)
+        step, state, sc, dL, plist, launch = ctx["step"], ctx["state"], ctx["sc"], ctx["dL"], ctx["plist"], ctx["launch"]
+        R, Rp, E, vtiles = ctx["counts"]
+        allreduce_info = exchange["info"]
+        images_per_s = world * 1e3 / ms_per_step
 
-    line = {
-        "metric": "train-step images/sec (fwd+bwd raster) @ 1M Gaussians 1080p",
-        "value": images_per_s, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{args.config}: {P} Gaussians, {W}x{H}, SH degree {deg}, "
-                               f"{'HDR radiance + CRF tone-map' if hdr else 'LDR'}, {n_poses} pose(s)/view, "
-                               f"{world} view(s)/step (one per GPU)" + (", gradients summed over views (config.gradient_exchange)" if world > 1 else ""),
-                   "num_rendered_R": R, "R_prime": Rp, "pixel_pair_evals_E": E,
-                   "seed": ctx["seed"],
-                   "seeds": f"value / ms_per_step = the median of seeds {seeds}, each timed alike ({args.warmup} warm-up + "
-                            f"{args.steps} steps); roofline / stages / counts belong to seed {ctx['seed']}",
-                   "binning": "sync-free fixed capacity 1.25*R", "launch": launch},
-        "mpix_per_s": world * W * H * n_poses / ms_per_step / 1e3,
-        "seeds_ms_per_step": {**{str(k): v["ms_per_step"] for k, v in per_seed.items()},
-                              **{f"R_{k}": v["R"] for k, v in per_seed.items()},
-                              **{f"R_prime_{k}": v["R_prime"] for k, v in per_seed.items()},
-                              "median": ms_per_step, "median_seed": med_seed, "median_images_per_s": images_per_s,
-                              "spread": (max(v["ms_per_step"] for v in per_seed.values()) /
-                                         min(v["ms_per_step"] for v in per_seed.values()) - 1.0)},
-    }
-    if allreduce_info is not None:
-        line["config"]["gradient_exchange"] = allreduce_info
-
-    if rank == 0:
-        from casualhdrsplat_amd import _lib as L
-        from casualhdrsplat_amd.rasterizer import render_stats, replay_backward, replay_forward
-        # a fresh forward whose autograd graph is kept (never .backward()-ed) so its stages can be replayed
-        for p_ in plist:
-            p_.grad = None
-        out = state["rast"]["allreduce"](*[plist[i] for i in (0, 1, 2)], shs=plist[3], scales=plist[4], rotations=plist[5])
-        R, Rp, E, vtiles = derived_counts(out, W, H, n_poses)
-        WH = W * H * n_poses
-        it = args.kernel_iters
-        # order matters: the binning replay clears the pair flags the backward sets, so every backward stage is timed
-        # first, on the state a real step leaves behind (forward -> render bwd -> segmented sum + preprocess bwd)
-        bwd_ms, bwd_med = time_stage(lambda: replay_backward(out[0], dL, L.HS_BWD_RENDER), it)
-        stages = {"render_bwd": bwd_ms}
-        stages["segsum_and_preprocess_bwd"] = time_stage(lambda: replay_backward(out[0], dL, L.HS_BWD_PREPROCESS), it)[0]
-        if hdr:
-            stages["crf_gradient"] = time_stage(lambda: replay_backward(out[0], dL, L.HS_BWD_CRF), it)[0]
-        fwd_ms, fwd_med = time_stage(lambda: replay_forward(out[0], L.HS_STAGE_RENDER), it)
-        stages["render_fwd"] = fwd_ms
-        stats = render_stats(out[0], dL)
-        stages["binning"] = time_stage(lambda: replay_forward(out[0], L.HS_STAGE_BIN), it)[0]
-        stages["preprocess_fwd_and_binning"] = time_stage(
-            lambda: replay_forward(out[0], L.HS_STAGE_PREPROCESS | L.HS_STAGE_BIN), it)[0]
-        bytes_bwd = 76 * Rp + 20 * WH
-        bytes_fwd = 40 * Rp + 20 * WH + 8 * vtiles
-        ach = bytes_bwd / (bwd_ms * 1e-3) / 1e9
-        from casualhdrsplat_amd import inspect_state
-        n_visible = int((inspect_state(out[0])["radii"] > 0).sum())
-        step_bytes = whole_step_bytes(cfg, R, Rp, vtiles, n_visible)
-        step_gbs = step_bytes["total"] / (ms_per_step * 1e-3) / 1e9
-        line["roofline"] = {
-            "kernel": "render_bwd_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": ach / HBM_PEAK_GBS,
-            "frac_hbm_measured": ach / HBM_MEASURED_GBS, "peak_hbm_measured": HBM_MEASURED_GBS,
-            "whole_step": {"algorithmic_bytes": step_bytes, "ms_per_step": ms_per_step, "achieved": step_gbs,
-                           "frac": step_gbs / HBM_PEAK_GBS, "frac_hbm_measured": step_gbs / HBM_MEASURED_GBS,
-                           "note": "sum of SURVEY.md 8(d)'s per-stage algorithmic bytes / the timed step (all kernels, "
-                                   "host gaps included)"},
-            "traffic": None,  # PMC counters cannot be read inside a timed run: see `offline_profile`
-            "algorithmic_bytes": bytes_bwd, "avg_ms": bwd_ms, "median_ms": bwd_med,
-            "note": "the kernel is VALU-issue bound (roofline.valu; DESIGN.md 4), not HBM bound",
-            "fwd_bwd": {"kernels": "render_fwd_kernel + render_bwd_kernel", "algorithmic_bytes": bytes_fwd + bytes_bwd,
-                        "avg_ms": fwd_ms + bwd_ms,
-                        "achieved": (bytes_fwd + bytes_bwd) / ((fwd_ms + bwd_ms) * 1e-3) / 1e9,
-                        "frac": (bytes_fwd + bytes_bwd) / ((fwd_ms + bwd_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                        "frac_hbm_measured": (bytes_fwd + bytes_bwd) / ((fwd_ms + bwd_ms) * 1e-3) / 1e9 / HBM_MEASURED_GBS,
-                        "pair_evals_per_s": 2 * E / ((fwd_ms + bwd_ms) * 1e-3)},
-            "valu": valu_roofline(stats, isa_counts(), fwd_ms, bwd_ms),
+        line = {
+            "metric": "train-step images/sec (fwd+bwd raster) @ 1M Gaussians 1080p",
+            "value": images_per_s, "unit": "images/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{cfg_name}: {P} Gaussians, {W}x{H}, SH degree {deg}, "
+                                   f"{'HDR radiance + CRF tone-map' if hdr else 'LDR'}, {n_poses} pose(s)/view, "
+                                   f"{world} view(s)/step (one per GPU)" + (", gradients summed over views (config.gradient_exchange)" if world > 1 else ""),
+                       "num_rendered_R": R, "R_prime": Rp, "pixel_pair_evals_E": E,
+                       "seed": ctx["seed"],
+                       "seeds": f"value / ms_per_step = the median of seeds {seeds}, each timed alike ({warmup} warm-up + "
+                                f"{steps} steps); roofline / stages / counts belong to seed {ctx['seed']}",
+                       "binning": "sync-free fixed capacity 1.25*R", "launch": launch},
+            "mpix_per_s": world * W * H * n_poses / ms_per_step / 1e3,
+            "seeds_ms_per_step": {**{str(k): v["ms_per_step"] for k, v in per_seed.items()},
+                                  **{f"R_{k}": v["R"] for k, v in per_seed.items()},
+                                  **{f"R_prime_{k}": v["R_prime"] for k, v in per_seed.items()},
+                                  "median": ms_per_step, "median_seed": med_seed, "median_images_per_s": images_per_s,
+                                  "spread": (max(v["ms_per_step"] for v in per_seed.values()) /
+                                             min(v["ms_per_step"] for v in per_seed.values()) - 1.0)},
         }
-        off = offline_profile(args.config)
-        if off is not None:
-            line["roofline"]["offline_profile"] = off
-            if off.get("same_kernel_source") and off.get("render_bwd_kernel_hbm_bytes"):
-                # counters of an earlier rocprofv3 --pmc pass over this same workload, taken from kernels compiled
-                # from the very render.hip that is loaded now (hash checked); otherwise `traffic` stays null
-                line["roofline"]["traffic"] = off["render_bwd_kernel_hbm_bytes"]
-                line["roofline"]["traffic_note"] = ("bytes per launch at the L2-fabric interface from profiles/pmc_traffic.json "
-                                                    "(separate --pmc passes, gfx950 FETCH_SIZE correction), same render.hip")
-        line["stages_ms"] = {k: round(v, 4) for k, v in stages.items()}
-        line["render_stats"] = stats
+        if allreduce_info is not None:
+            line["config"]["gradient_exchange"] = allreduce_info
+
+        if rank == 0:
+            from casualhdrsplat_amd import _lib as L
+            from casualhdrsplat_amd.rasterizer import render_stats, replay_backward, replay_forward
+            # a fresh forward whose autograd graph is kept (never .backward()-ed) so its stages can be replayed
+            for p_ in plist:
+                p_.grad = None
+            out = state["rast"]["allreduce"](*[plist[i] for i in (0, 1, 2)], shs=plist[3], scales=plist[4], rotations=plist[5])
+            R, Rp, E, vtiles = derived_counts(out, W, H, n_poses)
+            WH = W * H * n_poses
+            it = args.kernel_iters
+            # order matters: the binning replay clears the pair flags the backward sets, so every backward stage is timed
+            # first, on the state a real step leaves behind (forward -> render bwd -> segmented sum + preprocess bwd)
+            bwd_ms, bwd_med = time_stage(lambda: replay_backward(out[0], dL, L.HS_BWD_RENDER), it)
+            stages = {"render_bwd": bwd_ms}
+            stages["segsum_and_preprocess_bwd"] = time_stage(lambda: replay_backward(out[0], dL, L.HS_BWD_PREPROCESS), it)[0]
+            if hdr:
+                stages["crf_gradient"] = time_stage(lambda: replay_backward(out[0], dL, L.HS_BWD_CRF), it)[0]
+            fwd_ms, fwd_med = time_stage(lambda: replay_forward(out[0], L.HS_STAGE_RENDER), it)
+            stages["render_fwd"] = fwd_ms
+            stats = render_stats(out[0], dL)
+            stages["binning"] = time_stage(lambda: replay_forward(out[0], L.HS_STAGE_BIN), it)[0]
+            stages["preprocess_fwd_and_binning"] = time_stage(
+                lambda: replay_forward(out[0], L.HS_STAGE_PREPROCESS | L.HS_STAGE_BIN), it)[0]
+            # the preprocess kernel exactly as a single-enqueue forward runs it (it carries the binning stage's prologue), and
+            # the two kernels of the backward's last stage on their own
+            stages["preprocess_fwd"] = time_stage(
+                lambda: replay_forward(out[0], L.HS_STAGE_PREPROCESS | L.HS_STAGE_BIN | L.HS_STAGE_PREPROCESS_ONLY), it)[0]
+            stages["binning_in_step"] = stages["preprocess_fwd_and_binning"] - stages["preprocess_fwd"]
+            stages["pair_segsum"] = time_stage(lambda: replay_backward(out[0], dL, L.HS_BWD_SEGSUM), it)[0]
+            stages["preprocess_bwd"] = time_stage(lambda: replay_backward(out[0], dL, L.HS_BWD_PROJECT), it)[0]
+            # (leave the state as a step leaves it for whatever follows: the binning replays cleared the pair flags)
+            replay_forward(out[0], L.HS_STAGE_RENDER)
+            bytes_bwd = 76 * Rp + 20 * WH
+            bytes_fwd = 40 * Rp + 20 * WH + 8 * vtiles
+            ach = bytes_bwd / (bwd_ms * 1e-3) / 1e9
+            from casualhdrsplat_amd import inspect_state
+            n_visible = int((inspect_state(out[0])["radii"] > 0).sum())
+            step_bytes = whole_step_bytes(cfg, R, Rp, vtiles, n_visible)
+            step_gbs = step_bytes["total"] / (ms_per_step * 1e-3) / 1e9
+            line["roofline"] = {
+                "kernel": "render_bwd_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": ach / HBM_PEAK_GBS,
+                "frac_hbm_measured": ach / HBM_MEASURED_GBS, "peak_hbm_measured": HBM_MEASURED_GBS,
+                "whole_step": {"algorithmic_bytes": step_bytes, "ms_per_step": ms_per_step, "achieved": step_gbs,
+                               "frac": step_gbs / HBM_PEAK_GBS, "frac_hbm_measured": step_gbs / HBM_MEASURED_GBS,
+                               "note": "sum of SURVEY.md 8(d)'s per-stage algorithmic bytes / the timed step (all kernels, "
+                                       "host gaps included)"},
+                "traffic": None,  # PMC counters cannot be read inside a timed run: see `offline_profile`
+                "algorithmic_bytes": bytes_bwd, "avg_ms": bwd_ms, "median_ms": bwd_med,
+                "note": "the kernel is VALU-issue bound (roofline.valu; DESIGN.md 4), not HBM bound",
+                "fwd_bwd": {"kernels": "render_fwd_kernel + render_bwd_kernel", "algorithmic_bytes": bytes_fwd + bytes_bwd,
+                            "avg_ms": fwd_ms + bwd_ms,
+                            "achieved": (bytes_fwd + bytes_bwd) / ((fwd_ms + bwd_ms) * 1e-3) / 1e9,
+                            "frac": (bytes_fwd + bytes_bwd) / ((fwd_ms + bwd_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "frac_hbm_measured": (bytes_fwd + bytes_bwd) / ((fwd_ms + bwd_ms) * 1e-3) / 1e9 / HBM_MEASURED_GBS,
+                            "pair_evals_per_s": 2 * E / ((fwd_ms + bwd_ms) * 1e-3)},
+                "valu": valu_roofline(stats, isa_counts(), fwd_ms, bwd_ms),
+            }
+            # The HBM-bound stages one by one (VERDICT r4 next #4): HIP-event time of the stage on the launch stream against the
+            # algorithmic bytes of SURVEY.md 8(d) (the segmented sum is this implementation's own stage: 36 B per record the
+            # render backward wrote + 40 B per instance sum), as fractions of the 8 TB/s peak and of the measured copy rate
+            M_ = (deg + 1) ** 2
+            I_ = P * n_poses
+            in_row = 12 + 12 + 16 + 4 + 12 * M_
+            pk_bytes = {
+                "preprocess_fwd": step_bytes["preprocess_fwd"],
+                "binning_in_step": step_bytes["scan"] + step_bytes["duplicate_with_keys"] + step_bytes["sort_one_ideal_pass"] + step_bytes["tile_ranges"],
+                "render_fwd": bytes_fwd, "render_bwd": bytes_bwd,
+                "pair_segsum": 36 * Rp + 40 * I_,
+                "preprocess_bwd": (in_row + 40) * I_ + in_row * P,
+            }
+            if hdr:
+                pk_bytes["crf_gradient"] = 2 * 12 * WH
+            line["roofline"]["per_kernel"] = {
+                k: {"ms": stages[k], "algorithmic_bytes": int(bts), "achieved_gbs": bts / (stages[k] * 1e-3) / 1e9,
+                    "frac": bts / (stages[k] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "frac_hbm_measured": bts / (stages[k] * 1e-3) / 1e9 / HBM_MEASURED_GBS}
+                for k, bts in pk_bytes.items() if stages.get(k, 0) > 0}
+            non_render = [k for k in pk_bytes if not k.startswith("render")]
+            nr_ms, nr_b = sum(stages[k] for k in non_render), sum(pk_bytes[k] for k in non_render)
+            line["roofline"]["non_render"] = {"stages": non_render, "ms": nr_ms, "algorithmic_bytes": int(nr_b),
+                                              "frac": nr_b / (nr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                              "frac_hbm_measured": nr_b / (nr_ms * 1e-3) / 1e9 / HBM_MEASURED_GBS}
+            off = offline_profile(cfg_name)
+            if off is not None:
+                line["roofline"]["offline_profile"] = off
+                if off.get("same_kernel_source") and off.get("render_bwd_kernel_hbm_bytes"):
+                    # counters of an earlier rocprofv3 --pmc pass over this same workload, taken from kernels compiled
+                    # from the very render.hip that is loaded now (hash checked); otherwise `traffic` stays null
+                    line["roofline"]["traffic"] = off["render_bwd_kernel_hbm_bytes"]
+                    line["roofline"]["traffic_note"] = ("bytes per launch at the L2-fabric interface from profiles/pmc_traffic.json "
+                                                        "(separate --pmc passes, gfx950 FETCH_SIZE correction), same render.hip")
+            line["stages_ms"] = {k: round(v, 4) for k, v in stages.items()}
+            line["render_stats"] = stats
+        return line, sc, cfg
+
+    seeds_main = [0] if (args.one_seed or args.no_extras) else [0, 1, 2]
+    line, sc, cfg = bench_config(args.config, seeds_main, args.steps, args.warmup)
+    if rank == 0:
+        # BASELINE configs[1] and configs[3] on the driver's record too (VERDICT r4 next #4): after the c3 legs the default
+        # run times c2 and c4 once each -- seed 0, the same time_seed procedure -- and prints their step, stages and roofline
+        if world == 1 and args.config == "c3" and not (args.no_extras or args.one_seed or args.no_other_configs):
+            other = {}
+            for name, k_steps in (("c2", max(args.steps, 50)), ("c4", max(5, min(args.steps, 12)))):
+                torch.cuda.empty_cache()
+                o, _, _ = bench_config(name, [0], k_steps, args.warmup)
+                other[name] = {"ms_per_step": o["ms_per_step"], "images_per_s": o["value"], "mpix_per_s": o["mpix_per_s"],
+                               "steps": k_steps, "warmup": args.warmup, "seed": 0, "workload": o["config"]["workload"],
+                               "launch": o["config"]["launch"], "num_rendered_R": o["config"]["num_rendered_R"],
+                               "R_prime": o["config"]["R_prime"], "stages_ms": o["stages_ms"],
+                               "roofline": {k: o["roofline"][k] for k in ("kernel", "achieved", "frac", "frac_hbm_measured",
+                                                                          "algorithmic_bytes", "avg_ms")},
+                               "roofline_fwd_bwd_frac": o["roofline"]["fwd_bwd"]["frac"],
+                               "roofline_whole_step_frac": o["roofline"]["whole_step"]["frac"],
+                               "per_kernel": o["roofline"]["per_kernel"]}
+            line["other_configs"] = other
+            torch.cuda.empty_cache()
         if world == 1 and not (args.no_cpu_baseline or args.no_extras):
             line["cpu_baseline"] = cpu_baseline(sc, cfg, with_c2=not args.no_cpu_c2)
         print(json.dumps(line), flush=True)

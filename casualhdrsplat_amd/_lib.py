@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("HS_LIB_PATH", os.path.join(_HERE, "libhdrsplat.so"))
 
 HS_OK, HS_EINVAL, HS_EHIP, HS_EOVERFLOW = 0, -1, -2, -3
 HS_STAGE_PREPROCESS, HS_STAGE_BIN, HS_STAGE_RENDER, HS_STAGE_ALL, HS_STAGE_OFFSETS = 1, 2, 4, 7, 8
+HS_STAGE_PREPROCESS_ONLY = 16
 HS_FLAG_HDR, HS_FLAG_BLUR_HDR, HS_FLAG_DEBUG, HS_FLAG_ANTIALIAS = 1, 2, 4, 8
 HS_FLAG_RADIANCE_EXP, HS_FLAG_RADIANCE_SOFTPLUS = 16, 32
 HS_BWD_RENDER, HS_BWD_PREPROCESS, HS_BWD_CRF, HS_BWD_ALL = 1, 2, 4, 7

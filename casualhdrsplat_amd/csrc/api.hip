@@ -4,6 +4,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
+#include <unistd.h>
 #include <atomic>
 
 #include "hs_common.h"
@@ -39,7 +41,9 @@ bool sort_tickets() {
 }
 
 bool scan_in_emission(int64_t I) {
-    static const int forced = [] { const char* e = getenv("HS_SCAN_IN_EMISSION"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+    // (read at every forward, not once: the driver's test suite switches it inside one process)
+    const char* e = getenv("HS_SCAN_IN_EMISSION");
+    const int forced = e ? (e[0] == '1' ? 1 : 0) : -1;
     // (the scan inside the emission is a blockIdx-ordered look-back chain like the radix passes': once the process has gone
     // to ticket order -- a chain stalled, several processes share the GPU -- the offsets come from the three kernels ahead
     // of the emission, which wait for nobody)
@@ -48,7 +52,15 @@ bool scan_in_emission(int64_t I) {
 
 // Stamp of a single-enqueue forward (hs_common.h, kDepthBitsAt): never 0, never the same for two calls of a process that
 // could meet in the same memory (2^32 - 1 calls apart).  The only thing the library counts.
-static std::atomic<uint32_t> g_frame_tag{0};
+// The count starts at a hashed value with the top bit set (process id x clock): small integers 1, 2, 3 ... are what recycled
+// int32 data in a fresh torch.empty workspace is most likely to hold, and a stale word that happens to carry the frame's
+// tag -- harmless for the order, see hs_common.h -- would cost the first frames an extra depth pass.
+static uint32_t frame_tag_seed() {
+    uint64_t x = (uint64_t)getpid() * 0x9E3779B97F4A7C15ull ^ (uint64_t)time(nullptr) * 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 31; x *= 0x94D049BB133111EBull; x ^= x >> 29;
+    return (uint32_t)x | 0x80000000u;
+}
+static std::atomic<uint32_t> g_frame_tag{frame_tag_seed()};
 static uint32_t next_frame_tag() {
     uint32_t t;
     do { t = g_frame_tag.fetch_add(1u, std::memory_order_relaxed) + 1u; } while (t == 0u);
@@ -232,7 +244,7 @@ int hs_forward(const hs_fwd_args* a, void* hip_stream) {
             if (rc) return rc;
         }
     }
-    if (a->stages & HS_STAGE_BIN) {
+    if ((a->stages & HS_STAGE_BIN) && !(a->stages & HS_STAGE_PREPROCESS_ONLY)) {
         if (!a->binning) { set_error("hs_forward: null binning workspace"); return HS_EINVAL; }
         if (a->dims.P > 0) {
             rc = launch_binning(*a, L, s, frame_tag);

@@ -657,12 +657,9 @@ __global__ void __launch_bounds__(256) depth_keys_kernel(int64_t I, const float*
             if (visible) { o |= key; nz |= ~key; }
         }
     }
-    // which bits vary (tag 0: bin_prepare_kernel zeroed the words); o / nz are ORs already: "visible key o, complement nz"
-    o = wave_or_hi(o); nz = wave_or_hi(nz);
-    if ((threadIdx.x & 63) == 63) { if (o) atomicOr(&s_two[0], o); if (nz) atomicOr(&s_two[1], nz); }
-    __syncthreads();
-    if (threadIdx.x < 2 && s_two[threadIdx.x])
-        tagged_or(bits + 2 * (blockIdx.x % kDepthBitsCopies) + threadIdx.x, 0u, s_two[threadIdx.x]);
+    // which bits vary (tag 0: bin_prepare_kernel zeroed the words): the ONE writer of the depth-bits words, fed with the
+    // OR of this thread's four keys and of their complements
+    depth_bits_accumulate2(o, nz, bits, 0u, s_two);
 }
 
 // Tile rectangles of the instances gathered into depth order (one 8-byte gather per instance) ahead of the emission --
@@ -725,6 +722,7 @@ __global__ void __launch_bounds__(256) emit_pairs_kernel(int64_t I, int P, int g
     __shared__ uint32_t s_beg[4][64];
     __shared__ uint4 s_own[4][64];         // per instance: key of its first tile, rectangle width, 1 / width (float), instance
     __shared__ uint32_t s_wsum[4];
+    __shared__ unsigned long long s_wsum64[4];
     __shared__ uint64_t s_excl;            // pairs of all earlier blocks; kScPoison in the flag bits: a wait gave up
     for (int t = threadIdx.x; t < passes * 256; t += 256) s_hist[t] = 0;
     // the depth sort is over: its tagged depth-bits words go back to empty, so a replayed graph (same tag every frame)
@@ -759,11 +757,14 @@ __global__ void __launch_bounds__(256) emit_pairs_kernel(int64_t I, int P, int g
         if (excl_ready) {
             if (threadIdx.x == 0) s_excl = block_excl[blk];
         } else {
-            uint32_t part = 0;
+            // (64-bit: a frame whose pair count wraps 2^32 must still trip the `bend > capacity` check below)
+            unsigned long long part = 0;
             for (int j = threadIdx.x; j < blk; j += 256) part += block_excl[j];
-            uint32_t before;
-            block_incl_scan(part, s_wsum, &before);
-            if (threadIdx.x == 0) s_excl = before;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) part += (unsigned long long)__shfl_xor((long long)part, d);
+            if ((threadIdx.x & 63) == 0) s_wsum64[threadIdx.x >> 6] = part;
+            __syncthreads();
+            if (threadIdx.x == 0) s_excl = (s_wsum64[0] + s_wsum64[1]) + (s_wsum64[2] + s_wsum64[3]);
         }
     } else if (wave == 0) {
         if (lane == 0) sc_publish(scan_status + blk, (blk == 0 ? kScIncl : kScAgg) | (uint64_t)block_total);

@@ -203,16 +203,21 @@ __device__ __forceinline__ uint32_t wave_or_hi(uint32_t v) {
     v |= dpp_u32<0x143, 0xC>(v);  // row_bcast:31 -> rows 2,3
     return v;
 }
-__device__ __forceinline__ void depth_bits_accumulate(uint32_t key, bool visible, unsigned long long* bits, uint32_t tag,
-                                                      uint32_t* s_two /*LDS[2], zeroed*/) {
+// (`o_in` / `nz_in`: OR of this thread's visible keys / of their complements)
+__device__ __forceinline__ void depth_bits_accumulate2(uint32_t o_in, uint32_t nz_in, unsigned long long* bits, uint32_t tag,
+                                                       uint32_t* s_two /*LDS[2], zeroed*/) {
     // (`s_two` was zeroed before the workgroup's last barrier.  Twelve DPP instructions per lane, then ONE lane per wave
     // ORs into the two LDS words.  Measured the hard way: every lane ORing into the LDS words itself -- 64 lanes on one
     // address -- took depth_keys_kernel from 2.4 to 26 us and preprocess_fwd from 81 to 88)
-    const uint32_t o = wave_or_hi(visible ? key : 0u), nz = wave_or_hi(visible ? ~key : 0u);
+    const uint32_t o = wave_or_hi(o_in), nz = wave_or_hi(nz_in);
     if ((threadIdx.x & 63) == 63) { if (o) atomicOr(&s_two[0], o); if (nz) atomicOr(&s_two[1], nz); }
     __syncthreads();
     if (threadIdx.x < 2 && s_two[threadIdx.x])
         tagged_or(bits + 2 * (blockIdx.x % kDepthBitsCopies) + threadIdx.x, tag, s_two[threadIdx.x]);
+}
+__device__ __forceinline__ void depth_bits_accumulate(uint32_t key, bool visible, unsigned long long* bits, uint32_t tag,
+                                                      uint32_t* s_two /*LDS[2], zeroed*/) {
+    depth_bits_accumulate2(visible ? key : 0u, visible ? ~key : 0u, bits, tag, s_two);
 }
 __device__ __forceinline__ float xform_row(const float* m, int i, float x, float y, float z) {
     return ((m[i] * x + m[4 + i] * y) + m[8 + i] * z) + m[12 + i];

@@ -546,7 +546,14 @@ __device__ __forceinline__ void stage_rows_out(float* dst, const float* s_rows, 
 // instruction; instead the block's rows are moved between HBM and LDS with fully coalesced accesses and each thread
 // works on its row in LDS (row stride M*3+1 words: conflict-free).
 // SHG = false: the SH-coefficient gradient is not formed here (view-parallel exchange, hs_sh_backward_views).
-#ifdef HS_TUNE_PB_WAVES
+// Occupancy the register allocator may be held to (0: none, the default): 128 rows of 3M + 1 floats in LDS (25 KB at degree
+// 3) allow six workgroups = three waves per SIMD; the degree-3 instantiation takes 183 registers = two.  Measured at c3
+// (round 5): forced to three waves (168 registers, 14 spilled) the stage is 1 us FASTER at best -- the kernel streams at
+// 4.9 TB/s either way.
+#ifndef HS_TUNE_PB_WAVES
+#define HS_TUNE_PB_WAVES 0
+#endif
+#if HS_TUNE_PB_WAVES > 0
 #define HS_PB_OCC __attribute__((amdgpu_waves_per_eu(HS_TUNE_PB_WAVES, HS_TUNE_PB_WAVES)))
 #else
 #define HS_PB_OCC

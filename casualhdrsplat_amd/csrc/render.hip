@@ -931,6 +931,11 @@ render_bwd_kernel(RenderBwd p) {
         o[512 + r0] = t0.q; o[512 + r1] = t1.q;
         o[640 + r0] = t0.dLd; o[640 + r1] = t1.dLd;
         o[768 + r0] = __uint_as_float(t0.last); o[768 + r1] = __uint_as_float(t1.last);
+        // the reads below take values OTHER lanes of this wave wrote: say so to the compiler (a wavefront-scope release
+        // fence + a wave barrier: no instruction is emitted, the LDS operations of a wave complete in order anyway, but
+        // the order of the stores and the loads is now a stated contract instead of an alias-analysis accident)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         const int p0 = (py0 - sy) * 16 + (px - sx), p1 = p0 + 16;
         s0.T = o[p0]; s0.dL0 = o[128 + p0]; s0.dL1 = o[256 + p0]; s0.dL2 = o[384 + p0]; s0.q = o[512 + p0];
         s0.dLd = o[640 + p0]; s0.last = __float_as_uint(o[768 + p0]);

@@ -40,7 +40,7 @@ class GraphedStep:
             if r.capacity is None:
                 raise ValueError("GraphedStep needs GaussianRasterizer(..., capacity=N): the synchronous mode reads "
                                  "num_rendered on the host inside every forward and cannot be captured")
-        self.rasterizers = list(rasterizers)
+        self.rasterizers = list({id(r): r for r in rasterizers}.values())   # (a rasterizer listed twice counts once)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -53,14 +53,23 @@ class GraphedStep:
         for r in self.rasterizers:
             r._cell["captured"] = []     # every forward a rasterizer enqueues while the stream captures lands here
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.outputs = fn()
+        try:
+            with torch.cuda.graph(self.graph):
+                self.outputs = fn()
+        finally:
+            # (also when `fn` throws inside the capture: a list left behind would make the rasterizer's later eager
+            # forwards believe they are being captured)
+            captured = {id(r): r._cell.pop("captured", []) for r in self.rasterizers}
         # the forwards captured above left their counter copies pending (nobody may wait inside a capture): ALL of them
         # -- `fn` may call one rasterizer several times (several views, an eval render in between), and a frame that
         # overflowed renders empty whichever call it was
-        self._pending = [(r, p) for r in self.rasterizers for p in r._cell.pop("captured", []) if p is not None]
-        if len({id(r) for r, _ in self._pending}) != len(self.rasterizers):
-            raise ValueError("GraphedStep: a rasterizer listed in `rasterizers` was not called by `fn` during the capture")
+        not_called = [i for i, r in enumerate(self.rasterizers) if not captured[id(r)]]
+        if not_called:
+            raise ValueError(f"GraphedStep: rasterizers {not_called} of `rasterizers` were not called by `fn` during the capture")
+        self._pending = [(r, p) for r in self.rasterizers for p in captured[id(r)] if p is not None]
+        if any(p is None for r in self.rasterizers for p in captured[id(r)]):
+            raise ValueError("GraphedStep: a captured forward left no device counters to check (was the rasterizer given "
+                             "capacity=None?)")
         self._warned_helps = False
         # `params`: the leaves whose gradients the step produces -- `grads` are the static tensors every replay rewrites
         self.grads = [p.grad for p in params]

@@ -35,7 +35,7 @@ extern "C" {
 /* libhdrsplat.so is built with -fvisibility=hidden: the hs_* entry points below are its only exported symbols */
 #define HS_API __attribute__((visibility("default")))
 
-#define HS_VERSION 303
+#define HS_VERSION 304
 
 #define HS_OK 0
 #define HS_EINVAL (-1)    /* bad argument (null pointer, bad shape, unsupported degree ...) */
@@ -54,6 +54,10 @@ extern "C" {
 #define HS_STAGE_OFFSETS 8    /* inspection only: inclusive scan of tiles_touched in instance order into the geom
                                  workspace (`offsets`; the pipeline itself scans the depth-ordered counts) and the 3-D
                                  covariances (`cov3D`; the pipeline recomputes them in the backward instead of storing) */
+
+#define HS_STAGE_PREPROCESS_ONLY 16 /* profiling (bench.py's per-kernel roofline leg): with PREPROCESS | BIN, enqueue the
+                                 preprocess kernel exactly as a single-enqueue forward does -- carrying the binning stage's
+                                 prologue: depth keys, cleared scratch and ranges -- and stop before the binning kernels */
 
 /* hs_bwd_args.stages */
 #define HS_BWD_RENDER 1      /* per-pixel backward -> one gradient record per (tile, instance) pair */

@@ -179,8 +179,15 @@ def pixel_reach(cam: Camera, fwd: dict, pix_mask, whole_list: bool = False, guar
 
 
 def backward(cam: Camera, fwd: dict, dL_dcolor_img, means3D, shs=None, colors_precomp=None,
-             scales=None, rotations=None, cov3D_precomp=None, dL_dinvdepth_img=None) -> dict:
-    """Runs a10..a12 given forward()'s intermediates and dL/d(out_color) [3,H,W] (+ optional dL/d(invdepth) [H,W])."""
+             scales=None, rotations=None, cov3D_precomp=None, dL_dinvdepth_img=None, bounds: bool = False) -> dict:
+    """Runs a10..a12 given forward()'s intermediates and dL/d(out_color) [3,H,W] (+ optional dL/d(invdepth) [H,W]).
+
+    bounds=True adds, next to every gradient tensor `dL_dX`, `abs_dL_dX` of the same shape = sum |terms| of that
+    element, and `n_terms` [P]: the render backward returns, for each of its ten per-Gaussian sums, the sum over the
+    pixels of the magnitude of what it added (hso_render_bwd, abs_terms); a11/a12 are linear in those sums, so the
+    magnitudes are carried through them by hso_preprocess_bwd_abs -- the same chain with every coefficient's absolute
+    value and every difference turned into a sum (a net Jacobian entry that is small by cancellation still carries the
+    rounding of the intermediates it cancelled from)."""
     L = lib()
     means3D = _f32(means3D)
     P = means3D.shape[0]
@@ -192,14 +199,14 @@ def backward(cam: Camera, fwd: dict, dL_dcolor_img, means3D, shs=None, colors_pr
     o = dict(
         dL_dmean2D=np.zeros((P, 2), np.float32), dL_dconic=np.zeros((P, 3), np.float32),
         dL_dopacity=np.zeros(P, np.float32), dL_dcolor=np.zeros((P, 3), np.float32),
-        abs_scale=np.zeros(P, np.float32),
+        abs_terms=np.zeros((P, 11), np.float32) if bounds else None,
     )
     gd = None if dL_dinvdepth_img is None else _f32(dL_dinvdepth_img).reshape(cam.H, cam.W)
     o["dL_dinvdepth"] = None if gd is None else np.zeros(P, np.float32)
     rc = L.hso_render_bwd(C.byref(c), _p(fwd["ranges"]), _p(fwd["point_list"]), _p(fwd["xy"]),
                           _p(fwd["conic_opacity"]), _p(fwd["rgb"]), _p(fwd["final_T"]), _p(fwd["n_contrib"]),
                           _p(g), _p(o["dL_dmean2D"]), _p(o["dL_dconic"]), _p(o["dL_dopacity"]),
-                          _p(o["dL_dcolor"]), _p(o["abs_scale"]),
+                          _p(o["dL_dcolor"]), _p(o["abs_terms"]),
                           _p(fwd["depths"]) if gd is not None else None, _p(gd), _p(o["dL_dinvdepth"]))
     assert rc == 0
     o["dL_dmeans3D"] = np.zeros((P, 3), np.float32)
@@ -217,6 +224,23 @@ def backward(cam: Camera, fwd: dict, dL_dcolor_img, means3D, shs=None, colors_pr
                               _p(_f32(fwd["opacities_in"])), _p(o["dL_dopacity"]), _p(o["dL_dinvdepth"]))
     assert rc == 0
     o["dL_dmeans2D"] = np.concatenate([o["dL_dmean2D"], np.zeros((P, 1), np.float32)], axis=1)
+    if bounds:
+        A = o["abs_terms"]
+        o["n_terms"] = A[:, 10].astype(np.int64)
+        outs = ["dL_dmeans3D", "dL_dshs", "dL_dcolors_precomp", "dL_dscales", "dL_drots", "dL_dcov3D"]
+        t = {q: (None if o[q] is None else np.zeros(o[q].shape, np.float32)) for q in outs}
+        m2, con, col = (np.ascontiguousarray(A[:, 0:2]), np.ascontiguousarray(A[:, 2:5]), np.ascontiguousarray(A[:, 6:9]))
+        op, invd = np.ascontiguousarray(A[:, 5]), np.ascontiguousarray(A[:, 9])
+        rc = L.hso_preprocess_bwd_abs(C.byref(c), _p(means3D), _p(shs), _p(scales), _p(rotations), _p(fwd["radii"]),
+                                      _p(fwd["cov3D"]), _p(fwd["clamped"]), _p(fwd["rgb"]), _p(m2), _p(con), _p(col),
+                                      _p(t["dL_dmeans3D"]), _p(t["dL_dshs"]), _p(t["dL_dcolors_precomp"]),
+                                      _p(t["dL_dscales"]), _p(t["dL_drots"]), _p(t["dL_dcov3D"]),
+                                      _p(_f32(fwd["opacities_in"])), _p(op), _p(invd if gd is not None else None))
+        assert rc == 0
+        for q in outs:
+            o["abs_" + q] = t[q]
+        o["abs_dL_dopacity"] = op        # (antialiasing scaled it in place; else it passed through)
+        o["abs_dL_dmeans2D"] = np.concatenate([A[:, :2], np.zeros((P, 1), np.float32)], axis=1)
     return o
 
 

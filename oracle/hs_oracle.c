@@ -537,13 +537,21 @@ int64_t hso_pixel_reach(const hso_camera* c, const uint32_t* ranges, const uint3
  *   dL_dmean2D [P,2]  in NDC-scaled units (pixel gradient * 0.5*W, 0.5*H),
  *   dL_dconic  [P,3]  true partials w.r.t. (A,B,C) of power = -0.5(A dx^2 + C dy^2) - B dx dy,
  *   dL_dopacity[P], dL_dcolor [P,3].
- * abs_* (optional, may be NULL) receive sum_k |term_k| for dL_dmean2D.x as a conditioning scale.
+ * abs_terms (optional, may be NULL; [P, 11]) receives, next to every one of the ten per-Gaussian sums (order: mean2D x, y;
+ * conic A, B, C; opacity; colour r, g, b; inverse depth), the sum over the pixels of  w * |term|:  |term| = the per-pixel
+ * term evaluated with every difference inside it replaced by the sum of the absolute values of its operands
+ * (|c - accum| -> |c| + |accum|, the background term's sum of |bg_ch dL_ch|, |gdx A| + |gdy B| ...), i.e. the scale against
+ * which an fp32 evaluation of that term, in any operation order, is accurate to a few ulp; w = 4 + the number of
+ * T <- T / (1 - alpha) steps the replay has taken on that pixel before this contributor -- every step adds an ulp to T's
+ * relative error, and T multiplies the whole term (the conditioning DESIGN.md's numerical contract speaks of) -- and in
+ * column 10 the number of terms n.  Tests bound |other implementation - this one| per element by
+ * 1e-4 |ref| + c 2^-24 sum w |term| (tests/helpers.py, assert_grads_bounded).
  * ------------------------------------------------------------------------------------------ */
 int hso_render_bwd(const hso_camera* c, const uint32_t* ranges, const uint32_t* point_list,
                    const float* xy, const float* conic_opacity, const float* rgb,
                    const float* final_T, const uint32_t* n_contrib, const float* dL_dpix,
                    float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
-                   float* abs_scale,
+                   float* abs_terms,
                    const float* depths, const float* dL_dinvdepth_pix, float* dL_dinvdepth) {
     /* depths, dL_dinvdepth_pix [H*W], dL_dinvdepth [P] (all or none): the inverse-depth image is a fourth blended
      * channel without a background term; dL_dinvdepth receives sum_pix alpha T dL/dD(pix) per Gaussian */
@@ -551,6 +559,8 @@ int hso_render_bwd(const hso_camera* c, const uint32_t* ranges, const uint32_t* 
     const int gx = (W + HSO_TILE - 1) / HSO_TILE;
     double* acc = (double*)calloc((size_t)P * 11, sizeof(double));
     if (!acc) return -1;
+    double* aab = abs_terms ? (double*)calloc((size_t)P * 11, sizeof(double)) : NULL;
+    if (abs_terms && !aab) { free(acc); return -1; }
     const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
     for (int py = 0; py < H; ++py)
         for (int px = 0; px < W; ++px) {
@@ -568,6 +578,7 @@ int hso_render_bwd(const hso_camera* c, const uint32_t* ranges, const uint32_t* 
             const float dLd = dL_dinvdepth_pix ? dL_dinvdepth_pix[pix] : 0.f;
             float last_alpha = 0.f;
             float pxf = (float)px, pyf = (float)py;
+            double wdepth = 4.0;   /* abs_terms weight: 4 + the T / (1 - alpha) steps behind this contributor (see below) */
             for (uint32_t kk = last; kk-- > 0;) {
                 uint32_t id = point_list[beg + kk];
                 float dx = xy[2 * id] - pxf, dy = xy[2 * id + 1] - pyf;
@@ -580,24 +591,33 @@ int hso_render_bwd(const hso_camera* c, const uint32_t* ranges, const uint32_t* 
                 T = T / (1.f - alpha);
                 float dchannel_dcolor = alpha * T;
                 float dL_dalpha = 0.f;
+                double mag_alpha = 0.0;   /* magnitude of dL_dalpha: sums of absolute values instead of differences */
                 double* a = acc + (size_t)id * 11;
+                double* ab = aab ? aab + (size_t)id * 11 : NULL;
                 if (dL_dinvdepth_pix) {
                     float invd = 1.f / depths[id];
                     accum_invd = last_alpha * last_invd + (1.f - last_alpha) * accum_invd;
                     last_invd = invd;
                     dL_dalpha += (invd - accum_invd) * dLd;
+                    mag_alpha += (fabs((double)invd) + fabs((double)accum_invd)) * fabs((double)dLd);
                     a[10] += (double)(dchannel_dcolor * dLd);
+                    if (ab) ab[9] += wdepth * fabs((double)(dchannel_dcolor * dLd));
                 }
                 for (int ch = 0; ch < 3; ++ch) {
                     float col = rgb[3 * id + ch];
                     accum_rec[ch] = last_alpha * last_color[ch] + (1.f - last_alpha) * accum_rec[ch];
                     last_color[ch] = col;
                     dL_dalpha += (col - accum_rec[ch]) * dLp[ch];
+                    mag_alpha += (fabs((double)col) + fabs((double)accum_rec[ch])) * fabs((double)dLp[ch]);
                     a[6 + ch] += (double)(dchannel_dcolor * dLp[ch]);
+                    if (ab) ab[6 + ch] += wdepth * fabs((double)(dchannel_dcolor * dLp[ch]));
                 }
                 dL_dalpha *= T;
+                mag_alpha *= (double)T;
                 last_alpha = alpha;
                 dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
+                mag_alpha += fabs((double)(T_final / (1.f - alpha))) *
+                             ((fabs((double)(c->bg[0] * dLp[0])) + fabs((double)(c->bg[1] * dLp[1]))) + fabs((double)(c->bg[2] * dLp[2])));
                 float dL_dG = co[3] * dL_dalpha;
                 float gdx = G * dx, gdy = G * dy;
                 float dG_ddelx = -gdx * co[0] - gdy * co[1];
@@ -609,7 +629,19 @@ int hso_render_bwd(const hso_camera* c, const uint32_t* ranges, const uint32_t* 
                 a[3] += (double)(-gdx * dy * dL_dG);
                 a[4] += (double)(-0.5f * gdy * dy * dL_dG);
                 a[5] += (double)(G * dL_dalpha);
-                a[9] += fabs((double)tmx);
+                if (ab) {
+                    const double mG = wdepth * fabs((double)co[3]) * mag_alpha;        /* weighted magnitude of dL_dG */
+                    const double mx = fabs((double)(gdx * co[0])) + fabs((double)(gdy * co[1]));
+                    const double my = fabs((double)(gdy * co[2])) + fabs((double)(gdx * co[1]));
+                    ab[0] += mG * mx * (double)ddelx_dx;
+                    ab[1] += mG * my * (double)ddely_dy;
+                    ab[2] += fabs((double)(0.5f * gdx * dx)) * mG;
+                    ab[3] += fabs((double)(gdx * dy)) * mG;
+                    ab[4] += fabs((double)(0.5f * gdy * dy)) * mG;
+                    ab[5] += wdepth * fabs((double)G) * mag_alpha;
+                    ab[10] += 1.0;
+                }
+                wdepth += 1.0;
             }
         }
     for (int i = 0; i < P; ++i) {
@@ -619,9 +651,10 @@ int hso_render_bwd(const hso_camera* c, const uint32_t* ranges, const uint32_t* 
         dL_dconic[3 * i] = (float)a[2]; dL_dconic[3 * i + 1] = (float)a[3]; dL_dconic[3 * i + 2] = (float)a[4];
         dL_dopacity[i] = (float)a[5];
         for (int ch = 0; ch < 3; ++ch) dL_dcolor[3 * i + ch] = (float)a[6 + ch];
-        if (abs_scale) abs_scale[i] = (float)a[9];
+        if (abs_terms) for (int k = 0; k < 11; ++k) abs_terms[(size_t)i * 11 + k] = (float)aab[(size_t)i * 11 + k];
     }
     free(acc);
+    free(aab);
     return 0;
 }
 
@@ -791,6 +824,165 @@ int hso_preprocess_bwd(const hso_camera* c, const float* means3D, const float* s
             for (int k = 0; k < 6; ++k) dL_dcov3D[6 * i + k] = gcov[k];
         }
         if (dL_dmeans3D) for (int k = 0; k < 3; ++k) dL_dmeans3D[3 * i + k] = gm[k];
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Magnitude shadow of hso_preprocess_bwd (test infrastructure of the per-element gradient bound, tests/helpers.py
+ * assert_grads_bounded): the same chain -- conic -> cov2D -> (Sigma, t); screen-space mean -> mean3D; colour -> SH
+ * coefficients and view direction; Sigma -> scale, rotation -- evaluated on MAGNITUDES: the inputs are the weighted
+ * sums of |term| that hso_render_bwd returns next to its ten per-Gaussian sums (abs_terms), every product enters with
+ * the absolute value of its coefficient and every difference becomes a sum.  The outputs bound, element by element,
+ * what an fp32 evaluation of a11 / a12 in any association order can be off by per unit of relative rounding: a net
+ * Jacobian entry that is tiny because the chain cancels (the scale gradient of a nearly isotropic Gaussian) still
+ * carries the rounding of the large intermediates it was cancelled from.
+ * A_* inputs >= 0; any output pointer may be NULL.  A_opacity is in/out like dL_dopacity (antialiasing scales it).
+ * ------------------------------------------------------------------------------------------ */
+int hso_preprocess_bwd_abs(const hso_camera* c, const float* means3D, const float* shs,
+                           const float* scales, const float* rotations, const int* radii, const float* cov3D,
+                           const uint8_t* clamped, const float* rgb, const float* A_mean2D, const float* A_conic,
+                           const float* A_color, float* B_means3D, float* B_shs, float* B_colors_precomp,
+                           float* B_scales, float* B_rots, float* B_cov3D,
+                           const float* opacities, float* A_opacity, const float* A_invdepth) {
+    const int P = c->P;
+    const int ncoef = (c->sh_degree + 1) * (c->sh_degree + 1);
+    const float* V = c->viewmatrix;
+    const float* PM = c->projmatrix;
+    for (int i = 0; i < P; ++i) {
+        double gm[3] = {0., 0., 0.};
+        double gcov[6] = {0., 0., 0., 0., 0., 0.};
+        if (B_shs) memset(B_shs + (size_t)i * c->M * 3, 0, sizeof(float) * c->M * 3);
+        if (B_colors_precomp) for (int k = 0; k < 3; ++k) B_colors_precomp[3 * i + k] = 0.f;
+        if (B_scales) for (int k = 0; k < 3; ++k) B_scales[3 * i + k] = 0.f;
+        if (B_rots) for (int k = 0; k < 4; ++k) B_rots[4 * i + k] = 0.f;
+        if (B_cov3D) for (int k = 0; k < 6; ++k) B_cov3D[6 * i + k] = 0.f;
+        if (B_means3D) for (int k = 0; k < 3; ++k) B_means3D[3 * i + k] = 0.f;
+        if (radii[i] <= 0) continue;
+        float x = means3D[3 * i], y = means3D[3 * i + 1], z = means3D[3 * i + 2];
+        float pvx = xform_row(V, 0, x, y, z), pvy = xform_row(V, 1, x, y, z), pvz = xform_row(V, 2, x, y, z);
+        const float* s6 = cov3D + 6 * i;
+        hso_ewa e;
+        ewa_setup(c, pvx, pvy, pvz, &e);
+        float u0[3], u1[3];
+        sym_mul(s6, e.a0, u0);
+        sym_mul(s6, e.a1, u1);
+        double a = dot3(e.a0, u0) + 0.3f, b = dot3(e.a1, u0), cc = dot3(e.a1, u1) + 0.3f;
+        double denom = a * cc - b * b;
+        double denom2inv = 1.0 / ((denom * denom) + 0.0000001);
+        double gA = A_conic[3 * i], gB = A_conic[3 * i + 1], gC = A_conic[3 * i + 2];
+        double aa_da = 0., aa_db = 0., aa_dc = 0.;
+        if (c->antialias && opacities && A_opacity) {
+            double det0 = (a - 0.3) * (cc - 0.3) - b * b;
+            double q = det0 / denom;
+            double sfac = sqrt(q > 0.000025 ? q : 0.000025);
+            double g_eff = A_opacity[i];
+            A_opacity[i] = (float)(g_eff * sfac);
+            if (q > 0.000025) {
+                double k = fabs(g_eff * opacities[i] * 0.5 / sfac / (denom * denom));
+                aa_da = k * (fabs((cc - 0.3) * denom) + fabs(det0 * cc));
+                aa_dc = k * (fabs((a - 0.3) * denom) + fabs(det0 * a));
+                aa_db = k * (fabs(2. * b * det0) + fabs(2. * b * denom));
+            }
+        }
+        if (A_invdepth && A_invdepth[i] != 0.f) {
+            double dz = A_invdepth[i] / ((double)pvz * pvz);
+            for (int j = 0; j < 3; ++j) gm[j] += fabs((double)V[4 * j + 2]) * dz;
+        }
+        if (denom2inv != 0.) {
+            double dLda = denom2inv * (cc * cc * gA + fabs(b * cc) * gB + (fabs(denom) + fabs(a * cc)) * gC) + aa_da;
+            double dLdc = denom2inv * (a * a * gC + fabs(a * b) * gB + (fabs(denom) + fabs(a * cc)) * gA) + aa_dc;
+            double dLdb = denom2inv * (2. * fabs(b * cc) * gA + (fabs(denom) + 2. * b * b) * gB + 2. * fabs(a * b) * gC) + aa_db;
+            double p[3], q[3];
+            for (int j = 0; j < 3; ++j) { p[j] = fabs((double)e.a0[j]); q[j] = fabs((double)e.a1[j]); }
+            gcov[0] = p[0] * p[0] * dLda + p[0] * q[0] * dLdb + q[0] * q[0] * dLdc;
+            gcov[3] = p[1] * p[1] * dLda + p[1] * q[1] * dLdb + q[1] * q[1] * dLdc;
+            gcov[5] = p[2] * p[2] * dLda + p[2] * q[2] * dLdb + q[2] * q[2] * dLdc;
+            gcov[1] = 2. * p[0] * p[1] * dLda + (p[0] * q[1] + p[1] * q[0]) * dLdb + 2. * q[0] * q[1] * dLdc;
+            gcov[2] = 2. * p[0] * p[2] * dLda + (p[0] * q[2] + p[2] * q[0]) * dLdb + 2. * q[0] * q[2] * dLdc;
+            gcov[4] = 2. * p[1] * p[2] * dLda + (p[1] * q[2] + p[2] * q[1]) * dLdb + 2. * q[1] * q[2] * dLdc;
+            double ga0[3], ga1[3];
+            for (int j = 0; j < 3; ++j) {
+                ga0[j] = 2. * dLda * fabs((double)u0[j]) + dLdb * fabs((double)u1[j]);
+                ga1[j] = 2. * dLdc * fabs((double)u1[j]) + dLdb * fabs((double)u0[j]);
+            }
+            double dJ00 = 0., dJ02 = 0., dJ11 = 0., dJ12 = 0.;
+            for (int j = 0; j < 3; ++j) {
+                dJ00 += ga0[j] * fabs((double)V[4 * j + 0]); dJ02 += ga0[j] * fabs((double)V[4 * j + 2]);
+                dJ11 += ga1[j] * fabs((double)V[4 * j + 1]); dJ12 += ga1[j] * fabs((double)V[4 * j + 2]);
+            }
+            double tz = 1. / e.tz, tz2 = tz * tz, tz3 = fabs(tz2 * tz);
+            double dtx = e.clamp_x ? 0. : fabs(e.fx * tz2) * dJ02;
+            double dty = e.clamp_y ? 0. : fabs(e.fy * tz2) * dJ12;
+            double dtz = fabs(e.fx * tz2) * dJ00 + fabs(e.fy * tz2) * dJ11 + fabs(2. * e.fx * e.tx) * tz3 * dJ02 +
+                         fabs(2. * e.fy * e.ty) * tz3 * dJ12;
+            for (int j = 0; j < 3; ++j)
+                gm[j] += fabs((double)V[4 * j + 0]) * dtx + fabs((double)V[4 * j + 1]) * dty + fabs((double)V[4 * j + 2]) * dtz;
+        }
+        {
+            double phx = xform_row(PM, 0, x, y, z), phy = xform_row(PM, 1, x, y, z), phw = xform_row(PM, 3, x, y, z);
+            double mw = 1.0 / (phw + 0.0000001);
+            double mul1 = phx * mw * mw, mul2 = phy * mw * mw;
+            double gx2 = A_mean2D[2 * i], gy2 = A_mean2D[2 * i + 1];
+            for (int j = 0; j < 3; ++j)
+                gm[j] += (fabs(PM[4 * j + 0] * mw) + fabs(PM[4 * j + 3] * mul1)) * gx2 +
+                         (fabs(PM[4 * j + 1] * mw) + fabs(PM[4 * j + 3] * mul2)) * gy2;
+        }
+        if (shs) {
+            float dx = x - c->campos[0], dy = y - c->campos[1], dz = z - c->campos[2];
+            float len = sqrtf((dx * dx + dy * dy) + dz * dz);
+            float ux = dx / len, uy = dy / len, uz = dz / len;
+            float bs[16], gb[16][3];
+            sh_basis(c->sh_degree, ux, uy, uz, bs);
+            sh_basis_grad(c->sh_degree, ux, uy, uz, gb);
+            const float* sh = shs + (size_t)i * c->M * 3;
+            double gdir[3] = {0., 0., 0.};
+            for (int ch = 0; ch < 3; ++ch) {
+                double g = fabs((double)radiance_dact(c->radiance_activation, rgb[3 * i + ch], clamped[3 * i + ch])) * A_color[3 * i + ch];
+                for (int k = 0; k < ncoef; ++k) {
+                    if (B_shs) B_shs[((size_t)i * c->M + k) * 3 + ch] = (float)(fabs((double)bs[k]) * g);
+                    for (int d = 0; d < 3; ++d) gdir[d] += fabs((double)gb[k][d] * sh[3 * k + ch]) * g;
+                }
+            }
+            double dd = (fabs((double)ux) * gdir[0] + fabs((double)uy) * gdir[1]) + fabs((double)uz) * gdir[2];
+            double inv = 1. / len;
+            gm[0] += (gdir[0] + fabs((double)ux) * dd) * inv;
+            gm[1] += (gdir[1] + fabs((double)uy) * dd) * inv;
+            gm[2] += (gdir[2] + fabs((double)uz) * dd) * inv;
+        } else if (B_colors_precomp) {
+            for (int ch = 0; ch < 3; ++ch) B_colors_precomp[3 * i + ch] = A_color[3 * i + ch];
+        }
+        if (scales && rotations) {
+            float R[9];
+            double Mx[9], sabs[3];
+            const float* q = rotations + 4 * i;
+            quat_to_R(q, R);
+            for (int k = 0; k < 3; ++k) {
+                sabs[k] = fabs((double)c->scale_modifier * scales[3 * i + k]);
+                for (int j = 0; j < 3; ++j) Mx[3 * k + j] = sabs[k] * fabs((double)R[3 * j + k]);
+            }
+            double G[9] = {gcov[0], 0.5 * gcov[1], 0.5 * gcov[2], 0.5 * gcov[1], gcov[3], 0.5 * gcov[4],
+                           0.5 * gcov[2], 0.5 * gcov[4], gcov[5]};
+            double dM[9], dR[9];
+            for (int k = 0; k < 3; ++k)
+                for (int j = 0; j < 3; ++j)
+                    dM[3 * k + j] = 2. * ((Mx[3 * k + 0] * G[0 + j] + Mx[3 * k + 1] * G[3 + j]) + Mx[3 * k + 2] * G[6 + j]);
+            for (int k = 0; k < 3; ++k) {
+                double ds = 0.;
+                for (int j = 0; j < 3; ++j) { ds += dM[3 * k + j] * fabs((double)R[3 * j + k]); dR[3 * j + k] = sabs[k] * dM[3 * k + j]; }
+                if (B_scales) B_scales[3 * i + k] = (float)(fabs((double)c->scale_modifier) * ds);
+            }
+            double r = fabs((double)q[0]), qx = fabs((double)q[1]), qy = fabs((double)q[2]), qz = fabs((double)q[3]);
+            if (B_rots) {
+                B_rots[4 * i + 0] = (float)(2. * (qz * dR[1] + qy * dR[2] + qz * dR[3] + qx * dR[5] + qy * dR[6] + qx * dR[7]));
+                B_rots[4 * i + 1] = (float)(2. * (qy * dR[1] + qz * dR[2] + qy * dR[3] + 2. * qx * dR[4] + r * dR[5] + qz * dR[6] + r * dR[7] + 2. * qx * dR[8]));
+                B_rots[4 * i + 2] = (float)(2. * (2. * qy * dR[0] + qx * dR[1] + r * dR[2] + qx * dR[3] + qz * dR[5] + r * dR[6] + qz * dR[7] + 2. * qy * dR[8]));
+                B_rots[4 * i + 3] = (float)(2. * (2. * qz * dR[0] + r * dR[1] + qx * dR[2] + r * dR[3] + 2. * qz * dR[4] + qy * dR[5] + qx * dR[6] + qy * dR[7]));
+            }
+        } else if (B_cov3D) {
+            for (int k = 0; k < 6; ++k) B_cov3D[6 * i + k] = (float)gcov[k];
+        }
+        if (B_means3D) for (int k = 0; k < 3; ++k) B_means3D[3 * i + k] = (float)gm[k];
     }
     return 0;
 }

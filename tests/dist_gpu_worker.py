@@ -69,6 +69,34 @@ def main():
             for k in names:
                 a, b = leaf[k].grad, want[k]
                 assert torch.allclose(a, b, rtol=1e-5, atol=1e-6 * float(b.abs().max())), (mode, algo, k)
+    # the usual 3DGS wiring -- activations between the parameters and the rasterizer, so the rasterizer's
+    # inputs are NOT leaves: autograd runs the activations' backward right after the rasterizer's, on rows the chunked
+    # all-reduce may still be summing.  The backward must have waited for its collectives by then (finish_reduce() finds
+    # nothing left), and the raw parameters receive the gradients summed over the views.
+    def activated(view_rank, chunked):
+        sc.camera = S.yaw_camera(W, Hh, -5.0 + 10.0 * view_rank / max(world - 1, 1))
+        rs, _, _ = H.settings_from_scene(sc, dev)
+        raw = dict(means3D=sc.means3D.clone(), raw_opac=torch.logit(sc.opacities.clamp(1e-4, 1 - 1e-4)),
+                   raw_scales=torch.log(sc.scales), raw_rot=sc.rotations * 1.7, dc=sc.shs[:, :1].clone(),
+                   rest=sc.shs[:, 1:].clone())
+        raw = {k: t.to(dev).requires_grad_(True) for k, t in raw.items()}
+        m2d = torch.zeros_like(raw["means3D"], requires_grad=True)
+        rast = GaussianRasterizer(rs, reduce_group=True if chunked else None, reduce_chunks=3)
+        out = rast(raw["means3D"], m2d, torch.sigmoid(raw["raw_opac"]), shs=torch.cat([raw["dc"], raw["rest"]], dim=1),
+                   scales=torch.exp(raw["raw_scales"]), rotations=torch.nn.functional.normalize(raw["raw_rot"], dim=1))
+        (out[0] * sc.dL_dimage.to(dev)).sum().backward()
+        return raw, rast
+
+    want_raw = None
+    for r in range(world):
+        raw, _ = activated(r, False)
+        g = {k: v.grad.clone() for k, v in raw.items()}
+        want_raw = g if want_raw is None else {k: want_raw[k] + g[k] for k in g}
+    raw, rast = activated(rank, True)
+    assert rast._cell.get("reduce_waited_in_backward", 0) > 0 and rast.finish_reduce() == 0
+    for k, v in raw.items():
+        b = want_raw[k]
+        assert torch.allclose(v.grad, b, rtol=1e-5, atol=1e-6 * float(b.abs().max())), ("activated", k)
     torch.cuda.synchronize()
     print("VIEW-EXCHANGE-OK", rank, flush=True)
     dist.barrier()

@@ -97,6 +97,46 @@ def test_ldr_forward_backward_vs_oracle(oracle, P, W, H, deg, seed):
     # strict bar on every row except the tile lists of pixels where a decision actually differed: >= 95 % of the rows at
     # BASELINE c2 size (the smaller frames: a single differing pixel already reaches a few per cent of 1000 Gaussians)
     Hh.assert_grads_close(g, b, what=f"P={P}", at_risk=m["rows"], min_strict=0.95 if P >= 20000 else 0.85)
+    # the pass that excuses nothing: dL zeroed on the pixels where a decision differed, both sides --
+    # every row on the strict bar, every element inside 1e-4 |ref| + C_BOUND 2^-24 sqrt(n) sum|terms|
+    g2, b2, _ = Hh.masked_backward_pass(oracle, sc, m, [f], hdr=False)
+    Hh.assert_grads_close(g2, b2, what=f"P={P} masked")
+    Hh.assert_grads_bounded(g2, b2, what=f"P={P} masked")
+
+
+@pytest.fixture(params=["default", "tickets", "scan_in_emission"])
+def binning_mode(request):
+    """The binning stage's alternate forms inside the driver's suite: chain positions of the radix
+    passes from start-order tickets (hs_sort_tickets(1): what a process on a shared GPU runs) and the pair emission
+    computing its block offsets itself by decoupled look-back (HS_SCAN_IN_EMISSION=1: what frames of >= 2^21 instances
+    run), each forced onto frames that would take the default form."""
+    from casualhdrsplat_amd import _lib as L
+    lib = L.load()
+    was, env = lib.hs_sort_tickets(-1), os.environ.get("HS_SCAN_IN_EMISSION")
+    if request.param == "tickets":
+        lib.hs_sort_tickets(1)
+    elif request.param == "scan_in_emission":
+        os.environ["HS_SCAN_IN_EMISSION"] = "1"
+    yield request.param
+    lib.hs_sort_tickets(was)
+    if env is None:
+        os.environ.pop("HS_SCAN_IN_EMISSION", None)
+    else:
+        os.environ["HS_SCAN_IN_EMISSION"] = env
+
+
+@pytest.mark.parametrize("case", ["ldr_20000", "tiles_14400", "c1_hdr_fixture"])
+def test_binning_modes_vs_oracle(oracle, binning_mode, case):
+    """Three frames of the suite -- 20 000 Gaussians at 500 x 300, the 14 400-tile frame, a c1-scale HDR golden fixture
+    with 8 poses -- through every form of the binning stage: the same bit-exact structure, images and gradients."""
+    if case == "ldr_20000":
+        test_ldr_forward_backward_vs_oracle(oracle, 20000, 500, 300, 1, 3)
+    elif case == "tiles_14400":
+        test_frame_of_14400_tiles_vs_oracle(oracle)
+    else:
+        path = [p for p in GOLDEN if os.path.basename(p) == "c1_hdr_deg3_n8_ldrblur.npz"]
+        assert path, "fixture c1_hdr_deg3_n8_ldrblur.npz is missing"
+        test_against_golden_fixtures(path[0])
 
 
 def _act(z):
@@ -1471,7 +1511,7 @@ def test_full_size_properties_c4_eight_poses():
     assert Hh.rel_err(same[0].detach().cpu().numpy(), out1[0].detach().cpu().numpy(), 1e-3)[0] <= 1e-5
 
 
-def _parity_row(name, sc, m, g, r, extra=None):
+def _parity_row(name, sc, m, g, r, extra=None, masked=None):
     """HS_PARITY_JSON=<file>: append this full-size frame's row (profiles/r04_parity_table.json: differing pixels, share
     of rows on the strict bar, per-tensor error of the HIP gradients against the C oracle's on those rows)."""
     path = os.environ.get("HS_PARITY_JSON")
@@ -1490,9 +1530,42 @@ def _parity_row(name, sc, m, g, r, extra=None):
                               "frac_gt_1e-4": float((e > 1e-4).mean()),
                               "l2": float(np.linalg.norm(got[rows] - ref[rows]) / max(np.linalg.norm(ref), 1e-30))}
     row.update(extra or {})
+    if masked is not None:
+        # the masked pass: dL zeroed on the excluded pixels on both sides -- EVERY row on the bar, every element inside the bound
+        g2, r2, bounded = masked
+        mrow = {"excluded_pixels": int(m["excluded"].sum()), "strict_share": 1.0, "c_bound": Hh.C_BOUND,
+                "n_outside_bound": int(sum(v[0] for v in bounded.values())),
+                "c_needed": {k: v[1] for k, v in bounded.items()}, "tensors": {}}
+        for gk, rk in Hh.GRAD_KEYS:
+            ref = np.asarray(r2[rk], np.float64)
+            got = np.asarray(g2["d_" + gk], np.float64).reshape(ref.shape)
+            e = np.abs(got - ref) / np.maximum(np.abs(ref), Hh.grad_floor(ref))
+            mrow["tensors"][gk] = {"max": float(e.max()), "p999": float(np.percentile(e, 99.9)),
+                                   "frac_gt_1e-4": float((e > 1e-4).mean()),
+                                   "l2": float(np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-30))}
+        row["masked_pass"] = mrow
     old = json.load(open(path)) if os.path.exists(path) else {"cases": []}
     old["cases"] = [c for c in old["cases"] if c["case"] != name] + [row]
     json.dump(old, open(path, "w"), indent=1)
+
+
+def _masked_pass(oracle, sc, m, fwds, what, cameras=None, workers=1, frac_tol=1e-3, max_tol=1e-2, l2_tol=2e-6):
+    """the second backward with dL zeroed on the pixels where a decision differed and on the CRF-knot
+    pixels, on BOTH sides.  No row is excused: every Gaussian on the (full-size) bar, every element inside
+    1e-4 |ref| + C_BOUND 2^-24 sqrt(n) sum|terms| (zero outside), CRF-table / exposure gradients against the oracle's
+    own within 1e-4 of max(|ref|, tensor RMS) and inside the stated fixed-point + interval-weight bound."""
+    g2, r2, dLm = Hh.masked_backward_pass(oracle, sc, m, fwds, cameras=cameras, workers=workers, what=what)
+    rep = Hh.assert_grads_close(g2, r2, what=what + " masked", frac_tol=frac_tol, max_tol=max_tol, l2_tol=l2_tol)
+    bounded = Hh.assert_grads_bounded(g2, r2, what=what + " masked")
+    tab = np.asarray(r2["dL_dcrf_table"], np.float64)
+    err = np.abs(np.asarray(g2["d_crf_table"], np.float64) - tab)
+    rms = float(np.sqrt((tab ** 2).mean()))
+    assert float((err / np.maximum(np.abs(tab), rms)).max()) <= 1e-4, (what, "d_crf_table", float((err / np.maximum(np.abs(tab), rms)).max()))
+    imgs = [f["color"] for f in fwds]
+    bound = 1e-4 * np.abs(tab) + Hh.crf_grad_bound(sc, imgs, dLm)
+    assert not (err > bound).any(), (what, "d_crf_table entries outside the stated bound", int((err > bound).sum()), float((err / bound).max()))
+    assert float(g2["d_exposure"]) == pytest.approx(r2["dL_dexposure"], rel=1e-4, abs=1e-4 * float(np.abs(dLm).sum()) * 1e-3)
+    return g2, r2, bounded, rep
 
 
 def test_c3_full_size_vs_oracle(oracle):
@@ -1529,8 +1602,10 @@ def test_c3_full_size_vs_oracle(oracle):
     assert Hh.rel_err(g["d_crf_table"], tab, 1e3 * Hh.grad_floor(tab))[0] <= 2e-4
     assert float(g["d_exposure"]) == pytest.approx(dexp, rel=2e-4, abs=1e-3)
     assert Hh.rel_err(g["d_crf_table"], r["dL_dcrf_table"], 1e3 * Hh.grad_floor(tab))[0] <= 2e-2
+    # ... and the pass that excuses nothing: dL zeroed on the 12 + ~200 excluded pixels, both sides
+    g2, r2, bounded, rep2 = _masked_pass(oracle, sc, m, [f], "c3")
     _parity_row("c3 (1M Gaussians, 1920x1080, SH3, HDR + CRF, seed 0): HIP vs fp32 C oracle, rows off the differing pixels",
-                sc, m, g, r, {"R": int(R), "report": {k: v for k, v in rep.items()}})
+                sc, m, g, r, {"R": int(R), "report": {k: v for k, v in rep.items()}}, masked=(g2, r2, bounded))
 
 
 def test_c4_eight_poses_full_size_vs_oracle(oracle):
@@ -1577,8 +1652,9 @@ def test_c4_eight_poses_full_size_vs_oracle(oracle):
     assert Hh.rel_err(g["d_crf_table"], tab, 1e3 * Hh.grad_floor(tab))[0] <= 2e-4
     assert float(g["d_exposure"]) == pytest.approx(dexp, rel=2e-4, abs=1e-3)
     assert Hh.rel_err(g["d_crf_table"], r["dL_dcrf_table"], 1e3 * Hh.grad_floor(tab))[0] <= 2e-2
+    g2, r2, bounded, rep2 = _masked_pass(oracle, sc, m, r["fwd"], "c4", cameras=cams, workers=workers, max_tol=2e-2)
     _parity_row("c4 (c3's cloud, 8 poses per frame): HIP vs fp32 C oracle, rows off the differing pixels",
-                sc, m, g, r, {"R": int(R), "report": {k: v for k, v in rep.items()}})
+                sc, m, g, r, {"R": int(R), "report": {k: v for k, v in rep.items()}}, masked=(g2, r2, bounded))
 
 
 def test_debug_flag_gives_identical_results():
