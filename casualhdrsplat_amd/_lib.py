@@ -48,7 +48,7 @@ class hs_fwd_args(C.Structure):
         ("means3D", _fp), ("opacities", _fp), ("shs", _fp), ("colors_precomp", _fp), ("scales", _fp),
         ("rotations", _fp), ("cov3D_precomp", _fp), ("exposure", _fp), ("crf_table", _fp),
         ("geom", _fp), ("binning", _fp), ("image", _fp),
-        ("out_color", _fp), ("out_hdr", _fp), ("radii", _fp), ("out_invdepth", _fp),
+        ("out_color", _fp), ("out_hdr", _fp), ("radii", _fp), ("out_invdepth", _fp), ("counters_host", _fp),
     ]
 
 

@@ -253,6 +253,8 @@ int hs_forward(const hs_fwd_args* a, void* hip_stream) {
         } else {
             const int64_t gx = (a->dims.W + kTile - 1) / kTile, gy = (a->dims.H + kTile - 1) / kTile;
             HS_HIP_CHECK(hipMemsetAsync((char*)a->binning + L.ranges, 0, (size_t)(gx * gy * a->dims.n_poses * 8), s));
+            if (a->counters_host)
+                HS_HIP_CHECK(hipMemcpyAsync(a->counters_host, (char*)a->geom + L.counters, sizeof(hs_counters), hipMemcpyDeviceToHost, s));
         }
     }
     if ((a->stages & HS_STAGE_OFFSETS) && a->dims.P > 0) {
@@ -315,15 +317,19 @@ int hs_backward(const hs_bwd_args* a, void* hip_stream) {
     // launch when this call goes on to it: one launch less on the critical path
     CrfReduce crf_reduce{nullptr, 0, 0, 0, nullptr, nullptr, 0};
     const bool sums_follow = (a->stages & (HS_BWD_PREPROCESS | HS_BWD_SEGSUM)) != 0 && !(a->flags & HS_FLAG_DEBUG);
+    // ... and when the whole per-Gaussian half follows in this call too (not a chunk of it), the FIRST stage shares the
+    // segmented sum's launch -- the two jobs run side by side -- and the second rides on the per-Gaussian kernel's
+    const bool whole_follows = sums_follow && ((a->stages & HS_BWD_PREPROCESS) || ((a->stages & HS_BWD_SEGSUM) && (a->stages & HS_BWD_PROJECT))) &&
+                               a->g_begin == 0 && a->g_end == 0 && HS_TUNE_CRF_WITH_SEGSUM;
     if (a->stages & HS_BWD_CRF) {
-        rc = launch_crf_bwd(*a, L, s, sums_follow ? &crf_reduce : nullptr);
+        rc = launch_crf_bwd(*a, L, s, sums_follow ? &crf_reduce : nullptr, whole_follows);
         if (rc) return rc;
         if ((rc = debug_sync(a->flags, s, "CRF gradient"))) return rc;
     }
     if (a->stages & (HS_BWD_PREPROCESS | HS_BWD_SEGSUM | HS_BWD_PROJECT)) {
         const bool whole = (a->stages & HS_BWD_PREPROCESS) != 0;
         rc = launch_preprocess_bwd(*a, L, s, whole || (a->stages & HS_BWD_SEGSUM), whole || (a->stages & HS_BWD_PROJECT),
-                                   crf_reduce.nblocks ? &crf_reduce : nullptr);
+                                   crf_reduce.nblocks ? &crf_reduce : nullptr, whole_follows && crf_reduce.nblocks != 0);
         if (rc) return rc;
         if ((rc = debug_sync(a->flags, s, "preprocess backward"))) return rc;
     }

@@ -913,7 +913,13 @@ __global__ void __launch_bounds__(256) emit_pairs_kernel(int64_t I, int P, int g
 // ---------------------------------------------------------------- tile ranges (a8)
 // Four consecutive sorted tile ids per thread (one 16-byte load; the id before the first comes from the neighbouring
 // lane): ranges[t] = [first, last + 1) of tile t's run; tiles without pairs keep the (0, 0) they were cleared to.
-__global__ void __launch_bounds__(256) tile_ranges_kernel(const uint32_t* tiles, const uint32_t* n_dev, uint2* ranges) {
+// (the stage's last kernel: its first thread also leaves a copy of the frame's counters at `counters_host`, hs_fwd_args --
+// every earlier kernel of the stage has finished, so num_rendered, the overflow verdict and the help count are final)
+__global__ void __launch_bounds__(256) tile_ranges_kernel(const uint32_t* tiles, const uint32_t* n_dev, uint2* ranges,
+                                                          const hs_counters* counters, uint32_t* counters_host) {
+    if (counters_host && blockIdx.x == 0 && threadIdx.x < 8)
+        __hip_atomic_store(counters_host + threadIdx.x, reinterpret_cast<const uint32_t*>(counters)[threadIdx.x],
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const int64_t n = *n_dev;
     const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
     const int lane = threadIdx.x & 63;
@@ -1084,8 +1090,11 @@ int launch_binning(const hs_fwd_args& a, const hs_layout& L, hipStream_t s, uint
                                                          /*zeroed=*/true, /*ghist_ready=*/true);
     if (rc != HS_OK) return rc;
     if (d.capacity > 0) {
-        tile_ranges_kernel<<<ceil_div(d.capacity, 1024), 256, 0, s>>>(keys_sorted, n_sort, ranges);
+        tile_ranges_kernel<<<ceil_div(d.capacity, 1024), 256, 0, s>>>(keys_sorted, n_sort, ranges, counters,
+                                                                      (uint32_t*)a.counters_host);
         HS_LAUNCH_CHECK();
+    } else if (a.counters_host) {
+        HS_HIP_CHECK(hipMemcpyAsync(a.counters_host, counters, sizeof(hs_counters), hipMemcpyDeviceToHost, s));
     }
     return HS_OK;
 }

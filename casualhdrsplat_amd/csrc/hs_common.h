@@ -19,6 +19,11 @@ void set_error(const char* fmt, ...);
     } while (0)
 #define HS_LAUNCH_CHECK() HS_HIP_CHECK(hipGetLastError())
 
+// A/B switch: the CRF gradient's first stage in the segmented sum's launch (render.hip, crf_segsum_kernel)
+#ifndef HS_TUNE_CRF_WITH_SEGSUM
+#define HS_TUNE_CRF_WITH_SEGSUM 1
+#endif
+
 constexpr int kTile = HS_TILE;
 // Gathered / scattered records occupy one aligned 64-byte memory sector each (kRecF4 float4): a 48-byte record at a
 // 48-byte stride straddles two sectors half of the time, which showed up as 2-3x the algorithmic HBM traffic.
@@ -70,10 +75,16 @@ int launch_render_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s, u
                       unsigned long long* timeline = nullptr);
 int render_stats_count();
 struct CrfReduce;
-// `defer`: non-null = do not launch the second stage; describe it there for the segmented sum's launch to run
-int launch_crf_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s, CrfReduce* defer);
+struct SegsumArgs;
+// `defer`: non-null = do not launch the second stage; describe it there for a later launch of the call to run.
+// `with_segsum`: non-null = do not launch the first stage either: it shares ONE launch with the segmented sum
+// (launch_preprocess_bwd passes the segmented sum's arguments to launch_crf_segsum)
+int launch_crf_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s, CrfReduce* defer, bool with_segsum = false);
+int launch_crf_segsum(const hs_bwd_args& a, const hs_layout& L, const SegsumArgs& sg, hipStream_t s);
+// `crf_reduce`: second stage of the CRF gradient to ride along; `crf_with_segsum`: its FIRST stage shares the segmented sum's
+// launch (then the second stage rides on the per-Gaussian kernel's)
 int launch_preprocess_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s, bool segsum, bool project,
-                          const CrfReduce* crf_reduce);
+                          const CrfReduce* crf_reduce, bool crf_with_segsum = false);
 int launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* vis, hipStream_t s);
 int launch_sh_backward_views(int P, int M, int deg, int V, const float* means3D, const float* camposes,
                              const float* view_colors, float* d_shs, hipStream_t s);
@@ -168,9 +179,10 @@ struct CrfReduce {
     const float* partials; int bx, planes, K; float* d_table; float* d_exposure;
     int nblocks;   // 256-thread workgroups the job takes: ceil((3K + 1) / 4); 0 = nothing to do
 };
-__device__ __forceinline__ void crf_reduce_block(const CrfReduce& c, int block) {
+// (`sub`: a two-wave workgroup -- preprocess_bwd_kernel's -- takes a group of four output elements in two calls, sub 0 and 2)
+__device__ __forceinline__ void crf_reduce_block(const CrfReduce& c, int block, int sub = 0) {
     const int K = c.K;
-    const int i = block * 4 + (threadIdx.x >> 6);  // 0 .. 3K: table entry ch * K + k, or 3K = exposure
+    const int i = block * 4 + sub + (threadIdx.x >> 6);  // 0 .. 3K: table entry ch * K + k, or 3K = exposure
     const int lane = threadIdx.x & 63;
     if (i > 3 * K) return;
     const bool expo = i == 3 * K;
@@ -219,6 +231,85 @@ __device__ __forceinline__ void depth_bits_accumulate(uint32_t key, bool visible
                                                       uint32_t* s_two /*LDS[2], zeroed*/) {
     depth_bits_accumulate2(visible ? key : 0u, visible ? ~key : 0u, bits, tag, s_two);
 }
+// d colour / d s of the radiance activation, from the stored colour (and the clamp bit for relu_shift)
+__device__ __forceinline__ float radiance_dact(int act, float col, bool was_clamped) {
+    if (act == 1) return col;
+    if (act == 2) return -expm1f(-col);  // sigmoid(s) = 1 - e^-softplus(s); expm1: exact also where col < 6e-8 (dark Gaussians)
+    return was_clamped ? 0.f : 1.f;
+}
+
+// Per-instance sum of the render-backward pair records (preprocess.hip, pair_segsum_kernel; also the second half of
+// render.hip's crf_segsum_kernel).  Thread `t` of the job: instance t >> 2 (in depth order), quad lane t & 3.
+struct SegsumArgs {
+    int64_t I;
+    const uint32_t* inst_sorted; const uint32_t* offs_sorted;
+    const float4* pair_grads; const uint8_t* pair_flags; float4* inst_grads; const hs_counters* counters;
+    const int* radii_inst; const uint8_t* clamped; float* view_colors; const float4* rec; int act;
+};
+__device__ __forceinline__ void pair_segsum_body(const SegsumArgs& a, int64_t t) {
+    // four lanes (one DPP quad) per instance: lane q adds records beg+q, beg+q+4, ...; the four partial sums are
+    // combined in a fixed butterfly, so the result does not depend on timing.  Quads shorten the longest run in a
+    // wave fourfold (run lengths are heavy-tailed) and make neighbouring lanes read neighbouring records.
+    const int64_t i = t >> 2;
+    const int q = (int)(t & 3);
+    // binning overflow (sync-free mode): nothing was emitted or rendered, and slots past the capacity do not exist
+    const bool valid = i < a.I && !a.counters->overflow;
+    const uint32_t beg = valid ? (i == 0 ? 0u : a.offs_sorted[i - 1]) : 0u;
+    const uint32_t end = valid ? a.offs_sorted[i] : 0u;
+    float r[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // two slots per trip: both flags first, then both records, so two record reads are in flight per lane; the
+    // sums keep the slot order (first slot added before the second)
+    for (uint32_t s = beg + q; s < end; s += 8) {
+        const bool two = s + 4 < end;
+        const bool f0 = a.pair_flags[s] != 0;  // unflagged: never written this backward (~55 % of pairs), not read
+        const bool f1 = two && a.pair_flags[s + 4] != 0;
+        float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, b0 = a0, b1 = a0;
+        float2 a2 = make_float2(0.f, 0.f), b2 = a2;
+        if (f0) {
+            a0 = a.pair_grads[kPairF4 * (int64_t)s + 0];
+            a1 = a.pair_grads[kPairF4 * (int64_t)s + 1];
+            a2 = reinterpret_cast<const float2*>(a.pair_grads + kPairF4 * (int64_t)s + 2)[0];
+        }
+        if (f1) {
+            b0 = a.pair_grads[kPairF4 * (int64_t)(s + 4) + 0];
+            b1 = a.pair_grads[kPairF4 * (int64_t)(s + 4) + 1];
+            b2 = reinterpret_cast<const float2*>(a.pair_grads + kPairF4 * (int64_t)(s + 4) + 2)[0];
+        }
+        r[0] += a0.x; r[1] += a0.y; r[2] += a0.z; r[3] += a0.w;
+        r[4] += a1.x; r[5] += a1.y; r[6] += a1.z; r[7] += a1.w;
+        r[8] += a2.x; r[9] += a2.y;
+        r[0] += b0.x; r[1] += b0.y; r[2] += b0.z; r[3] += b0.w;
+        r[4] += b1.x; r[5] += b1.y; r[6] += b1.z; r[7] += b1.w;
+        r[8] += b2.x; r[9] += b2.y;
+    }
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+        r[k] += __shfl_xor(r[k], 1);
+        r[k] += __shfl_xor(r[k], 2);
+    }
+    if (i < a.I && q == 0) {
+        // (a depth sort that gave up -- overflow = 2 -- left no instance list: zeros go to row i, any bijection will do)
+        const int64_t inst = a.counters->overflow >= 2u ? i : (int64_t)a.inst_sorted[i];
+        float4* o = a.inst_grads + kInstF4 * inst;
+        o[0] = make_float4(r[0], r[1], r[2], r[3]);
+        o[1] = make_float4(r[4], r[5], r[6], r[7]);
+        o[2] = make_float4(r[8], r[9], 0.f, 0.f);
+        if constexpr (kInstF4 == 4) o[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.view_colors) {  // colour gradient of the instance after the SH clamp mask (hs_sh_backward_views input)
+            const uint8_t cl = a.clamped[inst];
+            const bool on = a.radii_inst[inst] > 0;
+            float col[3] = {0.f, 0.f, 0.f};
+            if (a.act != 0 && on) {  // exp / softplus: the factor comes from the stored colour
+                const float4 rb = a.rec[kRecF4 * inst + 1];
+                col[0] = rb.z; col[1] = rb.w; col[2] = reinterpret_cast<const float*>(a.rec + kRecF4 * inst + 2)[0];
+            }
+            a.view_colors[3 * inst + 0] = on ? radiance_dact(a.act, col[0], cl & 1) * r[6] : 0.f;
+            a.view_colors[3 * inst + 1] = on ? radiance_dact(a.act, col[1], cl & 2) * r[7] : 0.f;
+            a.view_colors[3 * inst + 2] = on ? radiance_dact(a.act, col[2], cl & 4) * r[8] : 0.f;
+        }
+    }
+}
+
 __device__ __forceinline__ float xform_row(const float* m, int i, float x, float y, float z) {
     return ((m[i] * x + m[4 + i] * y) + m[8 + i] * z) + m[12 + i];
 }

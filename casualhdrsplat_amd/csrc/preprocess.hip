@@ -155,13 +155,6 @@ struct PreFwd {
     int act;  // radiance activation: 0 relu_shift, 1 exp, 2 softplus
 };
 
-// d colour / d s of the radiance activation, from the stored colour (and the clamp bit for relu_shift)
-__device__ __forceinline__ float radiance_dact(int act, float col, bool was_clamped) {
-    if (act == 1) return col;
-    if (act == 2) return -expm1f(-col);  // sigmoid(s) = 1 - e^-softplus(s); expm1: exact also where col < 6e-8 (dark Gaussians)
-    return was_clamped ? 0.f : 1.f;
-}
-
 #ifndef HS_TUNE_PF_EARLY
 #define HS_TUNE_PF_EARLY 1
 #endif
@@ -386,76 +379,11 @@ __global__ void mark_visible_kernel(int P, const float* means, const float* V, u
 // in which duplicateWithKeys laid the pair slots out, so neighbouring lanes read neighbouring slot runs (coalesced
 // through L1/L2) and each thread adds its own run front to back: a fixed order, hence bitwise reproducible sums.
 // Unflagged records were never written this backward (their tile's replay stopped before them): skipped by select.
-__global__ void __launch_bounds__(256) pair_segsum_kernel(int64_t I, const uint32_t* inst_sorted, const uint32_t* offs_sorted,
-                                                          const float4* pair_grads, const uint8_t* pair_flags,
-                                                          float4* inst_grads, const hs_counters* counters,
-                                                          const int* radii_inst, const uint8_t* clamped, float* view_colors,
-                                                          const float4* rec, int act, CrfReduce crf_reduce) {
+__global__ void __launch_bounds__(256) pair_segsum_kernel(SegsumArgs sg, CrfReduce crf_reduce) {
     // (the second stage of the CRF-table gradient rides on this launch's first workgroups when the same call computed the
-    // first: hs_common.h, CrfReduce)
+    // first in a launch of its own: hs_common.h, CrfReduce)
     for (int b = blockIdx.x; b < crf_reduce.nblocks; b += gridDim.x) crf_reduce_block(crf_reduce, b);
-    // four lanes (one DPP quad) per instance: lane q adds records beg+q, beg+q+4, ...; the four partial sums are
-    // combined in a fixed butterfly, so the result does not depend on timing.  Quads shorten the longest run in a
-    // wave fourfold (run lengths are heavy-tailed) and make neighbouring lanes read neighbouring records.
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t i = t >> 2;
-    const int q = (int)(t & 3);
-    // binning overflow (sync-free mode): nothing was emitted or rendered, and slots past the capacity do not exist
-    const bool valid = i < I && !counters->overflow;
-    const uint32_t beg = valid ? (i == 0 ? 0u : offs_sorted[i - 1]) : 0u;
-    const uint32_t end = valid ? offs_sorted[i] : 0u;
-    float r[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    // two slots per trip: both flags first, then both records, so two record reads are in flight per lane; the
-    // sums keep the slot order (first slot added before the second)
-    for (uint32_t s = beg + q; s < end; s += 8) {
-        const bool two = s + 4 < end;
-        const bool f0 = pair_flags[s] != 0;  // unflagged: never written this backward (~55 % of pairs), not read
-        const bool f1 = two && pair_flags[s + 4] != 0;
-        float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, b0 = a0, b1 = a0;
-        float2 a2 = make_float2(0.f, 0.f), b2 = a2;
-        if (f0) {
-            a0 = pair_grads[kPairF4 * (int64_t)s + 0];
-            a1 = pair_grads[kPairF4 * (int64_t)s + 1];
-            a2 = reinterpret_cast<const float2*>(pair_grads + kPairF4 * (int64_t)s + 2)[0];
-        }
-        if (f1) {
-            b0 = pair_grads[kPairF4 * (int64_t)(s + 4) + 0];
-            b1 = pair_grads[kPairF4 * (int64_t)(s + 4) + 1];
-            b2 = reinterpret_cast<const float2*>(pair_grads + kPairF4 * (int64_t)(s + 4) + 2)[0];
-        }
-        r[0] += a0.x; r[1] += a0.y; r[2] += a0.z; r[3] += a0.w;
-        r[4] += a1.x; r[5] += a1.y; r[6] += a1.z; r[7] += a1.w;
-        r[8] += a2.x; r[9] += a2.y;
-        r[0] += b0.x; r[1] += b0.y; r[2] += b0.z; r[3] += b0.w;
-        r[4] += b1.x; r[5] += b1.y; r[6] += b1.z; r[7] += b1.w;
-        r[8] += b2.x; r[9] += b2.y;
-    }
-#pragma unroll
-    for (int k = 0; k < 10; ++k) {
-        r[k] += __shfl_xor(r[k], 1);
-        r[k] += __shfl_xor(r[k], 2);
-    }
-    if (i < I && q == 0) {
-        // (a depth sort that gave up -- overflow = 2 -- left no instance list: zeros go to row i, any bijection will do)
-        const int64_t inst = counters->overflow >= 2u ? i : (int64_t)inst_sorted[i];
-        float4* o = inst_grads + kInstF4 * inst;
-        o[0] = make_float4(r[0], r[1], r[2], r[3]);
-        o[1] = make_float4(r[4], r[5], r[6], r[7]);
-        o[2] = make_float4(r[8], r[9], 0.f, 0.f);
-        if constexpr (kInstF4 == 4) o[3] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (view_colors) {  // colour gradient of the instance after the SH clamp mask (hs_sh_backward_views input)
-            const uint8_t cl = clamped[inst];
-            const bool on = radii_inst[inst] > 0;
-            float col[3] = {0.f, 0.f, 0.f};
-            if (act != 0 && on) {  // exp / softplus: the factor comes from the stored colour
-                const float4 rb = rec[kRecF4 * inst + 1];
-                col[0] = rb.z; col[1] = rb.w; col[2] = reinterpret_cast<const float*>(rec + kRecF4 * inst + 2)[0];
-            }
-            view_colors[3 * inst + 0] = on ? radiance_dact(act, col[0], cl & 1) * r[6] : 0.f;
-            view_colors[3 * inst + 1] = on ? radiance_dact(act, col[1], cl & 2) * r[7] : 0.f;
-            view_colors[3 * inst + 2] = on ? radiance_dact(act, col[2], cl & 4) * r[8] : 0.f;
-        }
-    }
+    pair_segsum_body(sg, (int64_t)blockIdx.x * 256 + threadIdx.x);
 }
 
 struct PreBwd {
@@ -473,6 +401,7 @@ struct PreBwd {
     float* dens_grad; float* dens_denom; int* dens_radii;  // densification statistics, updated in place, or null
     float* pose_partials;  // [blocks][N][kPoseVals] or null
     int blk0;              // first block of this launch (hs_bwd_args.g_begin / kPreBwdBlock: a chunk of the Gaussians)
+    CrfReduce crf_reduce;  // second stage of the CRF gradient riding on this launch's first workgroups (nblocks 0: none)
 };
 
 // Camera-pose gradient terms per pose: 12 view-matrix entries (flat 4j+i, i<3), 12 projection entries (rows 0,1,3),
@@ -562,6 +491,11 @@ template <int DEG, bool POSE, bool SHG>
 __global__ void __launch_bounds__(kPreBwdBlock) HS_PB_OCC preprocess_bwd_kernel(PreBwd p) {
     extern __shared__ float s_sh[];  // [kPreBwdBlock][M*3 + 1]
     __shared__ float s_pose[kPreBwdBlock / 64][kPoseVals];
+    // (the CRF gradient's second stage, when its first shared the segmented sum's launch: two waves here, so two calls)
+    for (int b = blockIdx.x; b < p.crf_reduce.nblocks; b += gridDim.x) {
+        crf_reduce_block(p.crf_reduce, b, 0);
+        crf_reduce_block(p.crf_reduce, b, 2);
+    }
     constexpr int NC = (DEG + 1) * (DEG + 1);
     const int blk = (int)blockIdx.x + p.blk0;
     const int g0 = blk * kPreBwdBlock;
@@ -1019,7 +953,7 @@ int launch_preprocess_fwd(const hs_fwd_args& a, const hs_layout& L, hipStream_t 
 }
 
 int launch_preprocess_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s, bool segsum, bool project,
-                          const CrfReduce* crf_reduce) {
+                          const CrfReduce* crf_reduce, bool crf_with_segsum) {
     const hs_dims& d = a.dims;
     const char* geom = (const char*)a.geom;
     PreBwd p;
@@ -1034,18 +968,24 @@ int launch_preprocess_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t 
     p.tiles = (const uint32_t*)(geom + L.tiles_touched); p.offsets = (const uint32_t*)(geom + L.offsets);
     p.cov_pre = a.cov3D_precomp; p.clamped = (const uint8_t*)(geom + L.clamped);
     p.inst_grads = (const float4*)((const char*)a.bwd + L.inst_grads);
+    const CrfReduce no_reduce{nullptr, 0, 0, 0, nullptr, nullptr, 0};
     if (segsum) {
         const int64_t I = (int64_t)d.P * d.n_poses;
         const char* bin = (const char*)a.binning;
-        pair_segsum_kernel<<<ceil_div(4 * I, 256), 256, 0, s>>>(I, (const uint32_t*)(bin + L.inst_sorted),
-                                                           (const uint32_t*)(bin + L.offs_sorted),
-                                                           (const float4*)((const char*)a.bwd + L.pair_grads),
-                                                           (const uint8_t*)bin + L.pair_flags,
-                                                           (float4*)((char*)a.bwd + L.inst_grads),
-                                                           (const hs_counters*)(geom + L.counters), p.radii_inst, p.clamped,
-                                                           a.colors_precomp ? nullptr : a.dL_dview_colors, p.rec, p.act,
-                                                           crf_reduce ? *crf_reduce : CrfReduce{nullptr, 0, 0, 0, nullptr, nullptr, 0});
-        HS_LAUNCH_CHECK();
+        SegsumArgs sg;
+        sg.I = I; sg.inst_sorted = (const uint32_t*)(bin + L.inst_sorted); sg.offs_sorted = (const uint32_t*)(bin + L.offs_sorted);
+        sg.pair_grads = (const float4*)((const char*)a.bwd + L.pair_grads); sg.pair_flags = (const uint8_t*)bin + L.pair_flags;
+        sg.inst_grads = (float4*)((char*)a.bwd + L.inst_grads); sg.counters = (const hs_counters*)(geom + L.counters);
+        sg.radii_inst = p.radii_inst; sg.clamped = p.clamped;
+        sg.view_colors = a.colors_precomp ? nullptr : a.dL_dview_colors; sg.rec = p.rec; sg.act = p.act;
+        if (crf_with_segsum) {
+            // ONE launch for the CRF gradient's first stage and the segmented sum (render.hip, crf_segsum_kernel)
+            const int rc = launch_crf_segsum(a, L, sg, s);
+            if (rc) return rc;
+        } else {
+            pair_segsum_kernel<<<ceil_div(4 * I, 256), 256, 0, s>>>(sg, crf_reduce ? *crf_reduce : no_reduce);
+            HS_LAUNCH_CHECK();
+        }
     }
     if (!project) return HS_OK;
     p.d_means3D = a.dL_dmeans3D; p.d_means2D = a.dL_dmeans2D; p.d_opac = a.dL_dopacities; p.d_shs = a.dL_dshs;
@@ -1064,6 +1004,7 @@ int launch_preprocess_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t 
     const size_t lds = (size_t)kPreBwdBlock * (d.M * 3 + 1) * sizeof(float);
     float* pose_partials = a.dL_dviewmatrices ? (float*)((char*)a.bwd + L.pose_partials) : nullptr;
     p.pose_partials = pose_partials;
+    p.crf_reduce = (crf_with_segsum && crf_reduce) ? *crf_reduce : no_reduce;
 #define HS_LAUNCH_PRE_BWD(DEG_)                                                                              \
     if (pose_partials && shg) preprocess_bwd_kernel<DEG_, true, true><<<grid, kPreBwdBlock, lds, s>>>(p);       \
     else if (pose_partials) preprocess_bwd_kernel<DEG_, true, false><<<grid, kPreBwdBlock, lds, s>>>(p);        \

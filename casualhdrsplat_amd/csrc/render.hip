@@ -1158,8 +1158,15 @@ render_bwd_kernel(RenderBwd p) {
 // fixed DPP tree over the wave, the four waves added in wave order.  crf_reduce_kernel adds the blocks in a fixed order.
 constexpr int kCrfPixPerBlock = 4096;
 
-__global__ void __launch_bounds__(256) crf_grad_kernel(int64_t HW, int N, int flags, const float* pose_hdr, Crf crf,
-                                                       const float* exposure, const float* dL_dcolor, float* partials) {
+struct CrfGradArgs {
+    int64_t HW; int N, flags; const float* pose_hdr; Crf crf; const float* exposure; const float* dL_dcolor; float* partials;
+    int bx, planes;   // the job's workgroups: bx pixel blocks x planes (pose, channel) image planes
+};
+
+// (`bxi`, `plane`: which pixel block of which plane this workgroup takes -- blockIdx of the stand-alone launch)
+__device__ __forceinline__ void crf_grad_body(const CrfGradArgs& A, const int bxi, const int plane_in) {
+    const int64_t HW = A.HW; const int N = A.N, flags = A.flags; const float* pose_hdr = A.pose_hdr; Crf crf = A.crf;
+    const float* exposure = A.exposure; const float* dL_dcolor = A.dL_dcolor; float* partials = A.partials;
     extern __shared__ unsigned long long s_tab64[];  // K - 1 intervals: two 32-bit fixed-point fields each
     int* const s_tab32 = reinterpret_cast<int*>(s_tab64);
     __shared__ float s_wave[4][4];
@@ -1170,14 +1177,14 @@ __global__ void __launch_bounds__(256) crf_grad_kernel(int64_t HW, int N, int fl
     const bool blur_hdr = (flags & HS_FLAG_BLUR_HDR) && N > 1;
     const float gs = blur_hdr ? 1.f : 1.f / (float)N;
     const float scale = (float)(K - 1) / (crf.umax - crf.umin);
-    const int plane = blockIdx.y;            // pose * 3 + ch
+    const int plane = plane_in;              // pose * 3 + ch
     const int pose = plane / 3, ch = plane - 3 * pose;
     const float* Hp = pose_hdr + ((int64_t)(blur_hdr ? N : pose) * 3 + ch) * HW;
     const float* gp = dL_dcolor + (int64_t)ch * HW;
     const float* t = crf.table + ch * K;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
-    const int64_t i16 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 16;
+    const int64_t i16 = ((int64_t)bxi * 256 + threadIdx.x) * 16;
     float Hv[16], g[16];
     if (i16 + 16 <= HW && (HW & 3) == 0) {
 #pragma unroll
@@ -1244,7 +1251,7 @@ __global__ void __launch_bounds__(256) crf_grad_kernel(int64_t HW, int N, int fl
     if (lane == 63) { s_wave[wave][0] = gexp; s_wave[wave][1] = g_lo; s_wave[wave][2] = g_hi; }
     __syncthreads();
     // partial row of this block: K knots of its channel + its exposure term
-    float* dst = partials + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (K + 1);
+    float* dst = partials + ((int64_t)plane_in * A.bx + bxi) * (K + 1);
     for (int k = threadIdx.x; k <= K; k += 256) {
         float v;
         if (k == K) {
@@ -1259,6 +1266,25 @@ __global__ void __launch_bounds__(256) crf_grad_kernel(int64_t HW, int N, int fl
         }
         dst[k] = v;
     }
+}
+
+__global__ void __launch_bounds__(256) crf_grad_kernel(CrfGradArgs A) { crf_grad_body(A, (int)blockIdx.x, (int)blockIdx.y); }
+
+// ONE launch for the CRF gradient's first stage and the per-instance sums of the pair records (round 5).  The two jobs are
+// independent and bound by different things -- 4096-pixel blocks adding fixed-point weights with LDS atomics; quads
+// walking 64-byte records whose sum rows leave in a scattered order -- so their workgroups are INTERLEAVED in one grid
+// (every `stride`-th workgroup is a CRF block until those run out) and run side by side instead of one after the
+// other: the 22 us of the CRF kernel disappear into the 77 of the segmented sum.  Same arithmetic as the two kernels:
+// the sums are pure additions (this TU's FMA contraction has nothing to contract), the CRF body is the one above.
+__global__ void __launch_bounds__(256) crf_segsum_kernel(CrfGradArgs A, SegsumArgs sg, int ncrf, int stride) {
+    const int b = (int)blockIdx.x;
+    const int qd = b / stride, r = b - qd * stride;
+    if (r == 0 && qd < ncrf) {
+        crf_grad_body(A, qd % A.bx, qd / A.bx);
+        return;
+    }
+    const int before = min(ncrf, qd + 1);                 // CRF workgroups at positions below b
+    pair_segsum_body(sg, (int64_t)(b - before) * 256 + threadIdx.x);
 }
 
 // The partial rows added up in a fixed order (hs_common.h, crf_reduce_block): stand-alone launch
@@ -1313,24 +1339,42 @@ int launch_render_fwd(const hs_fwd_args& a, const hs_layout& L, hipStream_t s, u
     return HS_OK;
 }
 
-int launch_crf_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s, CrfReduce* defer) {
+static bool crf_grad_args(const hs_bwd_args& a, const hs_layout& L, CrfGradArgs& A) {
     const hs_dims& d = a.dims;
-    if (!((a.flags & HS_FLAG_HDR) && (a.dL_dcrf_table || a.dL_dexposure))) return HS_OK;
-    Crf crf;
-    crf.table = a.crf_table; crf.K = a.crf_K; crf.umin = a.crf_umin; crf.umax = a.crf_umax; crf.dt = 1.f;
-    const int64_t HW = (int64_t)d.W * d.H;
-    float* partials = (float*)((char*)a.bwd + L.crf_partials);
-    const float* pose_hdr = (const float*)((const char*)a.image + L.pose_hdr);
+    if (!((a.flags & HS_FLAG_HDR) && (a.dL_dcrf_table || a.dL_dexposure))) return false;
+    A.crf.table = a.crf_table; A.crf.K = a.crf_K; A.crf.umin = a.crf_umin; A.crf.umax = a.crf_umax; A.crf.dt = 1.f;
+    A.HW = (int64_t)d.W * d.H; A.N = d.n_poses; A.flags = a.flags;
+    A.partials = (float*)((char*)a.bwd + L.crf_partials);
+    A.pose_hdr = (const float*)((const char*)a.image + L.pose_hdr);
+    A.exposure = a.exposure; A.dL_dcolor = a.dL_dout_color;
     const bool blur_hdr = (a.flags & HS_FLAG_BLUR_HDR) && d.n_poses > 1;
-    const int planes = 3 * (blur_hdr ? 1 : d.n_poses);
-    const int bx = ceil_div(HW, kCrfPixPerBlock);
-    crf_grad_kernel<<<dim3(bx, planes), 256, (size_t)(a.crf_K - 1) * sizeof(unsigned long long), s>>>(
-        HW, d.n_poses, a.flags, pose_hdr, crf, a.exposure, a.dL_dout_color, partials);
+    A.planes = 3 * (blur_hdr ? 1 : d.n_poses);
+    A.bx = ceil_div(A.HW, kCrfPixPerBlock);
+    return true;
+}
+
+int launch_crf_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s, CrfReduce* defer, bool with_segsum) {
+    CrfGradArgs A;
+    if (!crf_grad_args(a, L, A)) return HS_OK;
+    if (!with_segsum)
+        crf_grad_kernel<<<dim3(A.bx, A.planes), 256, (size_t)(a.crf_K - 1) * sizeof(unsigned long long), s>>>(A);
     CrfReduce cr;
-    cr.partials = partials; cr.bx = bx; cr.planes = planes; cr.K = a.crf_K; cr.d_table = a.dL_dcrf_table;
+    cr.partials = A.partials; cr.bx = A.bx; cr.planes = A.planes; cr.K = a.crf_K; cr.d_table = a.dL_dcrf_table;
     cr.d_exposure = a.dL_dexposure; cr.nblocks = ceil_div(3 * a.crf_K + 1, 4);
-    if (defer) *defer = cr;   // the segmented sum's launch adds the rows up (its first workgroups): one launch less
+    if (defer) *defer = cr;   // a later launch of the call adds the rows up (its first workgroups): one launch less
     else crf_reduce_kernel<<<cr.nblocks, 256, 0, s>>>(cr);
+    HS_LAUNCH_CHECK();
+    return HS_OK;
+}
+
+int launch_crf_segsum(const hs_bwd_args& a, const hs_layout& L, const SegsumArgs& sg, hipStream_t s) {
+    CrfGradArgs A;
+    if (!crf_grad_args(a, L, A)) { set_error("launch_crf_segsum: no CRF gradient to compute"); return HS_EINVAL; }
+    const int ncrf = A.bx * A.planes;
+    const int nseg = ceil_div(4 * sg.I, 256);
+    const int total = ncrf + nseg;
+    const int stride = max(1, total / max(ncrf, 1));
+    crf_segsum_kernel<<<total, 256, (size_t)(a.crf_K - 1) * sizeof(unsigned long long), s>>>(A, sg, ncrf, stride);
     HS_LAUNCH_CHECK();
     return HS_OK;
 }

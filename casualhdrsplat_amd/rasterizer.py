@@ -303,16 +303,19 @@ def _run_forward(settings: GaussianRasterizationSettings, means3D, opacities, sh
     binning = torch.empty(max(int(sizes.binning_bytes), 256), dtype=torch.uint8, device=dev)
     image = torch.empty(max(int(sizes.image_bytes), 256), dtype=torch.uint8, device=dev)
     a.binning, a.image = binning.data_ptr(), image.data_ptr()
+    # the frame's counters {num_rendered, overflow, helps} reach the host without a copy on the stream: the binning stage's
+    # last kernel writes them into this page-locked buffer (hs_fwd_args.counters_host); nobody waits for them until
+    # someone asks (the synchronous mode too: its sorts can report a stalled chain -- overflow = 2 -- like any other)
+    if not _PINNED_POOL and torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("GaussianRasterizer inside a graph capture needs one eager step first (graphs.GraphedStep "
+                           "does that): page-locked memory cannot be allocated while a stream is capturing")
+    host = _PINNED_POOL.pop() if _PINNED_POOL else torch.empty(8, dtype=torch.int32).pin_memory()
+    a.counters_host = host.data_ptr()
     L.check(lib.hs_forward(C.byref(a), stream), "hs_forward")
-    if True:   # (the synchronous mode too: its sorts can report a stalled chain -- overflow = 2 -- like any other)
-        if not _PINNED_POOL and torch.cuda.is_current_stream_capturing():
-            raise RuntimeError("GaussianRasterizer inside a graph capture needs one eager step first (graphs.GraphedStep "
-                               "does that): page-locked memory cannot be allocated while a stream is capturing")
-        host = _PINNED_POOL.pop() if _PINNED_POOL else torch.empty(8, dtype=torch.int32).pin_memory()
-        host.copy_(geom[:32].view(torch.int32), non_blocking=True)   # the whole hs_counters struct
-        ev = torch.cuda.Event()
-        ev.record()
-        st.pending = _Pending(host, ev, R if sync_mode else int(capacity), ticket_order)
+    a.counters_host = None   # (the saved argument struct may be replayed by profiling helpers: never into a recycled buffer)
+    ev = torch.cuda.Event()
+    ev.record()
+    st.pending = _Pending(host, ev, R if sync_mode else int(capacity), ticket_order)
 
     st.dims, st.layout, st.geom, st.binning, st.image = dims, layout, geom, binning, image
     st.num_rendered, st.flags, st.views, st.projs, st.camposes, st.bg = R, flags, views, projs, campos, bg

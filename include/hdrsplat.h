@@ -143,6 +143,10 @@ typedef struct hs_fwd_args {
     int32_t* radii;              /* [P] max over poses */
     float* out_invdepth;         /* [N,H,W] or NULL: expected inverse depth sum_i alpha_i T_i / z_i per pose
                                     (the caller averages the poses) */
+    void* counters_host;         /* (HS_VERSION 304) NULL, or a host address the GPU can write (page-locked, mapped: what
+                                    hipHostMalloc / torch pin_memory return): HS_STAGE_BIN leaves a copy of hs_counters
+                                    (32 bytes) there -- written by its last kernel, so a sync-free caller that wants to
+                                    look at num_rendered / overflow LATER needs no copy of its own on the stream */
 } hs_fwd_args;
 
 typedef struct hs_bwd_args {
