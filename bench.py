@@ -515,6 +515,11 @@ def choose_exchange(step, state, barrier, dev, rank, world, backend, cfg):
         return (time.perf_counter() - t0) / n * 1e3
 
     info = {"backend": backend,
+            # collectives one step puts on the wire per rank: the flat buffer is ONE all-reduce; its chunked
+            # overlap one coalesced all-reduce per chunk (4; distributed.LAST_EXCHANGE counts what was actually issued, below);
+            # the view forms one all-reduce of the non-SH gradients + two all-gathers (colour gradients, camera centres)
+            "collectives_per_step": {"allreduce/rccl": 1, "allreduce_overlap/rccl": 4, "views/rccl": 3, "views_overlap/rccl": 3,
+                                     "allreduce/direct": 3, "views/direct": 5, "views_overlap/direct": 5},
             "bytes": {f"{m}/{a}": exchange_bytes("views" if m.startswith("views") else "allreduce", world, cfg)
                       for m, a in EXCHANGES if a == "rccl"},
             "model_ms": {m: exchange_model(m, world, cfg) for m, a in EXCHANGES if a == "rccl"}}
@@ -575,6 +580,9 @@ def choose_exchange(step, state, barrier, dev, rank, world, backend, cfg):
             dropped[name] = err or "failed on another rank"
             continue
         times[name] = avg_ms
+        if mode == "allreduce_overlap":
+            from casualhdrsplat_amd import distributed as D_
+            info["collectives_per_step"][name] = int(D_.LAST_EXCHANGE["collectives"])   # counted, not assumed
     best = min(times, key=times.get) if times else "allreduce/rccl"
     state["exchange"] = tuple(best.split("/"))
     if rank == 0 and dropped:

@@ -155,11 +155,19 @@ struct PreFwd {
     int act;  // radiance activation: 0 relu_shift, 1 exp, 2 softplus
 };
 
+#ifndef HS_TUNE_PF_REC_LDS
+#define HS_TUNE_PF_REC_LDS 1
+#endif
 #ifndef HS_TUNE_PF_EARLY
 #define HS_TUNE_PF_EARLY 1
 #endif
 // a4.  instance = pose * P + g.
-#ifdef HS_TUNE_PF_WAVES
+// Occupancy the register allocator may be held to (0: none): with its SH row in flight the degree-3 instantiation takes 98
+// registers, which the allocation granule of 8 turns into FOUR waves per SIMD; asked for five it fits into 96 unspilled.
+#ifndef HS_TUNE_PF_WAVES
+#define HS_TUNE_PF_WAVES 5
+#endif
+#if HS_TUNE_PF_WAVES > 0
 #define HS_PF_OCC __attribute__((amdgpu_waves_per_eu(HS_TUNE_PF_WAVES, HS_TUNE_PF_WAVES)))
 #else
 #define HS_PF_OCC
@@ -181,6 +189,12 @@ __global__ void __launch_bounds__(256) HS_PF_OCC preprocess_fwd_kernel(PreFwd p)
     const int pose = seq % p.N;
     const int64_t g64 = ((int64_t)(seq / p.N) * 8 + xcd) * 256 + threadIdx.x;
     uint32_t ntiles = 0;
+#if HS_TUNE_PF_REC_LDS
+    // The 64-byte render records leave through a wave-private LDS stage, so a store instruction of the wave covers 1 KB of
+    // consecutive addresses instead of 16 bytes in each of 64 sectors (round 5: preprocess_fwd + binning -7 us at c3)
+    __shared__ float4 s_rec[4][64 * 4];
+    float4 rec_a = make_float4(0.f, 0.f, 0.f, 0.f), rec_b = rec_a, rec_c = rec_a;
+#endif
     if (g64 < (int64_t)p.P) {
     const int g = (int)g64;
     const int64_t idx = (int64_t)pose * p.P + g;
@@ -219,8 +233,10 @@ __global__ void __launch_bounds__(256) HS_PF_OCC preprocess_fwd_kernel(PreFwd p)
 #pragma unroll
     for (int k = 0; k < 3 * NCF; ++k) shr[k] = 0.f;
     bool have_sh = false;
+    bool vis = false;
 #if HS_TUNE_PF_EARLY
-    if (!p.colors && pvz > 0.2f && fabsf(ppx) < 1.5f && fabsf(ppy) < 1.5f) {
+    const bool early = !p.colors && pvz > 0.2f && fabsf(ppx) < 1.5f && fabsf(ppy) < 1.5f;
+    if (early) {
         const float* sh = p.shs + (int64_t)g * p.M * 3;
 #pragma unroll
         for (int k = 0; k < 3 * NCF; ++k) shr[k] = sh[k];
@@ -261,41 +277,7 @@ __global__ void __launch_bounds__(256) HS_PF_OCC preprocess_fwd_kernel(PreFwd p)
             const int rmaxy = min(gy, max(0, (int)((pix_y + (float)rad + (float)(kTile - 1)) / (float)kTile)));
             const int area = (rmaxx - rminx) * (rmaxy - rminy);
             if (area != 0) {
-                float col[3];
-                if (p.colors) {
-                    col[0] = p.colors[3 * g]; col[1] = p.colors[3 * g + 1]; col[2] = p.colors[3 * g + 2];
-                } else {
-                    const float* cp = p.campos + 3 * pose;
-                    const float dx = x - cp[0], dy = y - cp[1], dz = z - cp[2];
-                    const float len = sqrtf((dx * dx + dy * dy) + dz * dz);
-                    const float ux = dx / len, uy = dy / len, uz = dz / len;
-                    float b[(DEG + 1) * (DEG + 1)];
-                    sh_basis<DEG>(ux, uy, uz, b);
-                    if (!have_sh) {
-                        const float* sh = p.shs + (int64_t)g * p.M * 3;
-#pragma unroll
-                        for (int k = 0; k < 3 * NCF; ++k) shr[k] = sh[k];
-                    }
-                    float acc[3] = {b[0] * shr[0], b[0] * shr[1], b[0] * shr[2]};
-#pragma unroll
-                    for (int k = 1; k < (DEG + 1) * (DEG + 1); ++k) {
-                        acc[0] = acc[0] + b[k] * shr[3 * k + 0];
-                        acc[1] = acc[1] + b[k] * shr[3 * k + 1];
-                        acc[2] = acc[2] + b[k] * shr[3 * k + 2];
-                    }
-#pragma unroll
-                    for (int ch = 0; ch < 3; ++ch) {
-                        if (p.act == 1) {
-                            col[ch] = expf(acc[ch]);
-                        } else if (p.act == 2) {
-                            col[ch] = acc[ch] > 20.f ? acc[ch] : log1pf(expf(acc[ch]));
-                        } else {
-                            float v = acc[ch] + 0.5f;
-                            if (v < 0.f) clampbits |= (uint8_t)(1u << ch);
-                            col[ch] = fmaxf(v, 0.f);
-                        }
-                    }
-                }
+                vis = true;
                 my_radius = rad;
                 ntiles = (uint32_t)area;
                 bi = make_uint2((uint32_t)rminx | ((uint32_t)rminy << 16),
@@ -307,15 +289,61 @@ __global__ void __launch_bounds__(256) HS_PF_OCC preprocess_fwd_kernel(PreFwd p)
                     const float det0 = (ca - 0.3f) * (cc - 0.3f) - cb * cb;
                     opac = opac * sqrtf(fmaxf(0.000025f, det0 / det));
                 }
-                rb = make_float4(conC, opac, col[0], col[1]);
-                rc = make_float4(col[2], pvz, __int_as_float(rad), 0.f);
+                rb = make_float4(conC, opac, 0.f, 0.f);
+                rc = make_float4(0.f, pvz, __int_as_float(rad), 0.f);
             }
         }
     }
+    // (round 5, measured and removed: the wave loading the SH rows of its 64 Gaussians TOGETHER -- 48-byte pieces of ~21
+    // rows per load instruction instead of 16 bytes of 64 rows -- and handing them to their owners through this LDS stage
+    // chunk by chunk: preprocess_fwd + binning +6 us at c3, +80 us at c4.  The per-thread row loads are not what holds
+    // the kernel back once they are issued early; the 64-byte record STORES were, see s_rec)
+    if (vis) {   // colour of the survivors
+        float col[3];
+        if (p.colors) {
+            col[0] = p.colors[3 * g]; col[1] = p.colors[3 * g + 1]; col[2] = p.colors[3 * g + 2];
+        } else {
+            const float* cp = p.campos + 3 * pose;
+            const float dx = x - cp[0], dy = y - cp[1], dz = z - cp[2];
+            const float len = sqrtf((dx * dx + dy * dy) + dz * dz);
+            const float ux = dx / len, uy = dy / len, uz = dz / len;
+            float b[(DEG + 1) * (DEG + 1)];
+            sh_basis<DEG>(ux, uy, uz, b);
+            if (!have_sh) {
+                const float* sh = p.shs + (int64_t)g * p.M * 3;
+#pragma unroll
+                for (int k = 0; k < 3 * NCF; ++k) shr[k] = sh[k];
+            }
+            float acc[3] = {b[0] * shr[0], b[0] * shr[1], b[0] * shr[2]};
+#pragma unroll
+            for (int k = 1; k < (DEG + 1) * (DEG + 1); ++k) {
+                acc[0] = acc[0] + b[k] * shr[3 * k + 0];
+                acc[1] = acc[1] + b[k] * shr[3 * k + 1];
+                acc[2] = acc[2] + b[k] * shr[3 * k + 2];
+            }
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                if (p.act == 1) {
+                    col[ch] = expf(acc[ch]);
+                } else if (p.act == 2) {
+                    col[ch] = acc[ch] > 20.f ? acc[ch] : log1pf(expf(acc[ch]));
+                } else {
+                    float v = acc[ch] + 0.5f;
+                    if (v < 0.f) clampbits |= (uint8_t)(1u << ch);
+                    col[ch] = fmaxf(v, 0.f);
+                }
+            }
+        }
+        rb.z = col[0]; rb.w = col[1]; rc.x = col[2];
+    }
+#if HS_TUNE_PF_REC_LDS
+    rec_a = ra; rec_b = rb; rec_c = rc;
+#else
     p.rec[kRecF4 * idx + 0] = ra;
     p.rec[kRecF4 * idx + 1] = rb;
     p.rec[kRecF4 * idx + 2] = rc;
     p.rec[kRecF4 * idx + 3] = make_float4(0.f, 0.f, 0.f, 0.f);  // whole sector written: no partial-line write-back
+#endif
     p.depth[idx] = depth;
     p.radii_inst[idx] = my_radius;
     p.tiles[idx] = ntiles;
@@ -328,6 +356,28 @@ __global__ void __launch_bounds__(256) HS_PF_OCC preprocess_fwd_kernel(PreFwd p)
         p.depth_pairs[idx] = make_uint2(depth_key, (uint32_t)idx);
     }
     }  // g < P
+#if HS_TUNE_PF_REC_LDS
+    {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        float4* w = s_rec[wave];
+        const int sw = (lane >> 2) & 3;       // swizzle: the 16 lanes of a quarter-wave land on 16 different bank groups
+        w[lane * 4 + (0 ^ sw)] = rec_a;
+        w[lane * 4 + (1 ^ sw)] = rec_b;
+        w[lane * 4 + (2 ^ sw)] = rec_c;
+        w[lane * 4 + (3 ^ sw)] = make_float4(0.f, 0.f, 0.f, 0.f);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // the wave's 64 instances are consecutive (same pose, consecutive Gaussians): one 4 KB stretch of records
+        const int64_t g_w0 = g64 - lane;
+        const int nvalid = (int)min((int64_t)64, (int64_t)p.P - g_w0);
+        float4* dst = p.rec + kRecF4 * ((int64_t)pose * p.P + g_w0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int f = j * 64 + lane, r = f >> 2, k = f & 3;
+            if (r < nvalid) dst[f] = w[r * 4 + (k ^ ((r >> 2) & 3))];
+        }
+    }
+#endif
     if (p.depth_pairs) {
         // which bits of the visible depth keys vary (the depth sort sorts only those: binning.hip)
         depth_bits_accumulate(depth_key, depth_key != 0xFFFFFFFFu,
@@ -532,6 +582,10 @@ __global__ void __launch_bounds__(kPreBwdBlock) HS_PB_OCC preprocess_bwd_kernel(
     float4 pre_q0 = make_float4(0.f, 0.f, 0.f, 0.f), pre_q1 = pre_q0;
     float2 pre_q2 = make_float2(0.f, 0.f);
     uint8_t pre_cl = 0;
+    // (round 5, measured and removed: the wave loading its 64 sum rows together -- four instructions of 1 KB instead of three
+    // touching 64 sectors each -- and handing them out through a wave-private LDS stage, the mirror image of preprocess_fwd's
+    // record stores: stage +16 us.  The exchange waits for the rows at the kernel's head, where the per-thread loads just sit in
+    // flight beside the SH staging)
     if (rad0 > 0) {
         pre_q0 = p.inst_grads[kInstF4 * (int64_t)g + 0]; pre_q1 = p.inst_grads[kInstF4 * (int64_t)g + 1];
         pre_q2 = reinterpret_cast<const float2*>(p.inst_grads + kInstF4 * (int64_t)g + 2)[0];
@@ -540,8 +594,8 @@ __global__ void __launch_bounds__(kPreBwdBlock) HS_PB_OCC preprocess_bwd_kernel(
     if (stage_in) {
         if (fast_stage) { if constexpr (Q > 0) stage_rows_commit<Q>(s_sh, staged, ld); }
         else stage_rows_in(s_sh, p.shs + (int64_t)g0 * M3, rows, M3, ld);
-        __syncthreads();
     }
+    if (stage_in) __syncthreads();
     float gm[3] = {0.f, 0.f, 0.f};
     float gcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float gm2d[2] = {0.f, 0.f};

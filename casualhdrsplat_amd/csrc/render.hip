@@ -1274,7 +1274,8 @@ __global__ void __launch_bounds__(256) crf_grad_kernel(CrfGradArgs A) { crf_grad
 // independent and bound by different things -- 4096-pixel blocks adding fixed-point weights with LDS atomics; quads
 // walking 64-byte records whose sum rows leave in a scattered order -- so their workgroups are INTERLEAVED in one grid
 // (every `stride`-th workgroup is a CRF block until those run out) and run side by side instead of one after the
-// other: the 22 us of the CRF kernel disappear into the 77 of the segmented sum.  Same arithmetic as the two kernels:
+// other: about half of the CRF kernel's 22 us disappears into the 77 of the segmented sum (step -10 us; all CRF workgroups
+// first: -9, all last: -2, a launch of their own: 0).  Same arithmetic as the two kernels:
 // the sums are pure additions (this TU's FMA contraction has nothing to contract), the CRF body is the one above.
 __global__ void __launch_bounds__(256) crf_segsum_kernel(CrfGradArgs A, SegsumArgs sg, int ncrf, int stride) {
     const int b = (int)blockIdx.x;

@@ -1128,6 +1128,10 @@ def test_bench_bare_multi_gpu_invocation_launches_its_own_ranks():
     # the analytic cost of every library strategy rides along, so the measured probe can be read against it
     assert set(ex["model_ms"]) >= {"allreduce", "allreduce_overlap", "views", "views_overlap"}
     assert ex["model_ms"]["allreduce"]["all_reduce_ring_ms"] > ex["model_ms"]["views"]["all_reduce_ring_ms"] > 0
+    # one coalesced collective per chunk of the overlapped all-reduce (counted by the run, not assumed): <= chunks + 2
+    cps = ex["collectives_per_step"]
+    assert cps["allreduce/rccl"] == 1 and cps["views/rccl"] == 3
+    assert "allreduce_overlap/rccl" not in ex["step_ms"] or 1 <= cps["allreduce_overlap/rccl"] <= 4 + 2, cps
     # every strategy that was kept stayed under the probe's cap; the dropped ones say why
     assert all(t <= ex["first_step_cap_ms"] for t in ex["step_ms"].values()) and isinstance(ex["dropped"], dict), ex
     assert ex["bytes"]["allreduce/rccl"]["sent_per_rank_bytes"] == 100_000 * 14 * 4   # c2, SH degree 0, two ranks: 2 * 1/2 * payload
