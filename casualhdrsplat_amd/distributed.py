@@ -212,9 +212,11 @@ def chunk_bounds(P: int, chunks: int, align: int = 128) -> list:
 
 
 def _all_reduce_pieces(pieces: Sequence[torch.Tensor], group=None):
-    """ONE asynchronous collective summing several tensors over the ranks (`allreduce_coalesced`: RCCL brackets the
-    per-tensor all-reduces in one ncclGroupStart / End = one launch on the communication stream; gloo flattens them
-    into one buffer).  Returns a completion callable.  Backends without it fall back to one collective per tensor."""
+    """ONE asynchronous collective summing several tensors over the ranks; returns (completion callable, collectives issued).
+    RCCL (and gloo on host tensors): `allreduce_coalesced` -- RCCL brackets the per-tensor all-reduces in one
+    ncclGroupStart / End = one launch on the communication stream, no copies.  Where the backend cannot coalesce what it is
+    given (gloo with device tensors: the one-GPU plumbing check), the pieces are packed into one buffer, reduced by one
+    all-reduce and copied back when it is waited for -- still one collective."""
     pieces = [t for t in pieces if t.numel() > 0]
     for t in pieces:
         if not t.is_contiguous():
@@ -224,18 +226,25 @@ def _all_reduce_pieces(pieces: Sequence[torch.Tensor], group=None):
     if len(pieces) == 1:
         return dist.all_reduce(pieces[0], op=dist.ReduceOp.SUM, group=group, async_op=True).wait, 1
     pg = group if group is not None else dist.distributed_c10d._get_default_group()
-    try:
-        opts = dist.AllreduceCoalescedOptions()
-        opts.reduceOp = dist.ReduceOp.SUM
-        work = pg.allreduce_coalesced(list(pieces), opts)
-        return work.wait, 1
-    except (AttributeError, RuntimeError, NotImplementedError):
-        works = [dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True) for t in pieces]
+    if dist.get_backend(group) == "nccl" or not pieces[0].is_cuda:
+        try:
+            opts = dist.AllreduceCoalescedOptions()
+            opts.reduceOp = dist.ReduceOp.SUM
+            work = pg.allreduce_coalesced(list(pieces), opts)
+            return work.wait, 1
+        except (AttributeError, RuntimeError, NotImplementedError):
+            pass
+    flat = torch.cat([t.reshape(-1) for t in pieces])
+    work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
 
-        def wait_all(works=works):
-            for w in works:
-                w.wait()
-        return wait_all, len(works)
+    def finish(work=work, flat=flat, pieces=pieces):
+        work.wait()
+        o = 0
+        for t in pieces:
+            n = t.numel()
+            t.copy_(flat[o:o + n].view_as(t))
+            o += n
+    return finish, 1
 
 
 LAST_EXCHANGE = {"collectives": 0}   # collectives the latest chunked_all_reduce of this process issued (bench.py prints it)

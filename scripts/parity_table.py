@@ -5,8 +5,11 @@ threshold, so all three implementations take identical decisions) and on larger 
 tests hold to the strict bar: every Gaussian NOT on the tile list of a pixel where HIP and oracle actually decided
 differently (helpers.decision_masks; `strict_share` = their share of all rows).  The rows of the two FULL-SIZE frames
 (BASELINE c3 and c4: HIP against the fp32 C oracle only -- float64 autograd of a million Gaussians is out of reach) are
-written by the tests themselves (HS_PARITY_JSON=gpurun_out/r04_parity_fullsize.json pytest -k full_size_vs_oracle) and
-appended here.  Runs on the MI355X box; writes gpurun_out/r04_parity_table.json (committed under profiles/).
+written by the tests themselves (HS_PARITY_JSON=gpurun_out/r05_parity_fullsize.json pytest -k full_size_vs_oracle) and
+appended here.  Round 5: every case also carries the MASKED pass (helpers.masked_backward_pass: dL zeroed on the pixels
+where a decision differed, on both sides) -- strict_share 1.0 by construction, `n_outside_bound` = elements beyond
+1e-4 |ref| + C 2^-24 sum w|term| (must be 0), `c_needed` = the constant each tensor would have needed.
+Runs on the MI355X box; writes gpurun_out/<tag>_parity_table.json (committed under profiles/).
 usage: python scripts/parity_table.py [--big]"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -18,6 +21,7 @@ from oracle import c_oracle as O
 from test_oracle_cross import torch_run
 
 O.build()
+TAG = os.environ.get("HS_ROUND_TAG", "r05")
 KEYS = [("means3D", "dL_dmeans3D"), ("means2D", "dL_dmeans2D"), ("opacities", "dL_dopacity"), ("shs", "dL_dshs"),
         ("scales", "dL_dscales"), ("rotations", "dL_drots")]
 
@@ -69,6 +73,13 @@ for name, P, W, H, deg, guard in cases:
         truth = g64[k].reshape(b[ok].shape)
         case["tensors"][k] = {"hip_vs_fp64": stats(g["d_" + k], truth, rows), "c_fp32_vs_fp64": stats(b[ok], truth, rows),
                               "hip_vs_c_fp32": stats(g["d_" + k], b[ok].astype(np.float64), rows)}
+    g2, b2, _ = Hh.masked_backward_pass(O, sc, m, [f], hdr=False)
+    Hh.assert_grads_close(g2, b2, what=name + " masked")
+    bounded = Hh.assert_grads_bounded(g2, b2, what=name + " masked")
+    case["masked_pass"] = {"excluded_pixels": int(m["excluded"].sum()), "strict_share": 1.0, "c_bound": Hh.C_BOUND,
+                           "n_outside_bound": int(sum(v[0] for v in bounded.values())),
+                           "c_needed": {k: v[1] for k, v in bounded.items()},
+                           "tensors": {k: stats(g2["d_" + k], b2[ok].astype(np.float64)) for k, ok in KEYS}}
     case["seconds"] = round(time.time() - t0, 1)
     out["cases"].append(case)
     print(name, "seed", seed, "risky px", risk["n_risky_pixels"], "compared", int(rows.sum()), "flips hip", flips_hip, "fp64", same_decisions)
@@ -78,7 +89,7 @@ for name, P, W, H, deg, guard in cases:
               f" C/fp64 max {t['c_fp32_vs_fp64']['max']:.2e} p999 {t['c_fp32_vs_fp64']['p999']:.2e} l2 {t['c_fp32_vs_fp64']['l2']:.2e} frac {t['c_fp32_vs_fp64']['frac_gt_1e-4']:.1e} |"
               f" hip/C max {t['hip_vs_c_fp32']['max']:.2e} p999 {t['hip_vs_c_fp32']['p999']:.2e} frac {t['hip_vs_c_fp32']['frac_gt_1e-4']:.1e}")
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-full = os.path.join(ROOT, "gpurun_out", "r04_parity_fullsize.json")
+full = os.path.join(ROOT, "gpurun_out", TAG + "_parity_fullsize.json")
 if os.path.exists(full):
     out["cases"] += json.load(open(full))["cases"]
-json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r04_parity_table.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", TAG + "_parity_table.json"), "w"), indent=1)
