@@ -308,8 +308,12 @@ int hs_backward(const hs_bwd_args* a, void* hip_stream) {
         }
     }
     if (a->dims.P == 0) return HS_OK;
+    // the CRF gradient's first stage rides at the end of the render backward's launch when both run in this call
+    // (its table of K - 1 64-bit LDS words sits in the kernel's staging area: 9 KB, i.e. up to 1024 knots)
+    const bool crf_in_tail = HS_TUNE_CRF_IN_RENDER_TAIL && (a->stages & HS_BWD_RENDER) && (a->stages & HS_BWD_CRF) &&
+                             !(a->flags & HS_FLAG_DEBUG) && a->crf_K <= 1024;
     if (a->stages & HS_BWD_RENDER) {
-        rc = launch_render_bwd(*a, L, s);
+        rc = launch_render_bwd(*a, L, s, nullptr, nullptr, crf_in_tail);
         if (rc) return rc;
         if ((rc = debug_sync(a->flags, s, "render backward"))) return rc;
     }
@@ -317,19 +321,15 @@ int hs_backward(const hs_bwd_args* a, void* hip_stream) {
     // launch when this call goes on to it: one launch less on the critical path
     CrfReduce crf_reduce{nullptr, 0, 0, 0, nullptr, nullptr, 0};
     const bool sums_follow = (a->stages & (HS_BWD_PREPROCESS | HS_BWD_SEGSUM)) != 0 && !(a->flags & HS_FLAG_DEBUG);
-    // ... and when the whole per-Gaussian half follows in this call too (not a chunk of it), the FIRST stage shares the
-    // segmented sum's launch -- the two jobs run side by side -- and the second rides on the per-Gaussian kernel's
-    const bool whole_follows = sums_follow && ((a->stages & HS_BWD_PREPROCESS) || ((a->stages & HS_BWD_SEGSUM) && (a->stages & HS_BWD_PROJECT))) &&
-                               a->g_begin == 0 && a->g_end == 0 && HS_TUNE_CRF_WITH_SEGSUM;
     if (a->stages & HS_BWD_CRF) {
-        rc = launch_crf_bwd(*a, L, s, sums_follow ? &crf_reduce : nullptr, whole_follows);
+        rc = launch_crf_bwd(*a, L, s, sums_follow ? &crf_reduce : nullptr, crf_in_tail);
         if (rc) return rc;
         if ((rc = debug_sync(a->flags, s, "CRF gradient"))) return rc;
     }
     if (a->stages & (HS_BWD_PREPROCESS | HS_BWD_SEGSUM | HS_BWD_PROJECT)) {
         const bool whole = (a->stages & HS_BWD_PREPROCESS) != 0;
         rc = launch_preprocess_bwd(*a, L, s, whole || (a->stages & HS_BWD_SEGSUM), whole || (a->stages & HS_BWD_PROJECT),
-                                   crf_reduce.nblocks ? &crf_reduce : nullptr, whole_follows && crf_reduce.nblocks != 0);
+                                   crf_reduce.nblocks ? &crf_reduce : nullptr);
         if (rc) return rc;
         if ((rc = debug_sync(a->flags, s, "preprocess backward"))) return rc;
     }

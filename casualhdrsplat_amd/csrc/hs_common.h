@@ -19,9 +19,9 @@ void set_error(const char* fmt, ...);
     } while (0)
 #define HS_LAUNCH_CHECK() HS_HIP_CHECK(hipGetLastError())
 
-// A/B switch: the CRF gradient's first stage in the segmented sum's launch (render.hip, crf_segsum_kernel)
-#ifndef HS_TUNE_CRF_WITH_SEGSUM
-#define HS_TUNE_CRF_WITH_SEGSUM 1
+// A/B switch: the CRF gradient's first stage at the end of the render backward's launch (render.hip, render_bwd_kernel)
+#ifndef HS_TUNE_CRF_IN_RENDER_TAIL
+#define HS_TUNE_CRF_IN_RENDER_TAIL 1
 #endif
 
 constexpr int kTile = HS_TILE;
@@ -71,20 +71,17 @@ int launch_cov3d(const hs_fwd_args& a, const hs_layout& L, hipStream_t s);   // 
 int launch_binning(const hs_fwd_args& a, const hs_layout& L, hipStream_t s, uint32_t frame_tag);
 // `stats` (device, render_stats_count() u64 counters, or null) selects the diagnostic instantiation of the kernel
 int launch_render_fwd(const hs_fwd_args& a, const hs_layout& L, hipStream_t s, unsigned long long* stats = nullptr);
+// `crf_in_tail`: the CRF gradient's first stage rides at the END of the launch (workgroups behind the tiles')
 int launch_render_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s, unsigned long long* stats = nullptr,
-                      unsigned long long* timeline = nullptr);
+                      unsigned long long* timeline = nullptr, bool crf_in_tail = false);
 int render_stats_count();
 struct CrfReduce;
-struct SegsumArgs;
-// `defer`: non-null = do not launch the second stage; describe it there for a later launch of the call to run.
-// `with_segsum`: non-null = do not launch the first stage either: it shares ONE launch with the segmented sum
-// (launch_preprocess_bwd passes the segmented sum's arguments to launch_crf_segsum)
-int launch_crf_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s, CrfReduce* defer, bool with_segsum = false);
-int launch_crf_segsum(const hs_bwd_args& a, const hs_layout& L, const SegsumArgs& sg, hipStream_t s);
-// `crf_reduce`: second stage of the CRF gradient to ride along; `crf_with_segsum`: its FIRST stage shares the segmented sum's
-// launch (then the second stage rides on the per-Gaussian kernel's)
+// `defer`: non-null = do not launch the second stage; describe it there for the segmented sum's launch to run.
+// `in_render_tail`: the first stage already ran at the end of the render backward's launch (two-wave workgroups: the partial
+// rows are counted accordingly)
+int launch_crf_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s, CrfReduce* defer, bool in_render_tail = false);
 int launch_preprocess_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s, bool segsum, bool project,
-                          const CrfReduce* crf_reduce, bool crf_with_segsum = false);
+                          const CrfReduce* crf_reduce);
 int launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* vis, hipStream_t s);
 int launch_sh_backward_views(int P, int M, int deg, int V, const float* means3D, const float* camposes,
                              const float* view_colors, float* d_shs, hipStream_t s);
@@ -179,10 +176,9 @@ struct CrfReduce {
     const float* partials; int bx, planes, K; float* d_table; float* d_exposure;
     int nblocks;   // 256-thread workgroups the job takes: ceil((3K + 1) / 4); 0 = nothing to do
 };
-// (`sub`: a two-wave workgroup -- preprocess_bwd_kernel's -- takes a group of four output elements in two calls, sub 0 and 2)
-__device__ __forceinline__ void crf_reduce_block(const CrfReduce& c, int block, int sub = 0) {
+__device__ __forceinline__ void crf_reduce_block(const CrfReduce& c, int block) {
     const int K = c.K;
-    const int i = block * 4 + sub + (threadIdx.x >> 6);  // 0 .. 3K: table entry ch * K + k, or 3K = exposure
+    const int i = block * 4 + (threadIdx.x >> 6);  // 0 .. 3K: table entry ch * K + k, or 3K = exposure
     const int lane = threadIdx.x & 63;
     if (i > 3 * K) return;
     const bool expo = i == 3 * K;
@@ -238,8 +234,7 @@ __device__ __forceinline__ float radiance_dact(int act, float col, bool was_clam
     return was_clamped ? 0.f : 1.f;
 }
 
-// Per-instance sum of the render-backward pair records (preprocess.hip, pair_segsum_kernel; also the second half of
-// render.hip's crf_segsum_kernel).  Thread `t` of the job: instance t >> 2 (in depth order), quad lane t & 3.
+// Per-instance sum of the render-backward pair records (preprocess.hip, pair_segsum_kernel).  Thread `t` of the job: instance t >> 2 (in depth order), quad lane t & 3.
 struct SegsumArgs {
     int64_t I;
     const uint32_t* inst_sorted; const uint32_t* offs_sorted;

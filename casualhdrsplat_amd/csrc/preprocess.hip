@@ -431,7 +431,7 @@ __global__ void mark_visible_kernel(int P, const float* means, const float* V, u
 // Unflagged records were never written this backward (their tile's replay stopped before them): skipped by select.
 __global__ void __launch_bounds__(256) pair_segsum_kernel(SegsumArgs sg, CrfReduce crf_reduce) {
     // (the second stage of the CRF-table gradient rides on this launch's first workgroups when the same call computed the
-    // first in a launch of its own: hs_common.h, CrfReduce)
+    // first: hs_common.h, CrfReduce)
     for (int b = blockIdx.x; b < crf_reduce.nblocks; b += gridDim.x) crf_reduce_block(crf_reduce, b);
     pair_segsum_body(sg, (int64_t)blockIdx.x * 256 + threadIdx.x);
 }
@@ -451,7 +451,6 @@ struct PreBwd {
     float* dens_grad; float* dens_denom; int* dens_radii;  // densification statistics, updated in place, or null
     float* pose_partials;  // [blocks][N][kPoseVals] or null
     int blk0;              // first block of this launch (hs_bwd_args.g_begin / kPreBwdBlock: a chunk of the Gaussians)
-    CrfReduce crf_reduce;  // second stage of the CRF gradient riding on this launch's first workgroups (nblocks 0: none)
 };
 
 // Camera-pose gradient terms per pose: 12 view-matrix entries (flat 4j+i, i<3), 12 projection entries (rows 0,1,3),
@@ -541,11 +540,6 @@ template <int DEG, bool POSE, bool SHG>
 __global__ void __launch_bounds__(kPreBwdBlock) HS_PB_OCC preprocess_bwd_kernel(PreBwd p) {
     extern __shared__ float s_sh[];  // [kPreBwdBlock][M*3 + 1]
     __shared__ float s_pose[kPreBwdBlock / 64][kPoseVals];
-    // (the CRF gradient's second stage, when its first shared the segmented sum's launch: two waves here, so two calls)
-    for (int b = blockIdx.x; b < p.crf_reduce.nblocks; b += gridDim.x) {
-        crf_reduce_block(p.crf_reduce, b, 0);
-        crf_reduce_block(p.crf_reduce, b, 2);
-    }
     constexpr int NC = (DEG + 1) * (DEG + 1);
     const int blk = (int)blockIdx.x + p.blk0;
     const int g0 = blk * kPreBwdBlock;
@@ -1007,7 +1001,7 @@ int launch_preprocess_fwd(const hs_fwd_args& a, const hs_layout& L, hipStream_t 
 }
 
 int launch_preprocess_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s, bool segsum, bool project,
-                          const CrfReduce* crf_reduce, bool crf_with_segsum) {
+                          const CrfReduce* crf_reduce) {
     const hs_dims& d = a.dims;
     const char* geom = (const char*)a.geom;
     PreBwd p;
@@ -1032,14 +1026,8 @@ int launch_preprocess_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t 
         sg.inst_grads = (float4*)((char*)a.bwd + L.inst_grads); sg.counters = (const hs_counters*)(geom + L.counters);
         sg.radii_inst = p.radii_inst; sg.clamped = p.clamped;
         sg.view_colors = a.colors_precomp ? nullptr : a.dL_dview_colors; sg.rec = p.rec; sg.act = p.act;
-        if (crf_with_segsum) {
-            // ONE launch for the CRF gradient's first stage and the segmented sum (render.hip, crf_segsum_kernel)
-            const int rc = launch_crf_segsum(a, L, sg, s);
-            if (rc) return rc;
-        } else {
-            pair_segsum_kernel<<<ceil_div(4 * I, 256), 256, 0, s>>>(sg, crf_reduce ? *crf_reduce : no_reduce);
-            HS_LAUNCH_CHECK();
-        }
+        pair_segsum_kernel<<<ceil_div(4 * I, 256), 256, 0, s>>>(sg, crf_reduce ? *crf_reduce : no_reduce);
+        HS_LAUNCH_CHECK();
     }
     if (!project) return HS_OK;
     p.d_means3D = a.dL_dmeans3D; p.d_means2D = a.dL_dmeans2D; p.d_opac = a.dL_dopacities; p.d_shs = a.dL_dshs;
@@ -1058,7 +1046,6 @@ int launch_preprocess_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t 
     const size_t lds = (size_t)kPreBwdBlock * (d.M * 3 + 1) * sizeof(float);
     float* pose_partials = a.dL_dviewmatrices ? (float*)((char*)a.bwd + L.pose_partials) : nullptr;
     p.pose_partials = pose_partials;
-    p.crf_reduce = (crf_with_segsum && crf_reduce) ? *crf_reduce : no_reduce;
 #define HS_LAUNCH_PRE_BWD(DEG_)                                                                              \
     if (pose_partials && shg) preprocess_bwd_kernel<DEG_, true, true><<<grid, kPreBwdBlock, lds, s>>>(p);       \
     else if (pose_partials) preprocess_bwd_kernel<DEG_, true, false><<<grid, kPreBwdBlock, lds, s>>>(p);        \

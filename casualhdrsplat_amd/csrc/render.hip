@@ -731,6 +731,134 @@ __global__ void __launch_bounds__(1024) order_tiles_kernel(int nb, int gx, int n
     }
 }
 
+// CRF-table and exposure gradients (a15 backward), bitwise reproducible.
+// grid = (ceil(HW / 4096), planes): blockIdx.y selects the (pose, channel) image plane, each block owns 4096 consecutive
+// pixels of it, 16 per thread, all held in registers.  A pixel whose log-exposure falls between knots i and i+1 adds
+// (1 - f) g to dL/dtable[i] and f g to dL/dtable[i+1].  Both weights are added once per run of pixels that share an
+// interval (neighbouring pixels of a natural image mostly do), as 32-bit FIXED-POINT integers with a power-of-two
+// scale derived from the block's own max |g| (19 bits below 2^31, so 4096 addends cannot overflow a field) --
+// integer adds commute, so the block's table does not depend on the order in which lanes reach the LDS, unlike the
+// float atomics this replaces (and a CU retires integer LDS atomics several times faster than float or 64-bit
+// ones); the two fields of an interval are turned back into floats and written as the block's partial row.  Quantisation step = 2^-19 of the block's
+// largest |g|, unbiased.  Exposure gradient and the clamped ends of the table: per-thread float sums in pixel order,
+// fixed DPP tree over the wave, the four waves added in wave order.  crf_reduce_kernel adds the blocks in a fixed order.
+// NW waves per workgroup (4: a launch of its own or the segmented sum's; 2: the tail of the render backward's launch, whose
+// workgroups are 128 threads): a workgroup owns NW * 1024 pixels; the partial rows are per workgroup either way.
+constexpr int kCrfPixPerWave = 1024;
+
+struct CrfGradArgs {
+    int64_t HW; int N, flags; const float* pose_hdr; Crf crf; const float* exposure; const float* dL_dcolor; float* partials;
+    int bx, planes;   // the job's workgroups: bx pixel blocks x planes (pose, channel) image planes
+};
+
+// (`bxi`, `plane`: which pixel block of which plane this workgroup takes -- blockIdx of the stand-alone launch)
+// `s_tab64`: K - 1 64-bit LDS words (the stand-alone launches' dynamic LDS; a corner of the render backward's staging area)
+template <int NW>
+__device__ __forceinline__ void crf_grad_body(const CrfGradArgs& A, const int bxi, const int plane_in,
+                                              unsigned long long* const s_tab64) {
+    const int64_t HW = A.HW; const int N = A.N, flags = A.flags; const float* pose_hdr = A.pose_hdr; Crf crf = A.crf;
+    const float* exposure = A.exposure; const float* dL_dcolor = A.dL_dcolor; float* partials = A.partials;
+    int* const s_tab32 = reinterpret_cast<int*>(s_tab64);   // K - 1 intervals: two 32-bit fixed-point fields each
+    __shared__ float s_wave[NW][4];
+    __shared__ float s_max[NW];
+    const int K = crf.K;
+    for (int i = threadIdx.x; i < K - 1; i += NW * 64) s_tab64[i] = 0ull;
+    crf.dt = exposure[0];
+    const bool blur_hdr = (flags & HS_FLAG_BLUR_HDR) && N > 1;
+    const float gs = blur_hdr ? 1.f : 1.f / (float)N;
+    const float scale = (float)(K - 1) / (crf.umax - crf.umin);
+    const int plane = plane_in;              // pose * 3 + ch
+    const int pose = plane / 3, ch = plane - 3 * pose;
+    const float* Hp = pose_hdr + ((int64_t)(blur_hdr ? N : pose) * 3 + ch) * HW;
+    const float* gp = dL_dcolor + (int64_t)ch * HW;
+    const float* t = crf.table + ch * K;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+    const int64_t i16 = ((int64_t)bxi * (NW * 64) + threadIdx.x) * 16;
+    float Hv[16], g[16];
+    if (i16 + 16 <= HW && (HW & 3) == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 h4 = reinterpret_cast<const float4*>(Hp + i16)[q];
+            const float4 g4 = reinterpret_cast<const float4*>(gp + i16)[q];
+            Hv[4 * q] = h4.x; Hv[4 * q + 1] = h4.y; Hv[4 * q + 2] = h4.z; Hv[4 * q + 3] = h4.w;
+            g[4 * q] = g4.x * gs; g[4 * q + 1] = g4.y * gs; g[4 * q + 2] = g4.z * gs; g[4 * q + 3] = g4.w * gs;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const bool ok = i16 + e < HW;
+            Hv[e] = ok ? Hp[i16 + e] : 0.f;
+            g[e] = ok ? gp[i16 + e] * gs : 0.f;
+        }
+    }
+    // block maximum of |g| -> fixed-point scale (max is order independent)
+    float mx = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) mx = fmaxf(mx, fabsf(g[e]));
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
+    if (lane == 0) s_max[wave] = mx;
+    __syncthreads();  // also: the table is cleared
+    mx = fmaxf(s_max[0], s_max[1]);
+    if constexpr (NW == 4) mx = fmaxf(mx, fmaxf(s_max[2], s_max[3]));
+    // mx = m * 2^x with m in [0.5, 1)  ->  |g| * 2^(19 - x) < 2^19 ; non-finite or zero gradients: scale 1 (sums are
+    // zero or garbage-in-garbage-out, as with float adds)
+    int xexp = 0;
+    if (mx > 0.f && mx < 3.0e38f) (void)frexpf(mx, &xexp);
+    const float to_fix = ldexpf(1.f, 19 - xexp), from_fix = ldexpf(1.f, xexp - 19);
+
+    float gexp = 0.f, g_lo = 0.f, g_hi = 0.f;
+    int run = -1;              // knot interval of the pending run (-1: none)
+    float r0 = 0.f, r1 = 0.f;  // pending contributions to table[run], table[run + 1]
+    auto flush = [&]() {
+        // two 32-bit integer LDS atomics (a CU retires them several times faster than one 64-bit or float atomic,
+        // profiles/README.md "lane groups"); 19 bits below 2^31 leave room for the block's 4096 addends per field
+        atomicAdd(&s_tab32[2 * run], __float2int_rn(r0 * to_fix));
+        atomicAdd(&s_tab32[2 * run + 1], __float2int_rn(r1 * to_fix));
+    };
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        int idx; float f, xv; bool in;
+        crf_locate(crf, Hv[e], idx, f, xv, in);
+        // pixels clamped to an end of the table (black / saturated regions) are summed per thread
+        const bool lo = idx == 0 && f == 0.f, hi = idx == K - 2 && f == 1.f;
+        g_lo += lo ? g[e] : 0.f;
+        g_hi += hi ? g[e] : 0.f;
+        if (!lo && !hi) {
+            if (idx != run) {
+                if (run >= 0) flush();
+                run = idx; r0 = 0.f; r1 = 0.f;
+            }
+            r0 += (1.f - f) * g[e];
+            r1 += f * g[e];
+        }
+        if (in) gexp += g[e] * (t[idx + 1] - t[idx]) * scale * __builtin_amdgcn_rcpf(xv) * Hv[e];
+    }
+    if (run >= 0) flush();
+    gexp = wave_sum_hi(gexp);
+    g_lo = wave_sum_hi(g_lo);
+    g_hi = wave_sum_hi(g_hi);
+    if (lane == 63) { s_wave[wave][0] = gexp; s_wave[wave][1] = g_lo; s_wave[wave][2] = g_hi; }
+    __syncthreads();
+    // partial row of this block: K knots of its channel + its exposure term
+    float* dst = partials + ((int64_t)plane_in * A.bx + bxi) * (K + 1);
+    for (int k = threadIdx.x; k <= K; k += NW * 64) {
+        float v;
+        if (k == K) {
+            v = NW == 4 ? ((s_wave[0][0] + s_wave[1][0]) + s_wave[2 % NW][0]) + s_wave[3 % NW][0] : s_wave[0][0] + s_wave[1][0];
+        } else {
+            long long acc = 0;  // field 0 of interval k + field 1 of interval k - 1
+            if (k < K - 1) acc += (long long)s_tab32[2 * k];
+            if (k > 0) acc += (long long)s_tab32[2 * (k - 1) + 1];
+            v = (float)acc * from_fix;
+            if (k == 0) v += NW == 4 ? ((s_wave[0][1] + s_wave[1][1]) + s_wave[2 % NW][1]) + s_wave[3 % NW][1] : s_wave[0][1] + s_wave[1][1];
+            if (k == K - 1) v += NW == 4 ? ((s_wave[0][2] + s_wave[1][2]) + s_wave[2 % NW][2]) + s_wave[3 % NW][2] : s_wave[0][2] + s_wave[1][2];
+        }
+        dst[k] = v;
+    }
+}
+
 struct RenderBwd {
     int W, H, gx, gy, ntiles, N, flags;
     const uint2* ranges; const uint32_t* point_list; const float4* rec; const float* bg;
@@ -746,6 +874,8 @@ struct RenderBwd {
                                    // per workgroup
     uint32_t* queue;               // counter of the tail queue (zeroed by the forward's first kernel, then self-resetting)
     const uint32_t* tile_order;    // workgroup -> (pose, tile), written by order_tiles_kernel after the forward
+    int grid_tiles;                // workgroups of the launch that take tiles; those behind them (if any) ...
+    CrfGradArgs crf_tail;          // ... take 2048-pixel blocks of the CRF gradient's first stage (bx * planes of them)
 };
 
 // Upstream gradient w.r.t. this pose's radiance H_ch at one pixel (the HDR prologue).
@@ -877,8 +1007,21 @@ render_bwd_kernel(RenderBwd p) {
     // Measured at c3: -3 % on this kernel at 8 %, the same at 4 and 12 %, nothing at 25 %; the forward LOSES 2 % with
     // the same queue and keeps its static map.
     __shared__ uint32_t s_q;
-    const int n_tail = (int)((int64_t)gridDim.x * kTailPct / 100);
-    const int n_static = (int)gridDim.x - n_tail;
+    if constexpr (!STATS) {
+        // Workgroups behind the tiles' (round 5): the first stage of the CRF-table / exposure gradient -- independent of this
+        // kernel's results, bound by LDS atomics -- handed out by the dispatcher only after every tile has a workgroup, i.e.
+        // into the slots the draining launch leaves empty (its last round runs at half occupancy).  Measured at c3, same
+        // box: a launch of its own 1.1239 ms per step; its workgroups interleaved with the segmented sum's in one launch
+        // 1.1145 (all first 1.1153, all last 1.1224); here 1.097 (c4: 7.39 -> 7.32).  A side stream for the same kernel
+        // measured noise three times (rounds 1, 3, 4): what helps is WHEN its workgroups are dispatched, not the queue.
+        if ((int)blockIdx.x >= p.grid_tiles) {
+            const int qd = (int)blockIdx.x - p.grid_tiles;
+            crf_grad_body<2>(p.crf_tail, qd % p.crf_tail.bx, qd / p.crf_tail.bx, reinterpret_cast<unsigned long long*>(s_ent));
+            return;
+        }
+    }
+    const int n_tail = (int)((int64_t)p.grid_tiles * kTailPct / 100);
+    const int n_static = p.grid_tiles - n_tail;
     if (threadIdx.x < kAccF) s_ent[KB * kEntF + threadIdx.x] = 0.f;   // the sentinel record (ordered by the barriers below)
     for (;;) {
     int bidx = blockIdx.x;
@@ -893,7 +1036,7 @@ render_bwd_kernel(RenderBwd p) {
         if (s_q >= (uint32_t)n_tail) return;
         bidx = n_static + (int)s_q;
     }
-    const int vt = p.tile_order ? (int)p.tile_order[bidx] : xcd_strip_tile(bidx, gridDim.x, p.gx);
+    const int vt = p.tile_order ? (int)p.tile_order[bidx] : xcd_strip_tile(bidx, p.grid_tiles, p.gx);
     const int pose = vt / p.ntiles;
     const int tile = vt - pose * p.ntiles;
     const int tx = tile % p.gx, ty = tile / p.gx;
@@ -1145,147 +1288,9 @@ render_bwd_kernel(RenderBwd p) {
     }   // next tile of the queue
 }
 
-// CRF-table and exposure gradients (a15 backward), bitwise reproducible.
-// grid = (ceil(HW / 4096), planes): blockIdx.y selects the (pose, channel) image plane, each block owns 4096 consecutive
-// pixels of it, 16 per thread, all held in registers.  A pixel whose log-exposure falls between knots i and i+1 adds
-// (1 - f) g to dL/dtable[i] and f g to dL/dtable[i+1].  Both weights are added once per run of pixels that share an
-// interval (neighbouring pixels of a natural image mostly do), as 32-bit FIXED-POINT integers with a power-of-two
-// scale derived from the block's own max |g| (19 bits below 2^31, so 4096 addends cannot overflow a field) --
-// integer adds commute, so the block's table does not depend on the order in which lanes reach the LDS, unlike the
-// float atomics this replaces (and a CU retires integer LDS atomics several times faster than float or 64-bit
-// ones); the two fields of an interval are turned back into floats and written as the block's partial row.  Quantisation step = 2^-19 of the block's
-// largest |g|, unbiased.  Exposure gradient and the clamped ends of the table: per-thread float sums in pixel order,
-// fixed DPP tree over the wave, the four waves added in wave order.  crf_reduce_kernel adds the blocks in a fixed order.
-constexpr int kCrfPixPerBlock = 4096;
-
-struct CrfGradArgs {
-    int64_t HW; int N, flags; const float* pose_hdr; Crf crf; const float* exposure; const float* dL_dcolor; float* partials;
-    int bx, planes;   // the job's workgroups: bx pixel blocks x planes (pose, channel) image planes
-};
-
-// (`bxi`, `plane`: which pixel block of which plane this workgroup takes -- blockIdx of the stand-alone launch)
-__device__ __forceinline__ void crf_grad_body(const CrfGradArgs& A, const int bxi, const int plane_in) {
-    const int64_t HW = A.HW; const int N = A.N, flags = A.flags; const float* pose_hdr = A.pose_hdr; Crf crf = A.crf;
-    const float* exposure = A.exposure; const float* dL_dcolor = A.dL_dcolor; float* partials = A.partials;
-    extern __shared__ unsigned long long s_tab64[];  // K - 1 intervals: two 32-bit fixed-point fields each
-    int* const s_tab32 = reinterpret_cast<int*>(s_tab64);
-    __shared__ float s_wave[4][4];
-    __shared__ float s_max[4];
-    const int K = crf.K;
-    for (int i = threadIdx.x; i < K - 1; i += 256) s_tab64[i] = 0ull;
-    crf.dt = exposure[0];
-    const bool blur_hdr = (flags & HS_FLAG_BLUR_HDR) && N > 1;
-    const float gs = blur_hdr ? 1.f : 1.f / (float)N;
-    const float scale = (float)(K - 1) / (crf.umax - crf.umin);
-    const int plane = plane_in;              // pose * 3 + ch
-    const int pose = plane / 3, ch = plane - 3 * pose;
-    const float* Hp = pose_hdr + ((int64_t)(blur_hdr ? N : pose) * 3 + ch) * HW;
-    const float* gp = dL_dcolor + (int64_t)ch * HW;
-    const float* t = crf.table + ch * K;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-
-    const int64_t i16 = ((int64_t)bxi * 256 + threadIdx.x) * 16;
-    float Hv[16], g[16];
-    if (i16 + 16 <= HW && (HW & 3) == 0) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 h4 = reinterpret_cast<const float4*>(Hp + i16)[q];
-            const float4 g4 = reinterpret_cast<const float4*>(gp + i16)[q];
-            Hv[4 * q] = h4.x; Hv[4 * q + 1] = h4.y; Hv[4 * q + 2] = h4.z; Hv[4 * q + 3] = h4.w;
-            g[4 * q] = g4.x * gs; g[4 * q + 1] = g4.y * gs; g[4 * q + 2] = g4.z * gs; g[4 * q + 3] = g4.w * gs;
-        }
-    } else {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const bool ok = i16 + e < HW;
-            Hv[e] = ok ? Hp[i16 + e] : 0.f;
-            g[e] = ok ? gp[i16 + e] * gs : 0.f;
-        }
-    }
-    // block maximum of |g| -> fixed-point scale (max is order independent)
-    float mx = 0.f;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) mx = fmaxf(mx, fabsf(g[e]));
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
-    if (lane == 0) s_max[wave] = mx;
-    __syncthreads();  // also: the table is cleared
-    mx = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
-    // mx = m * 2^x with m in [0.5, 1)  ->  |g| * 2^(19 - x) < 2^19 ; non-finite or zero gradients: scale 1 (sums are
-    // zero or garbage-in-garbage-out, as with float adds)
-    int xexp = 0;
-    if (mx > 0.f && mx < 3.0e38f) (void)frexpf(mx, &xexp);
-    const float to_fix = ldexpf(1.f, 19 - xexp), from_fix = ldexpf(1.f, xexp - 19);
-
-    float gexp = 0.f, g_lo = 0.f, g_hi = 0.f;
-    int run = -1;              // knot interval of the pending run (-1: none)
-    float r0 = 0.f, r1 = 0.f;  // pending contributions to table[run], table[run + 1]
-    auto flush = [&]() {
-        // two 32-bit integer LDS atomics (a CU retires them several times faster than one 64-bit or float atomic,
-        // profiles/README.md "lane groups"); 19 bits below 2^31 leave room for the block's 4096 addends per field
-        atomicAdd(&s_tab32[2 * run], __float2int_rn(r0 * to_fix));
-        atomicAdd(&s_tab32[2 * run + 1], __float2int_rn(r1 * to_fix));
-    };
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        int idx; float f, xv; bool in;
-        crf_locate(crf, Hv[e], idx, f, xv, in);
-        // pixels clamped to an end of the table (black / saturated regions) are summed per thread
-        const bool lo = idx == 0 && f == 0.f, hi = idx == K - 2 && f == 1.f;
-        g_lo += lo ? g[e] : 0.f;
-        g_hi += hi ? g[e] : 0.f;
-        if (!lo && !hi) {
-            if (idx != run) {
-                if (run >= 0) flush();
-                run = idx; r0 = 0.f; r1 = 0.f;
-            }
-            r0 += (1.f - f) * g[e];
-            r1 += f * g[e];
-        }
-        if (in) gexp += g[e] * (t[idx + 1] - t[idx]) * scale * __builtin_amdgcn_rcpf(xv) * Hv[e];
-    }
-    if (run >= 0) flush();
-    gexp = wave_sum_hi(gexp);
-    g_lo = wave_sum_hi(g_lo);
-    g_hi = wave_sum_hi(g_hi);
-    if (lane == 63) { s_wave[wave][0] = gexp; s_wave[wave][1] = g_lo; s_wave[wave][2] = g_hi; }
-    __syncthreads();
-    // partial row of this block: K knots of its channel + its exposure term
-    float* dst = partials + ((int64_t)plane_in * A.bx + bxi) * (K + 1);
-    for (int k = threadIdx.x; k <= K; k += 256) {
-        float v;
-        if (k == K) {
-            v = ((s_wave[0][0] + s_wave[1][0]) + s_wave[2][0]) + s_wave[3][0];
-        } else {
-            long long acc = 0;  // field 0 of interval k + field 1 of interval k - 1
-            if (k < K - 1) acc += (long long)s_tab32[2 * k];
-            if (k > 0) acc += (long long)s_tab32[2 * (k - 1) + 1];
-            v = (float)acc * from_fix;
-            if (k == 0) v += ((s_wave[0][1] + s_wave[1][1]) + s_wave[2][1]) + s_wave[3][1];
-            if (k == K - 1) v += ((s_wave[0][2] + s_wave[1][2]) + s_wave[2][2]) + s_wave[3][2];
-        }
-        dst[k] = v;
-    }
-}
-
-__global__ void __launch_bounds__(256) crf_grad_kernel(CrfGradArgs A) { crf_grad_body(A, (int)blockIdx.x, (int)blockIdx.y); }
-
-// ONE launch for the CRF gradient's first stage and the per-instance sums of the pair records (round 5).  The two jobs are
-// independent and bound by different things -- 4096-pixel blocks adding fixed-point weights with LDS atomics; quads
-// walking 64-byte records whose sum rows leave in a scattered order -- so their workgroups are INTERLEAVED in one grid
-// (every `stride`-th workgroup is a CRF block until those run out) and run side by side instead of one after the
-// other: about half of the CRF kernel's 22 us disappears into the 77 of the segmented sum (step -10 us; all CRF workgroups
-// first: -9, all last: -2, a launch of their own: 0).  Same arithmetic as the two kernels:
-// the sums are pure additions (this TU's FMA contraction has nothing to contract), the CRF body is the one above.
-__global__ void __launch_bounds__(256) crf_segsum_kernel(CrfGradArgs A, SegsumArgs sg, int ncrf, int stride) {
-    const int b = (int)blockIdx.x;
-    const int qd = b / stride, r = b - qd * stride;
-    if (r == 0 && qd < ncrf) {
-        crf_grad_body(A, qd % A.bx, qd / A.bx);
-        return;
-    }
-    const int before = min(ncrf, qd + 1);                 // CRF workgroups at positions below b
-    pair_segsum_body(sg, (int64_t)(b - before) * 256 + threadIdx.x);
+__global__ void __launch_bounds__(256) crf_grad_kernel(CrfGradArgs A) {
+    extern __shared__ unsigned long long s_crf_tab[];
+    crf_grad_body<4>(A, (int)blockIdx.x, (int)blockIdx.y, s_crf_tab);
 }
 
 // The partial rows added up in a fixed order (hs_common.h, crf_reduce_block): stand-alone launch
@@ -1340,7 +1345,7 @@ int launch_render_fwd(const hs_fwd_args& a, const hs_layout& L, hipStream_t s, u
     return HS_OK;
 }
 
-static bool crf_grad_args(const hs_bwd_args& a, const hs_layout& L, CrfGradArgs& A) {
+static bool crf_grad_args(const hs_bwd_args& a, const hs_layout& L, CrfGradArgs& A, int waves = 4) {
     const hs_dims& d = a.dims;
     if (!((a.flags & HS_FLAG_HDR) && (a.dL_dcrf_table || a.dL_dexposure))) return false;
     A.crf.table = a.crf_table; A.crf.K = a.crf_K; A.crf.umin = a.crf_umin; A.crf.umax = a.crf_umax; A.crf.dt = 1.f;
@@ -1350,14 +1355,14 @@ static bool crf_grad_args(const hs_bwd_args& a, const hs_layout& L, CrfGradArgs&
     A.exposure = a.exposure; A.dL_dcolor = a.dL_dout_color;
     const bool blur_hdr = (a.flags & HS_FLAG_BLUR_HDR) && d.n_poses > 1;
     A.planes = 3 * (blur_hdr ? 1 : d.n_poses);
-    A.bx = ceil_div(A.HW, kCrfPixPerBlock);
+    A.bx = ceil_div(A.HW, (int64_t)waves * kCrfPixPerWave);
     return true;
 }
 
-int launch_crf_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s, CrfReduce* defer, bool with_segsum) {
+int launch_crf_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s, CrfReduce* defer, bool in_render_tail) {
     CrfGradArgs A;
-    if (!crf_grad_args(a, L, A)) return HS_OK;
-    if (!with_segsum)
+    if (!crf_grad_args(a, L, A, in_render_tail ? 2 : 4)) return HS_OK;
+    if (!in_render_tail)
         crf_grad_kernel<<<dim3(A.bx, A.planes), 256, (size_t)(a.crf_K - 1) * sizeof(unsigned long long), s>>>(A);
     CrfReduce cr;
     cr.partials = A.partials; cr.bx = A.bx; cr.planes = A.planes; cr.K = a.crf_K; cr.d_table = a.dL_dcrf_table;
@@ -1368,20 +1373,8 @@ int launch_crf_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s, CrfR
     return HS_OK;
 }
 
-int launch_crf_segsum(const hs_bwd_args& a, const hs_layout& L, const SegsumArgs& sg, hipStream_t s) {
-    CrfGradArgs A;
-    if (!crf_grad_args(a, L, A)) { set_error("launch_crf_segsum: no CRF gradient to compute"); return HS_EINVAL; }
-    const int ncrf = A.bx * A.planes;
-    const int nseg = ceil_div(4 * sg.I, 256);
-    const int total = ncrf + nseg;
-    const int stride = max(1, total / max(ncrf, 1));
-    crf_segsum_kernel<<<total, 256, (size_t)(a.crf_K - 1) * sizeof(unsigned long long), s>>>(A, sg, ncrf, stride);
-    HS_LAUNCH_CHECK();
-    return HS_OK;
-}
-
 int launch_render_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s, unsigned long long* stats,
-                      unsigned long long* timeline) {
+                      unsigned long long* timeline, bool crf_in_tail) {
     const hs_dims& d = a.dims;
     RenderBwd p;
     p.W = d.W; p.H = d.H; p.gx = (d.W + kTile - 1) / kTile; p.gy = (d.H + kTile - 1) / kTile;
@@ -1404,7 +1397,10 @@ int launch_render_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s, u
     p.stats = stats; p.timeline = timeline;
     p.queue = &((hs_counters*)((char*)a.geom + L.counters))->reserved[3];
     p.tile_order = orders_tiles(p.ntiles * d.n_poses) ? (const uint32_t*)(img + L.tile_order) : nullptr;
-    const int grid = p.ntiles * d.n_poses;
+    int grid = p.ntiles * d.n_poses;
+    p.grid_tiles = grid;
+    // (the CRF gradient's first stage as extra workgroups behind the tiles': see the kernel's head)
+    if (crf_in_tail && !stats && crf_grad_args(a, L, p.crf_tail, 2)) grid += p.crf_tail.bx * p.crf_tail.planes;
     if (stats) {
         if (a.dL_dout_invdepth) render_bwd_kernel<true, true><<<grid, kBatch, 0, s>>>(p);
         else render_bwd_kernel<false, true><<<grid, kBatch, 0, s>>>(p);
@@ -1418,7 +1414,7 @@ int render_stats_count() { return kStCount; }
 
 // scratch of the CRF-gradient stage: one row of K + 1 floats per (pixel block, pose, channel)
 int64_t crf_partial_floats(int K, int64_t HW, int n_poses) {
-    return K > 0 ? (int64_t)ceil_div(HW, kCrfPixPerBlock) * 3 * n_poses * (K + 1) : 0;
+    return K > 0 ? (int64_t)ceil_div(HW, 2 * kCrfPixPerWave) * 3 * n_poses * (K + 1) : 0;   // (the smaller workgroup: two waves)
 }
 
 }  // namespace hs
