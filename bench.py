@@ -241,10 +241,11 @@ def _cpu_full_frame(cfg, seed=0):
     return time.time() - t0
 
 
-def cpu_baseline(sc, cfg, n_tiles_sample=96, with_c2=False):
+def cpu_baseline(sc, cfg, n_tiles_sample=256, with_c2=False):
     """CPU baseline of the bench configuration.  `value` = the pure-PyTorch CPU autograd rasterizer of BASELINE.md
-    section 3 (oracle/torch_rasterizer.py) on the box's host cores, on a bounded sample of the same frame (full preprocess
-    + binning, then forward+backward of every k-th tile, extrapolated to images/s of the whole frame);
+    section 3 (oracle/torch_rasterizer.py) on the box's host cores, on a bounded sample of the same frame (preprocess
+    + binning forward and the preprocess backward of the WHOLE frame, timed exactly; render forward+backward of every k-th
+    tile in four interleaved subsets, extrapolated to all tiles -- `extrapolation` holds the four estimates and their spread);
     `c_oracle_single_thread` = the C oracle (one thread) on the WHOLE frame (_c_oracle_frame), no sampling; c1 in full
     with the PyTorch rasterizer (median of 5); c2 in full as well ("config 2 if it completes in < 10 min" --
     2.5 minutes on the 128 host cores of the MI355X box) unless --no-cpu-c2."""
@@ -263,18 +264,39 @@ def cpu_baseline(sc, cfg, n_tiles_sample=96, with_c2=False):
     ntiles = gx * gy
     stride = max(1, ntiles // n_tiles_sample)
     tiles = list(range(stride // 2, ntiles, stride))
+    # the frame's cost = preprocess + binning forward (whole frame, timed exactly) + the tile part (sampled) + the backward
+    # of preprocess (whole frame, timed exactly).  The tile sample is split into four interleaved subsets, each rendered and
+    # differentiated down to the preprocess outputs on its own: four independent estimates of the per-tile cost, whose
+    # spread is the extrapolation's error bar
     t0 = time.time()
     pre = TR.preprocess(view, leaves[0], leaves[1], deg, shs=leaves[2], scales=leaves[3], rotations=leaves[4])
     point_list, ranges, _ = TR.bin_tiles(view, pre)
-    t1 = time.time()
-    color, _, _ = TR.render(view, pre, point_list, ranges, sc.bg, tiles=tiles)
-    if hdr:
-        color = TR.tonemap(color, sc.exposure, sc.crf_table, sc.crf_range)
-    (color * sc.dL_dimage).sum().backward()
+    t_pre = time.time() - t0
+    mids = [pre[k] for k in ("xy", "conic", "opacity", "rgb")]
+    acc = [torch.zeros_like(m) for m in mids]
+    n_sub = 4
+    per_tile_est, t_tiles = [], 0.0
+    for k in range(n_sub):
+        sub = tiles[k::n_sub]
+        t1 = time.time()
+        color, _, _ = TR.render(view, pre, point_list, ranges, sc.bg, tiles=sub)
+        if hdr:
+            color = TR.tonemap(color, sc.exposure, sc.crf_table, sc.crf_range)
+        g = torch.autograd.grad((color * sc.dL_dimage).sum(), mids, allow_unused=True)
+        dt = time.time() - t1
+        for a_, g_ in zip(acc, g):
+            if g_ is not None:
+                a_ += g_
+        per_tile_est.append(dt / len(sub))
+        t_tiles += dt
     t2 = time.time()
-    t_pre, t_tiles = t1 - t0, t2 - t1
+    torch.autograd.backward(mids, acc)
+    t_pre_bwd = time.time() - t2
     per_tile = t_tiles / len(tiles)
-    t_full = t_pre + per_tile * ntiles
+    t_full = t_pre + t_pre_bwd + per_tile * ntiles
+    est = [1.0 / (t_pre + t_pre_bwd + e * ntiles) for e in per_tile_est]
+    mean_e = sum(per_tile_est) / n_sub
+    std_err = (sum((e - mean_e) ** 2 for e in per_tile_est) / (n_sub - 1)) ** 0.5 / n_sub ** 0.5
     # c2 in full costs ~170 x the c1 frame just timed (151-165 s on the MI355X box's 128 host threads): run it unless that
     # prediction says the box's CPU would need more than six minutes for it (the default run must finish within minutes)
     c2_predicted = 170.0 * c1_med
@@ -288,9 +310,14 @@ def cpu_baseline(sc, cfg, n_tiles_sample=96, with_c2=False):
         out["c2_full"] = {"skipped": "--no-cpu-c2 given (about 150 s of CPU time); last measured: profiles/r02_cpu_baseline_c2.json"}
     torch_port = {
         "value": 1.0 / t_full, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-        "sample": (f"pure-PyTorch fp32 autograd rasterizer (oracle/torch_rasterizer.py): full preprocess+binning of "
-                   f"the {P}-Gaussian {W}x{H} frame ({t_pre:.1f} s) + fwd+bwd of {len(tiles)} of {ntiles} tiles "
-                   f"({t_tiles:.1f} s, backward also covers preprocess); value extrapolates the tile part to all tiles"),
+        "sample": (f"pure-PyTorch fp32 autograd rasterizer (oracle/torch_rasterizer.py) on the {P}-Gaussian {W}x{H} frame: "
+                   f"preprocess+binning forward of the whole frame ({t_pre:.1f} s) + preprocess backward of the whole frame "
+                   f"({t_pre_bwd:.1f} s), both exact, + render fwd+bwd of {len(tiles)} of {ntiles} tiles in {n_sub} interleaved "
+                   f"subsets ({t_tiles:.1f} s); value extrapolates the tile part only"),
+        "extrapolation": {"tiles_sampled": len(tiles), "tiles": ntiles, "subsets": n_sub,
+                          "images_per_s_by_subset": est, "per_tile_seconds_by_subset": per_tile_est,
+                          "per_tile_rel_std_err": std_err / mean_e,
+                          "exact_seconds": {"preprocess_and_binning_fwd": t_pre, "preprocess_bwd": t_pre_bwd}},
     }
     # the headline baseline is the one BASELINE.json's north_star words: the pure-PyTorch CPU rasterizer on the box's host
     # cores (bounded sample, extrapolated); the C oracle on ONE core -- the whole frame, no sampling, and ~50x faster than
@@ -853,6 +880,15 @@ def main():
             line["roofline"]["non_render"] = {"stages": non_render, "ms": nr_ms, "algorithmic_bytes": int(nr_b),
                                               "frac": nr_b / (nr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                               "frac_hbm_measured": nr_b / (nr_ms * 1e-3) / 1e9 / HBM_MEASURED_GBS}
+            # ... and as the step sees them: the whole step minus the two render launches timed alone.  Smaller than
+            # the sum of the stages: inside the step the CRF gradient's first stage runs as the last workgroups of
+            # render_bwd_kernel's launch (`crf_gradient` above is the stand-alone launch), and a stage replayed alone pays a
+            # launch latency the captured step does not
+            in_step_ms = ms_per_step - fwd_ms - bwd_ms
+            if in_step_ms > 0:
+                line["roofline"]["non_render"].update({
+                    "ms_in_step": in_step_ms, "frac_in_step": nr_b / (in_step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "in_step_note": "ms_per_step (the seed the stages were timed on) - render_fwd - render_bwd stage times"})
             off = offline_profile(cfg_name)
             if off is not None:
                 line["roofline"]["offline_profile"] = off
