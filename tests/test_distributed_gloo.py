@@ -1,4 +1,4 @@
-"""The N>1 path on CPU: world_size-2 gloo.  Each rank holds the same Gaussians, renders its own view with
+"""The N>1 path on CPU: gloo, world size 2 (and 3 / 4 where the number of peers matters).  Each rank holds the same Gaussians, renders its own view with
 the CPU oracle standing in for the MI355X kernels (the collective code is device-agnostic), packs the
 gradients the way rasterizer._launch_backward lays them out and all-reduces them with
 casualhdrsplat_amd.distributed; the result must equal the sum of the single-view gradients."""
@@ -73,10 +73,10 @@ def _worker_views(rank, world, port, q, early_gather=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("early_gather", [False, True])
-def test_view_exchange_equals_sum_of_single_view_gradients(oracle, early_gather):
-    """all-gather of per-view colour gradients + local SH outer product == all-reduce of the SH gradient rows."""
-    world = 2
+@pytest.mark.parametrize("early_gather,world", [(False, 2), (True, 2), (True, 4)])
+def test_view_exchange_equals_sum_of_single_view_gradients(oracle, early_gather, world):
+    """all-gather of per-view colour gradients + local SH outer product == all-reduce of the SH gradient rows.
+    (world 4: what the driver's scaling run meets first -- more ranks than the two-rank box the GPU tests can get)"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -126,9 +126,10 @@ def _worker(rank, world, port, shared_flat, q, algo="rccl"):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("shared_flat,algo", [(True, "rccl"), (False, "rccl"), (True, "direct")])
-def test_allreduce_equals_sum_of_single_view_gradients(oracle, shared_flat, algo):
-    world = 2
+@pytest.mark.parametrize("shared_flat,algo,world", [(True, "rccl", 2), (False, "rccl", 2), (True, "direct", 2),
+                                                    (True, "direct", 3), (True, "direct", 4), (False, "rccl", 4)])
+def test_allreduce_equals_sum_of_single_view_gradients(oracle, shared_flat, algo, world):
+    """(world 3: the 1-hop form's shards do not divide the buffer evenly -- its leftover path; world 4: several peers)"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -141,7 +142,7 @@ def test_allreduce_equals_sum_of_single_view_gradients(oracle, shared_flat, algo
         assert p.exitcode == 0
     want = [sum(x) for x in zip(*[_view_grads(r, world) for r in range(world)])]
     for g, w in zip(got, want):
-        assert np.allclose(g, w, rtol=1e-6, atol=1e-6 * np.abs(w).max())
+        assert np.allclose(g, w, rtol=1e-6 * world, atol=1e-6 * np.abs(w).max())
     assert np.abs(want[0]).max() > 0
 
 
@@ -215,10 +216,12 @@ def _worker_chunked(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_chunked_exchange_equals_one_all_reduce_bit_for_bit(oracle):
+@pytest.mark.parametrize("world", [2, 4])
+def test_chunked_exchange_equals_one_all_reduce_bit_for_bit(oracle, world):
     """the per-Gaussian backward in K ascending chunks, each chunk's gradient rows all-reduced while the
-    next computes == the sum of the single-view gradients, bit for bit the unchunked exchange."""
-    world = 2
+    next computes == the sum of the single-view gradients, bit for bit the unchunked exchange (two ranks: a + b in either
+    order; with more ranks the library may add a buffer's elements in an order that depends on where they lie in it, so
+    four ranks are held to the sum within rounding)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -229,11 +232,15 @@ def test_chunked_exchange_equals_one_all_reduce_bit_for_bit(oracle):
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    assert same and m2d_local
+    assert m2d_local and (same or world > 2)
     views = [_view_grads(r, world) for r in range(world)]
     for got, i in zip(rows, [0, 2, 4, 5, 3]):
-        want = views[0][i] + views[1][i]
-        assert np.array_equal(got, want) and np.abs(want).max() > 0
+        want = sum(v[i] for v in views)
+        if world == 2:
+            assert np.array_equal(got, want)
+        else:
+            assert np.allclose(got, want, rtol=1e-5, atol=1e-6 * np.abs(want).max())
+        assert np.abs(want).max() > 0
 
 
 def test_chunk_bounds_cover_the_cloud_in_aligned_ascending_pieces():

@@ -1031,9 +1031,10 @@ def test_sh_backward_views_kernel_vs_reference(deg, M):
         assert torch.count_nonzero(got[:, (deg + 1) ** 2:]) == 0
 
 
-def test_view_parallel_step_two_ranks_on_one_gpu():
-    """World size 2 (gloo, both ranks on this GPU): every exchange strategy of bench.py leaves each rank with the
-    sum of the two views' gradients.  The RCCL run over xGMI is the driver's 8-GPU bench; this covers the logic."""
+@pytest.mark.parametrize("world", [2, 4])
+def test_view_parallel_step_two_ranks_on_one_gpu(world):
+    """World size 2 and 4 (gloo, all ranks on this GPU): every exchange strategy of bench.py leaves each rank with the
+    sum of all views' gradients.  The RCCL run over xGMI is the driver's 8-GPU bench; this covers the logic."""
     import socket
     import subprocess
     import sys
@@ -1043,11 +1044,11 @@ def test_view_parallel_step_two_ranks_on_one_gpu():
     s.close()
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dist_gpu_worker.py")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
                         "--master-addr", "127.0.0.1", "--master-port", str(port), worker],
                        capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    assert r.stdout.count("VIEW-EXCHANGE-OK") == 2, r.stdout[-2000:]
+    assert r.stdout.count("VIEW-EXCHANGE-OK") == world, r.stdout[-2000:]
 
 
 def test_backward_in_gaussian_chunks_is_bit_identical_to_the_whole_backward():
