@@ -79,7 +79,8 @@ class hs_layout(C.Structure):
         "keys_sorted", "point_list", "pairs_tmp", "ranges", "sort_tmp", "depth_pairs", "inst_sorted", "offs_sorted", "pair_sort_tmp",
         "pair_flags", "pair_act",
         "final_T", "n_contrib", "pose_hdr", "tile_work", "tile_order",
-        "pair_grads", "crf_partials", "inst_grads", "pose_partials")]
+        "pair_grads", "crf_partials", "inst_grads", "pose_partials",
+        "tile_matrix")]
 
 
 EXPORTS = ("hs_version", "hs_last_error", "hs_plan", "hs_forward", "hs_backward", "hs_mark_visible",

@@ -50,6 +50,12 @@ bool scan_in_emission(int64_t I) {
     return forced >= 0 ? forced == 1 : (I >= (2 << 20) && !sort_tickets());
 }
 
+bool tile_sort_by_counting(int64_t I, int64_t vtiles, int64_t capacity) {
+    if (!HS_TUNE_COUNT_SORT || !count_sort_fits(I, vtiles, capacity)) return false;
+    const char* e = getenv("HS_TILE_SORT");   // (read at every forward: the test suite switches it inside one process)
+    return !(e && e[0] == 'r');
+}
+
 // Stamp of a single-enqueue forward (hs_common.h, kDepthBitsAt): never 0, never the same for two calls of a process that
 // could meet in the same memory (2^32 - 1 calls apart).  The only thing the library counts.
 // The count starts at a hashed value with the top bit set (process id x clock): small integers 1, 2, 3 ... are what recycled
@@ -122,6 +128,7 @@ static int plan(const hs_dims& d, hs_sizes* sz, hs_layout* L) {
     l.pair_sort_tmp = carve(emit_scan_words(I) * 4 + sort_tmp_bytes(d.capacity));
     l.pair_flags = carve(d.capacity);  // cleared by the pair emission, set by the render backward
     l.pair_act = carve(d.capacity);    // written by the render forward, read by the render backward
+    l.tile_matrix = carve(count_matrix_words(I, vtiles, d.capacity) * 4);   // small frames only (else empty)
     sz->binning_bytes = o;
     // image
     o = 0;
@@ -261,6 +268,10 @@ int hs_forward(const hs_fwd_args* a, void* hip_stream) {
         rc = launch_scan(*a, L, s);  // inspection only: a5 in instance order
         if (rc) return rc;
         if ((rc = launch_cov3d(*a, L, s))) return rc;   // ... and the 3-D covariances, which the pipeline does not keep
+        // ... and, for a frame whose pairs were sorted by counting, the sorted tile ids (the radix path leaves them behind)
+        const int64_t gx = (a->dims.W + kTile - 1) / kTile, gy = (a->dims.H + kTile - 1) / kTile;
+        if (a->binning && tile_sort_by_counting((int64_t)a->dims.P * a->dims.n_poses, gx * gy * a->dims.n_poses, a->dims.capacity))
+            if ((rc = launch_tile_keys(*a, L, s))) return rc;
     }
     if (a->stages & HS_STAGE_RENDER) {
         if (!a->binning || !a->image || !a->out_color) { set_error("hs_forward: null binning/image/out_color"); return HS_EINVAL; }

@@ -710,21 +710,26 @@ __device__ __forceinline__ uint64_t sc_read(const uint64_t* p) {
 // the verdict for the later kernels: n_sort = R, or 0 when R exceeds the binning capacity (or a wait gave up) -- then
 // nothing is sorted, the frame renders empty, and the host sees counters.overflow and replays with a larger capacity
 // (blocks that lie below the capacity have emitted their pairs by then: harmless, they are never looked at).
-template <bool BIG>   // BIG: the large-frame path (srect / block_excl null, non-temporal hints: see the rectangle gather below)
+// COUNT: the tile sort of a small frame is a counting sort (tile_colscan_kernel / tile_scatter_kernel below): instead of the
+// radix passes' digit totals the workgroup leaves, per (pose, tile) key, how many pairs EACH OF ITS FOUR WAVES emitted --
+// four byte fields of one word (a wave's 64 instances touch a tile at most once each) -- as row blockIdx of `tile_counts`.
+template <bool BIG, bool COUNT = false>   // BIG: the large-frame path (srect / block_excl null, non-temporal hints: see the rectangle gather below)
 __global__ void __launch_bounds__(256) emit_pairs_kernel(int64_t I, int P, int gx, int gy, float4* rec,
                                                          const uint32_t* inst_sorted, const uint2* binfo, const uint2* srect,
                                                          const uint32_t* block_excl, uint64_t* scan_status,
                                                          uint32_t* offs_sorted, uint2* pairs,
                                                          uint8_t* pair_flags, hs_counters* counters, uint64_t capacity,
                                                          uint32_t* ghist, int nbits, int passes,
-                                                         unsigned long long* depth_bits, int excl_ready) {
-    __shared__ uint32_t s_hist[4 * 256];   // digit totals of the tile sort's passes (<= 4), this block's pairs
+                                                         unsigned long long* depth_bits, int excl_ready,
+                                                         uint32_t* tile_counts = nullptr, int vtiles = 0) {
+    // digit totals of the tile sort's passes (<= 4), this block's pairs; COUNT: pairs per key, one byte field per wave
+    __shared__ uint32_t s_hist[COUNT ? kCountTilesMax : 4 * 256];
     __shared__ uint32_t s_beg[4][64];
     __shared__ uint4 s_own[4][64];         // per instance: key of its first tile, rectangle width, 1 / width (float), instance
     __shared__ uint32_t s_wsum[4];
     __shared__ unsigned long long s_wsum64[4];
     __shared__ uint64_t s_excl;            // pairs of all earlier blocks; kScPoison in the flag bits: a wait gave up
-    for (int t = threadIdx.x; t < passes * 256; t += 256) s_hist[t] = 0;
+    for (int t = threadIdx.x; t < (COUNT ? vtiles : passes * 256); t += 256) s_hist[t] = 0;
     // the depth sort is over: its tagged depth-bits words go back to empty, so a replayed graph (same tag every frame)
     // starts each frame's OR from nothing instead of from every earlier frame's bits
     if (blockIdx.x == 0 && threadIdx.x < 2 * kDepthBitsCopies) depth_bits[threadIdx.x] = 0ull;
@@ -886,6 +891,10 @@ __global__ void __launch_bounds__(256) emit_pairs_kernel(int64_t I, int P, int g
         if constexpr (BIG && (HS_EMIT_NT_MASK & 4)) { __builtin_nontemporal_store(key, &pairs[pos].x); __builtin_nontemporal_store(o.w, &pairs[pos].y); }
         else pairs[pos] = make_uint2(key, o.w);
         pair_flags[pos] = 0;  // "gradient record written" flag of this slot, set by the render backward
+        if constexpr (COUNT) {
+            atomicAdd(&s_hist[key], 1u << (8 * wave));
+            continue;
+        }
         // digit totals for the single-sweep tile sort.  The lanes of a wave hold neighbouring tiles of a few Gaussians:
         // when they all agree on a digit, one lane adds the count
         const uint64_t act = __ballot(true);
@@ -903,11 +912,180 @@ __global__ void __launch_bounds__(256) emit_pairs_kernel(int64_t I, int P, int g
         }
     }
     __syncthreads();
+    if constexpr (COUNT) {
+        uint32_t* row = tile_counts + (int64_t)blockIdx.x * vtiles;
+        for (int t = threadIdx.x; t < vtiles; t += 256) row[t] = s_hist[t];
+        return;
+    }
     uint32_t* mine = ghist + (blockIdx.x % kGhistCopies) * (8 * 256);
     for (int t = threadIdx.x; t < passes * 256; t += 256) {
         const uint32_t c = s_hist[t];
         if (c) atomicAdd(&mine[t], c);
     }
+}
+
+// ---------------------------------------------------------------- tile sort of small frames by counting (a7 + a8)
+// A frame of few tiles and few instances (count_sort_fits, hs_common.h: <= 4096 (pose, tile) keys, <= 2^21 entries in the
+// matrix below; BASELINE c2 = 2500 tiles x 391 emission workgroups) does not need radix passes over its pairs: the pair
+// emission walks the instances in depth order, so the sorted position of a pair is
+//     start of its tile + pairs of that tile emitted by EARLIER workgroups + ... by earlier waves of its workgroup
+//     + ... earlier in its own wave's walk,
+// i.e. a counting sort by the whole tile id, stable by construction.  Three kernels instead of emission + two radix passes
+// + tile ranges (each bound by its chain of dependent round trips at this size, not by bytes):
+//   1. emit_pairs_kernel<., COUNT>: row b of `counts` = pairs per tile of emission workgroup b, one byte per wave;
+//   2. tile_colscan_kernel: per tile, the exclusive prefix of the rows' totals down the column (`bases`) and the column
+//      total (`totals`);
+//   3. tile_scatter_kernel: workgroup b turns (scan of `totals`) + bases[b] + its waves' byte fields into one running
+//      position per (wave, tile) in LDS, and its waves re-walk their pairs (still in the emission's buffer, depth order)
+//      in the emission's order, handing out positions: point_list; workgroup 0 also writes the tile ranges
+//      (start, start + total) and the host copy of the frame's counters.  (The sorted tile ids -- keys_sorted, which the
+//      radix path needs for its tile ranges -- are nobody's input here: a second scattered 4-byte store per pair took the
+//      kernel from 15 to 22 us, so the inspection stage writes them from the ranges when somebody asks: tile_keys_kernel.)
+// No look-back chain, no status words, nothing to clear; results are bit for bit the radix path's (tests run both).
+constexpr int kColscanCols = 16, kColscanSlots = 64;   // a workgroup of tile_colscan_kernel: 16 columns x 64 row slots
+
+__device__ __forceinline__ uint32_t bytes_sum(uint32_t v) { return (v & 0xFFu) + ((v >> 8) & 0xFFu) + ((v >> 16) & 0xFFu) + (v >> 24); }
+
+__global__ void __launch_bounds__(kColscanCols * kColscanSlots) tile_colscan_kernel(const uint32_t* counts, int nrows, int vtiles,
+                                                                                const uint32_t* n_sort, uint32_t* bases,
+                                                                                uint32_t* totals) {
+    __shared__ uint32_t s_wsum[kColscanSlots / 4][kColscanCols];   // per wave (four row slots) and column
+    if (*n_sort == 0u) return;   // nothing to sort (no pairs, or the frame overflowed its capacity: rows may be missing)
+    const int c = threadIdx.x % kColscanCols, rs = threadIdx.x / kColscanCols;
+    const int t = blockIdx.x * kColscanCols + c;
+    const int rps = (nrows + kColscanSlots - 1) / kColscanSlots;          // consecutive rows per slot
+    const int r0 = min(nrows, rs * rps), r1 = min(nrows, r0 + rps);
+    const bool on = t < vtiles;
+    uint32_t sum = 0;
+    if (on) {
+#pragma unroll 8
+        for (int r = r0; r < r1; ++r) sum += bytes_sum(counts[(int64_t)r * vtiles + t]);
+    }
+    // rows above this thread's, same column: the wave's lanes are (row slot % 4, column) = (lane / 16, lane % 16) -- two
+    // shuffle steps inside the wave, then the sums of the waves in front
+    static_assert(kColscanCols == 16, "lane = 16 * (row slot % 4) + column");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = sum;
+    { const uint32_t u = __shfl_up(incl, 16); if (lane >= 16) incl += u; }
+    { const uint32_t u = __shfl_up(incl, 32); if (lane >= 32) incl += u; }
+    if (lane >= 48) s_wsum[wave][c] = incl;
+    __syncthreads();
+    uint32_t run = incl - sum, total = 0;
+#pragma unroll
+    for (int w = 0; w < kColscanSlots / 4; ++w) {
+        const uint32_t v = s_wsum[w][c];
+        if (w < wave) run += v;
+        total += v;
+    }
+    if (!on) return;
+    if (rs == 0) totals[t] = total;
+#pragma unroll 8
+    for (int r = r0; r < r1; ++r) {   // (second read of the rows: L2 hits)
+        const uint32_t v = counts[(int64_t)r * vtiles + t];
+        bases[(int64_t)r * vtiles + t] = run;
+        run += bytes_sum(v);
+    }
+}
+
+__global__ void __launch_bounds__(256) tile_scatter_kernel(int64_t I, int vtiles, const uint2* pairs, const uint32_t* offs_sorted,
+                                                           const uint32_t* counts, const uint32_t* bases, const uint32_t* totals,
+                                                           const uint32_t* n_sort, uint32_t* point_list,
+                                                           uint2* ranges, const hs_counters* counters, uint32_t* counters_host) {
+    extern __shared__ uint32_t s_pos[];      // [4][vtiles]: next position of (wave, key); [vtiles] more: tile starts
+    __shared__ uint32_t s_wave[4];
+    if (counters_host && blockIdx.x == 0 && threadIdx.x < 8)   // (what tile_ranges_kernel does on the radix path)
+        __hip_atomic_store(counters_host + threadIdx.x, reinterpret_cast<const uint32_t*>(counters)[threadIdx.x],
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (*n_sort == 0u) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int blk = blockIdx.x;
+    // Tile starts = exclusive scan of the column totals.  Everything is fetched with coalesced loads issued together (key
+    // k = thread + 256 j: the totals, this workgroup's rows of `counts` and `bases` -- up to 48 loads in flight per
+    // thread); the totals pass through LDS so that a thread can scan E CONSECUTIVE keys.
+    constexpr int JMAX = kCountTilesMax / 256;
+    uint32_t* const s_start = s_pos + 4 * vtiles;
+    const uint32_t* crow = counts + (int64_t)blk * vtiles;
+    const uint32_t* brow = bases + (int64_t)blk * vtiles;
+    uint32_t tv[JMAX], cv[JMAX], bv[JMAX];
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) {
+        const int k = (int)threadIdx.x + 256 * j;
+        const bool in = k < vtiles;
+        tv[j] = in ? totals[k] : 0u; cv[j] = in ? crow[k] : 0u; bv[j] = in ? brow[k] : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) {
+        const int k = (int)threadIdx.x + 256 * j;
+        if (k < vtiles) s_start[k] = tv[j];
+    }
+    __syncthreads();
+    {
+        const int E = (vtiles + 255) / 256;   // <= 16 consecutive keys per thread
+        const int k0 = min(vtiles, (int)threadIdx.x * E), k1 = min(vtiles, k0 + E);
+        uint32_t mine = 0;
+        for (int k = k0; k < k1; ++k) mine += s_start[k];
+        uint32_t all;
+        uint32_t start = block_incl_scan(mine, s_wave, &all) - mine;   // (its barriers order the reads above before the writes below)
+        for (int k = k0; k < k1; ++k) { const uint32_t tot = s_start[k]; s_start[k] = start; start += tot; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) {
+        const int k = (int)threadIdx.x + 256 * j;
+        if (k < vtiles) {
+            const uint32_t start = s_start[k], v = cv[j];
+            uint32_t p = start + bv[j];
+            s_pos[k] = p;                 p += v & 0xFFu;
+            s_pos[vtiles + k] = p;        p += (v >> 8) & 0xFFu;
+            s_pos[2 * vtiles + k] = p;    p += (v >> 16) & 0xFFu;
+            s_pos[3 * vtiles + k] = p;
+            if (blk == 0 && tv[j]) ranges[k] = make_uint2(start, start + tv[j]);   // (tiles without pairs keep their cleared (0, 0))
+        }
+    }
+    __syncthreads();
+    // this wave's slots: those of its 64 instances, [end of the instance before them, end of their last)
+    const int64_t i_first = (int64_t)blk * 256 + wave * 64;
+    if (i_first >= I) return;
+    const int64_t i_last = min(I, i_first + 64) - 1;
+    const uint32_t ws = i_first ? offs_sorted[i_first - 1] : 0u, we = offs_sorted[i_last];
+    uint32_t* const pos_w = s_pos + wave * vtiles;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    // (four rounds of 64 pairs requested at once: the walk is a chain of dependent LDS updates, its loads need not be)
+    for (uint32_t base4 = ws; base4 < we; base4 += 256) {
+        uint2 e4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t p = base4 + 64 * q + lane;
+            e4[q] = p < we ? pairs[p] : make_uint2(0u, 0u);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t base = base4 + 64 * q;
+            if (base >= we) break;
+            const uint2 e = e4[q];
+            const bool valid = base + lane < we;
+            uint64_t peers = __ballot(valid);   // match-any: lanes holding the same key
+#pragma unroll
+            for (int b = 0; b < 12; ++b) {
+                const uint64_t m = __ballot((e.x >> b) & 1u);
+                peers &= ((e.x >> b) & 1u) ? m : ~m;
+            }
+            if (valid) {
+                const uint32_t before = pos_w[e.x];                       // (all peers read before the last one writes: same wave)
+                const uint32_t dst = before + (uint32_t)__popcll(peers & lt_mask);
+                if ((peers >> lane) == 1ull) pos_w[e.x] = dst + 1u;
+                point_list[dst] = e.y;
+            }
+        }
+    }
+}
+
+// keys_sorted of a frame sorted by counting, from its tile ranges (HS_STAGE_OFFSETS, inspection only): one wave per tile
+__global__ void __launch_bounds__(256) tile_keys_kernel(const uint2* ranges, int vtiles, uint32_t capacity, uint32_t* keys_sorted) {
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= vtiles) return;
+    const uint2 r = ranges[t];
+    for (uint32_t p = r.x + (threadIdx.x & 63); p < min(r.y, capacity); p += 64) keys_sorted[p] = (uint32_t)t;
 }
 
 // ---------------------------------------------------------------- tile ranges (a8)
@@ -997,6 +1175,17 @@ int launch_scan(const hs_fwd_args& a, const hs_layout& L, hipStream_t s) {
                     (uint32_t*)(geom + L.offsets), &counters->num_rendered, s);
 }
 
+int launch_tile_keys(const hs_fwd_args& a, const hs_layout& L, hipStream_t s) {
+    const hs_dims& d = a.dims;
+    const int gx = (d.W + kTile - 1) / kTile, gy = (d.H + kTile - 1) / kTile;
+    const int vtiles = gx * gy * d.n_poses;
+    char* bin = (char*)a.binning;
+    tile_keys_kernel<<<ceil_div(vtiles, 4), 256, 0, s>>>((const uint2*)(bin + L.ranges), vtiles, (uint32_t)d.capacity,
+                                                        (uint32_t*)(bin + L.keys_sorted));
+    HS_LAUNCH_CHECK();
+    return HS_OK;
+}
+
 int launch_binning(const hs_fwd_args& a, const hs_layout& L, hipStream_t s, uint32_t frame_tag) {
     const hs_dims& d = a.dims;
     char* geom = (char*)a.geom;
@@ -1061,8 +1250,13 @@ int launch_binning(const hs_fwd_args& a, const hs_layout& L, hipStream_t s, uint
     uint32_t* offs = (uint32_t*)(bin + L.offs_sorted);   // inclusive pair offsets in depth order (the backward's segmented sum walks them)
     uint2* pA = (uint2*)(bin + L.keys_sorted);
     uint2* pB = (uint2*)(bin + L.pairs_tmp);
-    uint2* p0 = (passes % 2 == 0) ? pA : pB;
-    uint2* p1 = (passes % 2 == 0) ? pB : pA;
+    // small frames: counting sort by tile id (the kernels above); the emission then always writes buffer B
+    const bool counting = tile_sort_by_counting(I, ntiles, d.capacity);
+    uint2* p0 = (counting || passes % 2 != 0) ? pB : pA;
+    uint2* p1 = p0 == pA ? pB : pA;
+    uint32_t* t_counts = (uint32_t*)(bin + L.tile_matrix);            // [emission workgroup][key]: pairs, one byte per wave
+    uint32_t* t_bases = t_counts + (int64_t)ceil_div(I, 256) * ntiles; // ... pairs of that key in earlier workgroups
+    uint32_t* t_totals = t_bases + (int64_t)ceil_div(I, 256) * ntiles; // [key]
     // (the depth sort's two buffers are free again: they hold the gathered rectangles and their block sums when the
     // offsets are computed ahead of the emission)
     const int eblk = ceil_div(I, 256);
@@ -1079,10 +1273,22 @@ int launch_binning(const hs_fwd_args& a, const hs_layout& L, hipStream_t s, uint
 #define HS_EMIT_ARGS I, d.P, gx, gy, (float4*)(geom + L.rec), inst_sorted, (const uint2*)(geom + L.binfo), srect, block_excl,       \
                      scan_status, offs, p0, (uint8_t*)(bin + L.pair_flags), counters, (uint64_t)d.capacity, (uint32_t*)tmp2, tbits, \
                      passes, depth_bits, (int)excl_ready
-    if (srect) emit_pairs_kernel<false><<<eblk, 256, 0, s>>>(HS_EMIT_ARGS);
+    if (counting) {
+        if (srect) emit_pairs_kernel<false, true><<<eblk, 256, 0, s>>>(HS_EMIT_ARGS, t_counts, (int)ntiles);
+        else emit_pairs_kernel<true, true><<<eblk, 256, 0, s>>>(HS_EMIT_ARGS, t_counts, (int)ntiles);
+    } else if (srect) emit_pairs_kernel<false><<<eblk, 256, 0, s>>>(HS_EMIT_ARGS);
     else emit_pairs_kernel<true><<<eblk, 256, 0, s>>>(HS_EMIT_ARGS);
 #undef HS_EMIT_ARGS
     HS_LAUNCH_CHECK();
+    if (counting) {
+        tile_colscan_kernel<<<ceil_div(ntiles, kColscanCols), kColscanCols * kColscanSlots, 0, s>>>(
+            t_counts, eblk, (int)ntiles, n_sort, t_bases, t_totals);
+        tile_scatter_kernel<<<eblk, 256, (size_t)5 * ntiles * 4, s>>>(
+            I, (int)ntiles, p0, offs, t_counts, t_bases, t_totals, n_sort,
+            (uint32_t*)(bin + L.point_list), ranges, counters, (uint32_t*)a.counters_host);
+        HS_LAUNCH_CHECK();
+        return HS_OK;
+    }
     // 3. stable sort by tile id only
     uint32_t* keys_sorted = (uint32_t*)(bin + L.keys_sorted);
     int rc = radix_sort_packed<kPairSortItems, kPairSortLook>(p0, p1, keys_sorted, (uint32_t*)(bin + L.point_list), n_sort,

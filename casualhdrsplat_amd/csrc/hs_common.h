@@ -24,6 +24,11 @@ void set_error(const char* fmt, ...);
 #define HS_TUNE_CRF_IN_RENDER_TAIL 1
 #endif
 
+// A/B switch: the tile sort of small frames by counting (binning.hip)
+#ifndef HS_TUNE_COUNT_SORT
+#define HS_TUNE_COUNT_SORT 1
+#endif
+
 constexpr int kTile = HS_TILE;
 // Gathered / scattered records occupy one aligned 64-byte memory sector each (kRecF4 float4): a 48-byte record at a
 // 48-byte stride straddles two sectors half of the time, which showed up as 2-3x the algorithmic HBM traffic.
@@ -136,6 +141,21 @@ bool sort_tickets();
 // instances on; HS_SCAN_IN_EMISSION=1 / 0 in the environment forces it on / off (tests run both paths at small sizes).
 bool scan_in_emission(int64_t I);
 static inline int sort_passes(int nbits) { return (nbits + 7) / 8; }
+// Tile sort of a small frame by counting instead of radix passes (binning.hip): the dims qualify when the (pose, tile) keys
+// fit the per-workgroup tables and the (emission workgroup x key) matrices stay small; the binning workspace then carries
+// the matrices (hs_layout.tile_matrix: counts | bases | totals).  HS_TILE_SORT=radix in the environment keeps the radix
+// passes (tests run both paths; read at every forward).
+constexpr int kCountTilesMax = 4096;
+constexpr int64_t kCountMatrixMax = 1ll << 21;
+static inline bool count_sort_fits(int64_t I, int64_t vtiles, int64_t capacity) {
+    return capacity > 0 && I > 0 && vtiles <= kCountTilesMax && ((I + 255) / 256) * vtiles <= kCountMatrixMax;
+}
+static inline int64_t count_matrix_words(int64_t I, int64_t vtiles, int64_t capacity) {
+    return count_sort_fits(I, vtiles, capacity) ? 2 * ((I + 255) / 256) * vtiles + vtiles : 0;
+}
+bool tile_sort_by_counting(int64_t I, int64_t vtiles, int64_t capacity);
+// keys_sorted of a frame whose pairs were sorted by counting, from its tile ranges (inspection: HS_STAGE_OFFSETS)
+int launch_tile_keys(const hs_fwd_args& a, const hs_layout& L, hipStream_t s);
 
 // ---- small device helpers ----
 // OR `bits` into a tagged word (see kDepthBitsAt): a word carrying another tag counts as empty

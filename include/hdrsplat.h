@@ -35,7 +35,7 @@ extern "C" {
 /* libhdrsplat.so is built with -fvisibility=hidden: the hs_* entry points below are its only exported symbols */
 #define HS_API __attribute__((visibility("default")))
 
-#define HS_VERSION 304
+#define HS_VERSION 305
 
 #define HS_OK 0
 #define HS_EINVAL (-1)    /* bad argument (null pointer, bad shape, unsupported degree ...) */
@@ -53,7 +53,8 @@ extern "C" {
 #define HS_STAGE_ALL 7
 #define HS_STAGE_OFFSETS 8    /* inspection only: inclusive scan of tiles_touched in instance order into the geom
                                  workspace (`offsets`; the pipeline itself scans the depth-ordered counts) and the 3-D
-                                 covariances (`cov3D`; the pipeline recomputes them in the backward instead of storing) */
+                                 covariances (`cov3D`; the pipeline recomputes them in the backward instead of storing);
+                                 (HS_VERSION 305) with a binning workspace of a frame sorted by counting, also keys_sorted */
 
 #define HS_STAGE_PREPROCESS_ONLY 16 /* profiling (bench.py's per-kernel roofline leg): with PREPROCESS | BIN, enqueue the
                                  preprocess kernel exactly as a single-enqueue forward does -- carrying the binning stage's
@@ -244,6 +245,12 @@ typedef struct hs_layout {
     /* bwd workspace */
     /* inst_grads: 12 floats per instance, the per-instance sum of its (flagged) pair records */
     int64_t pair_grads, crf_partials, inst_grads, pose_partials;
+    /* (HS_VERSION 305) tile_matrix (binning workspace; empty unless the frame is small: <= 4096 (pose, tile) keys and
+     * <= 2^21 (emission workgroup, key) entries): scratch of the counting tile sort such frames get instead of radix passes
+     * -- u32 [ceil(I/256)][keys] pair counts (one byte per wave) | u32 [ceil(I/256)][keys] pairs of the key in earlier
+     * workgroups | u32 [keys] totals.  Such a forward writes point_list and ranges but NOT keys_sorted (nothing reads it);
+     * HS_STAGE_OFFSETS fills keys_sorted from the ranges for inspection. */
+    int64_t tile_matrix;
 } hs_layout;
 
 HS_API int hs_version(void);

@@ -104,25 +104,31 @@ def test_ldr_forward_backward_vs_oracle(oracle, P, W, H, deg, seed):
     Hh.assert_grads_bounded(g2, b2, what=f"P={P} masked")
 
 
-@pytest.fixture(params=["default", "tickets", "scan_in_emission"])
+@pytest.fixture(params=["default", "tickets", "scan_in_emission", "radix_tile_sort", "scan_in_emission+counting"])
 def binning_mode(request):
     """The binning stage's alternate forms inside the driver's suite: chain positions of the radix
     passes from start-order tickets (hs_sort_tickets(1): what a process on a shared GPU runs) and the pair emission
     computing its block offsets itself by decoupled look-back (HS_SCAN_IN_EMISSION=1: what frames of >= 2^21 instances
-    run), each forced onto frames that would take the default form."""
+    run), each forced onto frames that would take the default form.  Small frames (<= 4096 tiles, a few hundred thousand
+    instances: most of this suite) sort their pairs by counting instead of radix passes: "tickets" and "scan_in_emission"
+    keep the radix passes on them as well (HS_TILE_SORT=radix), "radix_tile_sort" only does that, and
+    "scan_in_emission+counting" runs the counting sort behind the chained-scan emission."""
     from casualhdrsplat_amd import _lib as L
     lib = L.load()
-    was, env = lib.hs_sort_tickets(-1), os.environ.get("HS_SCAN_IN_EMISSION")
+    was, env = lib.hs_sort_tickets(-1), {k: os.environ.get(k) for k in ("HS_SCAN_IN_EMISSION", "HS_TILE_SORT")}
     if request.param == "tickets":
         lib.hs_sort_tickets(1)
-    elif request.param == "scan_in_emission":
+    if request.param.startswith("scan_in_emission"):
         os.environ["HS_SCAN_IN_EMISSION"] = "1"
+    if request.param in ("tickets", "scan_in_emission", "radix_tile_sort"):
+        os.environ["HS_TILE_SORT"] = "radix"
     yield request.param
     lib.hs_sort_tickets(was)
-    if env is None:
-        os.environ.pop("HS_SCAN_IN_EMISSION", None)
-    else:
-        os.environ["HS_SCAN_IN_EMISSION"] = env
+    for k, v in env.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
 
 
 @pytest.mark.parametrize("case", ["ldr_20000", "tiles_14400", "c1_hdr_fixture"])
@@ -1379,6 +1385,10 @@ def test_randomized_configurations_vs_oracle(oracle):
     rng = np.random.default_rng(int(os.environ.get("HS_SWEEP_SEED", "2026")))
     for case in range(int(os.environ.get("HS_SWEEP_CASES", "24"))):
         c = Hh.sweep_case(rng, case)
+        # (these frames are small: by default their pairs are sorted by counting; every third case keeps the radix passes)
+        os.environ.pop("HS_TILE_SORT", None)
+        if case % 3 == 2:
+            os.environ["HS_TILE_SORT"] = "radix"
         P, W, H, n_poses, hdr, act, dom = c["P"], c["W"], c["H"], c["n_poses"], c["hdr"], c["act"], c["dom"]
         sc, cams, precomp, what = c["sc"], c["cams"], c["precomp"], c["what"]
         if hdr or n_poses > 1:
@@ -1428,6 +1438,7 @@ def test_randomized_configurations_vs_oracle(oracle):
             m = Hh.decision_masks(oracle, sc, [f], st, what=what)
             check_image(g["color"], f["color"], m, what)
             Hh.assert_grads_close(g, b, keys=keys, what=what, at_risk=m["rows"], **SWEEP_BAR)
+    os.environ.pop("HS_TILE_SORT", None)
 
 
 def test_c_abi_from_a_plain_cpp_host(tmp_path, oracle):
