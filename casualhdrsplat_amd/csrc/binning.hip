@@ -956,8 +956,18 @@ __global__ void __launch_bounds__(kColscanCols * kColscanSlots) tile_colscan_ker
     const int rps = (nrows + kColscanSlots - 1) / kColscanSlots;          // consecutive rows per slot
     const int r0 = min(nrows, rs * rps), r1 = min(nrows, r0 + rps);
     const bool on = t < vtiles;
+    // (up to eight rows per slot -- 512 emission workgroups, 131 k instances -- stay in registers for the second walk)
+    constexpr int KEEP = 8;
+    const bool keep = rps <= KEEP;
+    uint32_t kept[KEEP];
     uint32_t sum = 0;
-    if (on) {
+    if (on && keep) {
+#pragma unroll
+        for (int j = 0; j < KEEP; ++j) {
+            kept[j] = r0 + j < r1 ? counts[(int64_t)(r0 + j) * vtiles + t] : 0u;
+            sum += bytes_sum(kept[j]);
+        }
+    } else if (on) {
 #pragma unroll 8
         for (int r = r0; r < r1; ++r) sum += bytes_sum(counts[(int64_t)r * vtiles + t]);
     }
@@ -979,6 +989,14 @@ __global__ void __launch_bounds__(kColscanCols * kColscanSlots) tile_colscan_ker
     }
     if (!on) return;
     if (rs == 0) totals[t] = total;
+    if (keep) {
+#pragma unroll
+        for (int j = 0; j < KEEP; ++j) {
+            if (r0 + j < r1) bases[(int64_t)(r0 + j) * vtiles + t] = run;
+            run += bytes_sum(kept[j]);
+        }
+        return;
+    }
 #pragma unroll 8
     for (int r = r0; r < r1; ++r) {   // (second read of the rows: L2 hits)
         const uint32_t v = counts[(int64_t)r * vtiles + t];

@@ -545,6 +545,37 @@ def test_frame_of_14400_tiles_vs_oracle(oracle):
     Hh.assert_grads_close(g, b, what="14400 tiles", at_risk=m["rows"], min_strict=0.95)
 
 
+@pytest.mark.parametrize("P,W,H,n_poses", [(150000, 320, 240, 1), (3000, 1024, 1024, 1), (700, 256, 256, 16)])
+def test_counting_tile_sort_edges_vs_oracle(oracle, P, W, H, n_poses):
+    """The tile sort of small frames by counting (binning.hip) at its edges: 586 emission workgroups (more than eight rows
+    per row slot of the column scan: the rows are walked twice instead of kept in registers), exactly 4096 tiles (the
+    largest key table; every thread of the scatter owns 16 keys), 16 poses x 256 tiles (keys = pose * tiles + tile up to
+    the limit).  Structure bit-exact against the oracle, and the same bits with the radix passes forced."""
+    sc = S.make_scene(P, W, H, 1, seed=41)
+    cams = S.blur_poses(W, H, n_poses, step=0.01) if n_poses > 1 else [sc.camera]
+    fs = [Hh.run_oracle(oracle, sc, cam=c, backward=False)[0] for c in cams]
+    R = sum(f["R"] for f in fs)
+    pl = np.concatenate([f["point_list"].astype(np.int64) + k * P for k, f in enumerate(fs)])
+    off = np.cumsum([0] + [f["R"] for f in fs])
+    ranges = np.concatenate([np.where((f["ranges"][:, 1] > f["ranges"][:, 0])[:, None], f["ranges"].astype(np.int64) + off[k], 0)
+                             for k, f in enumerate(fs)])
+    got = {}
+    for mode in ("count", "radix"):
+        os.environ.pop("HS_TILE_SORT", None)
+        if mode == "radix":
+            os.environ["HS_TILE_SORT"] = "radix"
+        try:
+            g = Hh.run_hip(sc, cameras=cams if n_poses > 1 else None, capacity=R + 5)
+        finally:
+            os.environ.pop("HS_TILE_SORT", None)
+        st = g["state"]
+        assert st["num_rendered"] == R
+        assert np.array_equal(st["point_list"][:R].astype(np.int64), pl), mode
+        assert np.array_equal(st["ranges"].astype(np.int64), ranges), mode
+        got[mode] = (st["keys_sorted"][:R].copy(), g["color"].copy())
+    assert np.array_equal(got["count"][0], got["radix"][0]) and np.array_equal(Hh.bits(got["count"][1]), Hh.bits(got["radix"][1]))
+
+
 def _with_depths(sc, z_new):
     """The same cloud as seen on screen, moved to the depths `z_new` (means and scales scale with z / z_old)."""
     z_new = torch.as_tensor(z_new, dtype=torch.float32)
