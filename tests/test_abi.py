@@ -85,6 +85,23 @@ def test_version_and_plan(lib):
     assert sz8.geom_bytes > 7 * sz.geom_bytes * 0.8 and sz8.image_bytes > 8 * 1920 * 1080 * 20
 
 
+def test_plan_carries_the_counting_sorts_matrices_for_small_frames_only(lib):
+    """hs_layout.tile_matrix (HS_VERSION 305): frames of <= 4096 (pose, tile) keys and <= 2^21 (emission workgroup, key)
+    entries get the two u32 matrices + the totals row of the counting tile sort at the end of the binning workspace; larger
+    frames -- BASELINE c3, c4 -- get an empty region."""
+    def tail(P, W, H, N, cap):
+        _, sz, lay = lib.plan(P, 1, 0, W, H, N, cap)
+        assert lay.tile_matrix % 256 == 0 and lay.tile_matrix >= lay.pair_act
+        return sz.binning_bytes - lay.tile_matrix
+    rows, keys = (100_000 + 255) // 256, 50 * 50
+    assert (2 * rows * keys + keys) * 4 <= tail(100_000, 800, 800, 1, 900_000) < (2 * rows * keys + keys) * 4 + 256   # c2
+    assert tail(1_000_000, 1920, 1080, 1, 7_000_000) == 0                                                           # c3: 8160 tiles
+    assert tail(600_000, 800, 800, 1, 4_000_000) == 0            # 2344 workgroups x 2500 keys > 2^21 entries
+    assert tail(10_000, 1024, 1024, 1, 100_000) > 0 and tail(10_000, 1040, 1024, 1, 100_000) == 0   # 4096 / 4160 tiles
+    assert tail(700, 256, 256, 16, 10_000) > 0 and tail(700, 256, 256, 17, 10_000) == 0             # 16 / 17 poses x 256 tiles
+    assert tail(10_000, 800, 800, 1, 0) == 0                    # no binning capacity: nothing to sort
+
+
 def test_plan_rejects_bad_dims(lib):
     L = lib.load()
     d = lib.hs_dims(-1, 0, 0, 16, 16, 1, 0)
