@@ -223,8 +223,29 @@ class HDRBlurFormation(nn.Module):
         campos = -(w2c[:, :3, :3].transpose(1, 2) @ w2c[:, :3, 3:])[..., 0]
         return w2c.transpose(1, 2).contiguous(), full.transpose(1, 2).contiguous(), campos.contiguous()
 
-    def forward(self, i: int, means3D, opacities, shs, scales, rotations, bg=None):
-        V, PV, Cp = self.cameras(i)
+    def cameras_all(self):
+        """The cameras of EVERY captured frame from one pass over the spline: (viewmatrices [F,N,4,4], projmatrices
+        [F,N,4,4], camposes [F,N,3]).  The pose arithmetic is a few hundred tiny tensor operations whatever the number of
+        poses, and its cost is the host's launch time (about 9 ms per call forward + backward in eager mode, against
+        0.5 ms for the rasterizer at 20 k Gaussians): a step over several frames computes them once, hands frame i its
+        slice (`forward(i, ..., cameras=...)`) and back-propagates the summed loss once."""
+        dt = self.log_exposure.dtype
+        n = self.n_virtual
+        width = (torch.exp(self.log_exposure) * self.window_scale if self.window_from_exposure
+                 else torch.ones_like(self.log_exposure))
+        s = (torch.arange(n, dtype=dt, device=width.device) + 0.5) / n - 0.5
+        times = self.frame_times.to(dt)[:, None] + s[None, :] * width[:, None]                 # [F, N]
+        w2c = self.trajectory.pose_at(times.reshape(-1))
+        proj = projection_matrix(self.tanfovx, self.tanfovy, device=w2c.device).to(w2c.dtype)
+        full = proj[None] @ w2c
+        campos = -(w2c[:, :3, :3].transpose(1, 2) @ w2c[:, :3, 3:])[..., 0]
+        F = times.shape[0]
+        return (w2c.transpose(1, 2).reshape(F, n, 4, 4).contiguous(), full.transpose(1, 2).reshape(F, n, 4, 4).contiguous(),
+                campos.reshape(F, n, 3).contiguous())
+
+    def forward(self, i: int, means3D, opacities, shs, scales, rotations, bg=None, cameras=None):
+        """`cameras`: the result of cameras_all() (frame i takes its slice) instead of a spline pass of its own."""
+        V, PV, Cp = self.cameras(i) if cameras is None else (cameras[0][i], cameras[1][i], cameras[2][i])
         dev = means3D.device
         bg = torch.zeros(3, device=dev) if bg is None else bg
         settings = GaussianRasterizationSettings(

@@ -85,14 +85,19 @@ def run(P=20000, W=320, H=208, frames=4, virtual=5, steps=200, seed=0, deg=1, lo
     for it in range(steps + 1):
         opt.zero_grad(set_to_none=True)
         total, ps = 0.0, 0.0
+        # one pass over the spline for all frames (its few hundred tiny tensor operations are the step's host cost), one
+        # rasterizer call per frame, one backward of the summed loss
+        cams = model.cameras_all()
+        opac = torch.sigmoid(raw_opac)
+        loss_sum = 0.0
         for i in range(frames):
-            ldr, _, _, _ = model(i, fixed["means3D"], torch.sigmoid(raw_opac), shs, fixed["scales"], fixed["rotations"])
+            ldr, _, _, _ = model(i, fixed["means3D"], opac, shs, fixed["scales"], fixed["rotations"], cameras=cams)
             loss = (ldr - targets[i]).abs().mean()
-            if it < steps:
-                loss.backward()
+            loss_sum = loss_sum + loss
             total += float(loss.detach())
             ps += psnr(ldr.detach(), targets[i])
         if it < steps:
+            loss_sum.backward()
             g0 = model.log_exposure.grad
             if g0 is not None:
                 g0[0] = 0.0                                    # frame 0's exposure is the gauge

@@ -136,6 +136,33 @@ def test_exposure_time_sets_the_blur_extent():
     assert pinned.log_exposure.grad is None or float(pinned.log_exposure.grad.abs().sum()) == 0
 
 
+def test_cameras_of_all_frames_in_one_pass_equal_the_per_frame_cameras():
+    """HDRBlurFormation.cameras_all(): one pass over the spline for every captured frame (the pose arithmetic's cost is the
+    host's launch time, independent of the number of poses) gives frame i exactly cameras(i), values and gradients --
+    also the gradient of the exposure times through the window length."""
+    torch.manual_seed(5)
+    for wfe in (False, True):
+        m = IF.HDRBlurFormation(IF.TrajectorySpline(IF.knots_from_lookat(7, radius=0.25), kind="cubic"), 4, 64, 48, 0.5, 0.4,
+                                n_virtual=5, crf=IF.ImplicitCRF(K=16), sh_degree=1, window_from_exposure=wfe, window_scale=0.6,
+                                rasterizer_factory=None)
+        with torch.no_grad():
+            m.log_exposure.copy_(torch.tensor([0.0, -0.5, 0.4, 0.1]))
+            m.trajectory.delta.normal_(0, 0.01)
+        w = [torch.randn(5, 4, 4), torch.randn(5, 4, 4), torch.randn(5, 3)]
+        allc = m.cameras_all()
+        assert allc[0].shape == (4, 5, 4, 4) and allc[2].shape == (4, 5, 3)
+        for i in range(4):
+            one = m.cameras(i)
+            assert all(torch.equal(a[i], b) for a, b in zip(allc, one))
+        g_all = torch.autograd.grad(sum((a[2] * x).sum() for a, x in zip(allc, w)), [m.trajectory.delta, m.log_exposure],
+                                    allow_unused=True)
+        g_one = torch.autograd.grad(sum((a * x).sum() for a, x in zip(m.cameras(2), w)), [m.trajectory.delta, m.log_exposure],
+                                    allow_unused=True)
+        assert torch.allclose(g_all[0], g_one[0], rtol=1e-5, atol=1e-7)
+        if wfe:
+            assert g_one[1].abs().sum() > 0 and torch.allclose(g_all[1], g_one[1], rtol=1e-5, atol=1e-7)
+
+
 def test_crf_table_is_monotone_and_normalised():
     crf = IF.ImplicitCRF(K=64)
     tab = crf.table()
