@@ -935,22 +935,40 @@ __global__ void __launch_bounds__(256) pose_reduce1_kernel(const float* partials
     for (int r = r0; r < r1; ++r) acc += partials[(int64_t)r * cols + col];
     stage[(int64_t)chunk * cols + col] = acc;
 }
+// One thread per OUTPUT element -- 16 + 16 + 3 per pose -- so that the matrix entries no pose term maps to (column 3 of the view
+// matrix rows, column 2 of the projection rows) are written as zeros by this kernel.  (They used to be cleared by two
+// hipMemsetAsync ahead of it: inside a captured step -- graphs.GraphedStep -- those became memset nodes whose effect raced with
+// this kernel's stores: the two gradients differed from replay to replay.  No memset on the backward's path any more.)
 __global__ void __launch_bounds__(256) pose_reduce2_kernel(const float* stage, int N, float* d_view, float* d_proj,
                                                            float* d_campos) {
-    const int col = blockIdx.x * 256 + threadIdx.x;
-    const int cols = N * kPoseVals;
-    if (col >= cols) return;
-    float acc = 0.f;
-    for (int c = 0; c < kPoseChunks; ++c) acc += stage[(int64_t)c * cols + col];
-    const int pose = col / kPoseVals, k = col % kPoseVals;
-    if (k < 12) {  // pg[3j+i] <-> viewmatrix flat[4j+i], i < 3
-        d_view[16 * pose + 4 * (k / 3) + (k % 3)] = acc;
-    } else if (k < 24) {  // pg[12+3j+r] <-> projmatrix flat[4j + {0,1,3}[r]]
-        const int q = k - 12, r = q % 3;
-        d_proj[16 * pose + 4 * (q / 3) + (r == 2 ? 3 : r)] = acc;
-    } else if (k < 27) {
-        d_campos[3 * pose + (k - 24)] = acc;
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= N * 35) return;
+    const int pose = o / 35, e = o % 35;
+    int k = -1;   // the pose term behind this element (none: zero)
+    if (e < 16) {            // pg[3j+i] <-> viewmatrix flat[4j+i], i < 3
+        const int j = e / 4, i = e % 4;
+        if (i < 3) k = 3 * j + i;
+    } else if (e < 32) {     // pg[12+3j+r] <-> projmatrix flat[4j + {0,1,3}[r]]
+        const int q = e - 16, j = q / 4, c = q % 4;
+        if (c != 2) k = 12 + 3 * j + (c == 3 ? 2 : c);
+    } else {
+        k = 24 + (e - 32);
     }
+    float acc = 0.f;
+    if (k >= 0) {
+        const int cols = N * kPoseVals, col = pose * kPoseVals + k;
+        for (int c = 0; c < kPoseChunks; ++c) acc += stage[(int64_t)c * cols + col];
+    }
+    if (e < 16) d_view[16 * pose + e] = acc;
+    else if (e < 32) d_proj[16 * pose + (e - 16)] = acc;
+    else d_campos[3 * pose + (e - 32)] = acc;
+}
+
+__global__ void __launch_bounds__(256) fill_i32_kernel(int* dst, int64_t n, int v) {
+    const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (i0 + k < n) dst[i0 + k] = v;
 }
 
 }  // namespace
@@ -986,7 +1004,10 @@ int launch_preprocess_fwd(const hs_fwd_args& a, const hs_layout& L, hipStream_t 
         p.n_pair_zero = pair_scratch_words((int64_t)d.P * d.n_poses, d.capacity,
                                            sort_passes(tile_bits((uint32_t)p.n_vtiles)));
     }
-    if (d.n_poses > 1) HS_HIP_CHECK(hipMemsetAsync(a.radii, 0, sizeof(int) * (size_t)d.P, s));
+    // (N poses: the per-Gaussian output radius is the max over the poses, by atomicMax -- cleared by a kernel, not by
+    // hipMemsetAsync: inside a captured step a memset node's effect was seen to race with the kernel behind it, see
+    // pose_reduce2_kernel)
+    if (d.n_poses > 1 && d.P > 0) fill_i32_kernel<<<ceil_div((int64_t)d.P, 1024), 256, 0, s>>>(a.radii, (int64_t)d.P, 0);
     // chunks of 256 Gaussians, padded to a multiple of the 8 XCDs, times the poses (see the kernel's block map)
     const int grid = (int)(ceil_div(ceil_div((int64_t)d.P, 256), 8) * 8 * d.n_poses);
     const int deg = a.colors_precomp ? 0 : d.sh_degree;
@@ -1063,12 +1084,9 @@ int launch_preprocess_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t 
         const int grid = nblk_all;
         const int cols = d.n_poses * kPoseVals;
         float* stage = pose_partials + (int64_t)grid * cols;
-        // unused matrix entries (row 3 of the view matrix, row 2 of the projection) stay zero
-        HS_HIP_CHECK(hipMemsetAsync(a.dL_dviewmatrices, 0, sizeof(float) * 16 * d.n_poses, s));
-        HS_HIP_CHECK(hipMemsetAsync(a.dL_dprojmatrices, 0, sizeof(float) * 16 * d.n_poses, s));
         pose_reduce1_kernel<<<dim3(ceil_div(cols, 256), kPoseChunks), 256, 0, s>>>(pose_partials, grid, cols, stage);
-        pose_reduce2_kernel<<<ceil_div(cols, 256), 256, 0, s>>>(stage, d.n_poses, a.dL_dviewmatrices, a.dL_dprojmatrices,
-                                                               a.dL_dcamposes);
+        pose_reduce2_kernel<<<ceil_div(d.n_poses * 35, 256), 256, 0, s>>>(stage, d.n_poses, a.dL_dviewmatrices,
+                                                                        a.dL_dprojmatrices, a.dL_dcamposes);
         HS_LAUNCH_CHECK();
     }
     return HS_OK;

@@ -41,6 +41,7 @@ class GraphedStep:
                 raise ValueError("GraphedStep needs GaussianRasterizer(..., capacity=N): the synchronous mode reads "
                                  "num_rendered on the host inside every forward and cannot be captured")
         self.rasterizers = list({id(r): r for r in rasterizers}.values())   # (a rasterizer listed twice counts once)
+        self._drop_stale_graph_refs()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -50,11 +51,16 @@ class GraphedStep:
         torch.cuda.synchronize()
         for r in self.rasterizers:   # an overflow during warm-up: fail before capturing a graph that renders empty frames
             r.check_overflow()
+        self._drop_stale_graph_refs()
         for r in self.rasterizers:
             r._cell["captured"] = []     # every forward a rasterizer enqueues while the stream captures lands here
         self.graph = torch.cuda.CUDAGraph()
         try:
-            with torch.cuda.graph(self.graph):
+            # (captured on the warm-up's stream: the AccumulateGrad nodes the warm-up left alive -- any leaf whose graph is
+            # still referenced somewhere -- belong to that stream; on another stream the engine would run them across a
+            # fork of the capture, where a gradient buffer can be handed back to the pool and reused before the forked
+            # copy has read it: replays then deliver garbage gradients now and then)
+            with torch.cuda.graph(self.graph, stream=side):
                 self.outputs = fn()
         finally:
             # (also when `fn` throws inside the capture: a list left behind would make the rasterizer's later eager
@@ -73,6 +79,20 @@ class GraphedStep:
         self._warned_helps = False
         # `params`: the leaves whose gradients the step produces -- `grads` are the static tensors every replay rewrites
         self.grads = [p.grad for p in params]
+
+    def _drop_stale_graph_refs(self):
+        """A rasterizer keeps its `raster_settings` between calls; when a step assigns settings whose tensors are COMPUTED
+        (camera matrices from a trajectory, an exposure from its logarithm: non-leaves with a grad_fn), the rasterizer keeps
+        the previous step's autograd graph alive through them -- and with it the AccumulateGrad nodes of the leaves behind,
+        bound to the stream that step ran on.  The next step finds those nodes still alive and reuses them; if the earlier
+        step ran eagerly on the default stream, the capture's backward then touches the default stream and the capture
+        dies (a segmentation fault inside hipStreamEndCapture on ROCm 7).  A computed tensor left in the settings by an
+        earlier step can only be stale, so it is replaced by its detached self before the warm-up and before the capture."""
+        for r in self.rasterizers:
+            rs = r.raster_settings
+            stale = {k: v.detach() for k, v in rs._asdict().items() if isinstance(v, torch.Tensor) and v.grad_fn is not None}
+            if stale:
+                r.raster_settings = rs._replace(**stale)
 
     def step(self):
         """Enqueue one replay; returns the (static) outputs of `fn`."""

@@ -36,6 +36,12 @@ import torch.nn as nn
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
 
 
+def _mm(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
+    """A @ B for stacks of 3 x 3 / 4 x 4 blocks as one broadcast multiply and one sum: a BLAS call per product costs the
+    host five times as much at this size (26 us against 2 x 5), and a step makes dozens of them."""
+    return (A.unsqueeze(-1) * B.unsqueeze(-3)).sum(-2)
+
+
 def _hat(w: torch.Tensor) -> torch.Tensor:
     z = torch.zeros_like(w[..., 0])
     return torch.stack([torch.stack([z, -w[..., 2], w[..., 1]], -1), torch.stack([w[..., 2], z, -w[..., 0]], -1),
@@ -53,11 +59,11 @@ def se3_exp(xi: torch.Tensor) -> torch.Tensor:
     B = torch.where(small, 0.5 - th2 / 24, (1 - torch.cos(th)) / (th2 + 1e-20))
     Cc = torch.where(small, 1.0 / 6 - th2 / 120, (1 - A) / (th2 + 1e-20))
     K = _hat(om)
-    K2 = K @ K
+    K2 = _mm(K, K)
     eye = torch.eye(3, dtype=xi.dtype, device=xi.device).expand(K.shape)
     R = eye + A[..., None, None] * K + B[..., None, None] * K2
     V = eye + B[..., None, None] * K + Cc[..., None, None] * K2
-    t = (V @ rho[..., None])[..., 0]
+    t = _mm(V, rho[..., None])[..., 0]
     T = torch.zeros(*xi.shape[:-1], 4, 4, dtype=xi.dtype, device=xi.device)
     T[..., :3, :3] = R
     T[..., :3, 3] = t
@@ -103,11 +109,11 @@ class TrajectorySpline(nn.Module):
         return (1.0, float(J - 2)) if self.kind == "cubic" else (0.0, float(J - 1))
 
     def knot(self, j: int) -> torch.Tensor:
-        return se3_exp(self.delta[j]) @ self.base[j]
+        return _mm(se3_exp(self.delta[j]), self.base[j])
 
     def knots(self) -> torch.Tensor:
         """All corrected control knots [J, 4, 4]."""
-        return se3_exp(self.delta) @ self.base.to(self.delta.dtype)
+        return _mm(se3_exp(self.delta), self.base.to(self.delta.dtype))
 
     def pose_at(self, t: torch.Tensor) -> torch.Tensor:
         """World-to-camera matrices [n, 4, 4] at times t [n]; differentiable w.r.t. the knots AND w.r.t. t.  Pure tensor
@@ -115,17 +121,17 @@ class TrajectorySpline(nn.Module):
         t = t.reshape(-1)
         J = self.base.shape[0]
         Tk = self.knots()
-        inc = se3_log(Tk[1:] @ torch.linalg.inv(Tk[:-1]))        # [J - 1, 6]: knot(j + 1) = exp(inc[j]) knot(j)
+        inc = se3_log(_mm(Tk[1:], rigid_inv(Tk[:-1])))           # [J - 1, 6]: knot(j + 1) = exp(inc[j]) knot(j)
         fl = torch.floor(t.detach()).long()
         if self.kind == "linear":
             j = fl.clamp(0, J - 2)
             u = t - j.to(t.dtype)
-            return se3_exp(u[:, None] * inc.index_select(0, j)) @ Tk.index_select(0, j)
+            return _mm(se3_exp(u[:, None] * inc.index_select(0, j)), Tk.index_select(0, j))
         j = (fl - 1).clamp(0, J - 4)
         u = t - (j + 1).to(t.dtype)
         b1, b2, b3 = _cubic_cumulative_basis(u)
         x1, x2, x3 = inc.index_select(0, j), inc.index_select(0, j + 1), inc.index_select(0, j + 2)
-        return (se3_exp(b3[:, None] * x3) @ se3_exp(b2[:, None] * x2) @ se3_exp(b1[:, None] * x1)) @ Tk.index_select(0, j)
+        return _mm(_mm(_mm(se3_exp(b3[:, None] * x3), se3_exp(b2[:, None] * x2)), se3_exp(b1[:, None] * x1)), Tk.index_select(0, j))
 
     def window_times(self, t_mid, width, n: int) -> torch.Tensor:
         """n sample times uniformly inside [t_mid - width / 2, t_mid + width / 2] (midpoint rule); differentiable
@@ -141,6 +147,17 @@ class TrajectorySpline(nn.Module):
         return self.pose_at(self.window_times(t_mid, 1.0, n))
 
 
+def rigid_inv(T: torch.Tensor) -> torch.Tensor:
+    """Inverse of rigid transforms [..., 4, 4]: [R t; 0 1]^-1 = [R^T, -R^T t; 0 1].  (Not torch.linalg.inv: that is a solver
+    call with a host-side status check -- slower for 4 x 4 blocks and not allowed inside a graph capture.)"""
+    Rt = T[..., :3, :3].transpose(-1, -2)
+    t = -_mm(Rt, T[..., :3, 3:])
+    top = torch.cat([Rt, t], -1)
+    bottom = torch.zeros_like(T[..., 3:, :])
+    bottom[..., 0, 3] = 1.0
+    return torch.cat([top, bottom], -2)
+
+
 def se3_log(T: torch.Tensor) -> torch.Tensor:
     """Logarithm SE(3) -> se(3) for rotations well below pi (adjacent video frames); T [..., 4, 4] -> [..., 6]."""
     R, t = T[..., :3, :3], T[..., :3, 3]
@@ -154,8 +171,8 @@ def se3_log(T: torch.Tensor) -> torch.Tensor:
     A = torch.where(small, 1 - th2 / 6, torch.sin(th) / (th + 1e-20))
     B = torch.where(small, 0.5 - th2 / 24, (1 - torch.cos(th)) / (th2 + 1e-20))
     coef = torch.where(small, torch.full_like(th, 1.0 / 12), (1 - A / (2 * B)) / (th2 + 1e-20))
-    Vinv = torch.eye(3, dtype=T.dtype, device=T.device) - 0.5 * K + coef[..., None, None] * (K @ K)
-    return torch.cat([(Vinv @ t[..., None])[..., 0], om], -1)
+    Vinv = torch.eye(3, dtype=T.dtype, device=T.device) - 0.5 * K + coef[..., None, None] * _mm(K, K)
+    return torch.cat([_mm(Vinv, t[..., None])[..., 0], om], -1)
 
 
 class ImplicitCRF(nn.Module):
@@ -206,6 +223,9 @@ class HDRBlurFormation(nn.Module):
         if frame_times is None:
             frame_times = t0 + 0.5 + torch.arange(n_frames, dtype=torch.float32)
         self.register_buffer("frame_times", torch.as_tensor(frame_times, dtype=torch.float32).clone())
+        # (built once: filling a device matrix element by element from host scalars is a run of host-to-device copies, which
+        # a graph capture does not allow)
+        self.register_buffer("proj", projection_matrix(tanfovx, tanfovy))
         self.window_from_exposure, self.window_scale = bool(window_from_exposure), float(window_scale)
 
     def window(self, i: int) -> torch.Tensor:
@@ -218,9 +238,9 @@ class HDRBlurFormation(nn.Module):
         """(viewmatrices [N,4,4], projmatrices [N,4,4], camposes [N,3]) in the rasterizer's transposed convention."""
         times = self.trajectory.window_times(self.frame_times[i].to(self.log_exposure.dtype), self.window(i), self.n_virtual)
         w2c = self.trajectory.pose_at(times)
-        proj = projection_matrix(self.tanfovx, self.tanfovy, device=w2c.device).to(w2c.dtype)
-        full = proj[None] @ w2c
-        campos = -(w2c[:, :3, :3].transpose(1, 2) @ w2c[:, :3, 3:])[..., 0]
+        proj = self.proj.to(w2c.dtype)
+        full = _mm(proj[None], w2c)
+        campos = -_mm(w2c[:, :3, :3].transpose(1, 2), w2c[:, :3, 3:])[..., 0]
         return w2c.transpose(1, 2).contiguous(), full.transpose(1, 2).contiguous(), campos.contiguous()
 
     def cameras_all(self):
@@ -236,9 +256,9 @@ class HDRBlurFormation(nn.Module):
         s = (torch.arange(n, dtype=dt, device=width.device) + 0.5) / n - 0.5
         times = self.frame_times.to(dt)[:, None] + s[None, :] * width[:, None]                 # [F, N]
         w2c = self.trajectory.pose_at(times.reshape(-1))
-        proj = projection_matrix(self.tanfovx, self.tanfovy, device=w2c.device).to(w2c.dtype)
-        full = proj[None] @ w2c
-        campos = -(w2c[:, :3, :3].transpose(1, 2) @ w2c[:, :3, 3:])[..., 0]
+        proj = self.proj.to(w2c.dtype)
+        full = _mm(proj[None], w2c)
+        campos = -_mm(w2c[:, :3, :3].transpose(1, 2), w2c[:, :3, 3:])[..., 0]
         F = times.shape[0]
         return (w2c.transpose(1, 2).reshape(F, n, 4, 4).contiguous(), full.transpose(1, 2).reshape(F, n, 4, 4).contiguous(),
                 campos.reshape(F, n, 3).contiguous())
