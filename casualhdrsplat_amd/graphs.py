@@ -7,6 +7,14 @@ loss + backward once (torch.cuda.graph -- hipGraph on ROCm) and replays it.  Inp
 update them IN PLACE between replays (optimizer steps do), never rebind them.
 
 The reference is a trainer around this hot path (Readme.md:54); nothing in it prescribes how launches reach the GPU.
+
+What `fn` may contain (ROCm 7.2 / PyTorch 2.10 on MI355X, found the hard way): everything this package enqueues is kernels
+only -- no hipMemsetAsync / hipMemcpyAsync on a captured path, because MEMSET NODES of a captured graph were seen to
+misbehave from the second replay on (camera gradients that differed between identical replays).  PyTorch
+itself issues such a memset in front of its two-pass reduction kernel: a `.mean()` / `.sum()` over more than a few ten
+thousand elements inside `fn` returned a wrong VALUE from the second replay on (examples/train_synthetic.py: mean_by_rows
+avoids it; gradients of such a loss are unaffected, they do not depend on its value).  No torch.linalg solver calls, no
+element-wise fills of device tensors from host scalars (host-to-device copies).
 """
 from __future__ import annotations
 

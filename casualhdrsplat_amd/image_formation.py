@@ -185,8 +185,20 @@ class ImplicitCRF(nn.Module):
         self.net = nn.Sequential(nn.Linear(1, hidden), nn.Tanh(), nn.Linear(hidden, hidden), nn.Tanh(), nn.Linear(hidden, 3))
         self.register_buffer("knots", torch.linspace(self.u_range[0], self.u_range[1], K)[:, None])
 
+    def _mlp(self, x: torch.Tensor) -> torch.Tensor:
+        """self.net(x), written as broadcast multiplies and sums (the layers are 1 -> h -> h -> 3 on K points: nothing a
+        BLAS call is good for).  Not only speed: a BLAS call inside a captured step (graphs.GraphedStep) brings its
+        workspace with it, and on ROCm 7 / PyTorch 2.10 replays of such a graph were seen to scribble GEMM partials over
+        neighbouring tensors of the graph's memory pool (a captured loss read 94.41 for ever after the first replay)."""
+        for layer in self.net:
+            if isinstance(layer, nn.Linear):
+                x = (x.unsqueeze(-2) * layer.weight).sum(-1) + layer.bias     # [K, out] = sum_in x[K, 1, in] * W[out, in]
+            else:
+                x = layer(x)
+        return x
+
     def table(self) -> torch.Tensor:
-        inc = torch.nn.functional.softplus(self.net(self.knots))        # [K,3] positive slopes
+        inc = torch.nn.functional.softplus(self._mlp(self.knots))       # [K,3] positive slopes
         cdf = torch.cumsum(inc, dim=0)
         tab = (cdf - cdf[:1]) / (cdf[-1:] - cdf[:1] + 1e-12)            # 0 at u_min, 1 at u_max, increasing
         return tab.t().contiguous()                                     # [3,K]
@@ -274,9 +286,41 @@ class HDRBlurFormation(nn.Module):
             prefiltered=False, debug=False, exposure=torch.exp(self.log_exposure[i]), crf_table=self.crf.table(),
             crf_range=self.crf.u_range, viewmatrices=V, projmatrices=PV, camposes=Cp, blur_domain=self.blur_domain)
         means2D = torch.zeros_like(means3D, requires_grad=means3D.requires_grad)
-        ldr, radii, hdr = self._factory(settings)(means3D, means2D, opacities, shs=shs, scales=scales,
-                                                   rotations=rotations)
+        per_frame = getattr(self._factory, "for_frame", None)     # (FrameRasterizers: one persistent rasterizer per frame)
+        rast = per_frame(i, settings) if per_frame is not None else self._factory(settings)
+        ldr, radii, hdr = rast(means3D, means2D, opacities, shs=shs, scales=scales, rotations=rotations)
         return ldr, hdr, radii, means2D
+
+
+class FrameRasterizers:
+    """`rasterizer_factory` for HDRBlurFormation that keeps ONE sync-free GaussianRasterizer per captured frame -- what a
+    captured step needs (graphs.GraphedStep takes persistent rasterizers with a fixed binning capacity; the formation's
+    default makes a fresh, synchronous one per call):
+
+        frames = FrameRasterizers(capacity=2_000_000)
+        model = HDRBlurFormation(trajectory, n_frames, ..., rasterizer_factory=frames)
+        step = GraphedStep(fn, frames.rasterizers(n_frames), params=[...])   # after one eager fn() has created them
+
+    The settings of every call are swapped into the frame's rasterizer."""
+
+    def __init__(self, capacity: int, **rasterizer_kwargs):
+        self.capacity, self.kw, self._by_frame = int(capacity), rasterizer_kwargs, {}
+
+    def for_frame(self, i: int, settings):
+        r = self._by_frame.get(int(i))
+        if r is None:
+            r = self._by_frame[int(i)] = GaussianRasterizer(settings, capacity=self.capacity, **self.kw)
+        r.raster_settings = settings
+        return r
+
+    def __call__(self, settings):          # (a caller that does not say which frame: frame 0's rasterizer)
+        return self.for_frame(0, settings)
+
+    def rasterizers(self, n_frames: Optional[int] = None) -> list:
+        """The rasterizers made so far, in frame order (n_frames given: all of them must exist)."""
+        if n_frames is not None and any(i not in self._by_frame for i in range(n_frames)):
+            raise RuntimeError("FrameRasterizers: run one eager step over all frames before asking for the rasterizers")
+        return [self._by_frame[i] for i in sorted(self._by_frame)]
 
 
 def knots_from_lookat(n: int, radius: float = 0.05, depth: float = 6.0) -> torch.Tensor:

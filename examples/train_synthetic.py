@@ -25,16 +25,30 @@ sys.path.insert(0, ROOT)
 import torch
 
 from casualhdrsplat_amd import synthetic as S
-from casualhdrsplat_amd.image_formation import HDRBlurFormation, ImplicitCRF, TrajectorySpline, knots_from_lookat
+from casualhdrsplat_amd.graphs import GraphedStep
+from casualhdrsplat_amd.image_formation import (FrameRasterizers, HDRBlurFormation, ImplicitCRF, TrajectorySpline,
+                                                  knots_from_lookat)
 
 CLOUD = ("means3D", "opacities", "shs", "scales", "rotations")
 
 
-def psnr(a, b):
-    return -10.0 * math.log10(max(float(((a - b) ** 2).mean()), 1e-12))
+def mean_by_rows(x: torch.Tensor) -> torch.Tensor:
+    """x.mean() as two small reductions (rows of 256, then the row sums).  Inside a captured step a plain .mean() / .sum()
+    over more than a few ten thousand elements is PyTorch's two-pass kernel, which clears a semaphore with a memset ahead
+    of it -- and on ROCm 7 / PyTorch 2.10 memset nodes of a captured graph were seen to misbehave from the second replay
+    on (this very loss read 94.41 for ever; the library's own kernels had the same trouble with two hipMemsetAsync, see
+    DESIGN.md 4.11).  The gradient of a mean does not depend on its value, so training was right all along; the printed
+    numbers were not."""
+    n = x.numel()
+    pad = (-n) % 256
+    flat = x.reshape(-1)
+    if pad:
+        flat = torch.cat([flat, flat.new_zeros(pad)])
+    return flat.reshape(-1, 256).sum(dim=1).sum() / n
 
 
-def run(P=20000, W=320, H=208, frames=4, virtual=5, steps=200, seed=0, deg=1, log_every=25, device="cuda", quiet=False):
+def run(P=20000, W=320, H=208, frames=4, virtual=5, steps=200, seed=0, deg=1, log_every=25, device="cuda", quiet=False,
+        graph=False, capacity=None):
     """Returns a dict of the run's first / last loss, PSNR and parameter errors (also what the GPU test checks)."""
     dev = torch.device(device)
     sc = S.make_scene(P, W, H, deg, seed=seed, hdr=True)
@@ -43,10 +57,10 @@ def run(P=20000, W=320, H=208, frames=4, virtual=5, steps=200, seed=0, deg=1, lo
     knots = knots_from_lookat(frames + 3, radius=0.25)
     dt_true = torch.tensor([1.0, 0.5, 1.6, 0.8, 1.3, 0.6, 1.1, 0.9])[:frames]
 
-    def formation(crf):
+    def formation(crf, **kw):
         traj = TrajectorySpline(knots, kind="cubic")
         return HDRBlurFormation(traj, frames, W, H, cam.tanfovx, cam.tanfovy, n_virtual=virtual, crf=crf, sh_degree=deg,
-                                window_from_exposure=True, window_scale=0.6).to(dev)
+                                window_from_exposure=True, window_scale=0.6, **kw).to(dev)
 
     truth = formation(ImplicitCRF(K=128))
     with torch.no_grad():
@@ -57,7 +71,10 @@ def run(P=20000, W=320, H=208, frames=4, virtual=5, steps=200, seed=0, deg=1, lo
         targets = [truth(i, *[cloud_true[k] for k in CLOUD])[0] for i in range(frames)]
 
     # the learner: the response curve is given, everything else starts off
-    model = formation(ImplicitCRF(K=128))
+    # --graph: one persistent sync-free rasterizer per captured frame, so that the step's gradient computation can be
+    # recorded once and replayed (graphs.GraphedStep): no host time for the few thousand tiny kernels of the pose arithmetic
+    per_frame = FrameRasterizers(capacity=capacity or 40 * P * virtual) if graph else None
+    model = formation(ImplicitCRF(K=128), **({"rasterizer_factory": per_frame} if graph else {}))
     model.crf.load_state_dict(truth.crf.state_dict())
     for p_ in model.crf.parameters():
         p_.requires_grad_(False)
@@ -80,24 +97,44 @@ def run(P=20000, W=320, H=208, frames=4, virtual=5, steps=200, seed=0, deg=1, lo
             e_pose = float((model.trajectory.knots()[:, :3, 3] - truth.trajectory.knots()[:, :3, 3]).norm(dim=1).mean())
             return e_dt, e_pose
 
-    hist = []
-    t0 = time.time()
-    for it in range(steps + 1):
-        opt.zero_grad(set_to_none=True)
-        total, ps = 0.0, 0.0
+    learn = [shs, raw_opac, model.log_exposure, model.trajectory.delta]
+
+    def gradients():
+        """Forward of every frame + backward of the summed loss; returns (per-frame losses, per-frame MSE) as tensors."""
+        for p_ in learn:
+            p_.grad = None
         # one pass over the spline for all frames (its few hundred tiny tensor operations are the step's host cost), one
         # rasterizer call per frame, one backward of the summed loss
         cams = model.cameras_all()
         opac = torch.sigmoid(raw_opac)
-        loss_sum = 0.0
+        losses, mses = [], []
         for i in range(frames):
             ldr, _, _, _ = model(i, fixed["means3D"], opac, shs, fixed["scales"], fixed["rotations"], cameras=cams)
-            loss = (ldr - targets[i]).abs().mean()
-            loss_sum = loss_sum + loss
-            total += float(loss.detach())
-            ps += psnr(ldr.detach(), targets[i])
+            losses.append(mean_by_rows((ldr - targets[i]).abs()))
+            mses.append(mean_by_rows((ldr.detach() - targets[i]) ** 2))
+        torch.stack(losses).sum().backward()
+        return torch.stack([l_.detach() for l_ in losses]), torch.stack(mses)
+
+    step_fn = gradients
+    if graph:
+        gradients()                                   # (creates the per-frame rasterizers)
+        captured = GraphedStep(gradients, per_frame.rasterizers(frames), params=learn)
+
+        def step_fn():
+            out = captured.step()
+            for p_, g_ in zip(learn, captured.grads):   # (the optimizer reads .grad: the graph's static gradient tensors)
+                p_.grad = g_
+            return out
+
+    hist = []
+    t0 = time.time()
+    for it in range(steps + 1):
+        losses, mses = step_fn()
+        if graph and (it % 50 == 0 or it == steps):
+            captured.check_overflow()
+        total = float(losses.sum())
+        ps = float((-10.0 * torch.log10(mses.clamp_min(1e-12))).sum())
         if it < steps:
-            loss_sum.backward()
             g0 = model.log_exposure.grad
             if g0 is not None:
                 g0[0] = 0.0                                    # frame 0's exposure is the gauge
@@ -120,8 +157,9 @@ def main(argv=None):
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--deg", type=int, default=1)
+    ap.add_argument("--graph", action="store_true", help="record the gradient computation once as a HIP graph and replay it")
     a = ap.parse_args(argv)
-    r = run(a.P, a.W, a.H, a.frames, a.virtual, a.steps, a.seed, a.deg)
+    r = run(a.P, a.W, a.H, a.frames, a.virtual, a.steps, a.seed, a.deg, graph=a.graph)
     f, l = r["first"], r["last"]
     print(f"loss {f['loss']:.5f} -> {l['loss']:.5f}; PSNR {f['psnr']:.2f} -> {l['psnr']:.2f} dB; exposure error "
           f"{f['exposure_log_err']:.4f} -> {l['exposure_log_err']:.4f}; knot error {f['knot_pos_err']:.5f} -> {l['knot_pos_err']:.5f}")
