@@ -84,7 +84,7 @@ class hs_layout(C.Structure):
 
 
 EXPORTS = ("hs_version", "hs_last_error", "hs_plan", "hs_forward", "hs_backward", "hs_mark_visible",
-           "hs_sh_backward_views", "hs_sort_tmp_bytes", "hs_sort_pairs", "hs_render_stats", "hs_sort_tickets")
+           "hs_sh_backward_views", "hs_sort_tmp_bytes", "hs_sort_pairs", "hs_render_stats", "hs_sort_tickets", "hs_spline_poses")
 HS_RENDER_STATS = 24
 
 _lib = None
@@ -124,6 +124,9 @@ def load() -> C.CDLL:
     lib.hs_sort_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
                                   C.c_void_p, C.c_void_p]
     lib.hs_sort_pairs.restype = C.c_int
+    lib.hs_spline_poses.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p]
+    lib.hs_spline_poses.restype = C.c_int
     lib.hs_sort_tickets.argtypes = [C.c_int]
     lib.hs_sort_tickets.restype = C.c_int
     _lib = lib

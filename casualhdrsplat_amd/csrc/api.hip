@@ -369,6 +369,17 @@ int hs_sh_backward_views(int32_t P, int32_t M, int32_t sh_degree, int32_t V, con
     return launch_sh_backward_views(P, M, sh_degree, V, means3D, camposes, dL_dview_colors, dL_dshs, (hipStream_t)hip_stream);
 }
 
+int hs_spline_poses(int32_t n_knots, int32_t n_times, int32_t kind, const float* delta, const float* base_w2c,
+                    const float* times, float* w2c, float* jacobian, int32_t* segment, void* hip_stream) {
+    if (n_times < 0 || (kind != 0 && kind != 1) || n_knots < (kind == 1 ? 4 : 2) ||
+        (n_times > 0 && (!delta || !base_w2c || !times || !w2c || !jacobian || !segment))) {
+        set_error("hs_spline_poses: bad argument (kind 0 = linear needs >= 2 knots, 1 = cubic >= 4)");
+        return HS_EINVAL;
+    }
+    if (n_times == 0) return HS_OK;
+    return launch_spline_poses(n_knots, n_times, kind, delta, base_w2c, times, w2c, jacobian, segment, (hipStream_t)hip_stream);
+}
+
 int hs_render_stats(const hs_fwd_args* fwd, const hs_bwd_args* bwd, uint64_t* stats, uint64_t* bwd_timeline, void* hip_stream) {
     if ((!fwd && !bwd) || !stats) { set_error("hs_render_stats: null argument"); return HS_EINVAL; }
     hipStream_t s = (hipStream_t)hip_stream;

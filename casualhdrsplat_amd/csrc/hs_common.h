@@ -88,6 +88,9 @@ int launch_crf_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s, CrfR
 int launch_preprocess_bwd(const hs_bwd_args& a, const hs_layout& L, hipStream_t s, bool segsum, bool project,
                           const CrfReduce* crf_reduce);
 int launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* vis, hipStream_t s);
+// spline.hip: camera poses along the trajectory spline with their Jacobian (hs_spline_poses)
+int launch_spline_poses(int J, int T, int kind, const float* delta, const float* base, const float* times, float* w2c,
+                        float* jac, int* seg, hipStream_t s);
 int launch_sh_backward_views(int P, int M, int deg, int V, const float* means3D, const float* camposes,
                              const float* view_colors, float* d_shs, hipStream_t s);
 

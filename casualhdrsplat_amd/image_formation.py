@@ -79,6 +79,43 @@ def _cubic_cumulative_basis(u: torch.Tensor):
     return (5.0 + 3.0 * u - 3.0 * u2 + u3) / 6.0, (1.0 + 3.0 * u + 3.0 * u2 - 2.0 * u3) / 6.0, u3 / 6.0
 
 
+class _SplinePoses(torch.autograd.Function):
+    """pose_at on the GPU as ONE kernel (libhdrsplat's hs_spline_poses: forward-mode dual numbers in float64, one thread per
+    sample time) instead of ~300 tiny tensor kernels forward and ~700 backward: the launch returns the poses and their
+    Jacobian with respect to the knot corrections governing each sample's segment and to the sample time; backward is a
+    multiply-sum with it and a deterministic scatter into the knots' rows."""
+
+    @staticmethod
+    def forward(ctx, delta, base, t, kind):
+        from . import _lib as L
+        from .rasterizer import _stream
+        J, T = delta.shape[0], t.numel()
+        d32 = delta.detach().to(torch.float32).contiguous()
+        b32 = base.detach().to(torch.float32).contiguous()
+        t32 = t.detach().to(torch.float32).contiguous().reshape(-1)
+        w2c = torch.empty(T, 4, 4, dtype=torch.float32, device=delta.device)
+        jac = torch.empty(T, 12, 25, dtype=torch.float32, device=delta.device)
+        seg = torch.empty(T, dtype=torch.int32, device=delta.device)
+        with torch.cuda.device(delta.device):
+            L.check(L.load().hs_spline_poses(J, T, 1 if kind == "cubic" else 0, d32.data_ptr(), b32.data_ptr(), t32.data_ptr(),
+                                             w2c.data_ptr(), jac.data_ptr(), seg.data_ptr(), _stream()), "hs_spline_poses")
+        ctx.save_for_backward(jac, seg)
+        ctx.J, ctx.dtypes = J, (delta.dtype, t.dtype)
+        return w2c.to(delta.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        jac, seg = ctx.saved_tensors
+        T, J = jac.shape[0], ctx.J
+        gi = (g[:, :3, :].reshape(T, 12, 1).to(torch.float32) * jac).sum(1)                     # [T, 25]
+        # rows seg .. seg + 3 of the knots receive gi[:, 6k : 6k + 6]: a one-hot multiply-sum (fixed summation order: the
+        # same bits every run, unlike index_add_'s atomics)
+        rows = seg.to(torch.int64)[:, None] + torch.arange(4, device=g.device)[None, :]        # [T, 4]
+        onehot = (rows[..., None] == torch.arange(J, device=g.device)).to(torch.float32)       # [T, 4, J]
+        gd = (onehot[..., None] * gi[:, :24].reshape(T, 4, 1, 6)).sum((0, 1))                   # [J, 6]
+        return gd.to(ctx.dtypes[0]), None, gi[:, 24].to(ctx.dtypes[1]), None
+
+
 class TrajectorySpline(nn.Module):
     """Learnable camera trajectory over se(3) control knots (T_j in the figure; knot j sits at time j).
 
@@ -99,6 +136,9 @@ class TrajectorySpline(nn.Module):
         if kind == "linear" and init_w2c.shape[0] < 2:
             raise ValueError("a trajectory needs at least two control knots")
         self.kind = kind
+        # on the GPU pose_at is one kernel of libhdrsplat (hs_spline_poses); False: the tensor-operation form below, which is
+        # also the CPU path and the kernel's oracle in the tests
+        self.fused = True
         self.register_buffer("base", init_w2c.clone().float())
         self.delta = nn.Parameter(torch.zeros(init_w2c.shape[0], 6))  # left-multiplied se(3) corrections
 
@@ -120,6 +160,8 @@ class TrajectorySpline(nn.Module):
         code (segment look-up by index_select): no host read of t, so it neither synchronises nor breaks a graph capture."""
         t = t.reshape(-1)
         J = self.base.shape[0]
+        if self.fused and t.is_cuda and self.delta.is_cuda:
+            return _SplinePoses.apply(self.delta, self.base, t, self.kind)
         Tk = self.knots()
         inc = se3_log(_mm(Tk[1:], rigid_inv(Tk[:-1])))           # [J - 1, 6]: knot(j + 1) = exp(inc[j]) knot(j)
         fl = torch.floor(t.detach()).long()

@@ -35,7 +35,7 @@ extern "C" {
 /* libhdrsplat.so is built with -fvisibility=hidden: the hs_* entry points below are its only exported symbols */
 #define HS_API __attribute__((visibility("default")))
 
-#define HS_VERSION 305
+#define HS_VERSION 306
 
 #define HS_OK 0
 #define HS_EINVAL (-1)    /* bad argument (null pointer, bad shape, unsupported degree ...) */
@@ -271,6 +271,19 @@ HS_API int hs_mark_visible(int32_t P, const float* means3D, const float* viewmat
 HS_API int hs_sh_backward_views(int32_t P, int32_t M, int32_t sh_degree, int32_t V, const float* means3D,
                          const float* camposes /* [V,3] */, const float* dL_dview_colors /* [V,P,3] */,
                          float* dL_dshs /* [P,M,3] */, void* hip_stream);
+
+/* (HS_VERSION 306) Camera poses along the trajectory spline of the image-formation model -- the N virtual poses inside each
+ * captured frame's exposure window (/root/reference/assets/pipeline.png: "camera motion spline" through the control knots
+ * T_j .. T_{j+3}; Readme.md:54) -- together with their Jacobian, in one launch (spline.hip; the tensor-operation form of the
+ * same arithmetic, image_formation.TrajectorySpline.pose_at, is ~1000 tiny kernels forward + backward per call).
+ *   knot_j = exp(delta[j]) * base_w2c[j]   (delta: [n_knots, 6] se(3) corrections (rho, omega); base: [n_knots, 4, 4] row-major)
+ *   kind 1 (cubic cumulative B-spline): times in [1, n_knots - 2]; kind 0 (geodesic between two knots): times in [0, n_knots - 1]
+ * Outputs per sample time s: w2c[s] (4 x 4 row-major world-to-camera), segment[s] = j, the first knot governing the sample, and
+ * jacobian[s][o][i], o = 4 * row + column over the first three rows of w2c[s] (12 values), i < 24: d / d delta[j + i / 6][i % 6]
+ * (knots beyond the two of a linear segment: zeros), i = 24: d / d times[s].  Device pointers; 25 threads per sample. */
+HS_API int hs_spline_poses(int32_t n_knots, int32_t n_times, int32_t kind, const float* delta, const float* base_w2c,
+                    const float* times, float* w2c /* [n_times,4,4] */, float* jacobian /* [n_times,12,25] */,
+                    int32_t* segment /* [n_times] */, void* hip_stream);
 
 /* Bench/profiling only: re-runs the render stage(s) of a finished hs_forward (and hs_backward) call -- same argument
  * structs, same buffers, so the outputs are simply rewritten -- with the diagnostic instantiation of the kernels, which

@@ -70,7 +70,7 @@ def test_struct_sizes_match_c(lib, tmp_path):
 
 def test_version_and_plan(lib):
     L = lib.load()
-    assert L.hs_version() == 305
+    assert L.hs_version() == 306
     d, sz, lay = lib.plan(1_000_000, 16, 3, 1920, 1080, 1, 7_000_000)
     assert sz.geom_bytes > 1_000_000 * 48 and sz.binning_bytes > 7_000_000 * 16
     assert sz.image_bytes >= 1920 * 1080 * (8 + 12) and sz.bwd_bytes >= 7_000_000 * 48

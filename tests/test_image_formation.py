@@ -417,3 +417,38 @@ def test_formation_step_is_capturable_as_one_hip_graph():
             assert float((want2[5] - want[5]).abs().sum()) > 0     # (the trajectory gradient did change)
         for a, b in zip(got, want2):
             assert torch.equal(a, b), rep
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["linear", "cubic"])
+def test_fused_spline_kernel_matches_the_tensor_implementation(kind):
+    """hs_spline_poses (spline.hip: one thread per sample time, float64 dual numbers) against TrajectorySpline.pose_at written
+    with tensor operations in float64 on the CPU: poses, and the gradients of a random functional of them with respect to the
+    knots and to the sample times -- at generic knots, at untouched knots (delta = 0: the small-angle series of exp) and with
+    two identical neighbouring knots (the clamped arc-cosine of log)."""
+    torch.manual_seed(11)
+    J = 7
+    base = IF.knots_from_lookat(J, radius=0.3)
+    base[3] = base[2]                                       # two identical neighbours: log of the identity
+    for scale in (0.0, 0.02):
+        ref = IF.TrajectorySpline(base.double(), kind=kind).double()
+        ref.fused = False
+        gpu = IF.TrajectorySpline(base, kind=kind).cuda()
+        delta0 = scale * torch.randn(J, 6, dtype=torch.float64)
+        with torch.no_grad():
+            ref.delta.copy_(delta0)
+            gpu.delta.copy_(delta0.float())
+        lo, hi = ref.t_range
+        t_ref = (lo + (hi - lo) * torch.rand(23, dtype=torch.float64)).requires_grad_(True)
+        t_gpu = t_ref.detach().float().cuda().requires_grad_(True)
+        w = torch.randn(23, 4, 4, dtype=torch.float64)
+        a = ref.pose_at(t_ref)
+        b = gpu.pose_at(t_gpu)
+        assert b.shape == (23, 4, 4) and b.dtype == torch.float32
+        assert torch.allclose(b.cpu().double(), a, rtol=1e-5, atol=2e-6)
+        (a * w).sum().backward()
+        (b * w.float().cuda()).sum().backward()
+        for g_ref, g_gpu in ((ref.delta.grad, gpu.delta.grad), (t_ref.grad, t_gpu.grad)):
+            assert torch.isfinite(g_gpu).all()
+            assert torch.allclose(g_gpu.cpu().double(), g_ref, rtol=2e-4, atol=2e-5 * float(g_ref.abs().max())), (kind, scale)
+        assert float(gpu.delta.grad.abs().sum()) > 0 and float(t_gpu.grad.abs().sum()) > 0
