@@ -1,6 +1,6 @@
 // Host-side sanitizer driver ("-fsanitize=address on the host-side C++ in CI on the CPU box").
 // Exercises every C-ABI entry point's HOST code -- hs_plan's carving arithmetic, the argument validation of
-// hs_forward / hs_backward / hs_mark_visible / hs_sh_backward_views / hs_sort_pairs / hs_render_stats, the
+// hs_forward / hs_backward / hs_mark_visible / hs_sh_backward_views / hs_sort_pairs / hs_render_stats / hs_spline_poses, the
 // thread-local error text -- with AddressSanitizer + UBSan on the host objects of libhdrsplat (built by
 // `make -C casualhdrsplat_amd/csrc asan`).  No GPU is needed or touched: every call here must return before its first
 // HIP call (bad arguments) or is pure host code (hs_plan).  Exit code 0 = clean.
@@ -90,6 +90,10 @@ static int run() {
     CHECK(hs_sh_backward_views(10, 4, 3, 2, fake, fake, fake, fake, nullptr) == HS_EINVAL);
     CHECK(hs_sh_backward_views(0, 16, 3, 2, nullptr, nullptr, nullptr, nullptr, nullptr) == HS_OK);
     CHECK(hs_render_stats(nullptr, nullptr, nullptr, nullptr, nullptr) == HS_EINVAL);
+    CHECK(hs_spline_poses(3, 5, 1, fake, fake, fake, fake, fake, (int32_t*)fake, nullptr) == HS_EINVAL);   // a cubic segment needs four knots
+    CHECK(hs_spline_poses(4, 5, 2, fake, fake, fake, fake, fake, (int32_t*)fake, nullptr) == HS_EINVAL && std::strstr(hs_last_error(), "kind"));
+    CHECK(hs_spline_poses(4, 5, 1, nullptr, fake, fake, fake, fake, (int32_t*)fake, nullptr) == HS_EINVAL);
+    CHECK(hs_spline_poses(2, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr) == HS_OK);
     return 0;
 }
 
