@@ -203,3 +203,33 @@ def test_bench_exchange_bytes_and_probe_order():
     v = bench.exchange_bytes("views", 8, bench.CONFIGS["c3"])
     assert v["all_reduced_bytes"] == 4 * (1_000_000 * 11 + 1 + 3 * 256) and v["all_gathered_bytes_per_rank"] == 4 * (3_000_000 + 3)
     assert v["sent_per_rank_bytes"] < 0.55 * b["sent_per_rank_bytes"]
+
+
+def test_no_memset_or_copy_on_the_paths_a_captured_step_takes():
+    """Memset nodes of a captured HIP graph misbehaved from the second replay on (camera gradients that differed
+    between identical replays): the library enqueues KERNELS only on the paths a training step takes.  The remaining
+    hipMemsetAsync / hipMemcpyAsync / hipMemsetD32Async calls are the ones listed here -- an empty cloud (P == 0), a frame
+    without binning capacity, the stand-alone hs_sort_pairs entry point, the fault-injection hook of the test library -- and a
+    new one has to be added to this list on purpose."""
+    import os
+    import re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "casualhdrsplat_amd", "csrc")
+    allowed = {
+        "api.hip": ["if (a->stages & HS_STAGE_PREPROCESS) HS_HIP_CHECK(hipMemsetAsync(a->geom, 0, sizeof(hs_counters), s));",   # P == 0
+                    "hipMemsetAsync((char*)a->binning + L.ranges, 0,",                                                        # P == 0
+                    "hipMemcpyAsync(a->counters_host, (char*)a->geom + L.counters,",                                          # P == 0
+                    "hipMemsetD32Async((hipDeviceptr_t)n_dev,", "hipMemsetD32Async((hipDeviceptr_t)fail_word,",               # hs_sort_pairs
+                    "hipMemcpyAsync(ka, keys_in,", "hipMemcpyAsync(va, vals_in,", "hipMemcpyAsync(keys_out,", "hipMemcpyAsync(vals_out,"],
+        "binning.hip": ["if (!zeroed) HS_HIP_CHECK(hipMemsetAsync(tmp, 0,",            # radix_sort_packed outside the pipeline (never: zeroed = true)
+                        "HS_HIP_CHECK(hipMemsetAsync(tmp, 0, (size_t)sort_scratch_words(n_launch, passes, TILE) * 4, s));",   # hs_sort_pairs
+                        "hipMemsetD32Async((hipDeviceptr_t)sc.tickets, 1, 1, s)",      # fault injection (test library)
+                        "hipMemsetD32Async((hipDeviceptr_t)&counters->overflow, 2, 1, s)",   # fault injection (test library)
+                        "hipMemcpyAsync(a.counters_host, counters, sizeof(hs_counters), hipMemcpyDeviceToHost, s)"],   # capacity == 0
+    }
+    for name in sorted(os.listdir(root)):
+        if not name.endswith(".hip"):
+            continue
+        for ln in open(os.path.join(root, name), encoding="utf-8"):
+            code = ln.split("//")[0]
+            if re.search(r"hipMem(set|cpy)\w*\(", code):
+                assert any(a in code for a in allowed.get(name, [])), f"{name}: {ln.strip()}"
