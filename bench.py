@@ -178,20 +178,24 @@ def build_step(cfg, rank, world, dev, seed=0):
 
 def whole_step_bytes(cfg, R, Rp, vtiles, n_visible):
     """Algorithmic bytes of ONE whole step (every row of the table; I = P x poses instances): what a
-    perfect implementation must move, whatever this one moves.  Sort = one ideal pass (24 R)."""
+    perfect implementation must move, whatever this one moves.  Sort = one ideal pass (24 R).  The Gaussian ROW (means,
+    scales, rotation, opacity, SH: 236 B at degree 3) is charged once per GAUSSIAN -- N poses project the same row, and a
+    perfect implementation reads it once (this one does: 1.06 GB counted for c4's preprocess forward, profiles/
+    r05_pmc_traffic_c4.csv) -- and only the per-instance outputs / gradient inputs once per instance (VERDICT r5 weak #3:
+    until round 6 the row was charged per instance, which put c4's preprocess stages ABOVE the measured copy rate)."""
     P, W, H, deg, hdr, n_poses = cfg
     M = (deg + 1) ** 2
     I, WH = P * n_poses, W * H * n_poses
     in_row = 12 + 12 + 16 + 4 + 12 * M                     # means, scales, rotation, opacity, SH coefficients
     parts = {
-        "preprocess_fwd": in_row * I + 75 * n_visible,
+        "preprocess_fwd": in_row * P + 75 * n_visible,
         "scan": 8 * I,
         "duplicate_with_keys": 20 * I + 12 * R,
         "sort_one_ideal_pass": 24 * R,
         "tile_ranges": 8 * R + 8 * vtiles,
         "render_fwd": 40 * Rp + 20 * WH + 8 * vtiles,
         "render_bwd": 76 * Rp + 20 * WH,
-        "preprocess_bwd": (in_row + 60) * I + in_row * P,
+        "preprocess_bwd": in_row * P + 60 * I + in_row * P,   # read the row + 60 B per instance, write the row
         "hdr_images": (2 * 12 * WH) if hdr else 0,
     }
     parts["total"] = sum(parts.values())
@@ -430,6 +434,7 @@ def offline_profile(cfg_name):
                 "source_commit": pmc.get("source_commit"), "same_kernel_source": same,
                 "render_bwd_kernel_hbm_bytes": pmc.get("render_bwd_kernel_hbm_bytes"),
                 "render_fwd_kernel_hbm_bytes": pmc.get("render_fwd_kernel_hbm_bytes"),
+                "render_bwd_kernel_tile_replay_hbm_bytes": pmc.get("render_bwd_kernel_tile_replay_hbm_bytes"),
                 "render_bwd_kernel_valu_busy_frac": pmc.get("render_bwd_kernel_valu_busy_frac"),
                 "render_fwd_kernel_valu_busy_frac": pmc.get("render_fwd_kernel_valu_busy_frac"),
                 "method": pmc.get("method")}
@@ -877,6 +882,11 @@ def main():
                     "frac": bts / (stages[k] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "frac_hbm_measured": bts / (stages[k] * 1e-3) / 1e9 / HBM_MEASURED_GBS}
                 for k, bts in pk_bytes.items() if stages.get(k, 0) > 0}
+            # a stage "faster" than the measured copy rate means its byte model is wrong, not that the kernel is fast
+            over = {k: round(v["frac_hbm_measured"], 3) for k, v in line["roofline"]["per_kernel"].items() if v["frac_hbm_measured"] > 1.0}
+            if over:
+                raise SystemExit(f"[bench] per_kernel.frac_hbm_measured > 1.0 for {over} at {cfg_name}: the algorithmic byte "
+                                 "model charges bytes the kernel cannot have moved -- fix whole_step_bytes / pk_bytes")
             non_render = [k for k in pk_bytes if not k.startswith("render")]
             nr_ms, nr_b = sum(stages[k] for k in non_render), sum(pk_bytes[k] for k in non_render)
             line["roofline"]["non_render"] = {"stages": non_render, "ms": nr_ms, "algorithmic_bytes": int(nr_b),
@@ -897,9 +907,22 @@ def main():
                 if off.get("same_kernel_source") and off.get("render_bwd_kernel_hbm_bytes"):
                     # counters of an earlier rocprofv3 --pmc pass over this same workload, taken from kernels compiled
                     # from the very render.hip that is loaded now (hash checked); otherwise `traffic` stays null
+                    # The launch of a whole step carries the CRF gradient's first stage as its last workgroups (HDR): those
+                    # read dL/dLDR and the radiance image(s), 24 B per pixel -- on the algorithmic side of THIS comparison
+                    # (VERDICT r5 weak #4).  `traffic_tile_replay`: the same kernel launched by HS_BWD_RENDER alone (no tail),
+                    # to be set against `algorithmic_bytes` = 76 R' + 20 W H directly.
+                    tail_b = 24 * WH if hdr else 0
                     line["roofline"]["traffic"] = off["render_bwd_kernel_hbm_bytes"]
-                    line["roofline"]["traffic_note"] = ("bytes per launch at the L2-fabric interface from profiles/pmc_traffic.json "
-                                                        "(separate --pmc passes, gfx950 FETCH_SIZE correction), same render.hip")
+                    line["roofline"]["traffic_algorithmic_bytes"] = bytes_bwd + tail_b
+                    line["roofline"]["traffic_over_algorithmic"] = off["render_bwd_kernel_hbm_bytes"] / (bytes_bwd + tail_b)
+                    if off.get("render_bwd_kernel_tile_replay_hbm_bytes"):
+                        line["roofline"]["traffic_tile_replay"] = off["render_bwd_kernel_tile_replay_hbm_bytes"]
+                        line["roofline"]["traffic_tile_replay_over_algorithmic"] = off["render_bwd_kernel_tile_replay_hbm_bytes"] / bytes_bwd
+                    line["roofline"]["traffic_note"] = (
+                        "bytes per launch at the L2-fabric interface from profiles/pmc_traffic.json (separate --pmc passes, gfx950 "
+                        "FETCH_SIZE correction), same render.hip.  `traffic` = the launch of a whole step, which in HDR mode ends with "
+                        "the CRF gradient's first-stage workgroups (+ 24 W H algorithmic bytes: traffic_algorithmic_bytes); "
+                        "`traffic_tile_replay` = the kernel launched without that tail, against algorithmic_bytes = 76 R' + 20 W H")
             line["stages_ms"] = {k: round(v, 4) for k, v in stages.items()}
             line["render_stats"] = stats
         return line, sc, cfg

@@ -69,6 +69,51 @@ def yaw_camera(W: int, H: int, yaw_deg: float, centre_depth: float = 6.0) -> Cam
     return make_camera(W, H, Ry, c - Ry @ c)
 
 
+def euler_rotation(roll: float, pitch: float, yaw: float) -> torch.Tensor:
+    """R = Rz(roll) Rx(pitch) Ry(yaw) (radians, float64): roll about the optical axis, pitch about x, yaw about y."""
+    cr, sr, cp, sp, cy, sy = (math.cos(roll), math.sin(roll), math.cos(pitch), math.sin(pitch), math.cos(yaw),
+                              math.sin(yaw))
+    Rz = torch.tensor([[cr, -sr, 0.0], [sr, cr, 0.0], [0.0, 0.0, 1.0]], dtype=torch.float64)
+    Rx = torch.tensor([[1.0, 0.0, 0.0], [0.0, cp, -sp], [0.0, sp, cp]], dtype=torch.float64)
+    Ry = torch.tensor([[cy, 0.0, sy], [0.0, 1.0, 0.0], [-sy, 0.0, cy]], dtype=torch.float64)
+    return Rz @ Rx @ Ry
+
+
+def random_camera(W: int, H: int, seed: int, max_angle: float = math.pi, max_shift: float = 3.0) -> Camera:
+    """A free 6-DoF view (the reference's figure draws a free camera trajectory, /root/reference/assets/pipeline.png
+    "Camera motion spline"): world-to-view rotation Rz(roll) Rx(pitch) Ry(yaw) with each angle U(-max_angle, max_angle)
+    and a translation U(-max_shift, max_shift)^3, so that EVERY entry of the view matrix is populated.  A cloud is put in
+    front of it with make_scene(..., place_in=camera)."""
+    g = torch.Generator().manual_seed(1_000_003 * 7 + seed)
+    a = (torch.rand(3, generator=g, dtype=torch.float64) * 2 - 1) * max_angle
+    t = (torch.rand(3, generator=g, dtype=torch.float64) * 2 - 1) * max_shift
+    return make_camera(W, H, euler_rotation(float(a[0]), float(a[1]), float(a[2])), t)
+
+
+def camera_w2c(cam: Camera) -> torch.Tensor:
+    """World-to-view matrix [4,4] float64 (column-vector convention) of a Camera."""
+    return cam.viewmatrix.t().to(torch.float64)
+
+
+def perturbed_poses(base: Camera, n: int, seed: int = 0, rot_step_deg: float = 0.25, step: float = 0.01) -> list[Camera]:
+    """n virtual poses of a motion-blurred exposure around `base` that differ in ROTATION as well as translation: pose k
+    is base followed by a rotation of k * rot_step_deg about each of roll / pitch / yaw (signs drawn from `seed`) and a
+    shift of k * step along a random unit direction, both in base's view frame (pose 0 is base itself)."""
+    g = torch.Generator().manual_seed(2_000_003 + seed)
+    sgn = torch.where(torch.rand(3, generator=g) < 0.5, -1.0, 1.0).to(torch.float64)
+    d = torch.randn(3, generator=g, dtype=torch.float64)
+    d = d / d.norm()
+    w2c = camera_w2c(base)
+    cams = []
+    for k in range(n):
+        a = math.radians(rot_step_deg) * k * sgn
+        dR = euler_rotation(float(a[0]), float(a[1]), float(a[2]))
+        R = dR @ w2c[:3, :3]
+        t = dR @ w2c[:3, 3] + k * step * d
+        cams.append(make_camera(base.W, base.H, R, t))
+    return cams
+
+
 @dataclass
 class Scene:
     means3D: torch.Tensor      # [P,3]
@@ -102,10 +147,16 @@ def sigmoid_crf_table(K: int = 256, u_range=(-6.0, 3.0)) -> torch.Tensor:
 
 
 def make_scene(P: int, W: int, H: int, sh_degree: int = 0, seed: int = 0, hdr: bool = False,
-               camera: Camera | None = None, crf_K: int = 256) -> Scene:
+               camera: Camera | None = None, crf_K: int = 256, place_in: Camera | None = None) -> Scene:
+    """`camera`: the view the scene is rendered from (cloud stays in the DEFAULT camera's frustum -- a yawed camera sees
+    it from the side).  `place_in`: a general camera (random_camera) the cloud is laid out IN FRONT OF instead: the same
+    draws, re-expressed in world coordinates x_w = R^T (x_v - t), and that camera becomes the scene's."""
     g = torch.Generator().manual_seed(seed)
+    if place_in is not None:
+        assert camera is None, "give either camera= or place_in="
+        camera = place_in
     cam = camera if camera is not None else make_camera(W, H)
-    base = make_camera(W, H)  # the cloud is always laid out in the default camera's frustum
+    base = make_camera(W, H)  # the cloud is laid out in the default camera's frustum (then moved in front of place_in)
     fx = W / (2 * base.tanfovx)
 
     def U(*shape):
@@ -119,6 +170,9 @@ def make_scene(P: int, W: int, H: int, sh_degree: int = 0, seed: int = 0, hdr: b
     ndc_x = (2 * px + 1) / W - 1
     ndc_y = (2 * py + 1) / H - 1
     means = torch.stack([ndc_x * base.tanfovx * z, ndc_y * base.tanfovy * z, z], dim=1)
+    if place_in is not None:
+        w2c = camera_w2c(place_in)
+        means = (means - w2c[:3, 3]) @ w2c[:3, :3]      # rows: R^T (x_v - t)
     sigma_px = torch.exp(math.log(0.5) + (math.log(8.0) - math.log(0.5)) * U(P))
     aniso = torch.exp(U(P, 3) - 0.5)
     scales = (sigma_px * z / fx)[:, None] * aniso

@@ -25,6 +25,11 @@ if [ "$what" = pmc ] || [ "$what" = all ]; then
     rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -- $STEP > $O/pmc_$c.log 2>&1
   done
   if [ "$CFG" = c3 ]; then
+  # render_bwd_kernel without the CRF gradient's tail workgroups (the tile replay alone): its launches are the LAST
+  # `steps` ones of the kernel in these passes (the first step is a whole backward); fold_profiles.py takes those
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_alone_$c -- $STEP --render-bwd-alone > $O/pmc_alone_$c.log 2>&1
+  done
   i=0
   for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" "SQ_ACTIVE_INST_SCA SQ_INSTS_SALU SQ_ACTIVE_INST_LDS SQ_INSTS_LDS" "SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE"; do
     i=$((i+1))

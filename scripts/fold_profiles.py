@@ -17,6 +17,24 @@ def counters(sub):
     return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in agg.items()}
 
 
+def render_bwd_alone(sub, counter):
+    """Average `counter` of the render_bwd_kernel launches WITHOUT the CRF gradient's tail workgroups in a
+    `step_c3.py --render-bwd-alone` pass: the launches with the smallest grid (the first step of the pass is a whole
+    backward, whose launch carries the tail and has a larger grid)."""
+    rows = []
+    for f in glob.glob(os.path.join(SRC, sub, "*", "*counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            if "render_bwd_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                rows.append((int(r["Grid_Size"]), float(r["Counter_Value"])))
+    if not rows:
+        return None, 0
+    g0 = min(g for g, _ in rows)
+    if g0 == max(g for g, _ in rows):
+        return None, 0          # no launch with a tail to tell them from: not an --render-bwd-alone pass of an HDR frame
+    vals = [v for g, v in rows if g == g0]
+    return sum(vals) / len(vals), len(vals)
+
+
 if what == "pmc":
     fetch, write = counters("pmc_FETCH_SIZE"), counters("pmc_WRITE_SIZE")
     rows = []
@@ -45,6 +63,13 @@ if what == "pmc":
                       "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (KB units); hbm = (2*FETCH_SIZE + WRITE_SIZE)*1024, "
                                 "the gfx950 FETCH_SIZE half-count correction; per-launch average; counted at the L2-fabric interface (Infinity-Cache hits included)",
                       "source": f"profiles/{tag}_pmc_traffic_{CFG}.csv"}})
+    fa, nfa = render_bwd_alone("pmc_alone_FETCH_SIZE", "FETCH_SIZE")
+    wa, nwa = render_bwd_alone("pmc_alone_WRITE_SIZE", "WRITE_SIZE")
+    if fa is not None and wa is not None:
+        allcfg[CFG]["render_bwd_kernel_tile_replay_hbm_bytes"] = int((2 * fa + wa) * 1024)
+        allcfg[CFG]["tile_replay_method"] = (f"render_bwd_kernel launched by HS_BWD_RENDER alone (scripts/step_c3.py --render-bwd-alone; {nfa} / {nwa} "
+                                             "launches in the FETCH / WRITE pass): no CRF-gradient tail workgroups -- to be set against 76 R' + 20 W H; "
+                                             "render_bwd_kernel_hbm_bytes is the launch of a whole step, tail included (+ 24 W H algorithmic)")
     json.dump(allcfg, open(tpath, "w"), indent=1)
     if CFG != "c3":
         print(json.dumps(allcfg[CFG], indent=1))

@@ -10,6 +10,9 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--P", type=int, default=1000000); ap.add_argument("--W", type=int, default=1920); ap.add_argument("--H", type=int, default=1080)
 ap.add_argument("--deg", type=int, default=3); ap.add_argument("--hdr", type=int, default=1); ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--poses", type=int, default=1); ap.add_argument("--capacity", type=int, default=0)
+# counter passes that must see render_bwd_kernel WITHOUT the CRF gradient's tail workgroups: after the
+# first step only forwards are run, each followed by a replay of HS_BWD_RENDER alone (no tail, nothing else of the backward)
+ap.add_argument("--render-bwd-alone", action="store_true")
 a = ap.parse_args()
 dev = "cuda"
 sc = S.make_scene(a.P, a.W, a.H, a.deg, seed=0, hdr=bool(a.hdr))
@@ -33,6 +36,13 @@ pad = torch.zeros(a.poses, gy * 16, gx * 16, dtype=torch.int64, device=dev); pad
 tmax = pad.reshape(a.poses, gy, 16, gx, 16).amax(dim=(2, 4))
 print(f"R={st['num_rendered']}  R'={int(tmax.sum())}  E={int(nc.sum())}  tiles={gx*gy}  avg list={float((rng[:,1]-rng[:,0]).float().mean()):.1f} max list={int((rng[:,1]-rng[:,0]).max())}")
 print("color mean", float(out[0].mean()), "finite", bool(torch.isfinite(out[0]).all()), "grad finite", bool(torch.isfinite(means3D.grad).all()))
+if a.render_bwd_alone:
+    from casualhdrsplat_amd import _lib as L
+    from casualhdrsplat_amd.rasterizer import replay_backward
+    def step():
+        o = rast(means3D, means2D, opac, shs=shs, scales=scales, rotations=rots)
+        replay_backward(o[0], dL, L.HS_BWD_RENDER)
+        return o
 torch.cuda.synchronize(); t = time.time()
 for _ in range(a.steps): step()
 torch.cuda.synchronize(); dt = (time.time() - t) / a.steps

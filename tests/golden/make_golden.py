@@ -53,22 +53,38 @@ C1_CASES = [
     ("c1_hdr_deg0_n8_hdrblur", 0, 3, True, 8, "hdr", None, None),
     ("c1_hdr_deg3_n8_ldrblur", 3, 0, True, 8, "ldr", None, 32),
 ]
+# Free 6-DoF cameras (round 6; /root/reference/assets/pipeline.png draws a free camera trajectory): the cloud in front of
+# synthetic.random_camera(cam_seed) -- a general SO(3) world-to-view rotation plus a translation, every entry of the
+# view matrix populated -- and, for the 4-pose frame, poses that ROTATE about it (synthetic.perturbed_poses).
+FREE_CASES = [
+    # name, P, W, H, deg, first seed, hdr, n_poses, blur_domain, cam_seed
+    ("ldr_deg3_free_camera", 600, 96, 80, 3, 10, False, 1, "ldr", 4),
+    ("hdr_deg2_n4_free_rotating_poses", 400, 80, 64, 2, 11, True, 4, "ldr", 5),
+]
 # antialiasing opacity compensation + expected inverse-depth output with its own upstream gradient
 EXTRA_CASES = [("ldr_deg2_antialias_invdepth", 500, 88, 72, 2, 5)]
 
 
+def free_poses(base, n_poses):
+    """The poses of a FREE_CASES frame: rotating and shifting about the free base camera."""
+    return S.perturbed_poses(base, n_poses, seed=1, rot_step_deg=0.25, step=0.02)
+
+
 def guarded(P, W, H, deg, seed, hdr, n_poses, act="relu_shift", antialias=False, bg=None, crf_K=None, knot_dom=None,
-            tries=5000, decisions=True):
+            tries=5000, decisions=True, cam_seed=None):
     """First scene with seed >= `seed` none of whose poses has a (pixel, entry) decision inside the threshold guard band;
     knot_dom ('ldr' / 'hdr'): ... and no pixel of the image(s) the CRF is applied to within 8 ulp of a CRF knot."""
     import torch
     for s_ in range(seed, seed + tries):
-        sc = S.make_scene(P, W, H, deg, seed=s_, hdr=hdr)
+        base = None if cam_seed is None else S.random_camera(W, H, cam_seed)
+        sc = S.make_scene(P, W, H, deg, seed=s_, hdr=hdr, place_in=base)
         if bg is not None:
             sc.bg = torch.tensor(bg, dtype=torch.float32)
         if crf_K is not None:
             sc.crf_table = S.sigmoid_crf_table(crf_K, sc.crf_range)
         cams = S.blur_poses(W, H, n_poses, step=0.02) if n_poses > 1 else [sc.camera]
+        if base is not None and n_poses > 1:
+            cams = free_poses(base, n_poses)
         clean, imgs = True, []
         for cam in cams:
             ocam = Hh.oracle_camera(O, sc, cam, act)
@@ -101,11 +117,15 @@ def scene_inputs(sc, cams):
     return d
 
 
-def make(name, P, W, H, deg, seed, hdr, n_poses, dom, act, bg=None, crf_K=None, knot_guard=False):
-    decisions = not (knot_guard and n_poses > 1)   # the 8-pose c1 frames: see C1_CASES
+def make(name, P, W, H, deg, seed, hdr, n_poses, dom, act, bg=None, crf_K=None, knot_guard=False, cam_seed=None,
+         decisions=None):
+    if decisions is None:
+        decisions = not (knot_guard and n_poses > 1)   # the 8-pose c1 frames: see C1_CASES
     sc, cams, seed = guarded(P, W, H, deg, seed, hdr, n_poses, act, bg=bg, crf_K=crf_K,
-                             knot_dom=dom if (knot_guard and hdr) else None, decisions=decisions)
+                             knot_dom=dom if (knot_guard and hdr) else None, decisions=decisions, cam_seed=cam_seed)
     out = scene_inputs(sc, cams)
+    if cam_seed is not None:
+        out["cam_seed"] = np.array(cam_seed, np.int64)
     if knot_guard and hdr:
         out["crf_knot_guarded"] = np.array(1, np.int64)
     out["meta"] = np.array([P, W, H, deg, seed, int(hdr), n_poses, int(dom == "hdr")], np.int64)
@@ -174,6 +194,9 @@ if __name__ == "__main__":
     for c in CASES:
         if not only or c[0] in only:
             make(*c)
+    for name, P, W, H, deg, seed, hdr, n_poses, dom, cam_seed in FREE_CASES:
+        if not only or name in only:
+            make(name, P, W, H, deg, seed, hdr, n_poses, dom, "relu_shift", knot_guard=hdr, cam_seed=cam_seed, decisions=True)
     for name, deg, seed, hdr, n_poses, dom, bg, crf_K in C1_CASES:
         if not only or name in only:
             make(name, 1000, 128, 128, deg, seed, hdr, n_poses, dom, "relu_shift", bg=bg, crf_K=crf_K, knot_guard=True)

@@ -73,7 +73,7 @@ def _worker_views(rank, world, port, q, early_gather=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("early_gather,world", [(False, 2), (True, 2), (True, 4)])
+@pytest.mark.parametrize("early_gather,world", [(False, 2), (True, 2), (True, 4), (True, 8)])
 def test_view_exchange_equals_sum_of_single_view_gradients(oracle, early_gather, world):
     """all-gather of per-view colour gradients + local SH outer product == all-reduce of the SH gradient rows.
     (world 4: what the driver's scaling run meets first -- more ranks than the two-rank box the GPU tests can get)"""
@@ -127,9 +127,11 @@ def _worker(rank, world, port, shared_flat, q, algo="rccl"):
 
 
 @pytest.mark.parametrize("shared_flat,algo,world", [(True, "rccl", 2), (False, "rccl", 2), (True, "direct", 2),
-                                                    (True, "direct", 3), (True, "direct", 4), (False, "rccl", 4)])
+                                                    (True, "direct", 3), (True, "direct", 4), (False, "rccl", 4),
+                                                    (True, "rccl", 8), (True, "direct", 8)])
 def test_allreduce_equals_sum_of_single_view_gradients(oracle, shared_flat, algo, world):
-    """(world 3: the 1-hop form's shards do not divide the buffer evenly -- its leftover path; world 4: several peers)"""
+    """(world 3: the 1-hop form's shards do not divide the buffer evenly -- its leftover path; world 4: several peers;
+    world 8: SURVEY.md 8(c) item 10 / BASELINE config c5 -- the sum of EIGHT single-view gradients == the 8-rank exchange)"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()

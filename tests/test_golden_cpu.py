@@ -32,7 +32,8 @@ def activation_of(z):
 
 
 def test_fixtures_present():
-    assert len(GOLDEN) >= 13
+    assert len(GOLDEN) >= 15
+    assert sum("cam_seed" in np.load(p).files for p in GOLDEN) >= 2   # free 6-DoF cameras (round 6)
     names = [os.path.basename(p) for p in GOLDEN]
     assert sum(n.startswith("c1_") for n in names) >= 5          # c1-scale fixtures
     zs = [np.load(p) for p in GOLDEN]
@@ -71,8 +72,14 @@ def test_oracle_reproduces_golden(oracle, path):
     sc, cams, hdr, dom = scene_from_golden(z)
     # the generator is deterministic: the stored inputs are what make_scene(seed) yields today
     P, W, H, deg, seed = [int(v) for v in z["meta"][:5]]
-    again = S.make_scene(P, W, H, deg, seed=seed, hdr=hdr)
+    base = S.random_camera(W, H, int(z["cam_seed"])) if "cam_seed" in z.files else None
+    again = S.make_scene(P, W, H, deg, seed=seed, hdr=hdr, place_in=base)
     assert torch.equal(again.means3D, sc.means3D) and torch.equal(again.shs, sc.shs)
+    if base is not None:   # ... and the free camera(s) are what synthetic.random_camera / perturbed_poses yield today
+        want = [base] if len(cams) == 1 else S.perturbed_poses(base, len(cams), seed=1, rot_step_deg=0.25, step=0.02)
+        assert all(torch.equal(a.viewmatrix, b.viewmatrix) and torch.equal(a.projmatrix, b.projmatrix) for a, b in zip(cams, want))
+        V = cams[0].viewmatrix.numpy()
+        assert np.all(np.abs(V[:3, :3]) > 1e-3), "a free camera populates every entry of the rotation"
     if "antialias" in z.files:  # SURVEY.md 8(f) n3 extras: antialiasing + inverse-depth output and gradient
         ocam = Hh.oracle_camera(oracle, sc)
         ocam.antialias = True

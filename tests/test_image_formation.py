@@ -246,9 +246,10 @@ class _OracleRasterizer:
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("free", [False, True], ids=["yaw_knots", "free_knots"])
 @pytest.mark.parametrize("dom", ["ldr", "hdr"])
 @pytest.mark.parametrize("kind", ["linear", "cubic"])
-def test_image_formation_matches_the_fp64_oracle_through_the_same_modules(dom, kind):
+def test_image_formation_matches_the_fp64_oracle_through_the_same_modules(dom, kind, free):
     """SURVEY.md 8(f) n2, oracle-backed: HDRBlurFormation on the MI355X (one HIP rasterizer call: N virtual poses,
     exposure, CRF, blur average, pose gradients) against the float64 autograd rasterizer driven by the SAME
     TrajectorySpline / exposure / ImplicitCRF modules -- blurred LDR image, mean radiance, and the gradients that reach
@@ -258,10 +259,20 @@ def test_image_formation_matches_the_fp64_oracle_through_the_same_modules(dom, k
     motion-blur term (through the rasterizer's pose gradients) next to the brightness term."""
     dev = "cuda"
     W, H, P, deg, n_virtual = 112, 80, 1500, 1, 3
-    sc = S.make_scene(P, W, H, deg, seed=33, hdr=True)
-    cam = sc.camera
     cubic = kind == "cubic"
-    knots = IF.knots_from_lookat(5 if cubic else 3, radius=0.4 if cubic else 0.04)   # (cubic: ~3 px of blur per window)
+    if free:
+        # the figure's free trajectory: a 6-DoF base camera (roll, pitch and yaw up to +-pi), the control knots roll, pitch
+        # and yaw about it and shift -- every entry of every knot's rotation populated (VERDICT r5 weak #2: the knots of
+        # knots_from_lookat rotate about y only)
+        base = S.random_camera(W, H, 11)
+        sc = S.make_scene(P, W, H, deg, seed=33, hdr=True, place_in=base)
+        poses = S.perturbed_poses(base, 5 if cubic else 3, seed=4, rot_step_deg=0.5 if cubic else 0.05,
+                                  step=0.1 if cubic else 0.01)
+        knots = torch.stack([S.camera_w2c(c).float() for c in poses])
+    else:
+        sc = S.make_scene(P, W, H, deg, seed=33, hdr=True)
+        knots = IF.knots_from_lookat(5 if cubic else 3, radius=0.4 if cubic else 0.04)   # (cubic: ~3 px of blur per window)
+    cam = sc.camera
     torch.manual_seed(3)
     crf0 = IF.ImplicitCRF(K=48)
 
