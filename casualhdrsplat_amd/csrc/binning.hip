@@ -1106,6 +1106,391 @@ __global__ void __launch_bounds__(256) tile_keys_kernel(const uint2* ranges, int
     for (uint32_t p = r.x + (threadIdx.x & 63); p < min(r.y, capacity); p += 64) keys_sorted[p] = (uint32_t)t;
 }
 
+// ---------------------------------------------------------------- hierarchical tile sort (a6 + a7 + a8)
+// Coarse stable pass + on-chip expansion (round 6).  The radix tile sort moves every (tile, instance)
+// pair -- 8 bytes -- through two passes (read + write each) after writing it once: 5 x 8 x R bytes, R = 6.8 M at c3.  A
+// Gaussian's tile rectangle is a few tiles wide, so the pairs of one instance that fall into the same 8 x 8-tile SUPER-TILE
+// are described by ONE element: (super-tile id, rectangle clipped to the super-tile, instance) -- 1.5 M elements at c3.
+//   1. hier_gather_kernel: the rectangles gathered into depth order and, per 256 instances, the sums of their pair counts
+//      and of their element counts (the scan of both is finished by the emission, as on the radix path);
+//   2. hier_emit_kernel: walks the instances in depth order and writes their elements (a wave's 64 instances own one
+//      contiguous range of element slots; lanes walk it slot by slot); leaves the inclusive pair offsets in depth order
+//      and every instance's first pair slot (the render backward addresses its gradient records with it -- the slot of a
+//      pair is slot start + position of the tile inside the rectangle, nothing the sort decides), clears the pair flags,
+//      counts the elements per super-tile and the digit totals of the pass(es) below, and verdicts num_rendered;
+//   3. radix_sweep_kernel over the elements, by super-tile id only: ONE pass for up to 256 (pose, super-tile) keys (c3:
+//      135), two up to 65 536; stable, so every super-tile's elements stay in depth order;
+//   4. hier_plan_kernel (one workgroup): first element of every super-tile, its chunks of kHierChunk elements, one
+//      descriptor per chunk;
+//   5. hier_count_kernel, one workgroup per chunk: pairs per tile of the super-tile and per wave (a wave takes 256
+//      consecutive elements: four +-1 corner marks per element into a 9 x 9 grid, then a 2-D prefix sum), and the tile
+//      totals (atomics: a dozen per address);
+//   6. hier_tiles_kernel (one workgroup): exclusive scan of the tile totals in tile-id order = ranges, first positions;
+//   7. hier_scatter_kernel, one workgroup per chunk: first position of (wave, tile) = start of the tile + pairs of the
+//      tile in the super-tile's earlier chunks (summed here from their rows) + in earlier waves; the waves then walk the
+//      pairs of their elements in element order (row-major inside the clipped rectangle) and hand out positions by
+//      match-any over the six bits of the tile inside the super-tile: point_list.
+// Stable by construction: depth order -> stable pass -> chunks, waves and the walk in element order.  keys_sorted has no
+// reader (HS_STAGE_OFFSETS fills it from the ranges on request, as for the counting sort).
+constexpr int kHierM = 10;   // floor(t / w) for t < 64, w in 1..8 as (t * ceil(2^10 / w)) >> 10
+
+// rectangle (x0 | y0 << 16, w | h << 16) -> its super-tile rectangle: first super-tile column / row and the numbers of them
+__device__ __forceinline__ void hier_coarse_rect(uint2 rc, uint32_t& sx0, uint32_t& sy0, uint32_t& sw, uint32_t& sh) {
+    const uint32_t x0 = rc.x & 0xFFFFu, y0 = rc.x >> 16, w = rc.y & 0xFFFFu, h = rc.y >> 16;
+    sx0 = x0 / kSuper; sy0 = y0 / kSuper;
+    const bool any = w != 0u && h != 0u;
+    sw = any ? (x0 + w - 1u) / kSuper - sx0 + 1u : 0u;
+    sh = any ? (y0 + h - 1u) / kSuper - sy0 + 1u : 0u;
+}
+
+__global__ void __launch_bounds__(256) hier_gather_kernel(int64_t I, const uint32_t* inst_sorted, const uint2* binfo,
+                                                          uint2* srect, const hs_counters* counters, uint32_t* block_sums,
+                                                          uint32_t* block_csums, uint32_t* zero, int64_t n_zero) {
+    __shared__ uint32_t s_wave[4];
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < n_zero; t += (int64_t)gridDim.x * 256) zero[t] = 0u;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    uint2 rc = make_uint2(0u, 0u);
+    if (i < I) {
+        if (counters->overflow < 2u) rc = binfo[inst_sorted[i]];
+        srect[i] = rc;
+    }
+    uint32_t sx0, sy0, sw, sh;
+    hier_coarse_rect(rc, sx0, sy0, sw, sh);
+    uint32_t total, ctotal;
+    block_incl_scan((rc.y & 0xFFFFu) * (rc.y >> 16), s_wave, &total);
+    block_incl_scan(sw * sh, s_wave, &ctotal);
+    if (threadIdx.x == 0) { block_sums[blockIdx.x] = total; block_csums[blockIdx.x] = ctotal; }
+}
+
+// Element: .x = (pose, super-tile) key | clipped rectangle above bit `kb` (x0: 3 bits, y0: 3, w - 1: 3, h - 1: 3, all in
+// tiles relative to the super-tile), .y = instance.
+__global__ void __launch_bounds__(256) hier_emit_kernel(int64_t I, int P, int gx, int gy, float4* rec,
+                                                        const uint32_t* inst_sorted, const uint2* srect,
+                                                        const uint32_t* block_excl, const uint32_t* block_cexcl,
+                                                        uint32_t* offs_sorted, uint2* elems, uint8_t* pair_flags,
+                                                        hs_counters* counters, uint64_t capacity, uint32_t* ghist, int kb,
+                                                        int passes, unsigned long long* depth_bits, int excl_ready,
+                                                        uint32_t* hier /* header */, uint32_t* st_count, int nst, int nst_pad) {
+    __shared__ uint32_t s_hist[kHierStMax];    // elements per (pose, super-tile) key, this workgroup
+    __shared__ uint32_t s_dig[4 * 256];        // ... per digit of the pass(es)
+    __shared__ uint32_t s_beg[4][64];
+    __shared__ uint4 s_own[4][64];             // per instance: key of its first super-tile | columns of super-tiles, rectangle, 1 / columns, instance
+    __shared__ uint32_t s_wsum[4];
+    __shared__ unsigned long long s_wsum64[4];
+    __shared__ uint64_t s_excl;
+    __shared__ uint32_t s_cexcl;
+    for (int t = threadIdx.x; t < nst; t += 256) s_hist[t] = 0;
+    for (int t = threadIdx.x; t < passes * 256; t += 256) s_dig[t] = 0;
+    if (blockIdx.x == 0 && threadIdx.x < 2 * kDepthBitsCopies) depth_bits[threadIdx.x] = 0ull;   // (see emit_pairs_kernel)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int blk = blockIdx.x;
+    const int64_t i = (int64_t)blk * 256 + threadIdx.x;
+    uint32_t inst = 0;
+    uint2 rc = make_uint2(0u, 0u);
+    if (i < I && counters->overflow < 2u) { inst = inst_sorted[i]; rc = srect[i]; }
+    const uint32_t cnt = (rc.y & 0xFFFFu) * (rc.y >> 16);
+    uint32_t sx0, sy0, sw, sh;
+    hier_coarse_rect(rc, sx0, sy0, sw, sh);
+    const uint32_t ccnt = sw * sh;
+    uint32_t block_total, block_ctotal;
+    const uint32_t incl = block_incl_scan(cnt, s_wsum, &block_total);
+    const uint32_t cincl = block_incl_scan(ccnt, s_wsum, &block_ctotal);
+    if (excl_ready) {
+        if (threadIdx.x == 0) { s_excl = block_excl[blk]; s_cexcl = block_cexcl[blk]; }
+    } else {
+        unsigned long long part = 0, cpart = 0;    // (64-bit: see emit_pairs_kernel)
+        for (int j = threadIdx.x; j < blk; j += 256) { part += block_excl[j]; cpart += block_cexcl[j]; }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            part += (unsigned long long)__shfl_xor((long long)part, d);
+            cpart += (unsigned long long)__shfl_xor((long long)cpart, d);
+        }
+        if (lane == 0) { s_wsum64[wave] = part; s_beg[0][wave] = (uint32_t)cpart; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            s_excl = (s_wsum64[0] + s_wsum64[1]) + (s_wsum64[2] + s_wsum64[3]);
+            s_cexcl = (s_beg[0][0] + s_beg[0][1]) + (s_beg[0][2] + s_beg[0][3]);
+        }
+    }
+    __syncthreads();
+    const uint64_t bexcl = s_excl;
+    const uint64_t bend = bexcl + block_total;
+    const uint32_t cbexcl = s_cexcl;
+    if (blk == (int)gridDim.x - 1 && threadIdx.x == 0) {   // the last block knows R: the verdict for the later kernels
+        const bool over = bend > capacity;
+        counters->num_rendered = bend > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)bend;
+        if (over && counters->overflow < 2u) counters->overflow = 1u;
+        const bool empty = over || counters->overflow != 0u;
+        counters->reserved[0] = empty ? 0u : (uint32_t)bend;
+        counters->reserved[5] = (uint32_t)kTileSortHier;
+        hier[0] = empty ? 0u : cbexcl + block_ctotal;      // elements to sort
+    }
+    const uint32_t end = (uint32_t)bexcl + incl, beg = end - cnt;
+    if (i < I) offs_sorted[i] = end;   // written even on overflow: the segmented sum then finds nothing flagged
+    if (bend > capacity) return;
+    if (i < I && end > beg) reinterpret_cast<float*>(rec + kRecF4 * (int64_t)inst + 2)[3] = __uint_as_float(beg);
+    // "gradient record written" flags of this workgroup's pair slots [bexcl, bend): bytes up to the first 16-byte boundary,
+    // 16-byte stores, bytes behind the last one
+    {
+        const uint64_t a0 = min(bend, (bexcl + 15ull) & ~15ull), a1 = max(a0, bend & ~15ull);
+        for (uint64_t q = bexcl + threadIdx.x; q < a0; q += 256) pair_flags[q] = 0;
+        for (uint64_t q = a0 + 16ull * threadIdx.x; q < a1; q += 16ull * 256) *reinterpret_cast<uint4*>(pair_flags + q) = make_uint4(0u, 0u, 0u, 0u);
+        for (uint64_t q = a1 + threadIdx.x; q < bend; q += 256) pair_flags[q] = 0;
+    }
+    // element slots of this wave's 64 instances: one contiguous range, walked slot by slot
+    uint32_t cend = cbexcl + cincl, cbeg = cend - ccnt;
+    const uint32_t last_end = __shfl(cend, 63 - __builtin_clzll(__ballot(i < I) | 1ull));
+    if (i >= I) cbeg = cend = last_end;
+    {
+        const int sgx = (gx + kSuper - 1) / kSuper, sgy = (gy + kSuper - 1) / kSuper;
+        const uint32_t pose = I > (int64_t)P ? inst / (uint32_t)P : 0u;
+        const uint32_t key0 = pose * (uint32_t)(sgx * sgy) + sy0 * (uint32_t)sgx + sx0;
+        s_beg[wave][lane] = cbeg;
+        // (key0 < 2^11, sw <= 2^19 / 8: a frame has fewer than 2^22 tiles per pose)
+        s_own[wave][lane] = make_uint4(key0 | (sw << 12), rc.x, rc.y, inst);
+    }
+    const int sgx = (gx + kSuper - 1) / kSuper;
+    const uint32_t first = __shfl(cbeg, 0);
+    const uint32_t total = last_end - first;
+    for (uint32_t p = lane; p < total; p += 64) {
+        const uint32_t pos = first + p;
+        uint32_t k = 0;
+#pragma unroll
+        for (uint32_t step = 32; step >= 1; step >>= 1)   // largest k with beg[k] <= pos
+            k |= (uint32_t)((int32_t)(s_beg[wave][k + step] - pos - 1u) >> 31) & step;
+        const uint4 o = s_own[wave][k];
+        const uint32_t t = pos - s_beg[wave][k];
+        const uint32_t csw = o.x >> 12;
+        const uint32_t cy = (uint32_t)(((float)t + 0.5f) * (1.0f / (float)csw));   // exact: t < 2^22 (emit_pairs_kernel)
+        const uint32_t cx = t - cy * csw;
+        const uint32_t key = (o.x & 0xFFFu) + cy * (uint32_t)sgx + cx;
+        // the rectangle clipped to this super-tile, in tiles relative to it
+        const uint32_t x0 = o.y & 0xFFFFu, y0 = o.y >> 16, x1 = x0 + (o.z & 0xFFFFu), y1 = y0 + (o.z >> 16);
+        const uint32_t ox = (x0 / kSuper + cx) * kSuper, oy = (y0 / kSuper + cy) * kSuper;
+        const uint32_t lx0 = max(x0, ox) - ox, lx1 = min(x1, ox + kSuper) - ox;
+        const uint32_t ly0 = max(y0, oy) - oy, ly1 = min(y1, oy + kSuper) - oy;
+        const uint32_t word = key | ((lx0 | (ly0 << 3) | ((lx1 - lx0 - 1u) << 6) | ((ly1 - ly0 - 1u) << 9)) << kb);
+        elems[pos] = make_uint2(word, o.w);
+        atomicAdd(&s_hist[key], 1u);
+    }
+    __syncthreads();
+    uint32_t* mine = st_count + (int64_t)(blockIdx.x % kHierCopies) * nst_pad;
+    for (int t = threadIdx.x; t < nst; t += 256) {
+        const uint32_t c = s_hist[t];
+        if (c) {
+            atomicAdd(&mine[t], c);
+            int shift = 0;
+            for (int pass = 0; pass < passes; ++pass) {   // digit layout of radix_sort_packed
+                const int w = (kb - shift + (passes - pass) - 1) / (passes - pass);
+                atomicAdd(&s_dig[pass * 256 + (((uint32_t)t >> shift) & ((1u << w) - 1u))], c);
+                shift += w;
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t* gh = ghist + (blockIdx.x % kGhistCopies) * (8 * 256);
+    for (int t = threadIdx.x; t < passes * 256; t += 256) {
+        const uint32_t c = s_dig[t];
+        if (c) atomicAdd(&gh[t], c);
+    }
+}
+
+// One workgroup: the sorted elements' layout.  coarse_first[s] / chunk_first[s] = first element / first chunk of (pose,
+// super-tile) key s (nst + 1 entries each), desc[c] = (key, first element, one past the last, chunk index inside the key),
+// hier[1] = chunks.  An empty or overflowed frame has none.
+__global__ void __launch_bounds__(1024) hier_plan_kernel(const hs_counters* counters, uint32_t* hier, const uint32_t* st_count,
+                                                         int nst, int nst_pad, uint32_t* coarse_first, uint32_t* chunk_first,
+                                                         uint4* desc) {
+    __shared__ uint32_t s_wave[16];
+    const bool empty = counters->reserved[0] == 0u || counters->overflow != 0u || hier[0] == 0u;
+    uint32_t ccarry = 0, kcarry = 0;
+    for (int base = 0; base < nst; base += 1024) {
+        const int sidx = base + threadIdx.x;
+        uint32_t cnt = 0;
+        if (sidx < nst && !empty) {
+#pragma unroll
+            for (int c = 0; c < kHierCopies; ++c) cnt += st_count[(int64_t)c * nst_pad + sidx];
+        }
+        const uint32_t nch = (cnt + kHierChunk - 1) / kHierChunk;
+        uint32_t ctot, ktot;
+        const uint32_t cin = block_incl_scan<16>(cnt, s_wave, &ctot);
+        const uint32_t kin = block_incl_scan<16>(nch, s_wave, &ktot);
+        const uint32_t c0 = ccarry + cin - cnt, k0 = kcarry + kin - nch;
+        if (sidx < nst) {
+            coarse_first[sidx] = c0; chunk_first[sidx] = k0;
+            for (uint32_t k = 0; k < nch; ++k)
+                desc[k0 + k] = make_uint4((uint32_t)sidx, c0 + k * kHierChunk, min(c0 + cnt, c0 + (k + 1u) * kHierChunk), k);
+        }
+        ccarry += ctot; kcarry += ktot;
+    }
+    if (threadIdx.x == 0) { coarse_first[nst] = ccarry; chunk_first[nst] = kcarry; hier[1] = kcarry; }
+}
+
+// A wave's share of a chunk: elements [wb, we).  Unpacked rectangle of an element word (above bit kb).
+__device__ __forceinline__ void hier_unpack(uint32_t word, int kb, uint32_t& lx0, uint32_t& ly0, uint32_t& lw, uint32_t& lh) {
+    const uint32_t r = word >> kb;
+    lx0 = r & 7u; ly0 = (r >> 3) & 7u; lw = ((r >> 6) & 7u) + 1u; lh = ((r >> 9) & 7u) + 1u;
+}
+
+__global__ void __launch_bounds__(256) hier_count_kernel(const uint32_t* hier, const uint4* desc, const uint2* sorted, int kb,
+                                                         uint2* counts, uint32_t* tile_total) {
+    __shared__ int s_diff[4][9 * 9 + 3];
+    __shared__ int s_row[4][64];
+    __shared__ uint32_t s_cnt[4][64];
+    const int c = blockIdx.x;
+    if ((uint32_t)c >= hier[1]) return;
+    const uint4 d = desc[c];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int t = lane; t < 9 * 9; t += 64) s_diff[wave][t] = 0;
+    const uint32_t wb = min(d.z, d.y + (uint32_t)wave * 256u), we = min(d.z, wb + 256u);
+    // (same wave: the LDS operations of its lanes complete in order, no barrier needed for the wave-private rows)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const uint32_t idx = wb + r * 64 + lane;
+        if (idx < we) {
+            uint32_t lx0, ly0, lw, lh;
+            hier_unpack(sorted[idx].x, kb, lx0, ly0, lw, lh);
+            atomicAdd(&s_diff[wave][ly0 * 9 + lx0], 1);
+            atomicAdd(&s_diff[wave][ly0 * 9 + lx0 + lw], -1);
+            atomicAdd(&s_diff[wave][(ly0 + lh) * 9 + lx0], -1);
+            atomicAdd(&s_diff[wave][(ly0 + lh) * 9 + lx0 + lw], 1);
+        }
+    }
+    const int ty = lane >> 3, tx = lane & 7;
+    int row = 0;
+#pragma unroll
+    for (int x = 0; x < 8; ++x) row += x <= tx ? s_diff[wave][ty * 9 + x] : 0;
+    s_row[wave][lane] = row;
+    int cnt = 0;
+#pragma unroll
+    for (int y = 0; y < 8; ++y) cnt += y <= ty ? s_row[wave][y * 8 + tx] : 0;
+    s_cnt[wave][lane] = (uint32_t)cnt;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const uint32_t c0 = s_cnt[0][lane], c1 = s_cnt[1][lane], c2 = s_cnt[2][lane], c3 = s_cnt[3][lane];
+        counts[(int64_t)c * 64 + lane] = make_uint2(c0 | (c1 << 16), c2 | (c3 << 16));
+        const uint32_t tot = (c0 + c1) + (c2 + c3);
+        if (tot) atomicAdd(&tile_total[(int64_t)d.x * 64 + lane], tot);
+    }
+}
+
+// One workgroup: ranges = exclusive scan of the tile totals in tile-id order (pose, row, column); tiles without pairs keep
+// the (0, 0) they were cleared to.  tile_start[(pose, super-tile) key * 64 + tile inside it] = first sorted position.
+__global__ void __launch_bounds__(1024) hier_tiles_kernel(const hs_counters* counters, const uint32_t* hier, int gx, int gy,
+                                                          int n_poses, const uint32_t* tile_total, uint32_t* tile_start,
+                                                          uint2* ranges) {
+    __shared__ uint32_t s_wave[16];
+    if (counters->reserved[0] == 0u || counters->overflow != 0u || hier[0] == 0u) return;
+    const int sgx = (gx + kSuper - 1) / kSuper, sgy = (gy + kSuper - 1) / kSuper;
+    const int64_t vtiles = (int64_t)gx * gy * n_poses;
+    uint32_t carry = 0;
+    for (int64_t base = 0; base < vtiles; base += 4096) {
+        uint32_t v[4], at[4], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t t = base + threadIdx.x * 4 + k;
+            v[k] = 0u; at[k] = 0u;
+            if (t < vtiles) {
+                const uint32_t pose = (uint32_t)(t / ((int64_t)gx * gy)), rem = (uint32_t)(t - (int64_t)pose * gx * gy);
+                const uint32_t ty = rem / (uint32_t)gx, tx = rem - ty * (uint32_t)gx;
+                at[k] = (pose * (uint32_t)(sgx * sgy) + (ty / kSuper) * (uint32_t)sgx + tx / kSuper) * 64u + (ty % kSuper) * 8u + tx % kSuper;
+                v[k] = tile_total[at[k]];
+            }
+            sum += v[k];
+        }
+        uint32_t total;
+        const uint32_t incl = block_incl_scan<16>(sum, s_wave, &total);
+        uint32_t run = carry + incl - sum;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t t = base + threadIdx.x * 4 + k;
+            if (t < vtiles) {
+                tile_start[at[k]] = run;
+                if (v[k]) ranges[t] = make_uint2(run, run + v[k]);
+            }
+            run += v[k];
+        }
+        carry += total;
+    }
+}
+
+__global__ void __launch_bounds__(256) hier_scatter_kernel(const uint32_t* hier, const uint4* desc, const uint2* sorted, int kb,
+                                                           const uint2* counts, const uint32_t* chunk_first,
+                                                           const uint32_t* tile_start, uint32_t* point_list,
+                                                           const hs_counters* counters, uint32_t* counters_host) {
+    __shared__ uint32_t s_part[4][64];
+    __shared__ uint32_t s_pos[4][64];      // next position of (wave, tile)
+    __shared__ uint32_t s_beg[4][64];
+    __shared__ uint2 s_own[4][64];
+    if (counters_host && blockIdx.x == 0 && threadIdx.x < 8)   // (the stage's last kernel: see tile_ranges_kernel)
+        __hip_atomic_store(counters_host + threadIdx.x, reinterpret_cast<const uint32_t*>(counters)[threadIdx.x],
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const int c = blockIdx.x;
+    if ((uint32_t)c >= hier[1]) return;
+    const uint4 d = desc[c];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    {   // pairs of tile `lane` in the earlier chunks of this super-tile: wave w adds rows w, w + 4, ...
+        const int64_t c0 = (int64_t)c - d.w;          // (= chunk_first[key])
+        uint32_t part = 0;
+        for (int64_t q = c0 + wave; q < c; q += 4) {
+            const uint2 v = counts[q * 64 + lane];
+            part += (v.x & 0xFFFFu) + (v.x >> 16) + (v.y & 0xFFFFu) + (v.y >> 16);
+        }
+        s_part[wave][lane] = part;
+    }
+    __syncthreads();
+    {
+        const uint2 v = counts[(int64_t)c * 64 + lane];
+        uint32_t p = tile_start[(int64_t)d.x * 64 + lane] + (s_part[0][lane] + s_part[1][lane]) + (s_part[2][lane] + s_part[3][lane]);
+        if (wave > 0) p += v.x & 0xFFFFu;
+        if (wave > 1) p += v.x >> 16;
+        if (wave > 2) p += v.y & 0xFFFFu;
+        s_pos[wave][lane] = p;
+    }
+    const uint32_t wb = min(d.z, d.y + (uint32_t)wave * 256u), we = min(d.z, wb + 256u);
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    uint32_t* const pos_w = s_pos[wave];
+    // (wave-private LDS rows from here on: in-order LDS, no barriers)
+    for (uint32_t rb = wb; rb < we; rb += 64) {
+        const uint32_t idx = rb + lane;
+        const bool valid = idx < we;
+        const uint2 e = valid ? sorted[idx] : make_uint2(0u, 0u);
+        uint32_t lx0, ly0, lw, lh;
+        hier_unpack(e.x, kb, lx0, ly0, lw, lh);
+        const uint32_t n = valid ? lw * lh : 0u;
+        const uint32_t incl = wave_incl_scan(n, lane);
+        const uint32_t total = __shfl(incl, 63);
+        s_beg[wave][lane] = incl - n;
+        const uint32_t m = (uint32_t)((float)(1 << kHierM) / (float)lw + 0.999f);   // ceil(2^10 / lw)
+        s_own[wave][lane] = make_uint2(lx0 | (ly0 << 3) | (lw << 6) | (m << 10), e.y);
+        for (uint32_t p0 = 0; p0 < total; p0 += 64) {
+            const uint32_t p = p0 + lane;
+            const bool on = p < total;
+            uint32_t k = 0;
+#pragma unroll
+            for (uint32_t step = 32; step >= 1; step >>= 1)   // largest k with beg[k] <= p
+                k |= (uint32_t)((int32_t)(s_beg[wave][k + step] - p - 1u) >> 31) & step;
+            const uint2 o = s_own[wave][k];
+            const uint32_t t = p - s_beg[wave][k];
+            const uint32_t ow = (o.x >> 6) & 15u;
+            const uint32_t ly = (t * (o.x >> 10)) >> kHierM, lx = t - ly * ow;
+            const uint32_t lt = on ? (((o.x >> 3) & 7u) + ly) * 8u + (o.x & 7u) + lx : 0u;
+            uint64_t peers = __ballot(on);   // match-any: lanes holding the same tile
+#pragma unroll
+            for (int b = 0; b < 6; ++b) {
+                const uint64_t mm = __ballot((lt >> b) & 1u);
+                peers &= ((lt >> b) & 1u) ? mm : ~mm;
+            }
+            if (on) {
+                const uint32_t before = pos_w[lt];                      // (all peers read before the last one writes: same wave)
+                const uint32_t dst = before + (uint32_t)__popcll(peers & lt_mask);
+                if ((peers >> lane) == 1ull) pos_w[lt] = dst + 1u;
+                point_list[dst] = o.y;
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------- tile ranges (a8)
 // Four consecutive sorted tile ids per thread (one 16-byte load; the id before the first comes from the neighbouring
 // lane): ranges[t] = [first, last + 1) of tile t's run; tiles without pairs keep the (0, 0) they were cleared to.

@@ -157,6 +157,52 @@ static inline int64_t count_matrix_words(int64_t I, int64_t vtiles, int64_t capa
     return count_sort_fits(I, vtiles, capacity) ? 2 * ((I + 255) / 256) * vtiles + vtiles : 0;
 }
 bool tile_sort_by_counting(int64_t I, int64_t vtiles, int64_t capacity);
+// HIERARCHICAL tile sort (binning.hip, "coarse stable pass + on-chip expansion"): the instances, walked in depth order, emit
+// one (super-tile, instance) element per 8 x 8-tile SUPER-TILE their rectangle meets (carrying the rectangle clipped to
+// that super-tile); ONE stable radix pass per eight bits of the super-tile id orders those; workgroups then expand chunks of
+// kHierChunk sorted elements into their super-tile's 64 tile lists by counting.  Fits when the (pose, super-tile) keys fit
+// the per-workgroup histogram; the binning workspace then carries hs_layout.hier_ws.
+constexpr int kSuper = 8;                       // tiles per super-tile side
+constexpr int kHierStMax = 2048;                // (pose, super-tile) keys of a frame that qualifies
+constexpr int kHierChunk = 1024;                // sorted coarse elements per expansion workgroup (four waves x 256)
+constexpr int kHierCopies = 16;                 // copies of the per-super-tile element counts (same-address atomics)
+static inline int64_t hier_super_tiles(int64_t gx, int64_t gy, int64_t n_poses) {
+    return ((gx + kSuper - 1) / kSuper) * ((gy + kSuper - 1) / kSuper) * n_poses;
+}
+static inline bool hier_fits(int64_t I, int64_t gx, int64_t gy, int64_t n_poses, int64_t capacity) {
+    return capacity > 0 && I > 0 && hier_super_tiles(gx, gy, n_poses) <= kHierStMax;
+}
+// hs_layout.hier_ws, in u32 words: header | element counts per super-tile (kHierCopies copies) | pairs per tile -- these
+// three are cleared by the stage's first kernel -- | first sorted position of every tile | first element / first chunk of
+// every super-tile | one uint4 descriptor per chunk | one row of 64 uint2 (pairs per tile and wave) per chunk
+struct HierWs {
+    int64_t nst, chunks_max;
+    int64_t st_count, tile_total, zero_words, tile_start, coarse_first, chunk_first, desc, counts, words;
+    HierWs(int64_t gx, int64_t gy, int64_t n_poses, int64_t capacity) {
+        nst = hier_super_tiles(gx, gy, n_poses);
+        chunks_max = (capacity + kHierChunk - 1) / kHierChunk + nst;
+        const int64_t nst_pad = (nst + 63) / 64 * 64;
+        int64_t o = 64;                                              // header: [0] coarse elements, [1] chunks
+        st_count = o; o += kHierCopies * nst_pad;
+        tile_total = o; o += nst * 64;
+        zero_words = o;
+        tile_start = o; o += nst * 64;
+        coarse_first = o; o += nst_pad + 64;
+        chunk_first = o; o += nst_pad + 64;
+        desc = o; o += chunks_max * 4;
+        counts = o; o += chunks_max * 64 * 2;
+        words = o;
+    }
+    int64_t nst_pad() const { return (nst + 63) / 64 * 64; }
+};
+static inline int64_t hier_ws_words(int64_t I, int64_t gx, int64_t gy, int64_t n_poses, int64_t capacity) {
+    return hier_fits(I, gx, gy, n_poses, capacity) ? HierWs(gx, gy, n_poses, capacity).words : 0;
+}
+// Which tile sort a forward of these dims runs: HS_TILE_SORT=radix / count / hier in the environment forces a form where
+// the dims allow it (read at every forward: the test suite switches it inside one process); recorded in
+// hs_counters.reserved[5] by the binning stage so that later inspection calls need not ask the environment again.
+enum TileSort { kTileSortRadix = 0, kTileSortCount = 1, kTileSortHier = 2 };
+int tile_sort_mode(int64_t I, int64_t gx, int64_t gy, int64_t n_poses, int64_t capacity);
 // keys_sorted of a frame whose pairs were sorted by counting, from its tile ranges (inspection: HS_STAGE_OFFSETS)
 int launch_tile_keys(const hs_fwd_args& a, const hs_layout& L, hipStream_t s);
 

@@ -350,7 +350,15 @@ def test_motion_blur_n_poses(oracle, dom, free):
     m = Hh.decision_masks(oracle, sc, r["fwd"], st, cams, crf_got=got_imgs, crf_ref=ref_imgs, what=dom)
     for k, f in enumerate(r["fwd"]):
         check_image(st["pose_hdr"][k], f["color"], m, f"pose {k}", pose=k)
-    Hh.assert_grads_close(g, r, at_risk=m["rows"], min_strict=0.8)
+    # (worst element: 2e-2 as at c4 -- a sum over eight poses' worth of pixel terms; measured 1.16e-2 on ONE element of the
+    #  free-pose frame, a 3-pixel Gaussian deep inside long lists whose terms cancel to 1e-4 of their magnitudes: 0.08 of the
+    #  per-element bound below)
+    Hh.assert_grads_close(g, r, at_risk=m["rows"], min_strict=0.8, max_tol=2e-2)
+    # ... and the pass that excuses nothing: dL zeroed on the differing / knot pixels on both sides, every row strict, every
+    # element inside 1e-4 |ref| + C_BOUND 2^-24 sum w|term|
+    g2, r2, _ = Hh.masked_backward_pass(oracle, sc, m, r["fwd"], cameras=cams, hdr=True, blur_domain=dom)
+    Hh.assert_grads_close(g2, r2, what=f"{dom} masked")
+    Hh.assert_grads_bounded(g2, r2, what=f"{dom} masked")
     tab = r["dL_dcrf_table"]
     if dom == "ldr" and m["n_differ"]:
         # a decision differed on some pixel (inside the guard band, asserted above): one flipped contribution moves that
