@@ -80,7 +80,7 @@ class hs_layout(C.Structure):
         "pair_flags", "pair_act",
         "final_T", "n_contrib", "pose_hdr", "tile_work", "tile_order",
         "pair_grads", "crf_partials", "inst_grads", "pose_partials",
-        "tile_matrix")]
+        "tile_matrix", "hier_ws")]
 
 
 EXPORTS = ("hs_version", "hs_last_error", "hs_plan", "hs_forward", "hs_backward", "hs_mark_visible",

@@ -50,11 +50,22 @@ bool scan_in_emission(int64_t I) {
     return forced >= 0 ? forced == 1 : (I >= (2 << 20) && !sort_tickets());
 }
 
-bool tile_sort_by_counting(int64_t I, int64_t vtiles, int64_t capacity) {
-    if (!HS_TUNE_COUNT_SORT || !count_sort_fits(I, vtiles, capacity)) return false;
+// A/B switch: large frames (those the counting sort does not take) get the hierarchical tile sort by default
+#ifndef HS_TUNE_HIER_DEFAULT
+#define HS_TUNE_HIER_DEFAULT 0
+#endif
+int tile_sort_mode(int64_t I, int64_t gx, int64_t gy, int64_t n_poses, int64_t capacity) {
     const char* e = getenv("HS_TILE_SORT");   // (read at every forward: the test suite switches it inside one process)
-    return !(e && e[0] == 'r');
+    const char f = e ? e[0] : 0;
+    const bool can_count = HS_TUNE_COUNT_SORT && count_sort_fits(I, gx * gy * n_poses, capacity);
+    const bool can_hier = hier_fits(I, gx, gy, n_poses, capacity);
+    if (f == 'r') return kTileSortRadix;
+    if (f == 'h' && can_hier) return kTileSortHier;
+    if (f == 'c') return can_count ? kTileSortCount : kTileSortRadix;
+    if (can_count) return kTileSortCount;
+    return (HS_TUNE_HIER_DEFAULT && can_hier) ? kTileSortHier : kTileSortRadix;
 }
+
 
 // Stamp of a single-enqueue forward (hs_common.h, kDepthBitsAt): never 0, never the same for two calls of a process that
 // could meet in the same memory (2^32 - 1 calls apart).  The only thing the library counts.
@@ -129,6 +140,7 @@ static int plan(const hs_dims& d, hs_sizes* sz, hs_layout* L) {
     l.pair_flags = carve(d.capacity);  // cleared by the pair emission, set by the render backward
     l.pair_act = carve(d.capacity);    // written by the render forward, read by the render backward
     l.tile_matrix = carve(count_matrix_words(I, vtiles, d.capacity) * 4);   // small frames only (else empty)
+    l.hier_ws = carve(hier_ws_words(I, gx, gy, d.n_poses, d.capacity) * 4);  // frames of <= 2048 (pose, super-tile) keys
     sz->binning_bytes = o;
     // image
     o = 0;
@@ -269,8 +281,8 @@ int hs_forward(const hs_fwd_args* a, void* hip_stream) {
         if (rc) return rc;
         if ((rc = launch_cov3d(*a, L, s))) return rc;   // ... and the 3-D covariances, which the pipeline does not keep
         // ... and, for a frame whose pairs were sorted by counting, the sorted tile ids (the radix path leaves them behind)
-        const int64_t gx = (a->dims.W + kTile - 1) / kTile, gy = (a->dims.H + kTile - 1) / kTile;
-        if (a->binning && tile_sort_by_counting((int64_t)a->dims.P * a->dims.n_poses, gx * gy * a->dims.n_poses, a->dims.capacity))
+        // (the kernel asks the frame's counters which sort it had: hs_counters.reserved[5])
+        if (a->binning && a->dims.capacity > 0)
             if ((rc = launch_tile_keys(*a, L, s))) return rc;
     }
     if (a->stages & HS_STAGE_RENDER) {

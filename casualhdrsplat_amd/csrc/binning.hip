@@ -835,6 +835,7 @@ __global__ void __launch_bounds__(256) emit_pairs_kernel(int64_t I, int P, int g
         if (poison) counters->overflow = 2u;
         else if (over && counters->overflow < 2u) counters->overflow = 1u;
         counters->reserved[0] = (poison || over || counters->overflow != 0u) ? 0u : (uint32_t)bend;
+        counters->reserved[5] = COUNT ? (uint32_t)kTileSortCount : (uint32_t)kTileSortRadix;   // which tile sort follows
     }
     uint32_t beg = 0, end = 0;
     end = (uint32_t)bexcl + incl;   // (32 bits: exact whenever the block lies below the capacity < 2^30)
@@ -1099,9 +1100,12 @@ __global__ void __launch_bounds__(256) tile_scatter_kernel(int64_t I, int vtiles
 }
 
 // keys_sorted of a frame sorted by counting, from its tile ranges (HS_STAGE_OFFSETS, inspection only): one wave per tile
-__global__ void __launch_bounds__(256) tile_keys_kernel(const uint2* ranges, int vtiles, uint32_t capacity, uint32_t* keys_sorted) {
+__global__ void __launch_bounds__(256) tile_keys_kernel(const uint2* ranges, int vtiles, uint32_t capacity, uint32_t* keys_sorted,
+                                                        const hs_counters* counters) {
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (t >= vtiles) return;
+    // (the radix passes wrote the sorted tile ids themselves; which sort the frame had is on the device, so an inspection
+    // call need not ask the environment again -- it may have changed since the forward)
+    if (t >= vtiles || counters->reserved[5] == (uint32_t)kTileSortRadix) return;
     const uint2 r = ranges[t];
     for (uint32_t p = r.x + (threadIdx.x & 63); p < min(r.y, capacity); p += 64) keys_sorted[p] = (uint32_t)t;
 }
@@ -1132,7 +1136,18 @@ __global__ void __launch_bounds__(256) tile_keys_kernel(const uint2* ranges, int
 //      match-any over the six bits of the tile inside the super-tile: point_list.
 // Stable by construction: depth order -> stable pass -> chunks, waves and the walk in element order.  keys_sorted has no
 // reader (HS_STAGE_OFFSETS fills it from the ranges on request, as for the counting sort).
-constexpr int kHierM = 10;   // floor(t / w) for t < 64, w in 1..8 as (t * ceil(2^10 / w)) >> 10
+#ifndef HS_TUNE_HIER_GRID
+#define HS_TUNE_HIER_GRID 256
+#endif
+constexpr int kHierGridPerXcd = HS_TUNE_HIER_GRID;   // expansion workgroups per XCD (persistent: each walks its XCD's chunks)
+#ifndef HS_TUNE_HIER_STAGE
+#define HS_TUNE_HIER_STAGE 1
+#endif
+constexpr int kHierStage = 1024;   // pairs of one round (64 elements) a wave stages in LDS (8 KB per wave)
+// ablation switches of hier_emit_kernel (timing experiments only; the result is wrong with any of them set)
+#ifndef HS_ABL
+#define HS_ABL 0
+#endif
 
 // rectangle (x0 | y0 << 16, w | h << 16) -> its super-tile rectangle: first super-tile column / row and the numbers of them
 __device__ __forceinline__ void hier_coarse_rect(uint2 rc, uint32_t& sx0, uint32_t& sy0, uint32_t& sw, uint32_t& sh) {
@@ -1199,7 +1214,7 @@ __global__ void __launch_bounds__(256) hier_emit_kernel(int64_t I, int P, int gx
         if (threadIdx.x == 0) { s_excl = block_excl[blk]; s_cexcl = block_cexcl[blk]; }
     } else {
         unsigned long long part = 0, cpart = 0;    // (64-bit: see emit_pairs_kernel)
-        for (int j = threadIdx.x; j < blk; j += 256) { part += block_excl[j]; cpart += block_cexcl[j]; }
+        for (int j = threadIdx.x; j < ((HS_ABL & 8) ? 0 : blk); j += 256) { part += block_excl[j]; cpart += block_cexcl[j]; }
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) {
             part += (unsigned long long)__shfl_xor((long long)part, d);
@@ -1228,10 +1243,10 @@ __global__ void __launch_bounds__(256) hier_emit_kernel(int64_t I, int P, int gx
     const uint32_t end = (uint32_t)bexcl + incl, beg = end - cnt;
     if (i < I) offs_sorted[i] = end;   // written even on overflow: the segmented sum then finds nothing flagged
     if (bend > capacity) return;
-    if (i < I && end > beg) reinterpret_cast<float*>(rec + kRecF4 * (int64_t)inst + 2)[3] = __uint_as_float(beg);
+    if (!(HS_ABL & 1) && i < I && end > beg) reinterpret_cast<float*>(rec + kRecF4 * (int64_t)inst + 2)[3] = __uint_as_float(beg);
     // "gradient record written" flags of this workgroup's pair slots [bexcl, bend): bytes up to the first 16-byte boundary,
     // 16-byte stores, bytes behind the last one
-    {
+    if (!(HS_ABL & 2)) {
         const uint64_t a0 = min(bend, (bexcl + 15ull) & ~15ull), a1 = max(a0, bend & ~15ull);
         for (uint64_t q = bexcl + threadIdx.x; q < a0; q += 256) pair_flags[q] = 0;
         for (uint64_t q = a0 + 16ull * threadIdx.x; q < a1; q += 16ull * 256) *reinterpret_cast<uint4*>(pair_flags + q) = make_uint4(0u, 0u, 0u, 0u);
@@ -1252,7 +1267,7 @@ __global__ void __launch_bounds__(256) hier_emit_kernel(int64_t I, int P, int gx
     const int sgx = (gx + kSuper - 1) / kSuper;
     const uint32_t first = __shfl(cbeg, 0);
     const uint32_t total = last_end - first;
-    for (uint32_t p = lane; p < total; p += 64) {
+    for (uint32_t p = lane; p < ((HS_ABL & 4) ? 0u : total); p += 64) {
         const uint32_t pos = first + p;
         uint32_t k = 0;
 #pragma unroll
@@ -1295,35 +1310,55 @@ __global__ void __launch_bounds__(256) hier_emit_kernel(int64_t I, int P, int gx
     }
 }
 
-// One workgroup: the sorted elements' layout.  coarse_first[s] / chunk_first[s] = first element / first chunk of (pose,
-// super-tile) key s (nst + 1 entries each), desc[c] = (key, first element, one past the last, chunk index inside the key),
-// hier[1] = chunks.  An empty or overflowed frame has none.
+// One workgroup: the sorted elements' layout.  coarse_first[s] = first element of (pose, super-tile) key s (nst + 1
+// entries).  The chunks are numbered XCD-class-major: class x = s % 8 first to last, inside a class by s, inside a key by
+// position -- so the chunks of one key are consecutive and the expansion workgroups of XCD x (blockIdx % 8 == x) take the
+// chunks [xfirst[x], xfirst[x + 1]): every tile list of a super-tile is then written through ONE XCD's L2 (a 128-byte line
+// of point_list written by workgroups on several XCDs goes to memory in pieces: 49 us instead of ~20 at c3).
+// chunk_first[s] = first chunk of key s, desc[c] = (key, first element, one past the last, chunk index inside the key),
+// hier[1] = chunks, hier[8 + x] = xfirst[x] (9 entries).  An empty or overflowed frame has none.
 __global__ void __launch_bounds__(1024) hier_plan_kernel(const hs_counters* counters, uint32_t* hier, const uint32_t* st_count,
                                                          int nst, int nst_pad, uint32_t* coarse_first, uint32_t* chunk_first,
                                                          uint4* desc) {
     __shared__ uint32_t s_wave[16];
-    const bool empty = counters->reserved[0] == 0u || counters->overflow != 0u || hier[0] == 0u;
-    uint32_t ccarry = 0, kcarry = 0;
-    for (int base = 0; base < nst; base += 1024) {
+    __shared__ uint32_t s_cnt[kHierStMax], s_first[kHierStMax];
+    // (hier[0]: zeroed by the emission's verdict on overflow and by a radix pass that gave up -- its kill word)
+    const bool empty = hier[0] == 0u;
+    uint32_t ccarry = 0;
+    for (int base = 0; base < nst; base += 1024) {      // natural order: element counts and their exclusive scan
         const int sidx = base + threadIdx.x;
         uint32_t cnt = 0;
         if (sidx < nst && !empty) {
 #pragma unroll
             for (int c = 0; c < kHierCopies; ++c) cnt += st_count[(int64_t)c * nst_pad + sidx];
         }
-        const uint32_t nch = (cnt + kHierChunk - 1) / kHierChunk;
-        uint32_t ctot, ktot;
+        uint32_t ctot;
         const uint32_t cin = block_incl_scan<16>(cnt, s_wave, &ctot);
+        if (sidx < nst) { s_cnt[sidx] = cnt; s_first[sidx] = ccarry + cin - cnt; coarse_first[sidx] = ccarry + cin - cnt; }
+        ccarry += ctot;
+    }
+    __syncthreads();
+    const int per = (nst + 7) / 8;                      // keys per class (the last ones of a class may not exist)
+    uint32_t kcarry = 0;
+    for (int base = 0; base < 8 * per; base += 1024) {  // class-major order: chunk numbers
+        const int j = base + threadIdx.x;
+        const int x = j / per, sidx = (j - x * per) * 8 + x;
+        const bool on = j < 8 * per && sidx < nst;
+        const uint32_t cnt = on ? s_cnt[sidx] : 0u;
+        const uint32_t nch = (cnt + kHierChunk - 1) / kHierChunk;
+        uint32_t ktot;
         const uint32_t kin = block_incl_scan<16>(nch, s_wave, &ktot);
-        const uint32_t c0 = ccarry + cin - cnt, k0 = kcarry + kin - nch;
-        if (sidx < nst) {
-            coarse_first[sidx] = c0; chunk_first[sidx] = k0;
+        const uint32_t k0 = kcarry + kin - nch;
+        if (j < 8 * per && j - x * per == 0) hier[8 + x] = k0;     // first key of class x
+        if (on) {
+            chunk_first[sidx] = k0;
+            const uint32_t c0 = s_first[sidx];
             for (uint32_t k = 0; k < nch; ++k)
                 desc[k0 + k] = make_uint4((uint32_t)sidx, c0 + k * kHierChunk, min(c0 + cnt, c0 + (k + 1u) * kHierChunk), k);
         }
-        ccarry += ctot; kcarry += ktot;
+        kcarry += ktot;
     }
-    if (threadIdx.x == 0) { coarse_first[nst] = ccarry; chunk_first[nst] = kcarry; hier[1] = kcarry; }
+    if (threadIdx.x == 0) { coarse_first[nst] = ccarry; hier[1] = kcarry; hier[16] = kcarry; }
 }
 
 // A wave's share of a chunk: elements [wb, we).  Unpacked rectangle of an element word (above bit kb).
@@ -1332,45 +1367,66 @@ __device__ __forceinline__ void hier_unpack(uint32_t word, int kb, uint32_t& lx0
     lx0 = r & 7u; ly0 = (r >> 3) & 7u; lw = ((r >> 6) & 7u) + 1u; lh = ((r >> 9) & 7u) + 1u;
 }
 
+// Which of a wave's 64 elements (one per lane; `valid`) cover tile `lane` = 8 * row + column of the super-tile: a 64-bit
+// mask per lane, bit j = element j.  An element covers the rows [ly0, ly0 + lh) and the columns [lx0, lx0 + lw), so the
+// 64 x 64 bit matrix is the AND of eight row ballots and eight column ballots: 16 ballots, parked in lanes 0..15 of a
+// register pair and fetched by tile.
+__device__ __forceinline__ uint64_t hier_cover(uint32_t word, int kb, bool valid, int lane) {
+    uint32_t lx0, ly0, lw, lh;
+    hier_unpack(word, kb, lx0, ly0, lw, lh);
+    if (!valid) { lw = 0u; lh = 0u; }
+    int vlo = 0, vhi = 0;
+    // (v_writelane_b32 by inline assembly: this compiler has no builtin for it; the lane is an inline constant.  gfx940+: a
+    // VALU instruction that reads an SGPR written by a VALU instruction needs two wait states in between, which the
+    // compiler provides for its own instructions but cannot for the inside of an asm statement -- hence the s_nop 1: without
+    // it the column ballots arrived one v_cmp late)
+#define HS_COVER_Q(q)                                                                                                    \
+    {                                                                                                                    \
+        const uint64_t r = __ballot((uint32_t)(q) - ly0 < lh); /* (unsigned: ly0 <= q < ly0 + lh) */                     \
+        const uint64_t c = __ballot((uint32_t)(q) - lx0 < lw);                                                           \
+        asm volatile("s_nop 1\n\tv_writelane_b32 %0, %2, " #q "\n\tv_writelane_b32 %1, %3, " #q                                     \
+                     : "+v"(vlo), "+v"(vhi) : "s"((uint32_t)r), "s"((uint32_t)(r >> 32)));                               \
+        asm volatile("s_nop 1\n\tv_writelane_b32 %0, %2, 8+" #q "\n\tv_writelane_b32 %1, %3, 8+" #q                                 \
+                     : "+v"(vlo), "+v"(vhi) : "s"((uint32_t)c), "s"((uint32_t)(c >> 32)));                               \
+    }
+    HS_COVER_Q(0) HS_COVER_Q(1) HS_COVER_Q(2) HS_COVER_Q(3) HS_COVER_Q(4) HS_COVER_Q(5) HS_COVER_Q(6) HS_COVER_Q(7)
+#undef HS_COVER_Q
+    const int ra = (lane >> 3) * 4, ca = (8 + (lane & 7)) * 4;
+    const uint32_t rlo = (uint32_t)__builtin_amdgcn_ds_bpermute(ra, vlo), rhi = (uint32_t)__builtin_amdgcn_ds_bpermute(ra, vhi);
+    const uint32_t clo = (uint32_t)__builtin_amdgcn_ds_bpermute(ca, vlo), chi = (uint32_t)__builtin_amdgcn_ds_bpermute(ca, vhi);
+    return ((uint64_t)(rhi & chi) << 32) | (uint64_t)(rlo & clo);
+}
+
 __global__ void __launch_bounds__(256) hier_count_kernel(const uint32_t* hier, const uint4* desc, const uint2* sorted, int kb,
                                                          uint2* counts, uint32_t* tile_total) {
-    __shared__ int s_diff[4][9 * 9 + 3];
-    __shared__ int s_row[4][64];
     __shared__ uint32_t s_cnt[4][64];
-    const int c = blockIdx.x;
-    if ((uint32_t)c >= hier[1]) return;
-    const uint4 d = desc[c];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int t = lane; t < 9 * 9; t += 64) s_diff[wave][t] = 0;
-    const uint32_t wb = min(d.z, d.y + (uint32_t)wave * 256u), we = min(d.z, wb + 256u);
-    // (same wave: the LDS operations of its lanes complete in order, no barrier needed for the wave-private rows)
+    const int xcd = blockIdx.x % 8;
+    const uint32_t c_end = hier[8 + xcd + 1];
+    for (uint32_t c = hier[8 + xcd] + blockIdx.x / 8; c < c_end; c += gridDim.x / 8) {
+        const uint4 d = desc[c];
+        const uint32_t wb = min(d.z, d.y + (uint32_t)wave * 256u), we = min(d.z, wb + 256u);
+        uint32_t w4[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const uint32_t idx = wb + r * 64 + lane;
-        if (idx < we) {
-            uint32_t lx0, ly0, lw, lh;
-            hier_unpack(sorted[idx].x, kb, lx0, ly0, lw, lh);
-            atomicAdd(&s_diff[wave][ly0 * 9 + lx0], 1);
-            atomicAdd(&s_diff[wave][ly0 * 9 + lx0 + lw], -1);
-            atomicAdd(&s_diff[wave][(ly0 + lh) * 9 + lx0], -1);
-            atomicAdd(&s_diff[wave][(ly0 + lh) * 9 + lx0 + lw], 1);
+        for (int r = 0; r < 4; ++r) {   // (all four loads in flight)
+            const uint32_t idx = wb + r * 64 + lane;
+            w4[r] = idx < we ? sorted[idx].x : 0u;
         }
-    }
-    const int ty = lane >> 3, tx = lane & 7;
-    int row = 0;
+        uint32_t cnt = 0;   // pairs of tile `lane` among this wave's elements
 #pragma unroll
-    for (int x = 0; x < 8; ++x) row += x <= tx ? s_diff[wave][ty * 9 + x] : 0;
-    s_row[wave][lane] = row;
-    int cnt = 0;
-#pragma unroll
-    for (int y = 0; y < 8; ++y) cnt += y <= ty ? s_row[wave][y * 8 + tx] : 0;
-    s_cnt[wave][lane] = (uint32_t)cnt;
-    __syncthreads();
-    if (threadIdx.x < 64) {
-        const uint32_t c0 = s_cnt[0][lane], c1 = s_cnt[1][lane], c2 = s_cnt[2][lane], c3 = s_cnt[3][lane];
-        counts[(int64_t)c * 64 + lane] = make_uint2(c0 | (c1 << 16), c2 | (c3 << 16));
-        const uint32_t tot = (c0 + c1) + (c2 + c3);
-        if (tot) atomicAdd(&tile_total[(int64_t)d.x * 64 + lane], tot);
+        for (int r = 0; r < 4; ++r) {
+            if (wb + r * 64 >= we) break;
+            cnt += (uint32_t)__popcll(hier_cover(w4[r], kb, wb + r * 64 + lane < we, lane));
+        }
+        s_cnt[wave][lane] = cnt;
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            const uint32_t c0 = s_cnt[0][lane], c1 = s_cnt[1][lane], c2 = s_cnt[2][lane], c3 = s_cnt[3][lane];
+            counts[(int64_t)c * 64 + lane] = make_uint2(c0 | (c1 << 16), c2 | (c3 << 16));
+            const uint32_t tot = (c0 + c1) + (c2 + c3);
+            if (tot) atomicAdd(&tile_total[(int64_t)d.x * 64 + lane], tot);
+        }
+        __syncthreads();
     }
 }
 
@@ -1380,30 +1436,34 @@ __global__ void __launch_bounds__(1024) hier_tiles_kernel(const hs_counters* cou
                                                           int n_poses, const uint32_t* tile_total, uint32_t* tile_start,
                                                           uint2* ranges) {
     __shared__ uint32_t s_wave[16];
-    if (counters->reserved[0] == 0u || counters->overflow != 0u || hier[0] == 0u) return;
+    // (an empty or overflowed frame has no chunks, hence no pairs in any tile: nothing is written, the ranges stay cleared)
     const int sgx = (gx + kSuper - 1) / kSuper, sgy = (gy + kSuper - 1) / kSuper;
     const int64_t vtiles = (int64_t)gx * gy * n_poses;
     uint32_t carry = 0;
-    for (int64_t base = 0; base < vtiles; base += 4096) {
-        uint32_t v[4], at[4], sum = 0;
+    constexpr int E = 8;   // consecutive tiles per thread: BASELINE c3's 8160 tiles in one round
+    const uint32_t tpp = (uint32_t)(gx * gy);
+    for (int64_t base = 0; base < vtiles; base += 1024 * E) {
+        uint32_t v[E], at[E], sum = 0;
+        // (pose, row, column) of the thread's first tile by division, of the others by carrying
+        const uint32_t t0 = (uint32_t)base + threadIdx.x * E;
+        uint32_t pose = t0 / tpp, rem = t0 - pose * tpp, ty = rem / (uint32_t)gx, tx = rem - ty * (uint32_t)gx;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int64_t t = base + threadIdx.x * 4 + k;
+        for (int k = 0; k < E; ++k) {
+            const int64_t t = base + threadIdx.x * E + k;
             v[k] = 0u; at[k] = 0u;
             if (t < vtiles) {
-                const uint32_t pose = (uint32_t)(t / ((int64_t)gx * gy)), rem = (uint32_t)(t - (int64_t)pose * gx * gy);
-                const uint32_t ty = rem / (uint32_t)gx, tx = rem - ty * (uint32_t)gx;
                 at[k] = (pose * (uint32_t)(sgx * sgy) + (ty / kSuper) * (uint32_t)sgx + tx / kSuper) * 64u + (ty % kSuper) * 8u + tx % kSuper;
                 v[k] = tile_total[at[k]];
             }
             sum += v[k];
+            if (++tx == (uint32_t)gx) { tx = 0u; if (++ty == (uint32_t)gy) { ty = 0u; ++pose; } }
         }
         uint32_t total;
         const uint32_t incl = block_incl_scan<16>(sum, s_wave, &total);
         uint32_t run = carry + incl - sum;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int64_t t = base + threadIdx.x * 4 + k;
+        for (int k = 0; k < E; ++k) {
+            const int64_t t = base + threadIdx.x * E + k;
             if (t < vtiles) {
                 tile_start[at[k]] = run;
                 if (v[k]) ranges[t] = make_uint2(run, run + v[k]);
@@ -1419,75 +1479,76 @@ __global__ void __launch_bounds__(256) hier_scatter_kernel(const uint32_t* hier,
                                                            const uint32_t* tile_start, uint32_t* point_list,
                                                            const hs_counters* counters, uint32_t* counters_host) {
     __shared__ uint32_t s_part[4][64];
-    __shared__ uint32_t s_pos[4][64];      // next position of (wave, tile)
-    __shared__ uint32_t s_beg[4][64];
-    __shared__ uint2 s_own[4][64];
+    __shared__ uint32_t s_inst[4][64];
+    __shared__ uint2 s_stage[4][kHierStage];      // (instance, destination) of a round's pairs, tile after tile
     if (counters_host && blockIdx.x == 0 && threadIdx.x < 8)   // (the stage's last kernel: see tile_ranges_kernel)
         __hip_atomic_store(counters_host + threadIdx.x, reinterpret_cast<const uint32_t*>(counters)[threadIdx.x],
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    const int c = blockIdx.x;
-    if ((uint32_t)c >= hier[1]) return;
-    const uint4 d = desc[c];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    {   // pairs of tile `lane` in the earlier chunks of this super-tile: wave w adds rows w, w + 4, ...
-        const int64_t c0 = (int64_t)c - d.w;          // (= chunk_first[key])
-        uint32_t part = 0;
-        for (int64_t q = c0 + wave; q < c; q += 4) {
-            const uint2 v = counts[q * 64 + lane];
-            part += (v.x & 0xFFFFu) + (v.x >> 16) + (v.y & 0xFFFFu) + (v.y >> 16);
-        }
-        s_part[wave][lane] = part;
-    }
-    __syncthreads();
-    {
-        const uint2 v = counts[(int64_t)c * 64 + lane];
-        uint32_t p = tile_start[(int64_t)d.x * 64 + lane] + (s_part[0][lane] + s_part[1][lane]) + (s_part[2][lane] + s_part[3][lane]);
-        if (wave > 0) p += v.x & 0xFFFFu;
-        if (wave > 1) p += v.x >> 16;
-        if (wave > 2) p += v.y & 0xFFFFu;
-        s_pos[wave][lane] = p;
-    }
-    const uint32_t wb = min(d.z, d.y + (uint32_t)wave * 256u), we = min(d.z, wb + 256u);
-    const uint64_t lt_mask = (1ull << lane) - 1ull;
-    uint32_t* const pos_w = s_pos[wave];
-    // (wave-private LDS rows from here on: in-order LDS, no barriers)
-    for (uint32_t rb = wb; rb < we; rb += 64) {
-        const uint32_t idx = rb + lane;
-        const bool valid = idx < we;
-        const uint2 e = valid ? sorted[idx] : make_uint2(0u, 0u);
-        uint32_t lx0, ly0, lw, lh;
-        hier_unpack(e.x, kb, lx0, ly0, lw, lh);
-        const uint32_t n = valid ? lw * lh : 0u;
-        const uint32_t incl = wave_incl_scan(n, lane);
-        const uint32_t total = __shfl(incl, 63);
-        s_beg[wave][lane] = incl - n;
-        const uint32_t m = (uint32_t)((float)(1 << kHierM) / (float)lw + 0.999f);   // ceil(2^10 / lw)
-        s_own[wave][lane] = make_uint2(lx0 | (ly0 << 3) | (lw << 6) | (m << 10), e.y);
-        for (uint32_t p0 = 0; p0 < total; p0 += 64) {
-            const uint32_t p = p0 + lane;
-            const bool on = p < total;
-            uint32_t k = 0;
+    const int xcd = blockIdx.x % 8;
+    const uint32_t c_end = hier[8 + xcd + 1];
+    for (uint32_t c = hier[8 + xcd] + blockIdx.x / 8; c < c_end; c += gridDim.x / 8) {
+        const uint4 d = desc[c];
+        const uint32_t wb = min(d.z, d.y + (uint32_t)wave * 256u), we = min(d.z, wb + 256u);
+        uint2 e4[4];
 #pragma unroll
-            for (uint32_t step = 32; step >= 1; step >>= 1)   // largest k with beg[k] <= p
-                k |= (uint32_t)((int32_t)(s_beg[wave][k + step] - p - 1u) >> 31) & step;
-            const uint2 o = s_own[wave][k];
-            const uint32_t t = p - s_beg[wave][k];
-            const uint32_t ow = (o.x >> 6) & 15u;
-            const uint32_t ly = (t * (o.x >> 10)) >> kHierM, lx = t - ly * ow;
-            const uint32_t lt = on ? (((o.x >> 3) & 7u) + ly) * 8u + (o.x & 7u) + lx : 0u;
-            uint64_t peers = __ballot(on);   // match-any: lanes holding the same tile
-#pragma unroll
-            for (int b = 0; b < 6; ++b) {
-                const uint64_t mm = __ballot((lt >> b) & 1u);
-                peers &= ((lt >> b) & 1u) ? mm : ~mm;
+        for (int r = 0; r < 4; ++r) {   // (this wave's elements: all four loads in flight under the sums below)
+            const uint32_t idx = wb + r * 64 + lane;
+            e4[r] = idx < we ? sorted[idx] : make_uint2(0u, 0u);
+        }
+        {   // pairs of tile `lane` in the earlier chunks of this super-tile: wave w adds rows w, w + 4, ...
+            const int64_t c0 = (int64_t)c - d.w;          // (= chunk_first[key])
+            uint32_t part = 0;
+            for (int64_t q = c0 + wave; q < c; q += 4) {
+                const uint2 v = counts[q * 64 + lane];
+                part += (v.x & 0xFFFFu) + (v.x >> 16) + (v.y & 0xFFFFu) + (v.y >> 16);
             }
-            if (on) {
-                const uint32_t before = pos_w[lt];                      // (all peers read before the last one writes: same wave)
-                const uint32_t dst = before + (uint32_t)__popcll(peers & lt_mask);
-                if ((peers >> lane) == 1ull) pos_w[lt] = dst + 1u;
-                point_list[dst] = o.y;
+            s_part[wave][lane] = part;
+        }
+        __syncthreads();
+        // next position of tile `lane` for this wave: start of the tile + earlier chunks + earlier waves of this chunk
+        uint32_t pos;
+        {
+            const uint2 v = counts[(int64_t)c * 64 + lane];
+            pos = tile_start[(int64_t)d.x * 64 + lane] + (s_part[0][lane] + s_part[1][lane]) + (s_part[2][lane] + s_part[3][lane]);
+            if (wave > 0) pos += v.x & 0xFFFFu;
+            if (wave > 1) pos += v.x >> 16;
+            if (wave > 2) pos += v.y & 0xFFFFu;
+        }
+        // 64 elements at a time: lane = tile walks the elements that cover it, in element order (= depth order).  The pairs
+        // go through LDS -- tile after tile, each with its destination -- and leave it slot by slot, so that neighbouring lanes
+        // store to neighbouring addresses (a tile's run): 64 lanes each storing into its own tile's stream cost 22 of the
+        // kernel's 39 us at c3, whatever the addresses (measured with all stores folded into 256 KB: the cost is per
+        // uncoalesced lane, not per byte).  A round with more pairs than the buffer holds (large Gaussians) stores directly.
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (wb + r * 64 >= we) break;
+            uint64_t cover = hier_cover(e4[r].x, kb, wb + r * 64 + lane < we, lane);
+            s_inst[wave][lane] = e4[r].y;      // (wave-private rows, in-order LDS: no barriers)
+            const uint32_t m = (uint32_t)__popcll(cover);
+            const uint32_t incl = wave_incl_scan(m, lane);
+            const uint32_t total = __shfl(incl, 63);
+            if (HS_TUNE_HIER_STAGE && total <= (uint32_t)kHierStage) {
+                uint32_t o = incl - m, dst = pos;
+                while (cover) {
+                    const int j = __builtin_ctzll(cover);
+                    cover &= cover - 1ull;
+                    s_stage[wave][o++] = make_uint2(s_inst[wave][j], dst++);
+                }
+                pos = dst;
+                for (uint32_t q = lane; q < total; q += 64) {
+                    const uint2 v = s_stage[wave][q];
+                    point_list[v.y] = v.x;
+                }
+            } else {
+                while (cover) {
+                    const int j = __builtin_ctzll(cover);
+                    cover &= cover - 1ull;
+                    point_list[pos++] = s_inst[wave][j];
+                }
             }
         }
+        __syncthreads();
     }
 }
 
@@ -1584,7 +1645,8 @@ int launch_tile_keys(const hs_fwd_args& a, const hs_layout& L, hipStream_t s) {
     const int vtiles = gx * gy * d.n_poses;
     char* bin = (char*)a.binning;
     tile_keys_kernel<<<ceil_div(vtiles, 4), 256, 0, s>>>((const uint2*)(bin + L.ranges), vtiles, (uint32_t)d.capacity,
-                                                        (uint32_t*)(bin + L.keys_sorted));
+                                                        (uint32_t*)(bin + L.keys_sorted),
+                                                        (const hs_counters*)((const char*)a.geom + L.counters));
     HS_LAUNCH_CHECK();
     return HS_OK;
 }
@@ -1654,7 +1716,68 @@ int launch_binning(const hs_fwd_args& a, const hs_layout& L, hipStream_t s, uint
     uint2* pA = (uint2*)(bin + L.keys_sorted);
     uint2* pB = (uint2*)(bin + L.pairs_tmp);
     // small frames: counting sort by tile id (the kernels above); the emission then always writes buffer B
-    const bool counting = tile_sort_by_counting(I, ntiles, d.capacity);
+    const int mode = tile_sort_mode(I, gx, gy, d.n_poses, d.capacity);
+    if (mode == kTileSortHier) {
+        // hierarchical form (kernels above).  Elements start in packed buffer A when the pass count is odd, so that the
+        // sorted list ends in B: A's second half is point_list, which the expansion writes while it reads the list
+        const HierWs W(gx, gy, d.n_poses, d.capacity);
+        uint32_t* hw = (uint32_t*)(bin + L.hier_ws);
+        const int kb = tile_bits((uint32_t)W.nst), cpasses = sort_passes(kb);
+        const int eblk = ceil_div(I, 256);
+        uint2* srect = dp0;
+        uint32_t* bsum = (uint32_t*)dp1;
+        uint32_t* bcsum = bsum + eblk;
+        hier_gather_kernel<<<eblk, 256, 0, s>>>(I, inst_sorted, (const uint2*)(geom + L.binfo), srect, counters, bsum, bcsum,
+                                                hw, W.zero_words);
+        const bool excl_ready = eblk > 8192;
+        if (excl_ready) {
+            scan_spine_kernel<<<1, 256, 0, s>>>(bsum, eblk, nullptr);
+            scan_spine_kernel<<<1, 256, 0, s>>>(bcsum, eblk, nullptr);
+        }
+        uint2* e0 = cpasses % 2 != 0 ? pA : pB;
+        uint2* e1 = e0 == pA ? pB : pA;
+        const SortScratch sc(tmp2, d.capacity, kPairTile);
+        hier_emit_kernel<<<eblk, 256, 0, s>>>(I, d.P, gx, gy, (float4*)(geom + L.rec), inst_sorted, srect, bsum, bcsum, offs, e0,
+                                              (uint8_t*)(bin + L.pair_flags), counters, (uint64_t)d.capacity, sc.ghist, kb,
+                                              cpasses, depth_bits, (int)excl_ready, hw, hw + W.st_count, (int)W.nst,
+                                              (int)W.nst_pad());
+        HS_LAUNCH_CHECK();
+        {
+            const int nblk = ceil_div(d.capacity, kPairTile);
+            uint2* in = e0; uint2* out = e1;
+            int pass = 0;
+            for (int shift = 0, w = 0; shift < kb; shift += w, ++pass) {
+                w = (kb - shift + (cpasses - pass) - 1) / (cpasses - pass);
+                uint32_t* st = sc.status + (int64_t)pass * sc.pass_words;
+                const uint32_t mask = ((1u << w) - 1u) | (fault_injection() == 3 ? 0x80000000u : 0u);
+                if (sort_tickets())
+                    radix_sweep_kernel<uint32_t, kPairSortItems, kPairSortLook, true, true, true><<<nblk, kSortBlock, 0, s>>>(
+                        in, nullptr, out, nullptr, hw, shift, mask, st, sc.ghist + 256 * pass, sc.tickets + pass,
+                        &counters->overflow, hw);
+                else
+                    radix_sweep_kernel<uint32_t, kPairSortItems, kPairSortLook, true, true, false><<<nblk, kSortBlock, 0, s>>>(
+                        in, nullptr, out, nullptr, hw, shift, mask, st, sc.ghist + 256 * pass, sc.tickets + pass,
+                        &counters->overflow, hw);
+                HS_LAUNCH_CHECK();
+                uint2* t = in; in = out; out = t;
+            }
+            // `in` = the sorted elements (packed buffer B)
+            hier_plan_kernel<<<1, 1024, 0, s>>>(counters, hw, hw + W.st_count, (int)W.nst, (int)W.nst_pad(), hw + W.coarse_first,
+                                                hw + W.chunk_first, (uint4*)(hw + W.desc));
+            // expansion workgroups: 8 XCDs x kHierGridPerXcd, each walking its XCD's chunks
+            const int egrid = 8 * (int)min((int64_t)kHierGridPerXcd, (W.chunks_max + 7) / 8);
+            hier_count_kernel<<<egrid, 256, 0, s>>>(hw, (const uint4*)(hw + W.desc), in, kb, (uint2*)(hw + W.counts),
+                                                                hw + W.tile_total);
+            hier_tiles_kernel<<<1, 1024, 0, s>>>(counters, hw, gx, gy, d.n_poses, hw + W.tile_total, hw + W.tile_start, ranges);
+            hier_scatter_kernel<<<egrid, 256, 0, s>>>(hw, (const uint4*)(hw + W.desc), in, kb,
+                                                                  (const uint2*)(hw + W.counts), hw + W.chunk_first,
+                                                                  hw + W.tile_start, (uint32_t*)(bin + L.point_list), counters,
+                                                                  (uint32_t*)a.counters_host);
+            HS_LAUNCH_CHECK();
+        }
+        return HS_OK;
+    }
+    const bool counting = mode == kTileSortCount;
     uint2* p0 = (counting || passes % 2 != 0) ? pB : pA;
     uint2* p1 = p0 == pA ? pB : pA;
     uint32_t* t_counts = (uint32_t*)(bin + L.tile_matrix);            // [emission workgroup][key]: pairs, one byte per wave

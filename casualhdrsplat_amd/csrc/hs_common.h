@@ -156,7 +156,6 @@ static inline bool count_sort_fits(int64_t I, int64_t vtiles, int64_t capacity) 
 static inline int64_t count_matrix_words(int64_t I, int64_t vtiles, int64_t capacity) {
     return count_sort_fits(I, vtiles, capacity) ? 2 * ((I + 255) / 256) * vtiles + vtiles : 0;
 }
-bool tile_sort_by_counting(int64_t I, int64_t vtiles, int64_t capacity);
 // HIERARCHICAL tile sort (binning.hip, "coarse stable pass + on-chip expansion"): the instances, walked in depth order, emit
 // one (super-tile, instance) element per 8 x 8-tile SUPER-TILE their rectangle meets (carrying the rectangle clipped to
 // that super-tile); ONE stable radix pass per eight bits of the super-tile id orders those; workgroups then expand chunks of

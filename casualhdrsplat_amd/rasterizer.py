@@ -833,6 +833,8 @@ def inspect_state(out_tensor) -> dict:
         pose_hdr=pose_hdr,
         num_rendered=R,
         look_back_helps=int(view(st.geom, lay.counters, 8, torch.int32)[6].item()),   # hs_counters.reserved[4]
+        tile_sort=int(view(st.geom, lay.counters, 8, torch.int32)[7].item()),         # reserved[5]: 0 radix, 1 counting, 2 hierarchical
+        inst_sorted=view(st.binning, lay.inst_sorted, I, torch.int32), offs_sorted=view(st.binning, lay.offs_sorted, I, torch.int32),
         rec=rec, xy=rec[:, 0:2], conic_opacity=torch.stack([rec[:, 2], rec[:, 3], rec[:, 4], rec[:, 5]], 1),
         rgb=rec[:, 6:9], depths=depths,
         radii=view(st.geom, lay.radii, I, torch.int32), tiles_touched=view(st.geom, lay.tiles_touched, I, torch.int32),

@@ -35,7 +35,7 @@ extern "C" {
 /* libhdrsplat.so is built with -fvisibility=hidden: the hs_* entry points below are its only exported symbols */
 #define HS_API __attribute__((visibility("default")))
 
-#define HS_VERSION 306
+#define HS_VERSION 307
 
 #define HS_OK 0
 #define HS_EINVAL (-1)    /* bad argument (null pointer, bad shape, unsupported degree ...) */
@@ -110,7 +110,8 @@ typedef struct hs_counters {
     uint32_t reserved[6];  /* [0] = pairs actually binned (R, or 0 on overflow); [1] = instance count of the depth sort;
                               [3] = tile-queue counter of the render backward (zero between launches); [4] = times a
                               waiting workgroup of HS_STAGE_BIN had to compute a silent predecessor's counts itself
-                              (non-zero: other kernels kept its blocks off the GPU -- see hs_sort_tickets); others unused */
+                              (non-zero: other kernels kept its blocks off the GPU -- see hs_sort_tickets); [5] = the tile
+                              sort HS_STAGE_BIN ran (0 radix passes, 1 counting, 2 hierarchical); others unused */
 } hs_counters;
 
 typedef struct hs_fwd_args {
@@ -251,6 +252,12 @@ typedef struct hs_layout {
      * workgroups | u32 [keys] totals.  Such a forward writes point_list and ranges but NOT keys_sorted (nothing reads it);
      * HS_STAGE_OFFSETS fills keys_sorted from the ranges for inspection. */
     int64_t tile_matrix;
+    /* (HS_VERSION 307) hier_ws (binning workspace; empty unless the frame has <= 2048 (pose, 8 x 8-tile super-tile) keys):
+     * scratch of the hierarchical tile sort -- u32 header | element counts per super-tile | pairs per tile | first sorted
+     * position per tile | first element / chunk per super-tile | chunk descriptors | per-chunk pair counts.  Selected with
+     * HS_TILE_SORT=hier in the environment; like the counting sort it writes point_list and ranges but not keys_sorted.
+     * hs_counters.reserved[5] records which tile sort a forward ran (0 radix, 1 counting, 2 hierarchical). */
+    int64_t hier_ws;
 } hs_layout;
 
 HS_API int hs_version(void);

@@ -4,7 +4,7 @@ ROOT=${GRAFT_REPO_ROOT:-$PWD}
 O=$ROOT/gpurun_out/kstats
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O -- python3 $ROOT/scripts/step_c3.py --steps 10 "$@" > $O/log.txt 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O -- python3 $ROOT/scripts/step_c3.py --steps 10 "$@" > $O/log.txt 2>&1
 python3 - <<PY
 import csv, glob
 f = glob.glob("$O/*/*kernel_stats.csv")[0]

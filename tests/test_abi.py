@@ -70,7 +70,7 @@ def test_struct_sizes_match_c(lib, tmp_path):
 
 def test_version_and_plan(lib):
     L = lib.load()
-    assert L.hs_version() == 306
+    assert L.hs_version() == 307
     d, sz, lay = lib.plan(1_000_000, 16, 3, 1920, 1080, 1, 7_000_000)
     assert sz.geom_bytes > 1_000_000 * 48 and sz.binning_bytes > 7_000_000 * 16
     assert sz.image_bytes >= 1920 * 1080 * (8 + 12) and sz.bwd_bytes >= 7_000_000 * 48
@@ -92,7 +92,7 @@ def test_plan_carries_the_counting_sorts_matrices_for_small_frames_only(lib):
     def tail(P, W, H, N, cap):
         _, sz, lay = lib.plan(P, 1, 0, W, H, N, cap)
         assert lay.tile_matrix % 256 == 0 and lay.tile_matrix >= lay.pair_act
-        return sz.binning_bytes - lay.tile_matrix
+        return lay.hier_ws - lay.tile_matrix      # (hier_ws, HS_VERSION 307, is carved behind it)
     rows, keys = (100_000 + 255) // 256, 50 * 50
     assert (2 * rows * keys + keys) * 4 <= tail(100_000, 800, 800, 1, 900_000) < (2 * rows * keys + keys) * 4 + 256   # c2
     assert tail(1_000_000, 1920, 1080, 1, 7_000_000) == 0                                                           # c3: 8160 tiles
@@ -100,6 +100,19 @@ def test_plan_carries_the_counting_sorts_matrices_for_small_frames_only(lib):
     assert tail(10_000, 1024, 1024, 1, 100_000) > 0 and tail(10_000, 1040, 1024, 1, 100_000) == 0   # 4096 / 4160 tiles
     assert tail(700, 256, 256, 16, 10_000) > 0 and tail(700, 256, 256, 17, 10_000) == 0             # 16 / 17 poses x 256 tiles
     assert tail(10_000, 800, 800, 1, 0) == 0                    # no binning capacity: nothing to sort
+
+
+def test_plan_carries_the_hierarchical_sorts_workspace_up_to_2048_super_tile_keys(lib):
+    """hs_layout.hier_ws (HS_VERSION 307): frames of <= 2048 (pose, 8 x 8-tile super-tile) keys -- BASELINE c3 (135) and
+    c4 (1080) -- carry the scratch of the hierarchical tile sort at the end of the binning workspace."""
+    def tail(P, W, H, N, cap):
+        _, sz, lay = lib.plan(P, 1, 0, W, H, N, cap)
+        assert lay.hier_ws % 256 == 0 and lay.hier_ws >= lay.tile_matrix
+        return sz.binning_bytes - lay.hier_ws
+    chunks = (7_000_000 + 1023) // 1024 + 135
+    assert tail(1_000_000, 1920, 1080, 1, 7_000_000) >= chunks * (16 + 512) + 135 * 64 * 8      # descriptors + count rows + tiles
+    assert tail(1_000_000, 1920, 1080, 8, 60_000_000) > 0 and tail(1_000_000, 1920, 1080, 16, 60_000_000) == 0   # 1080 / 2160 keys
+    assert tail(10_000, 800, 800, 1, 0) == 0
 
 
 def test_plan_rejects_bad_dims(lib):

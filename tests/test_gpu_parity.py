@@ -16,6 +16,7 @@ Bars (BASELINE.json north_star): tile assignment / indexing bit-exact; pixel and
     The strict bar is what profiles/r02_parity_table.json measures: HIP and the fp32 C oracle are equally far from
     float64 autograd (test_hip_is_as_close_to_fp64_truth_as_the_fp32_oracle asserts that triangle directly).
 """
+import contextlib
 import glob
 import os
 
@@ -114,7 +115,8 @@ def test_ldr_forward_backward_vs_oracle(oracle, P, W, H, deg, seed, cam_seed):
     Hh.assert_grads_bounded(g2, b2, what=f"P={P} masked")
 
 
-@pytest.fixture(params=["default", "tickets", "scan_in_emission", "radix_tile_sort", "scan_in_emission+counting"])
+@pytest.fixture(params=["default", "tickets", "scan_in_emission", "radix_tile_sort", "scan_in_emission+counting", "hier",
+                        "hier+tickets"])
 def binning_mode(request):
     """The binning stage's alternate forms inside the driver's suite: chain positions of the radix
     passes from start-order tickets (hs_sort_tickets(1): what a process on a shared GPU runs) and the pair emission
@@ -122,12 +124,15 @@ def binning_mode(request):
     run), each forced onto frames that would take the default form.  Small frames (<= 4096 tiles, a few hundred thousand
     instances: most of this suite) sort their pairs by counting instead of radix passes: "tickets" and "scan_in_emission"
     keep the radix passes on them as well (HS_TILE_SORT=radix), "radix_tile_sort" only does that, and
-    "scan_in_emission+counting" runs the counting sort behind the chained-scan emission."""
+    "scan_in_emission+counting" runs the counting sort behind the chained-scan emission.  "hier" (round 6): the hierarchical
+    tile sort -- one element per (8 x 8-tile super-tile, instance), one stable radix pass, expansion by counting."""
     from casualhdrsplat_amd import _lib as L
     lib = L.load()
     was, env = lib.hs_sort_tickets(-1), {k: os.environ.get(k) for k in ("HS_SCAN_IN_EMISSION", "HS_TILE_SORT")}
-    if request.param == "tickets":
+    if request.param in ("tickets", "hier+tickets"):
         lib.hs_sort_tickets(1)
+    if request.param.startswith("hier"):   # round 6: coarse stable pass over (super-tile, instance) elements + expansion
+        os.environ["HS_TILE_SORT"] = "hier"
     if request.param.startswith("scan_in_emission"):
         os.environ["HS_SCAN_IN_EMISSION"] = "1"
     if request.param in ("tickets", "scan_in_emission", "radix_tile_sort"):
@@ -574,6 +579,93 @@ def test_frame_of_14400_tiles_vs_oracle(oracle):
     m = Hh.decision_masks(oracle, sc, [f], st, what="14400 tiles")
     check_image(g["color"], f["color"], m, "14400 tiles")
     Hh.assert_grads_close(g, b, what="14400 tiles", at_risk=m["rows"], min_strict=0.95)
+
+
+def skewed_scene(P=30000, W=640, H=384, deg=1, seed=31):
+    """Half of the cloud inside ONE 8 x 8-tile super-tile (the 128 x 128-pixel block at tiles (8..15, 8..15)): the skewed
+    load of the hierarchical tile sort -- one super-tile holds hundreds of chunks, its neighbours a handful."""
+    sc = S.make_scene(P, W, H, deg, seed=seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    half = torch.rand(P, generator=g) < 0.5
+    fx = W / (2 * sc.camera.tanfovx)
+    px = 128.0 + 128.0 * torch.rand(P, generator=g, dtype=torch.float64)
+    py = 128.0 + 128.0 * torch.rand(P, generator=g, dtype=torch.float64)
+    z = sc.means3D[:, 2].double()
+    x = ((2 * px + 1) / W - 1) * sc.camera.tanfovx * z
+    y = ((2 * py + 1) / H - 1) * sc.camera.tanfovy * z
+    sc.means3D[half, 0] = x[half].float()
+    sc.means3D[half, 1] = y[half].float()
+    return sc
+
+
+@contextlib.contextmanager
+def tile_sort(form):
+    """HS_TILE_SORT=form for the forwards inside (read by the library at every forward)."""
+    was = os.environ.get("HS_TILE_SORT")
+    os.environ["HS_TILE_SORT"] = form
+    try:
+        yield
+    finally:
+        if was is None:
+            os.environ.pop("HS_TILE_SORT", None)
+        else:
+            os.environ["HS_TILE_SORT"] = was
+
+
+@pytest.mark.parametrize("form", ["hier", "radix"])
+def test_skewed_scene_vs_oracle(oracle, form):
+    """Half the cloud inside one super-tile: structure bit-exact, images and gradients within the
+    contract, through the hierarchical tile sort and through the radix passes."""
+    sc = skewed_scene()
+    f, b = Hh.run_oracle(oracle, sc)
+    with tile_sort(form):
+        g = Hh.run_hip(sc)
+    st = g["state"]
+    R = f["R"]
+    assert st["num_rendered"] == R
+    assert int(st["tile_sort"]) == {"radix": 0, "hier": 2}[form]
+    check_structure(st, f)
+    assert np.array_equal(u32(st["offsets"]), u32(f["offsets"]))
+    assert np.array_equal(st["keys_sorted"].view(np.uint64)[:R], f["keys_sorted"])
+    assert np.array_equal(u32(st["point_list"][:R]), u32(f["point_list"]))
+    assert np.array_equal(u32(st["ranges"]), u32(f["ranges"]))
+    # the pair slots in depth order: inst_sorted is a permutation ordered by depth bits (ties by instance), offs_sorted
+    # the inclusive scan of its tile counts
+    order = np.lexsort((np.arange(len(f["depths"])), np.where(f["radii"] > 0, Hh.bits(f["depths"]), 0xFFFFFFFF)))
+    vis = int((f["radii"] > 0).sum())
+    assert np.array_equal(u32(st["inst_sorted"])[:vis], order[:vis])
+    assert np.array_equal(u32(st["offs_sorted"]), np.cumsum(u32(f["tiles_touched"])[u32(st["inst_sorted"])]))
+    lens = (f["ranges"][:, 1].astype(np.int64) - f["ranges"][:, 0]).reshape(24, 40)
+    assert lens[8:16, 8:16].sum() > 0.4 * R            # ... the scene is as skewed as it says
+    m = Hh.decision_masks(oracle, sc, [f], st, what="skewed")
+    check_image(g["color"], f["color"], m, "skewed")
+    Hh.assert_grads_close(g, b, what="skewed", at_risk=m["rows"], min_strict=0.9)
+
+
+@pytest.mark.parametrize("cfg", ["c3", "c4"])
+def test_hierarchical_tile_sort_equals_the_radix_passes_at_full_size(cfg):
+    """BASELINE c3 and c4 through both tile sorts of large frames: every array the binning stage leaves -- point_list,
+    ranges, the rebuilt sorted keys, the depth-ordered instance list and pair offsets, num_rendered -- and, downstream,
+    images and every gradient, bit for bit.  (The radix form is the one test_c3_... / test_c4_... hold against the oracle.)"""
+    P, W, H = 1_000_000, 1920, 1080
+    sc = S.make_scene(P, W, H, 3, seed=0, hdr=True)
+    cams = S.blur_poses(W, H, 8) if cfg == "c4" else None
+    out = {}
+    for form in ("radix", "hier"):
+        with tile_sort(form):
+            out[form] = Hh.run_hip(sc, cameras=cams, hdr=True)
+        torch.cuda.empty_cache()
+    a, b = out["radix"], out["hier"]
+    assert int(a["state"]["tile_sort"]) == 0 and int(b["state"]["tile_sort"]) == 2
+    R = a["state"]["num_rendered"]
+    assert R == b["state"]["num_rendered"] and R > (50_000_000 if cfg == "c4" else 6_000_000)
+    for k in ("point_list", "keys_sorted"):
+        assert np.array_equal(a["state"][k][:R], b["state"][k][:R]), k
+    for k in ("ranges", "inst_sorted", "offs_sorted", "n_contrib", "final_T", "tiles_touched"):
+        assert np.array_equal(a["state"][k], b["state"][k]), k
+    for k in a:
+        if k != "state" and a[k] is not None:
+            assert np.array_equal(Hh.bits(a[k]) if a[k].dtype == np.float32 else a[k], Hh.bits(b[k]) if b[k].dtype == np.float32 else b[k]), k
 
 
 @pytest.mark.parametrize("P,W,H,n_poses", [(150000, 320, 240, 1), (3000, 1024, 1024, 1), (700, 256, 256, 16)])
