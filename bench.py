@@ -699,6 +699,7 @@ def main():
             # c2 the host, not the GPU, paces the eager step).  Used only if the replay reproduces the eager step bit for bit.
             launch, run_step, gstep = "eager (one enqueue per kernel)", step, None
             want_graph = args.graph == "on"
+            probe = {"graph_flag": args.graph}
             if world == 1 and args.graph == "auto":
                 for _ in range(3):
                     step()
@@ -707,7 +708,14 @@ def main():
                 for _ in range(10):
                     step()
                 torch.cuda.synchronize()
-                want_graph = (time.perf_counter() - t0) / 10 < 0.6e-3   # a step this short is at the mercy of the box's CPU
+                probe_ms = (time.perf_counter() - t0) / 10 * 1e3
+                want_graph = probe_ms < 0.6   # a step this short is at the mercy of the box's CPU
+                # what the probe saw and why it chose (two boxes chose differently at c2 -- the eager
+                # step there is paced by the host, 0.3 ms of enqueue work, so either form times the same GPU work)
+                probe.update({"eager_probe_ms_per_step": round(probe_ms, 4), "threshold_ms": 0.6,
+                              "rule": "hip_graph iff 10 eager steps average below the threshold (host-paced step) and the "
+                                      "replay reproduces the eager step bit for bit",
+                              "wanted": "hip_graph" if want_graph else "eager"})
             if world == 1 and want_graph:
                 try:
                     from casualhdrsplat_amd.graphs import GraphedStep
@@ -726,7 +734,9 @@ def main():
                     if not all(torch.equal(a_, b_) for a_, b_ in zip(want, got)):
                         raise RuntimeError("graph replay differs from the eager step")
                     launch, run_step = "hip_graph (whole step captured once, replayed)", gstep.step
+                    probe["graph_bit_identical"] = True
                 except Exception as e:  # noqa: BLE001 -- any capture problem: the eager step is always there
+                    probe["graph_rejected"] = f"{type(e).__name__}: {str(e)[:120]}"
                     if args.graph == "on":
                         raise
                     print(f"[bench] HIP-graph step unavailable ({type(e).__name__}: {str(e)[:200]}); timing the eager step",
@@ -735,7 +745,7 @@ def main():
                     for p_ in plist:
                         p_.grad = None
             return dict(step=step, state=state, sc=sc, dL=dL, plist=plist, counts=counts, launch=launch, run_step=run_step,
-                        gstep=gstep, seed=seed)
+                        gstep=gstep, seed=seed, probe=probe)
 
         def time_seed(seed):
             """W untimed warm-up steps, then EXACTLY K timed steps between barrier + synchronize, MAX over ranks: the same
@@ -790,7 +800,7 @@ def main():
                        "seed": ctx["seed"],
                        "seeds": f"value / ms_per_step = the median of seeds {seeds}, each timed alike ({warmup} warm-up + "
                                 f"{steps} steps); roofline / stages / counts belong to seed {ctx['seed']}",
-                       "binning": "sync-free fixed capacity 1.25*R", "launch": launch},
+                       "binning": "sync-free fixed capacity 1.25*R", "launch": launch, "launch_probe": ctx["probe"]},
             "mpix_per_s": world * W * H * n_poses / ms_per_step / 1e3,
             "seeds_ms_per_step": {**{str(k): v["ms_per_step"] for k, v in per_seed.items()},
                                   **{f"R_{k}": v["R"] for k, v in per_seed.items()},
@@ -840,7 +850,10 @@ def main():
             bytes_fwd = 40 * Rp + 20 * WH + 8 * vtiles
             ach = bytes_bwd / (bwd_ms * 1e-3) / 1e9
             from casualhdrsplat_amd import inspect_state
-            n_visible = int((inspect_state(out[0])["radii"] > 0).sum())
+            ist = inspect_state(out[0])
+            n_visible = int((ist["radii"] > 0).sum())
+            line["config"]["tile_sort"] = {0: "radix passes over (tile, instance) pairs", 1: "counting (small frame)",
+                                           2: "hierarchical: one pass over (super-tile, instance) elements + expansion"}[int(ist["tile_sort"])]
             step_bytes = whole_step_bytes(cfg, R, Rp, vtiles, n_visible)
             step_gbs = step_bytes["total"] / (ms_per_step * 1e-3) / 1e9
             line["roofline"] = {
@@ -873,7 +886,7 @@ def main():
                 "binning_in_step": step_bytes["scan"] + step_bytes["duplicate_with_keys"] + step_bytes["sort_one_ideal_pass"] + step_bytes["tile_ranges"],
                 "render_fwd": bytes_fwd, "render_bwd": bytes_bwd,
                 "pair_segsum": 36 * Rp + 40 * I_,
-                "preprocess_bwd": (in_row + 40) * I_ + in_row * P,
+                "preprocess_bwd": in_row * P + 40 * I_ + in_row * P,   # row read once per Gaussian + 40 B per instance sum + row written
             }
             if hdr:
                 pk_bytes["crf_gradient"] = 2 * 12 * WH
@@ -939,7 +952,7 @@ def main():
                 o, _, _ = bench_config(name, [0], k_steps, args.warmup)
                 other[name] = {"ms_per_step": o["ms_per_step"], "images_per_s": o["value"], "mpix_per_s": o["mpix_per_s"],
                                "steps": k_steps, "warmup": args.warmup, "seed": 0, "workload": o["config"]["workload"],
-                               "launch": o["config"]["launch"], "num_rendered_R": o["config"]["num_rendered_R"],
+                               "launch": o["config"]["launch"], "launch_probe": o["config"]["launch_probe"], "num_rendered_R": o["config"]["num_rendered_R"],
                                "R_prime": o["config"]["R_prime"], "stages_ms": o["stages_ms"],
                                "roofline": {k: o["roofline"][k] for k in ("kernel", "achieved", "frac", "frac_hbm_measured",
                                                                           "algorithmic_bytes", "avg_ms")},

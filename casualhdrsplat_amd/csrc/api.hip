@@ -52,7 +52,7 @@ bool scan_in_emission(int64_t I) {
 
 // A/B switch: large frames (those the counting sort does not take) get the hierarchical tile sort by default
 #ifndef HS_TUNE_HIER_DEFAULT
-#define HS_TUNE_HIER_DEFAULT 0
+#define HS_TUNE_HIER_DEFAULT 1
 #endif
 int tile_sort_mode(int64_t I, int64_t gx, int64_t gy, int64_t n_poses, int64_t capacity) {
     const char* e = getenv("HS_TILE_SORT");   // (read at every forward: the test suite switches it inside one process)

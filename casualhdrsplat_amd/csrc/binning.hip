@@ -1179,6 +1179,7 @@ __global__ void __launch_bounds__(256) hier_gather_kernel(int64_t I, const uint3
 
 // Element: .x = (pose, super-tile) key | clipped rectangle above bit `kb` (x0: 3 bits, y0: 3, w - 1: 3, h - 1: 3, all in
 // tiles relative to the super-tile), .y = instance.
+template <bool BIG>   // BIG (>= 2^21 instances): non-temporal slot-start / element stores, as in emit_pairs_kernel<true>
 __global__ void __launch_bounds__(256) hier_emit_kernel(int64_t I, int P, int gx, int gy, float4* rec,
                                                         const uint32_t* inst_sorted, const uint2* srect,
                                                         const uint32_t* block_excl, const uint32_t* block_cexcl,
@@ -1243,7 +1244,11 @@ __global__ void __launch_bounds__(256) hier_emit_kernel(int64_t I, int P, int gx
     const uint32_t end = (uint32_t)bexcl + incl, beg = end - cnt;
     if (i < I) offs_sorted[i] = end;   // written even on overflow: the segmented sum then finds nothing flagged
     if (bend > capacity) return;
-    if (!(HS_ABL & 1) && i < I && end > beg) reinterpret_cast<float*>(rec + kRecF4 * (int64_t)inst + 2)[3] = __uint_as_float(beg);
+    if (!(HS_ABL & 1) && i < I && end > beg) {
+        float* slot_start = &reinterpret_cast<float*>(rec + kRecF4 * (int64_t)inst + 2)[3];
+        if constexpr (BIG && (HS_EMIT_NT_MASK & 2)) __builtin_nontemporal_store(__uint_as_float(beg), slot_start);
+        else *slot_start = __uint_as_float(beg);
+    }
     // "gradient record written" flags of this workgroup's pair slots [bexcl, bend): bytes up to the first 16-byte boundary,
     // 16-byte stores, bytes behind the last one
     if (!(HS_ABL & 2)) {
@@ -1285,7 +1290,8 @@ __global__ void __launch_bounds__(256) hier_emit_kernel(int64_t I, int P, int gx
         const uint32_t lx0 = max(x0, ox) - ox, lx1 = min(x1, ox + kSuper) - ox;
         const uint32_t ly0 = max(y0, oy) - oy, ly1 = min(y1, oy + kSuper) - oy;
         const uint32_t word = key | ((lx0 | (ly0 << 3) | ((lx1 - lx0 - 1u) << 6) | ((ly1 - ly0 - 1u) << 9)) << kb);
-        elems[pos] = make_uint2(word, o.w);
+        if constexpr (BIG && (HS_EMIT_NT_MASK & 4)) { __builtin_nontemporal_store(word, &elems[pos].x); __builtin_nontemporal_store(o.w, &elems[pos].y); }
+        else elems[pos] = make_uint2(word, o.w);
         atomicAdd(&s_hist[key], 1u);
     }
     __syncthreads();
@@ -1430,47 +1436,56 @@ __global__ void __launch_bounds__(256) hier_count_kernel(const uint32_t* hier, c
     }
 }
 
-// One workgroup: ranges = exclusive scan of the tile totals in tile-id order (pose, row, column); tiles without pairs keep
-// the (0, 0) they were cleared to.  tile_start[(pose, super-tile) key * 64 + tile inside it] = first sorted position.
-__global__ void __launch_bounds__(1024) hier_tiles_kernel(const hs_counters* counters, const uint32_t* hier, int gx, int gy,
-                                                          int n_poses, const uint32_t* tile_total, uint32_t* tile_start,
-                                                          uint2* ranges) {
+// ranges = exclusive scan of the tile totals in tile-id order (pose, row, column); tiles without pairs keep the (0, 0) they
+// were cleared to.  tile_start[(pose, super-tile) key * 64 + tile inside it] = first sorted position.  One workgroup per
+// 8192 tiles (BASELINE c3: one); a workgroup adds up the totals in front of its tiles itself (c4: 65 280 tiles, eight
+// workgroups, at most 56 gathered loads per thread) -- no chain, no second kernel.
+constexpr int kHierTilesPerThread = 8, kHierTilesPerBlock = 1024 * kHierTilesPerThread;
+__device__ __forceinline__ uint32_t hier_tile_slot(uint32_t t, uint32_t tpp, uint32_t gx, int sgx, int sgy) {
+    const uint32_t pose = t / tpp, rem = t - pose * tpp, ty = rem / gx, tx = rem - ty * gx;
+    return (pose * (uint32_t)(sgx * sgy) + (ty / kSuper) * (uint32_t)sgx + tx / kSuper) * 64u + (ty % kSuper) * 8u + tx % kSuper;
+}
+__global__ void __launch_bounds__(1024) hier_tiles_kernel(int gx, int gy, int n_poses, const uint32_t* tile_total,
+                                                          uint32_t* tile_start, uint2* ranges) {
     __shared__ uint32_t s_wave[16];
     // (an empty or overflowed frame has no chunks, hence no pairs in any tile: nothing is written, the ranges stay cleared)
     const int sgx = (gx + kSuper - 1) / kSuper, sgy = (gy + kSuper - 1) / kSuper;
-    const int64_t vtiles = (int64_t)gx * gy * n_poses;
-    uint32_t carry = 0;
-    constexpr int E = 8;   // consecutive tiles per thread: BASELINE c3's 8160 tiles in one round
+    const uint32_t vtiles = (uint32_t)(gx * gy * n_poses);   // (< 2^31: hs_plan)
+    constexpr int E = kHierTilesPerThread;
     const uint32_t tpp = (uint32_t)(gx * gy);
-    for (int64_t base = 0; base < vtiles; base += 1024 * E) {
-        uint32_t v[E], at[E], sum = 0;
-        // (pose, row, column) of the thread's first tile by division, of the others by carrying
-        const uint32_t t0 = (uint32_t)base + threadIdx.x * E;
-        uint32_t pose = t0 / tpp, rem = t0 - pose * tpp, ty = rem / (uint32_t)gx, tx = rem - ty * (uint32_t)gx;
+    const uint32_t base = blockIdx.x * (uint32_t)kHierTilesPerBlock;
+    uint32_t carry = 0;
+    if (blockIdx.x > 0) {   // pairs of all tiles in front of this workgroup's
+        uint32_t part = 0;
+        for (uint32_t t = threadIdx.x; t < base; t += 1024) part += tile_total[hier_tile_slot(t, tpp, (uint32_t)gx, sgx, sgy)];
+        uint32_t all;
+        block_incl_scan<16>(part, s_wave, &all);
+        carry = all;
+    }
+    uint32_t v[E], at[E], sum = 0;
+    // (pose, row, column) of the thread's first tile by division, of the others by carrying
+    const uint32_t t0 = base + threadIdx.x * E;
+    uint32_t pose = t0 / tpp, rem = t0 - pose * tpp, ty = rem / (uint32_t)gx, tx = rem - ty * (uint32_t)gx;
 #pragma unroll
-        for (int k = 0; k < E; ++k) {
-            const int64_t t = base + threadIdx.x * E + k;
-            v[k] = 0u; at[k] = 0u;
-            if (t < vtiles) {
-                at[k] = (pose * (uint32_t)(sgx * sgy) + (ty / kSuper) * (uint32_t)sgx + tx / kSuper) * 64u + (ty % kSuper) * 8u + tx % kSuper;
-                v[k] = tile_total[at[k]];
-            }
-            sum += v[k];
-            if (++tx == (uint32_t)gx) { tx = 0u; if (++ty == (uint32_t)gy) { ty = 0u; ++pose; } }
+    for (int k = 0; k < E; ++k) {
+        v[k] = 0u; at[k] = 0u;
+        if (t0 + k < vtiles) {
+            at[k] = (pose * (uint32_t)(sgx * sgy) + (ty / kSuper) * (uint32_t)sgx + tx / kSuper) * 64u + (ty % kSuper) * 8u + tx % kSuper;
+            v[k] = tile_total[at[k]];
         }
-        uint32_t total;
-        const uint32_t incl = block_incl_scan<16>(sum, s_wave, &total);
-        uint32_t run = carry + incl - sum;
+        sum += v[k];
+        if (++tx == (uint32_t)gx) { tx = 0u; if (++ty == (uint32_t)gy) { ty = 0u; ++pose; } }
+    }
+    uint32_t total;
+    const uint32_t incl = block_incl_scan<16>(sum, s_wave, &total);
+    uint32_t run = carry + incl - sum;
 #pragma unroll
-        for (int k = 0; k < E; ++k) {
-            const int64_t t = base + threadIdx.x * E + k;
-            if (t < vtiles) {
-                tile_start[at[k]] = run;
-                if (v[k]) ranges[t] = make_uint2(run, run + v[k]);
-            }
-            run += v[k];
+    for (int k = 0; k < E; ++k) {
+        if (t0 + k < vtiles) {
+            tile_start[at[k]] = run;
+            if (v[k]) ranges[t0 + k] = make_uint2(run, run + v[k]);
         }
-        carry += total;
+        run += v[k];
     }
 }
 
@@ -1737,10 +1752,12 @@ int launch_binning(const hs_fwd_args& a, const hs_layout& L, hipStream_t s, uint
         uint2* e0 = cpasses % 2 != 0 ? pA : pB;
         uint2* e1 = e0 == pA ? pB : pA;
         const SortScratch sc(tmp2, d.capacity, kPairTile);
-        hier_emit_kernel<<<eblk, 256, 0, s>>>(I, d.P, gx, gy, (float4*)(geom + L.rec), inst_sorted, srect, bsum, bcsum, offs, e0,
-                                              (uint8_t*)(bin + L.pair_flags), counters, (uint64_t)d.capacity, sc.ghist, kb,
-                                              cpasses, depth_bits, (int)excl_ready, hw, hw + W.st_count, (int)W.nst,
-                                              (int)W.nst_pad());
+#define HS_HEMIT_ARGS I, d.P, gx, gy, (float4*)(geom + L.rec), inst_sorted, srect, bsum, bcsum, offs, e0,                             \
+                      (uint8_t*)(bin + L.pair_flags), counters, (uint64_t)d.capacity, sc.ghist, kb, cpasses, depth_bits,             \
+                      (int)excl_ready, hw, hw + W.st_count, (int)W.nst, (int)W.nst_pad()
+        if (I >= (2 << 20)) hier_emit_kernel<true><<<eblk, 256, 0, s>>>(HS_HEMIT_ARGS);
+        else hier_emit_kernel<false><<<eblk, 256, 0, s>>>(HS_HEMIT_ARGS);
+#undef HS_HEMIT_ARGS
         HS_LAUNCH_CHECK();
         {
             const int nblk = ceil_div(d.capacity, kPairTile);
@@ -1768,7 +1785,8 @@ int launch_binning(const hs_fwd_args& a, const hs_layout& L, hipStream_t s, uint
             const int egrid = 8 * (int)min((int64_t)kHierGridPerXcd, (W.chunks_max + 7) / 8);
             hier_count_kernel<<<egrid, 256, 0, s>>>(hw, (const uint4*)(hw + W.desc), in, kb, (uint2*)(hw + W.counts),
                                                                 hw + W.tile_total);
-            hier_tiles_kernel<<<1, 1024, 0, s>>>(counters, hw, gx, gy, d.n_poses, hw + W.tile_total, hw + W.tile_start, ranges);
+            hier_tiles_kernel<<<ceil_div(ntiles, kHierTilesPerBlock), 1024, 0, s>>>(gx, gy, d.n_poses, hw + W.tile_total,
+                                                                                    hw + W.tile_start, ranges);
             hier_scatter_kernel<<<egrid, 256, 0, s>>>(hw, (const uint4*)(hw + W.desc), in, kb,
                                                                   (const uint2*)(hw + W.counts), hw + W.chunk_first,
                                                                   hw + W.tile_start, (uint32_t*)(bin + L.point_list), counters,

@@ -104,6 +104,7 @@ class _SplinePoses(torch.autograd.Function):
         return w2c.to(delta.dtype)
 
     @staticmethod
+    @torch.autograd.function.once_differentiable   # (the saved Jacobian is a constant: no second-order terms through here)
     def backward(ctx, g):
         jac, seg = ctx.saved_tensors
         T, J = jac.shape[0], ctx.J
@@ -126,8 +127,9 @@ class TrajectorySpline(nn.Module):
     kind="linear": geodesic between the two knots bracketing t (t in [0, J - 1]).
     """
 
-    def __init__(self, init_w2c: torch.Tensor, kind: str = "linear"):
-        """init_w2c: [J, 4, 4] initial world-to-camera matrices of the knots (e.g. from SfM)."""
+    def __init__(self, init_w2c: torch.Tensor, kind: str = "cubic"):
+        """init_w2c: [J, 4, 4] initial world-to-camera matrices of the knots (e.g. from SfM).  kind: "cubic" (default: the
+        figure's model -- four control knots around every exposure window, /root/reference/assets/pipeline.png) or "linear"."""
         super().__init__()
         if kind not in ("linear", "cubic"):
             raise ValueError("kind must be 'linear' or 'cubic'")
@@ -160,7 +162,9 @@ class TrajectorySpline(nn.Module):
         code (segment look-up by index_select): no host read of t, so it neither synchronises nor breaks a graph capture."""
         t = t.reshape(-1)
         J = self.base.shape[0]
-        if self.fused and t.is_cuda and self.delta.is_cuda:
+        # (the kernel computes in float64 but takes and returns float32: a module of another dtype -- the float64 twins of
+        # the tests -- keeps the tensor form, at its own precision)
+        if self.fused and t.is_cuda and self.delta.is_cuda and self.delta.dtype == torch.float32:
             return _SplinePoses.apply(self.delta, self.base, t, self.kind)
         Tk = self.knots()
         inc = se3_log(_mm(Tk[1:], rigid_inv(Tk[:-1])))           # [J - 1, 6]: knot(j + 1) = exp(inc[j]) knot(j)
@@ -261,11 +265,14 @@ class HDRBlurFormation(nn.Module):
     def __init__(self, trajectory: TrajectorySpline, n_frames: int, W: int, H: int, tanfovx: float, tanfovy: float,
                  n_virtual: int = 8, crf: Optional[ImplicitCRF] = None, blur_domain: str = "ldr", sh_degree: int = 3,
                  rasterizer_factory: Callable = GaussianRasterizer, frame_times: Optional[torch.Tensor] = None,
-                 window_from_exposure: bool = False, window_scale: float = 1.0):
+                 window_from_exposure: bool = True, window_scale: float = 1.0):
         """frame_times [n_frames]: mid-exposure time of every captured frame in knot units (default: the middle of
-        the i-th interval the trajectory defines).  window_from_exposure: the exposure window of frame i is
-        dt_i * window_scale knot intervals long (dt_i = exp(log_exposure_i), window_scale = knot intervals per unit of
-        exposure time, i.e. the capture's knot rate); False: one knot interval whatever the exposure."""
+        the i-th interval the trajectory defines).  window_from_exposure (default, the figure's "Exposure time range"): the
+        exposure window of frame i is dt_i * window_scale knot intervals long (dt_i = exp(log_exposure_i), window_scale =
+        knot intervals per unit of exposure time, i.e. the capture's knot rate; default 1: a frame of unit exposure -- the
+        initial value of every dt_i -- spans one knot interval); False: one knot interval whatever the exposure.
+        Raises ValueError when a frame's mid-exposure time lies outside trajectory.t_range (poses beyond it would be
+        extrapolated from the last segment) -- e.g. more frames than a cubic spline of J knots has segments (J - 3)."""
         super().__init__()
         self.trajectory = trajectory
         self.crf = crf if crf is not None else ImplicitCRF()
@@ -276,7 +283,12 @@ class HDRBlurFormation(nn.Module):
         t0 = trajectory.t_range[0]
         if frame_times is None:
             frame_times = t0 + 0.5 + torch.arange(n_frames, dtype=torch.float32)
-        self.register_buffer("frame_times", torch.as_tensor(frame_times, dtype=torch.float32).clone())
+        ft = torch.as_tensor(frame_times, dtype=torch.float32).clone().reshape(-1)
+        t_lo, t_hi = trajectory.t_range
+        if ft.numel() != n_frames or (n_frames and (float(ft.min()) < t_lo or float(ft.max()) > t_hi)):
+            raise ValueError(f"HDRBlurFormation: {n_frames} frame time(s) {ft.tolist()} must lie inside the trajectory's "
+                             f"t_range [{t_lo}, {t_hi}] ({trajectory.kind} spline over {trajectory.base.shape[0]} knots)")
+        self.register_buffer("frame_times", ft)
         # (built once: filling a device matrix element by element from host scalars is a run of host-to-device copies, which
         # a graph capture does not allow)
         self.register_buffer("proj", projection_matrix(tanfovx, tanfovy))

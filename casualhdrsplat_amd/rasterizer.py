@@ -29,6 +29,7 @@ import ctypes as C
 from typing import NamedTuple, Optional
 
 import warnings
+import weakref
 
 import torch
 import torch.nn as nn
@@ -328,6 +329,26 @@ def _run_forward(settings: GaussianRasterizationSettings, means3D, opacities, sh
     return out_color, out_hdr, radii, st, exposure, crf_table, invdepth
 
 
+# id(leaf) -> view-parallel rasterizer calls (reduce_group) that took the leaf and whose backward is still to come; see
+# _RasterizeGaussians.forward.  Keyed by id (a tensor's == is element-wise); a finalizer drops the entry with the tensor.
+_OPEN_CONSUMERS: dict = {}
+
+
+def _open_consumers(t: torch.Tensor) -> int:
+    return _OPEN_CONSUMERS.get(id(t), 0)
+
+
+def _open_consumers_add(t: torch.Tensor, n: int) -> None:
+    k = id(t)
+    if k not in _OPEN_CONSUMERS:
+        weakref.finalize(t, _OPEN_CONSUMERS.pop, k, None)
+    v = _OPEN_CONSUMERS.get(k, 0) + n
+    if v > 0:
+        _OPEN_CONSUMERS[k] = v
+    else:
+        _OPEN_CONSUMERS[k] = 0
+
+
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
@@ -352,10 +373,23 @@ class _RasterizeGaussians(torch.autograd.Function):
         # 3DGS wiring: scales = exp(raw), opacity = sigmoid(raw), rotations = normalize(raw), shs = cat(dc, rest) -- makes
         # autograd run the activation's backward on the compute stream right away, and a leaf with a .grad is added to:
         # both would read rows RCCL is still summing.  Then backward() waits for the collectives itself.
-        ctx.reduce_may_stay_in_flight = all(
-            (not t.requires_grad) or (t.is_leaf and t.grad is None)
-            for t in (means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, exposure, crf_table)
-            if isinstance(t, torch.Tensor))
+        # ... and only if this call is the SOLE consumer of those leaves until its backward has run: a leaf that
+        # feeds two rasterizer calls before one backward -- a multi-frame step, a second view -- has its two incoming
+        # gradients summed by the autograd engine on the compute stream, again while RCCL may still be reducing the rows.
+        # Every differentiable leaf carries the number of view-parallel calls whose backward is still to come
+        # (_OPEN_CONSUMERS); a count above one at forward OR at backward time makes backward() wait.  (A forward whose
+        # graph is dropped without a backward leaves its count behind: the conservative side -- later calls wait.)
+        diff = [t for t in (means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, exposure, crf_table)
+                if isinstance(t, torch.Tensor) and t.requires_grad]
+        ctx.reduce_may_stay_in_flight = all(t.is_leaf and t.grad is None for t in diff)
+        ctx.open_leaves = []
+        if aux is not None and aux.get("reduce_group") is not None and torch.is_grad_enabled():
+            for t in diff:
+                if t.is_leaf:
+                    _open_consumers_add(t, 1)
+                    ctx.open_leaves.append(weakref.ref(t))
+            if any(_open_consumers(t) > 1 for t in diff if t.is_leaf):
+                ctx.reduce_may_stay_in_flight = False
         if aux is not None:  # what GaussianRasterizer keeps of the call (never the outputs: see st.keep)
             aux["pending"], aux["num_rendered"] = st.pending, st.num_rendered
             if aux.get("keep_state"):
@@ -405,15 +439,26 @@ class _RasterizeGaussians(torch.autograd.Function):
                                  gather_direct=bool(ctx.deferred.get("gather_direct")) if ctx.deferred else False,
                                  reduce_group=None if ctx.aux is None else ctx.aux.get("reduce_group"),
                                  reduce_chunks=0 if ctx.aux is None else int(ctx.aux.get("reduce_chunks") or 0))
+        # this call's backward is here: its leaves have one consumer less to wait for -- but if another call took one of
+        # them in the meantime (count above one NOW), the engine will add that call's gradient to ours: wait below
+        shared = False
+        for ref in getattr(ctx, "open_leaves", ()):
+            t = ref()
+            if t is not None:
+                shared = shared or _open_consumers(t) > 1
+                _open_consumers_add(t, -1)
         if ctx.aux is not None and g.get("_reduce_pending") is not None:
-            if ctx.reduce_may_stay_in_flight:
-                ctx.aux["cell"]["reduce_pending"] = g["_reduce_pending"]   # GaussianRasterizer.finish_reduce() waits for these
+            if ctx.reduce_may_stay_in_flight and not shared:
+                # (extended, never replaced: several calls of one rasterizer may each leave collectives in flight before
+                # finish_reduce() is called)
+                ctx.aux["cell"].setdefault("reduce_pending", []).extend(g["_reduce_pending"])   # GaussianRasterizer.finish_reduce() waits for these
             else:
                 # (see forward: autograd is about to USE these gradients.  On RCCL waiting = the compute stream waits for
                 # the communication stream, the host does not block; the overlap with this backward's own chunks stays)
                 from .distributed import finish_pending
-                ctx.aux["cell"]["reduce_waited_in_backward"] = finish_pending(g["_reduce_pending"])
-                ctx.aux["cell"]["reduce_pending"] = []
+                ctx.aux["cell"]["reduce_waited_in_backward"] = (ctx.aux["cell"].get("reduce_waited_in_backward", 0)
+                                                                + finish_pending(g["_reduce_pending"]))
+                ctx.aux["cell"].setdefault("reduce_pending", [])
         if ctx.deferred is not None:
             # view-parallel exchange: hand the per-view colour gradients to distributed.exchange_view_gradients
             ctx.deferred.update(view_colors=g["view_colors"], camposes=st.camposes, means3D=saved[0],

@@ -97,6 +97,40 @@ def main():
     for k, v in raw.items():
         b = want_raw[k]
         assert torch.allclose(v.grad, b, rtol=1e-5, atol=1e-6 * float(b.abs().max())), ("activated", k)
+    # a leaf that feeds TWO rasterizer calls before one backward (a multi-frame step, a second view per
+    # rank).  The autograd engine then sums the two calls' gradients on the compute stream: neither call may leave its
+    # chunked all-reduce in flight -- both backwards must have waited (finish_reduce() finds nothing) -- and every leaf
+    # ends with the sum over ranks AND calls.  A single call on fresh leaves afterwards may again stay in flight.
+    def two_calls(view_ranks, chunked):
+        leaf = {k: t.clone().to(dev).requires_grad_(True) for k, t in
+                dict(means3D=sc.means3D, opacities=sc.opacities, shs=sc.shs, scales=sc.scales, rotations=sc.rotations).items()}
+        rasts, loss = [], 0.0
+        for vr in view_ranks:
+            sc.camera = S.yaw_camera(W, Hh, -5.0 + 10.0 * vr / max(2 * world - 1, 1))
+            rs, _, _ = H.settings_from_scene(sc, dev)
+            rast = GaussianRasterizer(rs, reduce_group=True if chunked else None, reduce_chunks=3)
+            out = rast(leaf["means3D"], torch.zeros_like(leaf["means3D"]), leaf["opacities"], shs=leaf["shs"],
+                       scales=leaf["scales"], rotations=leaf["rotations"])
+            loss = loss + (out[0] * sc.dL_dimage.to(dev)).sum()
+            rasts.append(rast)
+        loss.backward()
+        return leaf, rasts
+
+    want2 = None
+    for r in range(world):
+        leaf, _ = two_calls((2 * r, 2 * r + 1), False)
+        g = {k: v.grad.clone() for k, v in leaf.items()}
+        want2 = g if want2 is None else {k: want2[k] + g[k] for k in g}
+    leaf, rasts = two_calls((2 * rank, 2 * rank + 1), True)
+    assert all(r_._cell.get("reduce_waited_in_backward", 0) > 0 for r_ in rasts), [r_._cell for r_ in rasts]
+    assert all(r_.finish_reduce() == 0 for r_ in rasts)
+    for k, v in leaf.items():
+        b = want2[k]
+        assert torch.allclose(v.grad, b, rtol=1e-5, atol=1e-6 * float(b.abs().max())), ("two calls per backward", k)
+    from casualhdrsplat_amd.rasterizer import _OPEN_CONSUMERS
+    assert not any(_OPEN_CONSUMERS.values()), "every view-parallel call's backward has run: no consumer left open"
+    leaf, rast = backward(rank, False, chunked=True)     # a sole consumer again: the collectives outlive backward()
+    assert rast.finish_reduce() > 0
     torch.cuda.synchronize()
     print("VIEW-EXCHANGE-OK", rank, flush=True)
     dist.barrier()

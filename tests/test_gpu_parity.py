@@ -365,11 +365,16 @@ def test_motion_blur_n_poses(oracle, dom, free):
     Hh.assert_grads_close(g2, r2, what=f"{dom} masked")
     Hh.assert_grads_bounded(g2, r2, what=f"{dom} masked")
     tab = r["dL_dcrf_table"]
-    if dom == "ldr" and m["n_differ"]:
+    if m["n_differ"]:
         # a decision differed on some pixel (inside the guard band, asserted above): one flipped contribution moves that
         # pixel's log-exposure and with it |dL| of weight between two table entries -- 3.5e-2 of a knot's sum on a frame of
-        # 15 000 pixels.  The table gradient is then checked GIVEN the decisions, as at full size (test_c3_..., test_c4_...)
-        tab, _ = Hh.crf_grads_given_decisions(oracle, sc, m, ref_imgs, got_imgs)
+        # 15 000 pixels.  The table gradient is then checked GIVEN the decisions, as at full size (test_c3_..., test_c4_...);
+        # in the radiance domain the CRF sees the MEAN image: one image, differing where any pose's decision did
+        if dom == "ldr":
+            tab, _ = Hh.crf_grads_given_decisions(oracle, sc, m, ref_imgs, got_imgs)
+        else:
+            tab, _ = Hh.crf_grads_given_decisions(oracle, sc, {"differs": m["differs"].any(axis=0, keepdims=True)},
+                                                  [r["hdr"]], [g["hdr"]])
     assert Hh.rel_err(g["d_crf_table"], tab, 1e3 * Hh.grad_floor(tab))[0] <= 2e-4
 
 
@@ -646,7 +651,8 @@ def test_skewed_scene_vs_oracle(oracle, form):
 def test_hierarchical_tile_sort_equals_the_radix_passes_at_full_size(cfg):
     """BASELINE c3 and c4 through both tile sorts of large frames: every array the binning stage leaves -- point_list,
     ranges, the rebuilt sorted keys, the depth-ordered instance list and pair offsets, num_rendered -- and, downstream,
-    images and every gradient, bit for bit.  (The radix form is the one test_c3_... / test_c4_... hold against the oracle.)"""
+    images and every gradient, bit for bit.  (The hierarchical form is the default of large frames since round 6, hence the
+    one test_c3_... / test_c4_... hold against the oracle; this test ties the radix passes to it.)"""
     P, W, H = 1_000_000, 1920, 1080
     sc = S.make_scene(P, W, H, 3, seed=0, hdr=True)
     cams = S.blur_poses(W, H, 8) if cfg == "c4" else None

@@ -26,7 +26,7 @@ def test_se3_exp_log_roundtrip_and_group_properties():
 
 def test_trajectory_samples_lie_between_knots():
     knots = IF.knots_from_lookat(4, radius=0.2).double()
-    traj = IF.TrajectorySpline(knots).double()
+    traj = IF.TrajectorySpline(knots, kind="linear").double()
     P = traj.poses(1, 8)
     assert P.shape == (8, 4, 4)
     c = [-(p[:3, :3].t() @ p[:3, 3]) for p in P]                       # camera centres
@@ -39,7 +39,7 @@ def test_trajectory_samples_lie_between_knots():
     # a knot correction moves only the windows that touch the knot
     with torch.no_grad():
         traj.delta[3, 0] = 0.1
-    assert torch.allclose(traj.poses(1, 8), P) and not torch.allclose(traj.poses(2, 8), IF.TrajectorySpline(knots).double().poses(2, 8))
+    assert torch.allclose(traj.poses(1, 8), P) and not torch.allclose(traj.poses(2, 8), IF.TrajectorySpline(knots, kind="linear").double().poses(2, 8))
 
 
 def _random_knots(J, seed=0, step=0.05):
@@ -108,12 +108,16 @@ def test_exposure_time_sets_the_blur_extent():
     """The figure's "exposure time range" arc: with window_from_exposure the virtual poses of frame i spread over
     dt_i * window_scale knot intervals around the frame's time stamp, so dt_i reaches the poses (a motion-blur term
     in dL/d dt_i) -- and does not when the window is pinned."""
-    traj = IF.TrajectorySpline(_random_knots(6, seed=7), kind="cubic").double()
+    # a DEFAULT-constructed model (round 6: the defaults are the figure's -- cubic spline, window from the exposure, one knot
+    # interval per unit of exposure time); only the frames' time stamps are given
+    traj = IF.TrajectorySpline(_random_knots(6, seed=7)).double()
+    assert traj.kind == "cubic"
     m = IF.HDRBlurFormation(traj, 2, 64, 48, 0.5, 0.4, n_virtual=5, crf=IF.ImplicitCRF(K=8),
-                            frame_times=torch.tensor([2.2, 3.1]), window_from_exposure=True, window_scale=0.8).double()
+                            frame_times=torch.tensor([2.2, 3.1])).double()
+    assert m.window_from_exposure and m.window_scale == 1.0
     with torch.no_grad():
         m.log_exposure[0] = -0.5
-    w = float(torch.exp(m.log_exposure[0].detach())) * 0.8
+    w = float(torch.exp(m.log_exposure[0].detach())) * 1.0
     times = traj.window_times(m.frame_times[0].double(), m.window(0), 5)
     assert times.min() > 2.2 - w / 2 and times.max() < 2.2 + w / 2
     assert float(times.mean()) == pytest.approx(2.2, abs=1e-6)
@@ -129,11 +133,24 @@ def test_exposure_time_sets_the_blur_extent():
     fd = ((C2[-1] - C2[0]).norm() - (C[-1] - C[0]).norm()).item() / 1e-4
     assert fd == pytest.approx(float(g[0]), rel=1e-3)
     pinned = IF.HDRBlurFormation(traj, 2, 64, 48, 0.5, 0.4, n_virtual=5, crf=IF.ImplicitCRF(K=8),
-                                 frame_times=torch.tensor([2.2, 3.1])).double()
+                                 frame_times=torch.tensor([2.2, 3.1]), window_from_exposure=False).double()
     Cp = pinned.cameras(0)[2]
     m.zero_grad(); pinned.zero_grad()
     (Cp[-1] - Cp[0]).norm().backward()
     assert pinned.log_exposure.grad is None or float(pinned.log_exposure.grad.abs().sum()) == 0
+
+
+def test_frame_times_outside_the_trajectory_are_refused():
+    """A cubic spline over J knots is defined on [1, J - 2]: frames beyond it (or more frames than its J - 3 segments, with
+    the default time stamps) would be rendered from extrapolated poses without notice."""
+    traj = IF.TrajectorySpline(_random_knots(5, seed=1))          # t_range [1, 3]: two segments
+    IF.HDRBlurFormation(traj, 2, 64, 48, 0.5, 0.4)                 # default stamps 1.5, 2.5
+    with pytest.raises(ValueError, match="t_range"):
+        IF.HDRBlurFormation(traj, 3, 64, 48, 0.5, 0.4)             # 3.5 lies outside
+    with pytest.raises(ValueError, match="t_range"):
+        IF.HDRBlurFormation(traj, 1, 64, 48, 0.5, 0.4, frame_times=torch.tensor([0.5]))
+    with pytest.raises(ValueError):
+        IF.TrajectorySpline(_random_knots(3, seed=1))              # the default (cubic) kind needs four knots
 
 
 def test_cameras_of_all_frames_in_one_pass_equal_the_per_frame_cameras():
@@ -176,7 +193,7 @@ def test_crf_table_is_monotone_and_normalised():
 def test_camera_matrices_follow_the_rasterizer_convention():
     W, H = 160, 96
     cam = S.make_camera(W, H)
-    traj = IF.TrajectorySpline(torch.eye(4)[None].repeat(2, 1, 1))
+    traj = IF.TrajectorySpline(torch.eye(4)[None].repeat(2, 1, 1), kind="linear")
     model = IF.HDRBlurFormation(traj, 1, W, H, cam.tanfovx, cam.tanfovy, n_virtual=3, crf=IF.ImplicitCRF(K=16))
     V, PV, C = model.cameras(0)
     for k in range(3):  # identity trajectory == the synthetic default camera
@@ -198,7 +215,7 @@ def test_end_to_end_step_reaches_every_learnable():
     torch.manual_seed(0)
 
     def build():
-        traj = IF.TrajectorySpline(knots)
+        traj = IF.TrajectorySpline(knots, kind="linear")
         m = IF.HDRBlurFormation(traj, 2, W, H, cam.tanfovx, cam.tanfovy, n_virtual=4, crf=IF.ImplicitCRF(K=64), sh_degree=1)
         return m.to(dev)
 
