@@ -571,7 +571,7 @@ def choose_exchange(step, state, barrier, dev, rank, world, backend, cfg):
     info["model_ms"] = {m: exchange_model(m, world, cfg, base_ms) for m, a in EXCHANGES if a == "rccl"}
     candidates = probe_order(cfg[3], os.environ.get("HS_BENCH_PROBE") == "all")
     direct_ok = None
-    times, dropped = {}, {}
+    times, dropped, first_steps = {}, {}, {}
     for mode, algo in candidates:
         name = f"{mode}/{algo}"
         state["exchange"] = (mode, algo)
@@ -586,6 +586,7 @@ def choose_exchange(step, state, barrier, dev, rank, world, backend, cfg):
         except RuntimeError as e:
             ok, err = 0.0, str(e)[:200]
         first_ms, bad = agree([first_ms, 1.0 - ok])
+        first_steps[name] = [round(first_ms, 3)]      # (what a strategy is kept or dropped on: MAX over ranks, ms)
         # (the plain library all-reduce is the fallback whatever it costs: only a failure removes it)
         over = first_ms > cap_ms and (mode, algo) != FALLBACK
         if over and not bad and first_ms <= 50.0 * cap_ms:
@@ -597,6 +598,7 @@ def choose_exchange(step, state, barrier, dev, rank, world, backend, cfg):
             except RuntimeError as e:
                 ok, err = 0.0, str(e)[:200]
             second_ms, bad = agree([second_ms, 1.0 - ok])
+            first_steps[name].append(round(second_ms, 3))
             over = second_ms > cap_ms
             if over:
                 err = err or f"first two steps {first_ms:.1f}, {second_ms:.1f} ms > cap {cap_ms:.1f} ms"
@@ -617,9 +619,11 @@ def choose_exchange(step, state, barrier, dev, rank, world, backend, cfg):
             info["collectives_per_step"][name] = int(D_.LAST_EXCHANGE["collectives"])   # counted, not assumed
     best = min(times, key=times.get) if times else "allreduce/rccl"
     state["exchange"] = tuple(best.split("/"))
-    if rank == 0 and dropped:
-        print(f"[bench] exchange strategies dropped: {dropped}", file=sys.stderr)
-    info.update(choice=best, step_ms=times, dropped=dropped, no_exchange_step_ms=base_ms, first_step_cap_ms=cap_ms)
+    if rank == 0:
+        print(f"[bench] exchange probe: step without exchange {base_ms:.3f} ms, first-step cap {cap_ms:.1f} ms; first step(s) per "
+              f"strategy (ms, MAX over ranks) {first_steps}; kept {times}; dropped {dropped}; chosen {best}", file=sys.stderr)
+    info.update(choice=best, step_ms=times, dropped=dropped, no_exchange_step_ms=base_ms, first_step_cap_ms=cap_ms,
+                first_step_ms=first_steps)
     return info
 
 

@@ -1179,7 +1179,13 @@ __global__ void __launch_bounds__(256) hier_gather_kernel(int64_t I, const uint3
 
 // Element: .x = (pose, super-tile) key | clipped rectangle above bit `kb` (x0: 3 bits, y0: 3, w - 1: 3, h - 1: 3, all in
 // tiles relative to the super-tile), .y = instance.
-template <bool BIG>   // BIG (>= 2^21 instances): non-temporal slot-start / element stores, as in emit_pairs_kernel<true>
+// Non-temporal hints of the hierarchical emission at >= 2^21 instances (bit 2: slot start, bit 4: elements), measured at c4
+// (hier_emit_kernel, us): none 338, both 411 -- unlike the pair emission (HS_EMIT_NT_MASK) the element stream is short and
+// is read again at once by the radix pass, so keeping it out of the L2 only hurts.  None it is.
+#ifndef HS_HIER_NT_MASK
+#define HS_HIER_NT_MASK 0
+#endif
+template <bool BIG>   // BIG (>= 2^21 instances): the instantiation the hints above apply to
 __global__ void __launch_bounds__(256) hier_emit_kernel(int64_t I, int P, int gx, int gy, float4* rec,
                                                         const uint32_t* inst_sorted, const uint2* srect,
                                                         const uint32_t* block_excl, const uint32_t* block_cexcl,
@@ -1246,7 +1252,7 @@ __global__ void __launch_bounds__(256) hier_emit_kernel(int64_t I, int P, int gx
     if (bend > capacity) return;
     if (!(HS_ABL & 1) && i < I && end > beg) {
         float* slot_start = &reinterpret_cast<float*>(rec + kRecF4 * (int64_t)inst + 2)[3];
-        if constexpr (BIG && (HS_EMIT_NT_MASK & 2)) __builtin_nontemporal_store(__uint_as_float(beg), slot_start);
+        if constexpr (BIG && (HS_HIER_NT_MASK & 2)) __builtin_nontemporal_store(__uint_as_float(beg), slot_start);
         else *slot_start = __uint_as_float(beg);
     }
     // "gradient record written" flags of this workgroup's pair slots [bexcl, bend): bytes up to the first 16-byte boundary,
@@ -1290,7 +1296,7 @@ __global__ void __launch_bounds__(256) hier_emit_kernel(int64_t I, int P, int gx
         const uint32_t lx0 = max(x0, ox) - ox, lx1 = min(x1, ox + kSuper) - ox;
         const uint32_t ly0 = max(y0, oy) - oy, ly1 = min(y1, oy + kSuper) - oy;
         const uint32_t word = key | ((lx0 | (ly0 << 3) | ((lx1 - lx0 - 1u) << 6) | ((ly1 - ly0 - 1u) << 9)) << kb);
-        if constexpr (BIG && (HS_EMIT_NT_MASK & 4)) { __builtin_nontemporal_store(word, &elems[pos].x); __builtin_nontemporal_store(o.w, &elems[pos].y); }
+        if constexpr (BIG && (HS_HIER_NT_MASK & 4)) { __builtin_nontemporal_store(word, &elems[pos].x); __builtin_nontemporal_store(o.w, &elems[pos].y); }
         else elems[pos] = make_uint2(word, o.w);
         atomicAdd(&s_hist[key], 1u);
     }

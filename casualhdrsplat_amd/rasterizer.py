@@ -383,7 +383,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                 if isinstance(t, torch.Tensor) and t.requires_grad]
         ctx.reduce_may_stay_in_flight = all(t.is_leaf and t.grad is None for t in diff)
         ctx.open_leaves = []
-        if aux is not None and aux.get("reduce_group") is not None and torch.is_grad_enabled():
+        # (needs_input_grad: all False when the caller runs under torch.no_grad() -- no backward will come to close the count)
+        if aux is not None and aux.get("reduce_group") is not None and any(ctx.needs_input_grad):
             for t in diff:
                 if t.is_leaf:
                     _open_consumers_add(t, 1)

@@ -272,6 +272,12 @@ GRAD_KEYS = [("means3D", "dL_dmeans3D"), ("means2D", "dL_dmeans2D"), ("opacities
 # worst element up to 1e-2 of max(|x|, 1e-3 RMS) -- the fp32 conditioning of the T / (1 - alpha) recurrences), and
 # within a few 1e-4 of each other.  Bars below = those measurements with headroom, not round numbers.
 STRICT = dict(frac_tol=1e-2, max_tol=1e-2, l2_tol=1e-5)  # measured: frac <= 6e-3, max <= 3e-3, l2 <= 1e-6 (HIP vs C)
+# ... tensors of >= 5000 rows (Gaussians): the bar the measurements allow there (round 6, the whole suite
+# with HS_PARITY_REPORT=1: worst fraction beyond 1e-4 9.7e-4, worst element 5.8e-3 -- 100 000 Gaussians at 800 x 800 --,
+# relative L2 <= 3.2e-6).  A few thousand elements and more give the fraction its meaning; below that the two-element
+# escape of assert_grads_close and the wider STRICT stay.
+STRICT_LARGE = dict(frac_tol=2e-3, max_tol=6e-3, l2_tol=5e-6)
+LARGE_ROWS = 5000
 # Rows (Gaussians) that leave the strict bar -- ONLY those reached by a pixel on which the two implementations
 # demonstrably decided differently (decision_masks: contributor count or transmittance differs, which must itself lie
 # inside the oracle's threshold guard band), or by a pixel within rounding distance of a CRF knot (the interval, hence
@@ -292,19 +298,24 @@ def assert_grads_close(got: dict, ref: dict, keys=GRAD_KEYS, frac_tol=None, max_
     tensor RMS) <= frac_tol, the worst element <= max_tol, relative L2 <= l2_tol (defaults: STRICT).  `at_risk`: bool
     [P] (decision_masks()["rows"]) -- those Gaussians (rows) are held to AT_RISK instead, all others to the strict
     bar; without it every row is strict.  `min_strict`: the share of rows that must be on the strict bar."""
-    bar = dict(STRICT)
-    for k, v in (("frac_tol", frac_tol), ("max_tol", max_tol), ("l2_tol", l2_tol)):
-        if v is not None:
-            bar[k] = v
+    def bar_for(rows_total):
+        b = dict(STRICT_LARGE if rows_total >= LARGE_ROWS else STRICT)
+        for k, v in (("frac_tol", frac_tol), ("max_tol", max_tol), ("l2_tol", l2_tol)):
+            if v is not None:
+                b[k] = v
+        return b
     report = {}
     if at_risk is not None:
         report["strict_share"] = 1.0 - float(at_risk.mean()) if at_risk.size else 1.0
         if min_strict is not None:
             assert report["strict_share"] >= min_strict, (what, "rows on the strict bar", report["strict_share"])
+    if os.environ.get("HS_PARITY_REPORT") and at_risk is not None:
+        print("SHARE", what, os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0], round(report["strict_share"], 4), "min_strict", min_strict, flush=True)
     for gk, rk in keys:
         r = np.asarray(ref[rk])
         g = np.asarray(got["d_" + gk]).reshape(r.shape)
         floor = grad_floor(r)
+        bar = bar_for(r.shape[0] if r.ndim else 1)
         parts = [("", slice(None), bar)]
         if at_risk is not None and at_risk.any() and r.shape[0] == at_risk.shape[0]:
             parts = [("[clear]", ~at_risk, bar), ("[at risk]", at_risk, AT_RISK)]

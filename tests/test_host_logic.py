@@ -1,6 +1,7 @@
 """Host-side behaviour of the drop-in boundary that needs no GPU: the settings tuple, argument
 validation with the reference API's error messages, loud failure on CPU tensors, synthetic scenes."""
 import math
+import os
 
 import pytest
 import torch
@@ -233,3 +234,52 @@ def test_no_memset_or_copy_on_the_paths_a_captured_step_takes():
             code = ln.split("//")[0]
             if re.search(r"hipMem(set|cpy)\w*\(", code):
                 assert any(a in code for a in allowed.get(name, [])), f"{name}: {ln.strip()}"
+
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _kernel_resources(tu, contract):
+    """{demangled-ish kernel name: {field: int}} from hipcc -Rpass-analysis=kernel-resource-usage (device side only)."""
+    import re
+    import subprocess
+    import tempfile
+    src = os.path.join(ROOT, "casualhdrsplat_amd", "csrc", tu)
+    with tempfile.TemporaryDirectory() as tmp:
+        r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-fvisibility=hidden", "-std=c++17",
+                            f"-ffp-contract={contract}", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", "-c", src,
+                            "-o", os.path.join(tmp, "x.o")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out, cur = {}, None
+    for ln in r.stderr.splitlines():
+        m = re.search(r"remark: Function Name: (\S+)", ln)
+        if m:
+            cur = out.setdefault(m.group(1), {})
+            continue
+        m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\d+)", ln)
+        if m and cur is not None:
+            cur[m.group(1).strip()] = int(m.group(2))
+    return out
+
+
+def test_kernel_register_budgets_hold():
+    """Resource-usage guard: preprocess_bwd_kernel<3, *, *> needs 174-239 VGPRs -- the pose-gradient
+    instantiation is one register-allocation change away from spilling -- and the two render kernels carry ONE spilled
+    VGPR each under amdgpu_waves_per_eu(7).  A compiler or source change that adds spills fails here, on the CPU, before
+    anybody times it."""
+    pre = _kernel_resources("preprocess.hip", "off")
+    bwd3 = {k: v for k, v in pre.items() if "preprocess_bwd_kernelILi3E" in k}
+    assert len(bwd3) >= 4, sorted(pre)
+    for k, v in bwd3.items():
+        assert v["VGPRs Spill"] == 0 and v["ScratchSize"] == 0, (k, v)
+        assert v["Occupancy"] >= 2, (k, v)
+    fwd = [v for k, v in pre.items() if "preprocess_fwd_kernelILi3E" in k]
+    assert fwd and all(v["VGPRs Spill"] == 0 and v["Occupancy"] >= 5 for v in fwd), fwd     # 96 VGPRs: five waves per SIMD
+    ren = _kernel_resources("render.hip", "fast")
+    hot = {k: v for k, v in ren.items() if ("render_fwd_kernelILb0ELb0E" in k or "render_bwd_kernelILb0ELb0E" in k)}
+    assert len(hot) == 2, sorted(ren)
+    for k, v in hot.items():
+        assert v["VGPRs Spill"] <= 1 and v["ScratchSize"] <= 32, (k, v)
+    binn = _kernel_resources("binning.hip", "off")
+    for k, v in binn.items():
+        assert v.get("VGPRs Spill", 0) == 0, (k, v)
