@@ -26,6 +26,7 @@ include/hdrsplat.h; PyTorch only owns memory and streams.  There is no fallback 
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import NamedTuple, Optional
 
 import warnings
@@ -267,11 +268,11 @@ def _run_forward(settings: GaussianRasterizationSettings, means3D, opacities, sh
 
     sync_mode = capacity is None
     dims, sizes, layout = L.plan(P, M, int(settings.sh_degree), W, H, N, 0 if sync_mode else int(capacity), crf_K)
-    geom = torch.empty(max(int(sizes.geom_bytes), 256), dtype=torch.uint8, device=dev)
-    out_color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
-    out_hdr = torch.empty(3, H, W, dtype=torch.float32, device=dev) if hdr else None
-    radii = torch.empty(P, dtype=torch.int32, device=dev)
-    invdepth = torch.empty(N, H, W, dtype=torch.float32, device=dev) if want_invdepth else None
+    geom = _empty(max(int(sizes.geom_bytes), 256), torch.uint8, dev, "geom")
+    out_color = _empty((3, H, W), torch.float32, dev, "out_color")
+    out_hdr = _empty((3, H, W), torch.float32, dev, "out_hdr") if hdr else None
+    radii = _empty(P, torch.int32, dev, "radii")
+    invdepth = _empty((N, H, W), torch.float32, dev, "invdepth") if want_invdepth else None
 
     a = L.hs_fwd_args()
     a.dims = dims
@@ -301,8 +302,8 @@ def _run_forward(settings: GaussianRasterizationSettings, means3D, opacities, sh
     else:
         R = -1
         a.stages = L.HS_STAGE_ALL
-    binning = torch.empty(max(int(sizes.binning_bytes), 256), dtype=torch.uint8, device=dev)
-    image = torch.empty(max(int(sizes.image_bytes), 256), dtype=torch.uint8, device=dev)
+    binning = _empty(max(int(sizes.binning_bytes), 256), torch.uint8, dev, "binning")
+    image = _empty(max(int(sizes.image_bytes), 256), torch.uint8, dev, "image")
     a.binning, a.image = binning.data_ptr(), image.data_ptr()
     # the frame's counters {num_rendered, overflow, helps} reach the host without a copy on the stream: the binning stage's
     # last kernel writes them into this page-locked buffer (hs_fwd_args.counters_host); nobody waits for them until
@@ -329,24 +330,66 @@ def _run_forward(settings: GaussianRasterizationSettings, means3D, opacities, sh
     return out_color, out_hdr, radii, st, exposure, crf_table, invdepth
 
 
-# id(leaf) -> view-parallel rasterizer calls (reduce_group) that took the leaf and whose backward is still to come; see
-# _RasterizeGaussians.forward.  Keyed by id (a tensor's == is element-wise); a finalizer drops the entry with the tensor.
+# HS_GUARD=1 in the environment (read at import): every tensor the library writes -- the four state workspaces, the flat
+# gradient buffer, the output images -- is carved out of a larger allocation with _GUARD_BYTES of 0xA5 on either side, and
+# check_guards() (after a synchronisation) reports every guard byte that changed: the GPU build's stand-in for an address
+# sanitizer (there is none on this pool), tests/test_gpu_parity.py::test_no_kernel_writes_outside_its_buffers.  A kernel
+# that overruns its buffer is harmless next to torch's rounded eager allocations and fatal inside a captured graph's
+# packed pool, where the neighbour is somebody's live tensor.
+_GUARD = os.environ.get("HS_GUARD", "") not in ("", "0")
+_GUARD_BYTES = 4096
+_guarded: list = []
+
+
+def _empty(shape, dtype, dev, name: str) -> torch.Tensor:
+    if not _GUARD:
+        return torch.empty(shape, dtype=dtype, device=dev)
+    shape = (shape,) if isinstance(shape, int) else tuple(shape)
+    n = torch.empty((), dtype=dtype).element_size()
+    for d in shape:
+        n *= int(d)
+    full = torch.full((n + 2 * _GUARD_BYTES,), 0xA5, dtype=torch.uint8, device=dev)
+    _guarded.append((name, full, n))
+    return full[_GUARD_BYTES:_GUARD_BYTES + n].view(dtype).view(shape)
+
+
+def check_guards() -> list:
+    """HS_GUARD=1: [(buffer name, 'before' / 'after', first damaged offset from the buffer's edge, damaged bytes)] over every
+    guarded buffer handed out since the last call (waits for the device); [] = no kernel wrote outside its buffers."""
+    torch.cuda.synchronize()
+    bad = []
+    for name, full, n in _guarded:
+        for side, zone in (("before", full[:_GUARD_BYTES]), ("after", full[_GUARD_BYTES + n:])):
+            hit = (zone != 0xA5).nonzero()
+            if hit.numel():
+                first = int(hit[0]) if side == "after" else _GUARD_BYTES - 1 - int(hit[-1])
+                bad.append((name, side, first, int(hit.numel())))
+    _guarded.clear()
+    return bad
+
+
+# id(leaf) -> [open, peak]: view-parallel rasterizer calls (reduce_group) that took the leaf and whose backward is still to
+# come, and the largest that number has been since it was last zero; see _RasterizeGaussians.forward.  Keyed by id (a
+# tensor's == is element-wise); a finalizer drops the entry with the tensor.  `peak`, not `open`, decides at backward time:
+# of two calls sharing a leaf the LATER one's backward runs first and leaves open == 1 for the earlier one, whose gradient
+# the engine nevertheless adds to the later one's.
 _OPEN_CONSUMERS: dict = {}
 
 
 def _open_consumers(t: torch.Tensor) -> int:
-    return _OPEN_CONSUMERS.get(id(t), 0)
+    """Peak number of simultaneously open view-parallel calls on leaf `t` in the current episode (0: none open)."""
+    e = _OPEN_CONSUMERS.get(id(t))
+    return e[1] if e else 0
 
 
 def _open_consumers_add(t: torch.Tensor, n: int) -> None:
     k = id(t)
-    if k not in _OPEN_CONSUMERS:
+    e = _OPEN_CONSUMERS.get(k)
+    if e is None:
         weakref.finalize(t, _OPEN_CONSUMERS.pop, k, None)
-    v = _OPEN_CONSUMERS.get(k, 0) + n
-    if v > 0:
-        _OPEN_CONSUMERS[k] = v
-    else:
-        _OPEN_CONSUMERS[k] = 0
+        e = _OPEN_CONSUMERS[k] = [0, 0]
+    e[0] = max(0, e[0] + n)
+    e[1] = max(e[1], e[0]) if e[0] else 0      # (back to zero open calls: the episode is over)
 
 
 class _RasterizeGaussians(torch.autograd.Function):
@@ -446,7 +489,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         for ref in getattr(ctx, "open_leaves", ()):
             t = ref()
             if t is not None:
-                shared = shared or _open_consumers(t) > 1
+                shared = shared or _open_consumers(t) > 1     # (peak of the episode: see _OPEN_CONSUMERS)
                 _open_consumers_add(t, -1)
         if ctx.aux is not None and g.get("_reduce_pending") is not None:
             if ctx.reduce_may_stay_in_flight and not shared:
@@ -505,7 +548,7 @@ def _launch_backward(st: "_State", saved, gcol, ghdr, stages: int, want_pose: bo
     dev = m3.device
     P, M = st.dims.P, st.dims.M
     _, sizes, _ = L.plan(P, M, st.dims.sh_degree, st.W, st.H, st.dims.n_poses, st.dims.capacity, st.dims.crf_K)
-    bwd = torch.empty(max(int(sizes.bwd_bytes), 256), dtype=torch.uint8, device=dev)
+    bwd = _empty(max(int(sizes.bwd_bytes), 256), torch.uint8, dev, "bwd")
     hdr = bool(st.flags & L.HS_FLAG_HDR)
     # (the SH rows -- four fifths of the bytes at degree 3 -- come last of the summed span, so a chunked exchange moves the
     # other per-Gaussian rows as a few short slices and the SH rows of a chunk as ONE long one)
@@ -525,7 +568,7 @@ def _launch_backward(st: "_State", saved, gcol, ghdr, stages: int, want_pose: bo
                 n *= d
             offs[name] = (total, n, shape)
             total += (n + 3) // 4 * 4  # keep every slice 16-byte aligned
-    flat = torch.empty(max(total, 4), dtype=torch.float32, device=dev)  # fully written by the kernels (16-byte slice pads aside)
+    flat = _empty(max(total, 4), torch.float32, dev, "flat_gradients")  # fully written by the kernels (16-byte slice pads aside)
     g = {name: None for name, _, _ in spec}
     for name, (o, n, shape) in offs.items():
         g[name] = flat[o:o + n].view(shape)
@@ -534,7 +577,7 @@ def _launch_backward(st: "_State", saved, gcol, ghdr, stages: int, want_pose: bo
         g["crf_table"].zero_()
     g["_flat"] = flat
     # deferred SH gradient: the per-view colour gradients live outside the flat (all-reduced) buffer
-    g["view_colors"] = (torch.empty(st.dims.n_poses, P, 3, dtype=torch.float32, device=dev)
+    g["view_colors"] = (_empty((st.dims.n_poses, P, 3), torch.float32, dev, "view_colors")
                         if defer_sh and shs is not None else None)
 
     a = L.hs_bwd_args()

@@ -128,7 +128,7 @@ def main():
         b = want2[k]
         assert torch.allclose(v.grad, b, rtol=1e-5, atol=1e-6 * float(b.abs().max())), ("two calls per backward", k)
     from casualhdrsplat_amd.rasterizer import _OPEN_CONSUMERS
-    assert not any(_OPEN_CONSUMERS.values()), "every view-parallel call's backward has run: no consumer left open"
+    assert not any(e[0] for e in _OPEN_CONSUMERS.values()), "every view-parallel call's backward has run: no consumer left open"
     leaf, rast = backward(rank, False, chunked=True)     # a sole consumer again: the collectives outlive backward()
     assert rast.finish_reduce() > 0
     torch.cuda.synchronize()

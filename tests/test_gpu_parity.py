@@ -1839,6 +1839,20 @@ def test_c4_eight_poses_full_size_vs_oracle(oracle):
                 sc, m, g, r, {"R": int(R), "report": {k: v for k, v in rep.items()}}, masked=(g2, r2, bounded))
 
 
+def test_no_kernel_writes_outside_its_buffers():
+    """HS_GUARD=1 (rasterizer.py): guard zones of 4 KB around every buffer the library writes, over frames of every form --
+    three tile sorts, N poses in both blur domains, free cameras, wild clouds, an overflowing capacity, the sweep's
+    configurations, BASELINE c3 and c4 -- and not one guard byte changed.  (No address sanitizer exists for the GPU on this
+    pool; a kernel that overruns is harmless next to torch's rounded eager allocations and fatal inside a captured graph's
+    packed memory pool.)"""
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "guard_run.py")
+    r = subprocess.run([sys.executable, script, "full"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "GUARD-OK" in r.stdout, r.stdout[-3000:]
+
+
 def test_debug_flag_gives_identical_results():
     """settings.debug=True (HS_FLAG_DEBUG: the library waits for every stage and names a failing one) changes nothing
     but the synchronisation."""
