@@ -18,6 +18,7 @@ element-wise fills of device tensors from host scalars (host-to-device copies).
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, Sequence
 
 import torch
@@ -63,6 +64,9 @@ class GraphedStep:
         for r in self.rasterizers:
             r._cell["captured"] = []     # every forward a rasterizer enqueues while the stream captures lands here
         self.graph = torch.cuda.CUDAGraph()
+        dump = os.environ.get("HS_GRAPH_DUMP")      # (diagnostics: the captured DAG as a DOT file -- scripts/repro/graph_bisect.py)
+        if dump:
+            self.graph.enable_debug_mode()
         try:
             # (captured on the warm-up's stream: the AccumulateGrad nodes the warm-up left alive -- any leaf whose graph is
             # still referenced somewhere -- belong to that stream; on another stream the engine would run them across a
@@ -77,6 +81,8 @@ class GraphedStep:
         # the forwards captured above left their counter copies pending (nobody may wait inside a capture): ALL of them
         # -- `fn` may call one rasterizer several times (several views, an eval render in between), and a frame that
         # overflowed renders empty whichever call it was
+        if dump:
+            self.graph.debug_dump(dump)
         not_called = [i for i, r in enumerate(self.rasterizers) if not captured[id(r)]]
         if not_called:
             raise ValueError(f"GraphedStep: rasterizers {not_called} of `rasterizers` were not called by `fn` during the capture")

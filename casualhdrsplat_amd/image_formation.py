@@ -28,6 +28,7 @@ knot times (knot j at time j), the CRF as a monotone MLP on log-exposure sampled
 from __future__ import annotations
 
 import math
+import os
 from typing import Callable, Optional
 
 import torch
@@ -140,7 +141,7 @@ class TrajectorySpline(nn.Module):
         self.kind = kind
         # on the GPU pose_at is one kernel of libhdrsplat (hs_spline_poses); False: the tensor-operation form below, which is
         # also the CPU path and the kernel's oracle in the tests
-        self.fused = True
+        self.fused = os.environ.get("HS_SPLINE_FUSED", "1") != "0"   # (0: experiments that take the kernel out of the step)
         self.register_buffer("base", init_w2c.clone().float())
         self.delta = nn.Parameter(torch.zeros(init_w2c.shape[0], 6))  # left-multiplied se(3) corrections
 

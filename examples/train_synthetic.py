@@ -39,6 +39,8 @@ def mean_by_rows(x: torch.Tensor) -> torch.Tensor:
     on (this very loss read 94.41 for ever; the library's own kernels had the same trouble with two hipMemsetAsync, see
     DESIGN.md 4.11).  The gradient of a mean does not depend on its value, so training was right all along; the printed
     numbers were not."""
+    if os.environ.get("HS_EXAMPLE_PLAIN_MEAN"):      # (scripts/repro/graph_step_mean.py: the reduction this function avoids)
+        return x.mean()
     n = x.numel()
     pad = (-n) % 256
     flat = x.reshape(-1)
