@@ -1158,12 +1158,15 @@ __device__ __forceinline__ void hier_coarse_rect(uint2 rc, uint32_t& sx0, uint32
     sh = any ? (y0 + h - 1u) / kSuper - sy0 + 1u : 0u;
 }
 
-__global__ void __launch_bounds__(256) hier_gather_kernel(int64_t I, const uint32_t* inst_sorted, const uint2* binfo,
-                                                          uint2* srect, const hs_counters* counters, uint32_t* block_sums,
-                                                          uint32_t* block_csums, uint32_t* zero, int64_t n_zero) {
-    __shared__ uint32_t s_wave[4];
-    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < n_zero; t += (int64_t)gridDim.x * 256) zero[t] = 0u;
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+// (1024 instances per workgroup: the sums of every 256 -- the emission's workgroup -- AND of the whole 1024, so that an
+// emission workgroup adds up a quarter as many words for the pairs in front of it: 977 + 3 instead of 3906 at c3)
+__global__ void __launch_bounds__(1024) hier_gather_kernel(int64_t I, const uint32_t* inst_sorted, const uint2* binfo,
+                                                           uint2* srect, const hs_counters* counters, uint32_t* block_sums,
+                                                           uint32_t* block_csums, uint32_t* super_sums, uint32_t* super_csums,
+                                                           uint32_t* zero, int64_t n_zero) {
+    __shared__ uint32_t s_wave[16];
+    for (int64_t t = (int64_t)blockIdx.x * 1024 + threadIdx.x; t < n_zero; t += (int64_t)gridDim.x * 1024) zero[t] = 0u;
+    const int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x;
     uint2 rc = make_uint2(0u, 0u);
     if (i < I) {
         if (counters->overflow < 2u) rc = binfo[inst_sorted[i]];
@@ -1171,10 +1174,17 @@ __global__ void __launch_bounds__(256) hier_gather_kernel(int64_t I, const uint3
     }
     uint32_t sx0, sy0, sw, sh;
     hier_coarse_rect(rc, sx0, sy0, sw, sh);
-    uint32_t total, ctotal;
-    block_incl_scan((rc.y & 0xFFFFu) * (rc.y >> 16), s_wave, &total);
-    block_incl_scan(sw * sh, s_wave, &ctotal);
-    if (threadIdx.x == 0) { block_sums[blockIdx.x] = total; block_csums[blockIdx.x] = ctotal; }
+    const int64_t nsub = (I + 255) / 256;
+    uint32_t total;
+    block_incl_scan<16>((rc.y & 0xFFFFu) * (rc.y >> 16), s_wave, &total);     // (leaves the 16 wave totals in s_wave)
+    if (threadIdx.x < 4 && (int64_t)blockIdx.x * 4 + threadIdx.x < nsub)
+        block_sums[blockIdx.x * 4 + threadIdx.x] = (s_wave[4 * threadIdx.x] + s_wave[4 * threadIdx.x + 1]) + (s_wave[4 * threadIdx.x + 2] + s_wave[4 * threadIdx.x + 3]);
+    if (threadIdx.x == 0) super_sums[blockIdx.x] = total;
+    __syncthreads();
+    block_incl_scan<16>(sw * sh, s_wave, &total);
+    if (threadIdx.x < 4 && (int64_t)blockIdx.x * 4 + threadIdx.x < nsub)
+        block_csums[blockIdx.x * 4 + threadIdx.x] = (s_wave[4 * threadIdx.x] + s_wave[4 * threadIdx.x + 1]) + (s_wave[4 * threadIdx.x + 2] + s_wave[4 * threadIdx.x + 3]);
+    if (threadIdx.x == 0) super_csums[blockIdx.x] = total;
 }
 
 // Element: .x = (pose, super-tile) key | clipped rectangle above bit `kb` (x0: 3 bits, y0: 3, w - 1: 3, h - 1: 3, all in
@@ -1189,6 +1199,7 @@ template <bool BIG>   // BIG (>= 2^21 instances): the instantiation the hints ab
 __global__ void __launch_bounds__(256) hier_emit_kernel(int64_t I, int P, int gx, int gy, float4* rec,
                                                         const uint32_t* inst_sorted, const uint2* srect,
                                                         const uint32_t* block_excl, const uint32_t* block_cexcl,
+                                                        const uint32_t* super_sums, const uint32_t* super_csums,
                                                         uint32_t* offs_sorted, uint2* elems, uint8_t* pair_flags,
                                                         hs_counters* counters, uint64_t capacity, uint32_t* ghist, int kb,
                                                         int passes, unsigned long long* depth_bits, int excl_ready,
@@ -1221,7 +1232,10 @@ __global__ void __launch_bounds__(256) hier_emit_kernel(int64_t I, int P, int gx
         if (threadIdx.x == 0) { s_excl = block_excl[blk]; s_cexcl = block_cexcl[blk]; }
     } else {
         unsigned long long part = 0, cpart = 0;    // (64-bit: see emit_pairs_kernel)
-        for (int j = threadIdx.x; j < ((HS_ABL & 8) ? 0 : blk); j += 256) { part += block_excl[j]; cpart += block_cexcl[j]; }
+        // (the sums of the 1024-instance groups in front of this workgroup's, then of the 256-instance ones inside its group)
+        const int nsup = (HS_ABL & 8) ? 0 : blk / 4;
+        for (int j = threadIdx.x; j < nsup; j += 256) { part += super_sums[j]; cpart += super_csums[j]; }
+        if ((int)threadIdx.x < blk - 4 * (blk / 4)) { part += block_excl[4 * (blk / 4) + threadIdx.x]; cpart += block_cexcl[4 * (blk / 4) + threadIdx.x]; }
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) {
             part += (unsigned long long)__shfl_xor((long long)part, d);
@@ -1748,9 +1762,12 @@ int launch_binning(const hs_fwd_args& a, const hs_layout& L, hipStream_t s, uint
         uint2* srect = dp0;
         uint32_t* bsum = (uint32_t*)dp1;
         uint32_t* bcsum = bsum + eblk;
-        hier_gather_kernel<<<eblk, 256, 0, s>>>(I, inst_sorted, (const uint2*)(geom + L.binfo), srect, counters, bsum, bcsum,
-                                                hw, W.zero_words);
-        const bool excl_ready = eblk > 8192;
+        uint32_t* ssum = bcsum + eblk;                     // (sums of 1024 instances: ceil(I / 1024) words each)
+        uint32_t* scsum = ssum + ceil_div(I, 1024);
+        hier_gather_kernel<<<ceil_div(I, 1024), 1024, 0, s>>>(I, inst_sorted, (const uint2*)(geom + L.binfo), srect, counters, bsum,
+                                                              bcsum, ssum, scsum, hw, W.zero_words);
+        // (beyond 32768 emission workgroups -- 8 M instances -- a scan kernel turns the 256-instance sums into prefixes)
+        const bool excl_ready = eblk > 4 * 8192;
         if (excl_ready) {
             scan_spine_kernel<<<1, 256, 0, s>>>(bsum, eblk, nullptr);
             scan_spine_kernel<<<1, 256, 0, s>>>(bcsum, eblk, nullptr);
@@ -1758,7 +1775,7 @@ int launch_binning(const hs_fwd_args& a, const hs_layout& L, hipStream_t s, uint
         uint2* e0 = cpasses % 2 != 0 ? pA : pB;
         uint2* e1 = e0 == pA ? pB : pA;
         const SortScratch sc(tmp2, d.capacity, kPairTile);
-#define HS_HEMIT_ARGS I, d.P, gx, gy, (float4*)(geom + L.rec), inst_sorted, srect, bsum, bcsum, offs, e0,                             \
+#define HS_HEMIT_ARGS I, d.P, gx, gy, (float4*)(geom + L.rec), inst_sorted, srect, bsum, bcsum, ssum, scsum, offs, e0,                \
                       (uint8_t*)(bin + L.pair_flags), counters, (uint64_t)d.capacity, sc.ghist, kb, cpasses, depth_bits,             \
                       (int)excl_ready, hw, hw + W.st_count, (int)W.nst, (int)W.nst_pad()
         if (I >= (2 << 20)) hier_emit_kernel<true><<<eblk, 256, 0, s>>>(HS_HEMIT_ARGS);

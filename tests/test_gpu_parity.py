@@ -9,10 +9,13 @@ Bars (BASELINE.json north_star): tile assignment / indexing bit-exact; pixel and
   * decisions: where HIP and oracle disagree on a pixel (contributor count, or transmittance off by one contributor:
     helpers.decision_masks) that pixel must lie inside the oracle's threshold guard band (oracle.threshold_risk); the
     golden fixtures are reject-sampled to have NO such pixel, so on them zero flips are demanded;
-  * gradients: helpers.assert_grads_close with the STRICT bar (>= 99 % of elements within 1e-4 relative with a floor
-    of 1e-3 * RMS, worst element <= 1e-2, relative L2 <= 1e-5) on EVERY row except the Gaussians on the tile lists of
-    pixels where a decision ACTUALLY differed (no differing pixel: every row strict) and, in HDR mode, the contributors
-    of pixels within 4 ulp of a CRF knot; those rows get a finite bar (helpers.AT_RISK) and must stay few (`min_strict`).
+  * gradients: helpers.assert_grads_close with the STRICT bar -- tensors of >= 5000 Gaussians (helpers.STRICT_LARGE, round
+    6): >= 99.8 % of elements within 1e-4 relative with a floor of 1e-3 * RMS, worst element <= 6e-3, relative L2 <= 5e-6;
+    smaller ones: 99 %, 1e-2, 1e-5 -- on EVERY row except the Gaussians on the tile lists of pixels where a decision
+    ACTUALLY differed (no differing pixel: every row strict) and, in HDR mode, the contributors of pixels within 4 ulp of a
+    CRF knot; those rows get a finite bar (helpers.AT_RISK) and must stay as few as MEASURED for that very frame
+    (`min_strict` = the frame's own share less half a per cent).  The masked pass (dL zeroed on the excused pixels on both
+    sides) then holds every row to the bar and every element to 1e-4 |ref| + C 2^-24 sum w|term| (assert_grads_bounded).
     The strict bar is what profiles/r02_parity_table.json measures: HIP and the fp32 C oracle are equally far from
     float64 autograd (test_hip_is_as_close_to_fp64_truth_as_the_fp32_oracle asserts that triangle directly).
 """
@@ -84,6 +87,13 @@ def free_camera_scene(P, W, H, deg, seed, cam_seed, **kw):
     return S.make_scene(P, W, H, deg, seed=seed, place_in=None if cam_seed is None else S.random_camera(W, H, cam_seed), **kw)
 
 
+# (rows on the strict bar, measured on the MI355X in round 6 -- HIP path and oracle are both deterministic, so the share is
+#  a property of the frame: 1.0 / 1.0 / 0.9824 / 0.9974 / 1.0 and, under the free cameras, 1.0 / 1.0 / 0.9964 / 0.9993; the
+#  test asserts each frame's own share less half a per cent, not a blanket 0.85 / 0.95 -- VERDICT r5 next #5)
+STRICT_SHARE = {(1000, 0, None): 0.995, (1000, 3, None): 0.995, (5000, 2, None): 0.977, (20000, 1, None): 0.992, (100000, 0, None): 0.995,
+                (1000, 3, 0): 0.995, (5000, 2, 1): 0.995, (20000, 3, 2): 0.991, (100000, 0, 3): 0.994}
+
+
 @pytest.mark.parametrize("P,W,H,deg,seed,cam_seed", [
     (1000, 128, 128, 0, 0, None), (1000, 128, 128, 3, 1, None), (5000, 200, 136, 2, 2, None), (20000, 500, 300, 1, 3, None),
     (100000, 800, 800, 0, 0, None),
@@ -107,11 +117,13 @@ def test_ldr_forward_backward_vs_oracle(oracle, P, W, H, deg, seed, cam_seed):
     check_image(st["final_T"][0], f["final_T"], m, "final_T")
     # strict bar on every row except the tile lists of pixels where a decision actually differed: >= 95 % of the rows at
     # BASELINE c2 size (the smaller frames: a single differing pixel already reaches a few per cent of 1000 Gaussians)
-    Hh.assert_grads_close(g, b, what=f"P={P}", at_risk=m["rows"], min_strict=0.95 if P >= 20000 else 0.85)
+    Hh.assert_grads_close(g, b, what=f"P={P}", at_risk=m["rows"], min_strict=STRICT_SHARE[(P, deg, cam_seed)])
     # the pass that excuses nothing: dL zeroed on the pixels where a decision differed, both sides --
     # every row on the strict bar, every element inside 1e-4 |ref| + C_BOUND 2^-24 sqrt(n) sum|terms|
     g2, b2, _ = Hh.masked_backward_pass(oracle, sc, m, [f], hdr=False)
-    Hh.assert_grads_close(g2, b2, what=f"P={P} masked")
+    # (the bar of the masked pass at c3 / c4 -- _masked_pass -- on every size; the fraction: 2e-3 where the full-size
+    #  frames, with millions of elements, measure 3e-4 and these 1e-3: measured worst 9.7e-4 at 100 000 Gaussians)
+    Hh.assert_grads_close(g2, b2, what=f"P={P} masked", frac_tol=2e-3, max_tol=1e-2, l2_tol=2e-6)
     Hh.assert_grads_bounded(g2, b2, what=f"P={P} masked")
 
 
@@ -237,7 +249,7 @@ def test_against_golden_fixtures(path):
         at_risk = m["rows"]
         if "crf_knot_guarded" in z.files and m["n_differ"] == 0:
             assert not at_risk.any(), int(at_risk.sum())   # c1 fixtures: EVERY row on the strict bar
-    Hh.assert_grads_close(g, ref, what=os.path.basename(path), at_risk=at_risk, min_strict=0.8)
+    Hh.assert_grads_close(g, ref, what=os.path.basename(path), at_risk=at_risk, min_strict=0.96)   # (measured: 0.9675 for hdr_deg1_n4_hdrblur, 1.0 for every other fixture)
 
 
 def test_hip_is_as_close_to_fp64_truth_as_the_fp32_oracle(oracle):
@@ -281,7 +293,7 @@ def test_radiance_activations_vs_oracle(oracle, act):
     assert f["rgb"][f["radii"] > 0].min() > 0 and not st["clamped"].any()
     m = Hh.decision_masks(oracle, sc, [f], st, what=act)
     check_image(g["color"], f["color"], m, act)
-    Hh.assert_grads_close(g, b, what=act, at_risk=m["rows"], min_strict=0.9)
+    Hh.assert_grads_close(g, b, what=act, at_risk=m["rows"], min_strict=0.99)          # (measured 1.0)
     # N poses + exposure / CRF epilogue
     sch = S.make_scene(2500, 160, 96, 1, seed=13, hdr=True)
     sch.shs[:, 0] *= 0.25   # keep e^s inside the CRF table's range for most Gaussians
@@ -292,7 +304,7 @@ def test_radiance_activations_vs_oracle(oracle, act):
     assert_image_close(g["hdr"], r["hdr"], act)
     m = Hh.decision_masks(oracle, sch, r["fwd"], g["state"], cams, crf_got=list(g["state"]["pose_hdr"][:3]),
                           crf_ref=[f["color"] for f in r["fwd"]], what=act + " hdr")
-    Hh.assert_grads_close(g, r, what=act + " hdr", at_risk=m["rows"], min_strict=0.8)
+    Hh.assert_grads_close(g, r, what=act + " hdr", at_risk=m["rows"], min_strict={"exp": 0.99, "softplus": 0.86}[act])   # (measured 1.0 / 0.8688)
     tab = r["dL_dcrf_table"]
     assert Hh.rel_err(g["d_crf_table"], tab, 1e3 * Hh.grad_floor(tab))[0] <= 2e-4
     assert float(g["d_exposure"]) == pytest.approx(r["dL_dexposure"], rel=1e-3)
@@ -312,7 +324,7 @@ def test_precomputed_colors_and_covariance(oracle):
     check_image(g["color"], f["color"], m, "color")
     Hh.assert_grads_close(g, b, keys=[("means3D", "dL_dmeans3D"), ("opacities", "dL_dopacity"),
                                       ("colors_precomp", "dL_dcolors_precomp"), ("cov3D_precomp", "dL_dcov3D")],
-                          at_risk=m["rows"], min_strict=0.9)
+                          at_risk=m["rows"], min_strict=0.99)     # (measured 1.0)
     assert g["d_shs" if "d_shs" in g else "d_colors_precomp"] is not None
 
 
@@ -326,7 +338,7 @@ def test_hdr_with_direct_radiance_gradient(oracle):
     assert_image_close(g["hdr"], r["hdr"], "hdr")
     m = Hh.decision_masks(oracle, sc, r["fwd"], g["state"], crf_got=[g["hdr"]], crf_ref=[r["hdr"]], what="hdr+radiance")
     check_image(g["hdr"], r["hdr"], m, "hdr")
-    Hh.assert_grads_close(g, r, at_risk=m["rows"], min_strict=0.9)
+    Hh.assert_grads_close(g, r, at_risk=m["rows"], min_strict=0.97)       # (measured 0.9768)
     assert float(g["d_exposure"]) == pytest.approx(r["dL_dexposure"], rel=1e-3)
 
 
@@ -358,7 +370,9 @@ def test_motion_blur_n_poses(oracle, dom, free):
     # (worst element: 2e-2 as at c4 -- a sum over eight poses' worth of pixel terms; measured 1.16e-2 on ONE element of the
     #  free-pose frame, a 3-pixel Gaussian deep inside long lists whose terms cancel to 1e-4 of their magnitudes: 0.08 of the
     #  per-element bound below)
-    Hh.assert_grads_close(g, r, at_risk=m["rows"], min_strict=0.8, max_tol=2e-2)
+    # (rows on the strict bar, measured: x-shift poses 0.9177 / 1.0 (ldr / hdr domain), free rotating poses 0.8667 / 0.9473)
+    share = {("ldr", False): 0.91, ("hdr", False): 0.99, ("ldr", True): 0.86, ("hdr", True): 0.94}[(dom, free)]
+    Hh.assert_grads_close(g, r, at_risk=m["rows"], min_strict=share, max_tol=2e-2)
     # ... and the pass that excuses nothing: dL zeroed on the differing / knot pixels on both sides, every row strict, every
     # element inside 1e-4 |ref| + C_BOUND 2^-24 sum w|term|
     g2, r2, _ = Hh.masked_backward_pass(oracle, sc, m, r["fwd"], cameras=cams, hdr=True, blur_domain=dom)
@@ -437,7 +451,7 @@ def test_edge_cases(oracle):
     assert np.array_equal(u32(g["state"]["point_list"][:f["R"]]), u32(f["point_list"]))
     m = Hh.decision_masks(oracle, sc4, [f], g["state"], what="huge")
     check_image(g["color"], f["color"], m, "huge")
-    Hh.assert_grads_close(g, b, at_risk=m["rows"], min_strict=0.9)
+    Hh.assert_grads_close(g, b, at_risk=m["rows"], min_strict=0.99)   # (measured 1.0)
 
 
 def test_mark_visible(oracle):
@@ -583,7 +597,7 @@ def test_frame_of_14400_tiles_vs_oracle(oracle):
     assert np.array_equal(u32(st["point_list"][:f["R"]]), u32(f["point_list"])) and np.array_equal(u32(st["ranges"]), u32(f["ranges"]))
     m = Hh.decision_masks(oracle, sc, [f], st, what="14400 tiles")
     check_image(g["color"], f["color"], m, "14400 tiles")
-    Hh.assert_grads_close(g, b, what="14400 tiles", at_risk=m["rows"], min_strict=0.95)
+    Hh.assert_grads_close(g, b, what="14400 tiles", at_risk=m["rows"], min_strict=0.995)   # (measured 0.9995)
 
 
 def skewed_scene(P=30000, W=640, H=384, deg=1, seed=31):
@@ -644,7 +658,7 @@ def test_skewed_scene_vs_oracle(oracle, form):
     assert lens[8:16, 8:16].sum() > 0.4 * R            # ... the scene is as skewed as it says
     m = Hh.decision_masks(oracle, sc, [f], st, what="skewed")
     check_image(g["color"], f["color"], m, "skewed")
-    Hh.assert_grads_close(g, b, what="skewed", at_risk=m["rows"], min_strict=0.9)
+    Hh.assert_grads_close(g, b, what="skewed", at_risk=m["rows"], min_strict=0.99)   # (measured 1.0)
 
 
 @pytest.mark.parametrize("cfg", ["c3", "c4"])
@@ -1118,7 +1132,7 @@ def test_indefinite_precomputed_covariance_power_rule(oracle):
     # no differing pixel reaches, whether or not the frame has flips
     Hh.assert_grads_close(g, b, keys=[("means3D", "dL_dmeans3D"), ("opacities", "dL_dopacity"),
                                       ("colors_precomp", "dL_dcolors_precomp"), ("cov3D_precomp", "dL_dcov3D")],
-                          max_tol=5e-2, l2_tol=5e-5, at_risk=m["rows"], min_strict=0.9)
+                          max_tol=5e-2, l2_tol=5e-5, at_risk=m["rows"], min_strict=0.99)   # (measured 1.0)
 
 
 def test_accumulated_opacity_output_and_gradient():
@@ -1777,7 +1791,7 @@ def test_c3_full_size_vs_oracle(oracle):
     # at full size the bar is TIGHTER than helpers.STRICT: millions of elements give the fraction and the L2 their meaning.
     # Measured (profiles/r04_parity_fullsize.json): 12 differing pixels, 98.9 % of the rows strict, and on those <= 3.2e-4 of
     # the elements beyond 1e-4 relative (99.97 % within north_star's bar), worst element 6.7e-3, relative L2 5.4e-7
-    rep = Hh.assert_grads_close(g, r, what="c3", at_risk=m["rows"], min_strict=0.95, frac_tol=1e-3, max_tol=1e-2, l2_tol=2e-6)
+    rep = Hh.assert_grads_close(g, r, what="c3", at_risk=m["rows"], min_strict=0.985, frac_tol=1e-3, max_tol=1e-2, l2_tol=2e-6)
     # table / exposure gradients: against the oracle's tone-map backward given the same decisions (on the handful of
     # differing pixels the radiance the HIP path composited stands in), and loosely against the oracle's own
     tab, dexp = Hh.crf_grads_given_decisions(oracle, sc, m, [r["hdr"]], [g["hdr"]])
@@ -1829,7 +1843,7 @@ def test_c4_eight_poses_full_size_vs_oracle(oracle):
         assert not ((e > 1e-4).any(axis=0) & ~any_differs).any(), ("c4 " + name, float(e.max()))
     # (measured: 105 differing pixels over the eight poses, 93 % of the rows strict; on those <= 3e-4 of the elements beyond
     # 1e-4, worst element 9.5e-3 -- a sum over eight poses' worth of pixel terms --, relative L2 4.7e-7)
-    rep = Hh.assert_grads_close(g, r, what="c4", at_risk=m["rows"], min_strict=0.90, frac_tol=1e-3, max_tol=2e-2, l2_tol=2e-6)
+    rep = Hh.assert_grads_close(g, r, what="c4", at_risk=m["rows"], min_strict=0.925, frac_tol=1e-3, max_tol=2e-2, l2_tol=2e-6)
     tab, dexp = Hh.crf_grads_given_decisions(oracle, sc, m, [f["color"] for f in r["fwd"]], list(st["pose_hdr"][:N]))
     assert Hh.rel_err(g["d_crf_table"], tab, 1e3 * Hh.grad_floor(tab))[0] <= 2e-4
     assert float(g["d_exposure"]) == pytest.approx(dexp, rel=2e-4, abs=1e-3)
