@@ -250,8 +250,14 @@ int hs_forward(const hs_fwd_args* a, void* hip_stream) {
         return HS_EINVAL;
     }
     if (a->dims.P == 0) {
-        // nothing to rasterize: clear counters so the host sees R = 0, and paint the background
-        if (a->stages & HS_STAGE_PREPROCESS) HS_HIP_CHECK(hipMemsetAsync(a->geom, 0, sizeof(hs_counters), s));
+        // nothing to rasterize: clear counters so the host sees R = 0, and paint the background.  (By a kernel, like every
+        // other path: an empty cloud inside a captured step must not put memset / copy nodes into the graph -- ADVICE r5)
+        const int64_t gx0 = (a->dims.W + kTile - 1) / kTile, gy0 = (a->dims.H + kTile - 1) / kTile;
+        const bool bin = (a->stages & HS_STAGE_BIN) && !(a->stages & HS_STAGE_PREPROCESS_ONLY) && a->binning;
+        rc = launch_empty_frame((a->stages & HS_STAGE_PREPROCESS) ? (hs_counters*)((char*)a->geom + L.counters) : nullptr,
+                                bin ? (uint2*)((char*)a->binning + L.ranges) : nullptr, gx0 * gy0 * a->dims.n_poses,
+                                bin ? (uint32_t*)a->counters_host : nullptr, (const hs_counters*)((char*)a->geom + L.counters), s);
+        if (rc) return rc;
     }
     const uint32_t frame_tag = ((a->stages & HS_STAGE_PREPROCESS) && (a->stages & HS_STAGE_BIN) && a->binning) ? next_frame_tag() : 0u;
     if ((a->stages & HS_STAGE_PREPROCESS) && a->dims.P > 0) {
@@ -269,12 +275,7 @@ int hs_forward(const hs_fwd_args* a, void* hip_stream) {
             rc = launch_binning(*a, L, s, frame_tag);
             if (rc) return rc;
             if ((rc = debug_sync(a->flags, s, "binning"))) return rc;
-        } else {
-            const int64_t gx = (a->dims.W + kTile - 1) / kTile, gy = (a->dims.H + kTile - 1) / kTile;
-            HS_HIP_CHECK(hipMemsetAsync((char*)a->binning + L.ranges, 0, (size_t)(gx * gy * a->dims.n_poses * 8), s));
-            if (a->counters_host)
-                HS_HIP_CHECK(hipMemcpyAsync(a->counters_host, (char*)a->geom + L.counters, sizeof(hs_counters), hipMemcpyDeviceToHost, s));
-        }
+        }   // (an empty cloud: launch_empty_frame above cleared the ranges and wrote the host copy of the counters)
     }
     if ((a->stages & HS_STAGE_OFFSETS) && a->dims.P > 0) {
         rc = launch_scan(*a, L, s);  // inspection only: a5 in instance order

@@ -1158,15 +1158,19 @@ __device__ __forceinline__ void hier_coarse_rect(uint2 rc, uint32_t& sx0, uint32
     sh = any ? (y0 + h - 1u) / kSuper - sy0 + 1u : 0u;
 }
 
-// (1024 instances per workgroup: the sums of every 256 -- the emission's workgroup -- AND of the whole 1024, so that an
-// emission workgroup adds up a quarter as many words for the pairs in front of it: 977 + 3 instead of 3906 at c3)
-__global__ void __launch_bounds__(1024) hier_gather_kernel(int64_t I, const uint32_t* inst_sorted, const uint2* binfo,
-                                                           uint2* srect, const hs_counters* counters, uint32_t* block_sums,
-                                                           uint32_t* block_csums, uint32_t* super_sums, uint32_t* super_csums,
-                                                           uint32_t* zero, int64_t n_zero) {
-    __shared__ uint32_t s_wave[16];
-    for (int64_t t = (int64_t)blockIdx.x * 1024 + threadIdx.x; t < n_zero; t += (int64_t)gridDim.x * 1024) zero[t] = 0u;
-    const int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+// NT = 256: one workgroup per emission workgroup, its two sums (c3: 14.7 us; 1024-thread workgroups: 16.5).  NT = 1024
+// (frames of >= 2^21 instances): the sums of every 256 AND of the whole 1024, so that an emission workgroup adds up a
+// quarter as many words for what lies in front of it (c4: 7812 + 3 instead of 31 250 -- which used to take two single-workgroup
+// scan kernels of 32 us each ahead of the emission).
+template <int NT>
+__global__ void __launch_bounds__(NT) hier_gather_kernel(int64_t I, const uint32_t* inst_sorted, const uint2* binfo,
+                                                         uint2* srect, const hs_counters* counters, uint32_t* block_sums,
+                                                         uint32_t* block_csums, uint32_t* super_sums, uint32_t* super_csums,
+                                                         uint32_t* zero, int64_t n_zero) {
+    constexpr int NW = NT / 64, NSUB = NT / 256;
+    __shared__ uint32_t s_wave[NW];
+    for (int64_t t = (int64_t)blockIdx.x * NT + threadIdx.x; t < n_zero; t += (int64_t)gridDim.x * NT) zero[t] = 0u;
+    const int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x;
     uint2 rc = make_uint2(0u, 0u);
     if (i < I) {
         if (counters->overflow < 2u) rc = binfo[inst_sorted[i]];
@@ -1175,16 +1179,16 @@ __global__ void __launch_bounds__(1024) hier_gather_kernel(int64_t I, const uint
     uint32_t sx0, sy0, sw, sh;
     hier_coarse_rect(rc, sx0, sy0, sw, sh);
     const int64_t nsub = (I + 255) / 256;
+    const bool sub_on = (int)threadIdx.x < NSUB && (int64_t)blockIdx.x * NSUB + threadIdx.x < nsub;
+    const int w0 = 4 * (int)(threadIdx.x % NSUB);
     uint32_t total;
-    block_incl_scan<16>((rc.y & 0xFFFFu) * (rc.y >> 16), s_wave, &total);     // (leaves the 16 wave totals in s_wave)
-    if (threadIdx.x < 4 && (int64_t)blockIdx.x * 4 + threadIdx.x < nsub)
-        block_sums[blockIdx.x * 4 + threadIdx.x] = (s_wave[4 * threadIdx.x] + s_wave[4 * threadIdx.x + 1]) + (s_wave[4 * threadIdx.x + 2] + s_wave[4 * threadIdx.x + 3]);
-    if (threadIdx.x == 0) super_sums[blockIdx.x] = total;
+    block_incl_scan<NW>((rc.y & 0xFFFFu) * (rc.y >> 16), s_wave, &total);     // (leaves the wave totals in s_wave)
+    if (sub_on) block_sums[blockIdx.x * NSUB + threadIdx.x] = (s_wave[w0] + s_wave[w0 + 1]) + (s_wave[w0 + 2] + s_wave[w0 + 3]);
+    if (NSUB > 1 && threadIdx.x == 0) super_sums[blockIdx.x] = total;
     __syncthreads();
-    block_incl_scan<16>(sw * sh, s_wave, &total);
-    if (threadIdx.x < 4 && (int64_t)blockIdx.x * 4 + threadIdx.x < nsub)
-        block_csums[blockIdx.x * 4 + threadIdx.x] = (s_wave[4 * threadIdx.x] + s_wave[4 * threadIdx.x + 1]) + (s_wave[4 * threadIdx.x + 2] + s_wave[4 * threadIdx.x + 3]);
-    if (threadIdx.x == 0) super_csums[blockIdx.x] = total;
+    block_incl_scan<NW>(sw * sh, s_wave, &total);
+    if (sub_on) block_csums[blockIdx.x * NSUB + threadIdx.x] = (s_wave[w0] + s_wave[w0 + 1]) + (s_wave[w0 + 2] + s_wave[w0 + 3]);
+    if (NSUB > 1 && threadIdx.x == 0) super_csums[blockIdx.x] = total;
 }
 
 // Element: .x = (pose, super-tile) key | clipped rectangle above bit `kb` (x0: 3 bits, y0: 3, w - 1: 3, h - 1: 3, all in
@@ -1232,10 +1236,14 @@ __global__ void __launch_bounds__(256) hier_emit_kernel(int64_t I, int P, int gx
         if (threadIdx.x == 0) { s_excl = block_excl[blk]; s_cexcl = block_cexcl[blk]; }
     } else {
         unsigned long long part = 0, cpart = 0;    // (64-bit: see emit_pairs_kernel)
-        // (the sums of the 1024-instance groups in front of this workgroup's, then of the 256-instance ones inside its group)
-        const int nsup = (HS_ABL & 8) ? 0 : blk / 4;
-        for (int j = threadIdx.x; j < nsup; j += 256) { part += super_sums[j]; cpart += super_csums[j]; }
-        if ((int)threadIdx.x < blk - 4 * (blk / 4)) { part += block_excl[4 * (blk / 4) + threadIdx.x]; cpart += block_cexcl[4 * (blk / 4) + threadIdx.x]; }
+        if (super_sums) {
+            // (the sums of the 1024-instance groups in front of this workgroup's, then of the 256-instance ones inside its group)
+            const int nsup = (HS_ABL & 8) ? 0 : blk / 4;
+            for (int j = threadIdx.x; j < nsup; j += 256) { part += super_sums[j]; cpart += super_csums[j]; }
+            if ((int)threadIdx.x < blk - 4 * (blk / 4)) { part += block_excl[4 * (blk / 4) + threadIdx.x]; cpart += block_cexcl[4 * (blk / 4) + threadIdx.x]; }
+        } else {
+            for (int j = threadIdx.x; j < ((HS_ABL & 8) ? 0 : blk); j += 256) { part += block_excl[j]; cpart += block_cexcl[j]; }
+        }
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) {
             part += (unsigned long long)__shfl_xor((long long)part, d);
@@ -1622,7 +1630,27 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(const uint32_t* tiles,
     }
 }
 
+// P == 0: one small kernel instead of the memset + copy the call used to enqueue (a captured step holds kernels only)
+__global__ void __launch_bounds__(256) empty_frame_kernel(hs_counters* clear, uint2* ranges, int64_t ntiles, uint32_t* counters_host,
+                                                          const hs_counters* counters) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (ranges && i < ntiles) ranges[i] = make_uint2(0u, 0u);
+    if (blockIdx.x == 0 && threadIdx.x < 8) {
+        const uint32_t v = clear ? 0u : reinterpret_cast<const uint32_t*>(counters)[threadIdx.x];
+        if (clear) reinterpret_cast<uint32_t*>(clear)[threadIdx.x] = 0u;
+        if (counters_host) __hip_atomic_store(counters_host + threadIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 }  // namespace
+
+int launch_empty_frame(hs_counters* clear, uint2* ranges, int64_t ntiles, uint32_t* counters_host, const hs_counters* counters,
+                       hipStream_t s) {
+    if (!clear && !ranges && !counters_host) return HS_OK;
+    empty_frame_kernel<<<ranges ? ceil_div(ntiles, 256) : 1, 256, 0, s>>>(clear, ranges, ntiles, counters_host, counters);
+    HS_LAUNCH_CHECK();
+    return HS_OK;
+}
 
 int64_t sort_tmp_bytes(int64_t n) {
     // every sort uses the same tile; 8 passes of 256-bin status words (hs_sort_pairs on 64-bit keys) is also what the depth
@@ -1762,10 +1790,15 @@ int launch_binning(const hs_fwd_args& a, const hs_layout& L, hipStream_t s, uint
         uint2* srect = dp0;
         uint32_t* bsum = (uint32_t*)dp1;
         uint32_t* bcsum = bsum + eblk;
-        uint32_t* ssum = bcsum + eblk;                     // (sums of 1024 instances: ceil(I / 1024) words each)
-        uint32_t* scsum = ssum + ceil_div(I, 1024);
-        hier_gather_kernel<<<ceil_div(I, 1024), 1024, 0, s>>>(I, inst_sorted, (const uint2*)(geom + L.binfo), srect, counters, bsum,
-                                                              bcsum, ssum, scsum, hw, W.zero_words);
+        const bool big = I >= (2 << 20);
+        uint32_t* ssum = big ? bcsum + eblk : nullptr;     // (big frames: sums of 1024 instances too, ceil(I / 1024) words each)
+        uint32_t* scsum = big ? ssum + ceil_div(I, 1024) : nullptr;
+        if (big)
+            hier_gather_kernel<1024><<<ceil_div(I, 1024), 1024, 0, s>>>(I, inst_sorted, (const uint2*)(geom + L.binfo), srect, counters,
+                                                                        bsum, bcsum, ssum, scsum, hw, W.zero_words);
+        else
+            hier_gather_kernel<256><<<eblk, 256, 0, s>>>(I, inst_sorted, (const uint2*)(geom + L.binfo), srect, counters, bsum, bcsum,
+                                                         nullptr, nullptr, hw, W.zero_words);
         // (beyond 32768 emission workgroups -- 8 M instances -- a scan kernel turns the 256-instance sums into prefixes)
         const bool excl_ready = eblk > 4 * 8192;
         if (excl_ready) {
@@ -1778,7 +1811,7 @@ int launch_binning(const hs_fwd_args& a, const hs_layout& L, hipStream_t s, uint
 #define HS_HEMIT_ARGS I, d.P, gx, gy, (float4*)(geom + L.rec), inst_sorted, srect, bsum, bcsum, ssum, scsum, offs, e0,                \
                       (uint8_t*)(bin + L.pair_flags), counters, (uint64_t)d.capacity, sc.ghist, kb, cpasses, depth_bits,             \
                       (int)excl_ready, hw, hw + W.st_count, (int)W.nst, (int)W.nst_pad()
-        if (I >= (2 << 20)) hier_emit_kernel<true><<<eblk, 256, 0, s>>>(HS_HEMIT_ARGS);
+        if (big) hier_emit_kernel<true><<<eblk, 256, 0, s>>>(HS_HEMIT_ARGS);
         else hier_emit_kernel<false><<<eblk, 256, 0, s>>>(HS_HEMIT_ARGS);
 #undef HS_HEMIT_ARGS
         HS_LAUNCH_CHECK();

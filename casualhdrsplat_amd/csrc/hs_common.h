@@ -5,6 +5,12 @@
 
 #include "../../include/hdrsplat.h"
 
+// gfx950 only (MI355X): the kernels count on 160 KB of LDS per workgroup (the counting tile sort's scatter takes 80 KB of
+// dynamic LDS at its admitted maximum), wave64, the DPP / permlane forms and the wait states of this target.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "libhdrsplat is written for gfx950 (MI355X) only: build with --offload-arch=gfx950"
+#endif
+
 namespace hs {
 
 void set_error(const char* fmt, ...);
@@ -74,6 +80,9 @@ int launch_preprocess_fwd(const hs_fwd_args& a, const hs_layout& L, hipStream_t 
 int launch_scan(const hs_fwd_args& a, const hs_layout& L, hipStream_t s);
 int launch_cov3d(const hs_fwd_args& a, const hs_layout& L, hipStream_t s);   // inspection: fills hs_layout.cov3D
 int launch_binning(const hs_fwd_args& a, const hs_layout& L, hipStream_t s, uint32_t frame_tag);
+// an empty cloud (P == 0): cleared counters (when given), cleared tile ranges (when given), the host copy of the counters
+int launch_empty_frame(hs_counters* clear, uint2* ranges, int64_t ntiles, uint32_t* counters_host, const hs_counters* counters,
+                       hipStream_t s);
 // `stats` (device, render_stats_count() u64 counters, or null) selects the diagnostic instantiation of the kernel
 int launch_render_fwd(const hs_fwd_args& a, const hs_layout& L, hipStream_t s, unsigned long long* stats = nullptr);
 // `crf_in_tail`: the CRF gradient's first stage rides at the END of the launch (workgroups behind the tiles')

@@ -106,6 +106,12 @@ class GraphedStep:
             rs = r.raster_settings
             stale = {k: v.detach() for k, v in rs._asdict().items() if isinstance(v, torch.Tensor) and v.grad_fn is not None}
             if stale:
+                # (said out loud: a `fn` that does NOT assign fresh settings on every call would lose the gradients that
+                # flow through these tensors -- ADVICE r5)
+                import warnings
+                warnings.warn(f"GraphedStep: detached the computed tensors {sorted(stale)} a rasterizer's raster_settings still held "
+                              "from an earlier step (they keep that step's autograd graph alive); `fn` must assign the settings "
+                              "of every call itself, as image_formation.FrameRasterizers does", RuntimeWarning, stacklevel=3)
                 r.raster_settings = rs._replace(**stale)
 
     def step(self):

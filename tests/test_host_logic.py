@@ -207,19 +207,18 @@ def test_bench_exchange_bytes_and_probe_order():
 
 
 def test_no_memset_or_copy_on_the_paths_a_captured_step_takes():
-    """Memset nodes of a captured HIP graph misbehaved from the second replay on (camera gradients that differed
-    between identical replays): the library enqueues KERNELS only on the paths a training step takes.  The remaining
-    hipMemsetAsync / hipMemcpyAsync / hipMemsetD32Async calls are the ones listed here -- an empty cloud (P == 0), a frame
-    without binning capacity, the stand-alone hs_sort_pairs entry point, the fault-injection hook of the test library -- and a
-    new one has to be added to this list on purpose."""
+    """The library enqueues KERNELS only on the paths a training step takes -- no memset or copy nodes in a captured step
+    (graphs.GraphedStep).  (Round 5 believed memset nodes of a captured HIP graph misbehaved; round 6's reproducers --
+    scripts/repro/, profiles/r06_repro_graph_hazards.txt -- show they do not, in isolation or in a graph of 2752 nodes:
+    the rule stays as hygiene)  The remaining hipMemsetAsync / hipMemcpyAsync / hipMemsetD32Async calls are
+    the ones listed here -- a frame without binning capacity, the stand-alone hs_sort_pairs entry point, the fault-injection
+    hook of the test library -- and a new one has to be added to this list on purpose.  (An empty cloud, P == 0, is cleared
+    by a kernel since round 6.)"""
     import os
     import re
     root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "casualhdrsplat_amd", "csrc")
     allowed = {
-        "api.hip": ["if (a->stages & HS_STAGE_PREPROCESS) HS_HIP_CHECK(hipMemsetAsync(a->geom, 0, sizeof(hs_counters), s));",   # P == 0
-                    "hipMemsetAsync((char*)a->binning + L.ranges, 0,",                                                        # P == 0
-                    "hipMemcpyAsync(a->counters_host, (char*)a->geom + L.counters,",                                          # P == 0
-                    "hipMemsetD32Async((hipDeviceptr_t)n_dev,", "hipMemsetD32Async((hipDeviceptr_t)fail_word,",               # hs_sort_pairs
+        "api.hip": ["hipMemsetD32Async((hipDeviceptr_t)n_dev,", "hipMemsetD32Async((hipDeviceptr_t)fail_word,",               # hs_sort_pairs
                     "hipMemcpyAsync(ka, keys_in,", "hipMemcpyAsync(va, vals_in,", "hipMemcpyAsync(keys_out,", "hipMemcpyAsync(vals_out,"],
         "binning.hip": ["if (!zeroed) HS_HIP_CHECK(hipMemsetAsync(tmp, 0,",            # radix_sort_packed outside the pipeline (never: zeroed = true)
                         "HS_HIP_CHECK(hipMemsetAsync(tmp, 0, (size_t)sort_scratch_words(n_launch, passes, TILE) * 4, s));",   # hs_sort_pairs
