@@ -937,8 +937,9 @@ __global__ void __launch_bounds__(256) pose_reduce1_kernel(const float* partials
 }
 // One thread per OUTPUT element -- 16 + 16 + 3 per pose -- so that the matrix entries no pose term maps to (column 3 of the view
 // matrix rows, column 2 of the projection rows) are written as zeros by this kernel.  (They used to be cleared by two
-// hipMemsetAsync ahead of it: inside a captured step -- graphs.GraphedStep -- those became memset nodes whose effect raced with
-// this kernel's stores: the two gradients differed from replay to replay.  No memset on the backward's path any more.)
+// hipMemsetAsync ahead of it; a captured step -- graphs.GraphedStep -- holds kernels only since round 5, when gradients of a
+// captured formation step differed from replay to replay.  Round 6's reproducers exonerate HIP's memset nodes, DESIGN.md
+// 4.11; the rule stays: one node kind in the graph, nothing to clear that a kernel does not clear itself.)
 __global__ void __launch_bounds__(256) pose_reduce2_kernel(const float* stage, int N, float* d_view, float* d_proj,
                                                            float* d_campos) {
     const int o = blockIdx.x * 256 + threadIdx.x;
@@ -1005,8 +1006,7 @@ int launch_preprocess_fwd(const hs_fwd_args& a, const hs_layout& L, hipStream_t 
                                            sort_passes(tile_bits((uint32_t)p.n_vtiles)));
     }
     // (N poses: the per-Gaussian output radius is the max over the poses, by atomicMax -- cleared by a kernel, not by
-    // hipMemsetAsync: inside a captured step a memset node's effect was seen to race with the kernel behind it, see
-    // pose_reduce2_kernel)
+    // hipMemsetAsync: a captured step holds kernels only, see pose_reduce2_kernel)
     if (d.n_poses > 1 && d.P > 0) fill_i32_kernel<<<ceil_div((int64_t)d.P, 1024), 256, 0, s>>>(a.radii, (int64_t)d.P, 0);
     // chunks of 256 Gaussians, padded to a multiple of the 8 XCDs, times the poses (see the kernel's block map)
     const int grid = (int)(ceil_div(ceil_div((int64_t)d.P, 256), 8) * 8 * d.n_poses);

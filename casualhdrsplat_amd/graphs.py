@@ -8,12 +8,14 @@ update them IN PLACE between replays (optimizer steps do), never rebind them.
 
 The reference is a trainer around this hot path (Readme.md:54); nothing in it prescribes how launches reach the GPU.
 
-What `fn` may contain (ROCm 7.2 / PyTorch 2.10 on MI355X, found the hard way): everything this package enqueues is kernels
-only -- no hipMemsetAsync / hipMemcpyAsync on a captured path, because MEMSET NODES of a captured graph were seen to
-misbehave from the second replay on (camera gradients that differed between identical replays).  PyTorch
-itself issues such a memset in front of its two-pass reduction kernel: a `.mean()` / `.sum()` over more than a few ten
-thousand elements inside `fn` returned a wrong VALUE from the second replay on (examples/train_synthetic.py: mean_by_rows
-avoids it; gradients of such a loss are unaffected, they do not depend on its value).  No torch.linalg solver calls, no
+What `fn` may contain (ROCm 7.2 / PyTorch 2.10 on MI355X): everything this package enqueues is kernels only -- no
+hipMemsetAsync / hipMemcpyAsync on a captured path.  A LONG captured autograd step (the multi-frame image-formation step)
+returns wrong VALUES from PyTorch's two-pass reduction -- a `.mean()` / `.sum()` over more than a few ten thousand elements
+-- from the second replay on, while its gradients stay right (examples/train_synthetic.py: mean_by_rows avoids that
+kernel).  Round 5 blamed memset nodes of the runtime; round 6's reproducers (scripts/repro/) show that
+neither HIP's memset nodes nor torch's reduction fail in isolation, that rasterizer-only captured steps are right, and that
+the formation step fails with a torch-only stand-in for the rasterizer as well: it is the capture of that long torch step,
+not this library.  Check a captured step's printed scalars against an eager step once.  No torch.linalg solver calls, no
 element-wise fills of device tensors from host scalars (host-to-device copies).
 """
 from __future__ import annotations

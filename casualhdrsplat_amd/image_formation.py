@@ -234,9 +234,10 @@ class ImplicitCRF(nn.Module):
 
     def _mlp(self, x: torch.Tensor) -> torch.Tensor:
         """self.net(x), written as broadcast multiplies and sums (the layers are 1 -> h -> h -> 3 on K points: nothing a
-        BLAS call is good for).  Not only speed: a BLAS call inside a captured step (graphs.GraphedStep) brings its
-        workspace with it, and on ROCm 7 / PyTorch 2.10 replays of such a graph were seen to scribble GEMM partials over
-        neighbouring tensors of the graph's memory pool (a captured loss read 94.41 for ever after the first replay)."""
+        BLAS call is good for).  Not only speed: inside the captured multi-frame step (graphs.GraphedStep) round 5 saw
+        tensors next to a BLAS call hold wrong values from the second replay on.  Round 6 could not reproduce that with a
+        BLAS call alone (scripts/repro/graph_torch_sum.py: right on every replay) -- the failure belongs to the capture of
+        that long torch step as a whole, DESIGN.md 4.11 -- but nothing is lost by keeping the arithmetic BLAS-free."""
         for layer in self.net:
             if isinstance(layer, nn.Linear):
                 x = (x.unsqueeze(-2) * layer.weight).sum(-1) + layer.bias     # [K, out] = sum_in x[K, 1, in] * W[out, in]

@@ -33,12 +33,12 @@ CLOUD = ("means3D", "opacities", "shs", "scales", "rotations")
 
 
 def mean_by_rows(x: torch.Tensor) -> torch.Tensor:
-    """x.mean() as two small reductions (rows of 256, then the row sums).  Inside a captured step a plain .mean() / .sum()
-    over more than a few ten thousand elements is PyTorch's two-pass kernel, which clears a semaphore with a memset ahead
-    of it -- and on ROCm 7 / PyTorch 2.10 memset nodes of a captured graph were seen to misbehave from the second replay
-    on (this very loss read 94.41 for ever; the library's own kernels had the same trouble with two hipMemsetAsync, see
-    DESIGN.md 4.11).  The gradient of a mean does not depend on its value, so training was right all along; the printed
-    numbers were not."""
+    """x.mean() as two small reductions (rows of 256, then the row sums).  Inside THIS captured step a plain .mean() / .sum()
+    over more than a few ten thousand elements -- PyTorch's two-pass kernel -- reads a wrong value from the second replay on
+    (23.6 instead of 0.0406: scripts/repro/graph_step_mean.py).  Round 5 blamed a memset node; round 6's reproducers show
+    that neither HIP's memset nodes nor this reduction fail in isolation and that the step fails with a torch-only stand-in
+    for the rasterizer too: the capture of the long torch step, not the reduction, not this library.  The
+    gradient of a mean does not depend on its value, so training was right all along; the printed numbers were not."""
     if os.environ.get("HS_EXAMPLE_PLAIN_MEAN"):      # (scripts/repro/graph_step_mean.py: the reduction this function avoids)
         return x.mean()
     n = x.numel()
