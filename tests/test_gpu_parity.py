@@ -1565,10 +1565,11 @@ def test_randomized_configurations_vs_oracle(oracle):
     rng = np.random.default_rng(int(os.environ.get("HS_SWEEP_SEED", "2026")))
     for case in range(int(os.environ.get("HS_SWEEP_CASES", "24"))):
         c = Hh.sweep_case(rng, case)
-        # (these frames are small: by default their pairs are sorted by counting; every third case keeps the radix passes)
+        # (these frames are small: by default their pairs are sorted by counting; one case in three keeps the radix passes,
+        # one in three takes the hierarchical sort of large frames -- round 6 -- down to a handful of super-tiles)
         os.environ.pop("HS_TILE_SORT", None)
-        if case % 3 == 2:
-            os.environ["HS_TILE_SORT"] = "radix"
+        if case % 3:
+            os.environ["HS_TILE_SORT"] = ("radix", "hier")[case % 3 - 1]
         P, W, H, n_poses, hdr, act, dom = c["P"], c["W"], c["H"], c["n_poses"], c["hdr"], c["act"], c["dom"]
         sc, cams, precomp, what = c["sc"], c["cams"], c["precomp"], c["what"]
         if hdr or n_poses > 1:
