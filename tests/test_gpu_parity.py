@@ -1765,20 +1765,24 @@ def _masked_pass(oracle, sc, m, fwds, what, cameras=None, workers=1, frac_tol=1e
     return g2, r2, bounded, rep
 
 
-def test_c3_full_size_vs_oracle(oracle):
-    """BASELINE c3 itself -- the frame bench.py times: 1M Gaussians, 1920 x 1080, SH degree 3, HDR radiance + CRF, seed 0
+@pytest.mark.parametrize("cam_seed", [None, 9], ids=["default_camera", "free_camera"])
+def test_c3_full_size_vs_oracle(oracle, cam_seed):
+    """(free_camera, round 6: the same cloud laid out in front of a free 6-DoF view -- synthetic.random_camera(9): roll, pitch
+    and yaw of up to +-pi, every entry of the view matrix populated -- at the size the metric is quoted on.)
+    BASELINE c3 itself -- the frame bench.py times: 1M Gaussians, 1920 x 1080, SH degree 3, HDR radiance + CRF, seed 0
     -- against the C oracle (25 s of one host core): depths / screen positions / conics / radii / tile counts and the whole
     sorted list (6.78 M pairs: point_list, ranges, the rebuilt 64-bit keys) bit for bit, decisions confined to the
     oracle's guard band, radiance and LDR images within 1e-4 off the pixels where a decision differs, every gradient on
     the STRICT bar for >= 95 % of the Gaussians, d_crf_table / d_exposure as in the golden test.  Paths only this size
     reaches: a depth sort of 245 blocks, 8160 tiles through the ordered list + the tail queue of the backward."""
     P, W, H = 1_000_000, 1920, 1080
-    sc = S.make_scene(P, W, H, 3, seed=0, hdr=True)
+    sc = free_camera_scene(P, W, H, 3, 0, cam_seed, hdr=True)
     r = Hh.run_oracle_hdr(oracle, sc)
     g = Hh.run_hip(sc, hdr=True)
     st, f = g["state"], r["fwd"][0]
     R = f["R"]
     assert st["num_rendered"] == R and R > 6_000_000
+    assert int(st["tile_sort"]) == 2      # the hierarchical tile sort: the default of a frame this size
     check_structure(st, f)
     assert np.array_equal(u32(st["offsets"]), u32(f["offsets"]))
     assert np.array_equal(st["keys_sorted"].view(np.uint64)[:R], f["keys_sorted"])
@@ -1792,7 +1796,8 @@ def test_c3_full_size_vs_oracle(oracle):
     # at full size the bar is TIGHTER than helpers.STRICT: millions of elements give the fraction and the L2 their meaning.
     # Measured (profiles/r04_parity_fullsize.json): 12 differing pixels, 98.9 % of the rows strict, and on those <= 3.2e-4 of
     # the elements beyond 1e-4 relative (99.97 % within north_star's bar), worst element 6.7e-3, relative L2 5.4e-7
-    rep = Hh.assert_grads_close(g, r, what="c3", at_risk=m["rows"], min_strict=0.985, frac_tol=1e-3, max_tol=1e-2, l2_tol=2e-6)
+    rep = Hh.assert_grads_close(g, r, what="c3", at_risk=m["rows"], min_strict=0.985 if cam_seed is None else 0.97,
+                                frac_tol=1e-3, max_tol=1e-2, l2_tol=2e-6)
     # table / exposure gradients: against the oracle's tone-map backward given the same decisions (on the handful of
     # differing pixels the radiance the HIP path composited stands in), and loosely against the oracle's own
     tab, dexp = Hh.crf_grads_given_decisions(oracle, sc, m, [r["hdr"]], [g["hdr"]])
@@ -1801,7 +1806,8 @@ def test_c3_full_size_vs_oracle(oracle):
     assert Hh.rel_err(g["d_crf_table"], r["dL_dcrf_table"], 1e3 * Hh.grad_floor(tab))[0] <= 2e-2
     # ... and the pass that excuses nothing: dL zeroed on the 12 + ~200 excluded pixels, both sides
     g2, r2, bounded, rep2 = _masked_pass(oracle, sc, m, [f], "c3")
-    _parity_row("c3 (1M Gaussians, 1920x1080, SH3, HDR + CRF, seed 0): HIP vs fp32 C oracle, rows off the differing pixels",
+    _parity_row("c3 (1M Gaussians, 1920x1080, SH3, HDR + CRF, seed 0" + ("" if cam_seed is None else ", free 6-DoF camera") +
+                "): HIP vs fp32 C oracle, rows off the differing pixels",
                 sc, m, g, r, {"R": int(R), "report": {k: v for k, v in rep.items()}}, masked=(g2, r2, bounded))
 
 
