@@ -1796,7 +1796,7 @@ def test_c3_full_size_vs_oracle(oracle, cam_seed):
     # at full size the bar is TIGHTER than helpers.STRICT: millions of elements give the fraction and the L2 their meaning.
     # Measured (profiles/r04_parity_fullsize.json): 12 differing pixels, 98.9 % of the rows strict, and on those <= 3.2e-4 of
     # the elements beyond 1e-4 relative (99.97 % within north_star's bar), worst element 6.7e-3, relative L2 5.4e-7
-    rep = Hh.assert_grads_close(g, r, what="c3", at_risk=m["rows"], min_strict=0.985 if cam_seed is None else 0.97,
+    rep = Hh.assert_grads_close(g, r, what="c3", at_risk=m["rows"], min_strict=0.985,     # (measured: 0.9888 / 0.9908 under the free camera)
                                 frac_tol=1e-3, max_tol=1e-2, l2_tol=2e-6)
     # table / exposure gradients: against the oracle's tone-map backward given the same decisions (on the handful of
     # differing pixels the radiance the HIP path composited stands in), and loosely against the oracle's own
