@@ -1124,7 +1124,7 @@ __global__ void __launch_bounds__(256) tile_keys_kernel(const uint2* ranges, int
 //      counts the elements per super-tile and the digit totals of the pass(es) below, and verdicts num_rendered;
 //   3. radix_sweep_kernel over the elements, by super-tile id only: ONE pass for up to 256 (pose, super-tile) keys (c3:
 //      135), two up to 65 536; stable, so every super-tile's elements stay in depth order;
-//   4. hier_plan_kernel (one workgroup): first element of every super-tile, its chunks of kHierChunk elements, one
+//   4. hier_plan_kernel (one workgroup): first element of every super-tile, its chunks of hier_chunk(I) = 512 / 1024 elements, one
 //      descriptor per chunk;
 //   5. hier_count_kernel, one workgroup per chunk: pairs per tile of the super-tile and per wave (a wave takes 256
 //      consecutive elements: four +-1 corner marks per element into a 9 x 9 grid, then a 2-D prefix sum), and the tile
@@ -1353,7 +1353,7 @@ __global__ void __launch_bounds__(256) hier_emit_kernel(int64_t I, int P, int gx
 // hier[1] = chunks, hier[8 + x] = xfirst[x] (9 entries).  An empty or overflowed frame has none.
 __global__ void __launch_bounds__(1024) hier_plan_kernel(const hs_counters* counters, uint32_t* hier, const uint32_t* st_count,
                                                          int nst, int nst_pad, uint32_t* coarse_first, uint32_t* chunk_first,
-                                                         uint4* desc) {
+                                                         uint4* desc, uint32_t chunk) {
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_cnt[kHierStMax], s_first[kHierStMax];
     // (hier[0]: zeroed by the emission's verdict on overflow and by a radix pass that gave up -- its kill word)
@@ -1379,7 +1379,7 @@ __global__ void __launch_bounds__(1024) hier_plan_kernel(const hs_counters* coun
         const int x = j / per, sidx = (j - x * per) * 8 + x;
         const bool on = j < 8 * per && sidx < nst;
         const uint32_t cnt = on ? s_cnt[sidx] : 0u;
-        const uint32_t nch = (cnt + kHierChunk - 1) / kHierChunk;
+        const uint32_t nch = (cnt + chunk - 1u) / chunk;
         uint32_t ktot;
         const uint32_t kin = block_incl_scan<16>(nch, s_wave, &ktot);
         const uint32_t k0 = kcarry + kin - nch;
@@ -1388,7 +1388,7 @@ __global__ void __launch_bounds__(1024) hier_plan_kernel(const hs_counters* coun
             chunk_first[sidx] = k0;
             const uint32_t c0 = s_first[sidx];
             for (uint32_t k = 0; k < nch; ++k)
-                desc[k0 + k] = make_uint4((uint32_t)sidx, c0 + k * kHierChunk, min(c0 + cnt, c0 + (k + 1u) * kHierChunk), k);
+                desc[k0 + k] = make_uint4((uint32_t)sidx, c0 + k * chunk, min(c0 + cnt, c0 + (k + 1u) * chunk), k);
         }
         kcarry += ktot;
     }
@@ -1432,23 +1432,23 @@ __device__ __forceinline__ uint64_t hier_cover(uint32_t word, int kb, bool valid
 }
 
 __global__ void __launch_bounds__(256) hier_count_kernel(const uint32_t* hier, const uint4* desc, const uint2* sorted, int kb,
-                                                         uint2* counts, uint32_t* tile_total) {
+                                                         uint2* counts, uint32_t* tile_total, uint32_t wave_elems) {
     __shared__ uint32_t s_cnt[4][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int xcd = blockIdx.x % 8;
     const uint32_t c_end = hier[8 + xcd + 1];
     for (uint32_t c = hier[8 + xcd] + blockIdx.x / 8; c < c_end; c += gridDim.x / 8) {
         const uint4 d = desc[c];
-        const uint32_t wb = min(d.z, d.y + (uint32_t)wave * 256u), we = min(d.z, wb + 256u);
-        uint32_t w4[4];
+        const uint32_t wb = min(d.z, d.y + (uint32_t)wave * wave_elems), we = min(d.z, wb + wave_elems);
+        uint32_t w4[kHierRoundsMax];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {   // (all four loads in flight)
+        for (int r = 0; r < kHierRoundsMax; ++r) {   // (all loads in flight)
             const uint32_t idx = wb + r * 64 + lane;
             w4[r] = idx < we ? sorted[idx].x : 0u;
         }
         uint32_t cnt = 0;   // pairs of tile `lane` among this wave's elements
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < kHierRoundsMax; ++r) {
             if (wb + r * 64 >= we) break;
             cnt += (uint32_t)__popcll(hier_cover(w4[r], kb, wb + r * 64 + lane < we, lane));
         }
@@ -1520,7 +1520,8 @@ __global__ void __launch_bounds__(1024) hier_tiles_kernel(int gx, int gy, int n_
 __global__ void __launch_bounds__(256) hier_scatter_kernel(const uint32_t* hier, const uint4* desc, const uint2* sorted, int kb,
                                                            const uint2* counts, const uint32_t* chunk_first,
                                                            const uint32_t* tile_start, uint32_t* point_list,
-                                                           const hs_counters* counters, uint32_t* counters_host) {
+                                                           const hs_counters* counters, uint32_t* counters_host,
+                                                           uint32_t wave_elems) {
     __shared__ uint32_t s_part[4][64];
     __shared__ uint32_t s_inst[4][64];
     __shared__ uint2 s_stage[4][kHierStage];      // (instance, destination) of a round's pairs, tile after tile
@@ -1532,10 +1533,10 @@ __global__ void __launch_bounds__(256) hier_scatter_kernel(const uint32_t* hier,
     const uint32_t c_end = hier[8 + xcd + 1];
     for (uint32_t c = hier[8 + xcd] + blockIdx.x / 8; c < c_end; c += gridDim.x / 8) {
         const uint4 d = desc[c];
-        const uint32_t wb = min(d.z, d.y + (uint32_t)wave * 256u), we = min(d.z, wb + 256u);
-        uint2 e4[4];
+        const uint32_t wb = min(d.z, d.y + (uint32_t)wave * wave_elems), we = min(d.z, wb + wave_elems);
+        uint2 e4[kHierRoundsMax];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {   // (this wave's elements: all four loads in flight under the sums below)
+        for (int r = 0; r < kHierRoundsMax; ++r) {   // (this wave's elements: all loads in flight under the sums below)
             const uint32_t idx = wb + r * 64 + lane;
             e4[r] = idx < we ? sorted[idx] : make_uint2(0u, 0u);
         }
@@ -1564,7 +1565,7 @@ __global__ void __launch_bounds__(256) hier_scatter_kernel(const uint32_t* hier,
         // kernel's 39 us at c3, whatever the addresses (measured with all stores folded into 256 KB: the cost is per
         // uncoalesced lane, not per byte).  A round with more pairs than the buffer holds (large Gaussians) stores directly.
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < kHierRoundsMax; ++r) {
             if (wb + r * 64 >= we) break;
             uint64_t cover = hier_cover(e4[r].x, kb, wb + r * 64 + lane < we, lane);
             s_inst[wave][lane] = e4[r].y;      // (wave-private rows, in-order LDS: no barriers)
@@ -1835,18 +1836,19 @@ int launch_binning(const hs_fwd_args& a, const hs_layout& L, hipStream_t s, uint
                 uint2* t = in; in = out; out = t;
             }
             // `in` = the sorted elements (packed buffer B)
+            const uint32_t chunk = (uint32_t)hier_chunk(I);
             hier_plan_kernel<<<1, 1024, 0, s>>>(counters, hw, hw + W.st_count, (int)W.nst, (int)W.nst_pad(), hw + W.coarse_first,
-                                                hw + W.chunk_first, (uint4*)(hw + W.desc));
+                                                hw + W.chunk_first, (uint4*)(hw + W.desc), chunk);
             // expansion workgroups: 8 XCDs x kHierGridPerXcd, each walking its XCD's chunks
             const int egrid = 8 * (int)min((int64_t)kHierGridPerXcd, (W.chunks_max + 7) / 8);
             hier_count_kernel<<<egrid, 256, 0, s>>>(hw, (const uint4*)(hw + W.desc), in, kb, (uint2*)(hw + W.counts),
-                                                                hw + W.tile_total);
+                                                    hw + W.tile_total, chunk / 4u);
             hier_tiles_kernel<<<ceil_div(ntiles, kHierTilesPerBlock), 1024, 0, s>>>(gx, gy, d.n_poses, hw + W.tile_total,
                                                                                     hw + W.tile_start, ranges);
             hier_scatter_kernel<<<egrid, 256, 0, s>>>(hw, (const uint4*)(hw + W.desc), in, kb,
                                                                   (const uint2*)(hw + W.counts), hw + W.chunk_first,
                                                                   hw + W.tile_start, (uint32_t*)(bin + L.point_list), counters,
-                                                                  (uint32_t*)a.counters_host);
+                                                                  (uint32_t*)a.counters_host, chunk / 4u);
             HS_LAUNCH_CHECK();
         }
         return HS_OK;

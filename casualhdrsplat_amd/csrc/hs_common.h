@@ -168,11 +168,16 @@ static inline int64_t count_matrix_words(int64_t I, int64_t vtiles, int64_t capa
 // HIERARCHICAL tile sort (binning.hip, "coarse stable pass + on-chip expansion"): the instances, walked in depth order, emit
 // one (super-tile, instance) element per 8 x 8-tile SUPER-TILE their rectangle meets (carrying the rectangle clipped to
 // that super-tile); ONE stable radix pass per eight bits of the super-tile id orders those; workgroups then expand chunks of
-// kHierChunk sorted elements into their super-tile's 64 tile lists by counting.  Fits when the (pose, super-tile) keys fit
+// hier_chunk(I) sorted elements into their super-tile's 64 tile lists by counting.  Fits when the (pose, super-tile) keys fit
 // the per-workgroup histogram; the binning workspace then carries hs_layout.hier_ws.
 constexpr int kSuper = 8;                       // tiles per super-tile side
 constexpr int kHierStMax = 2048;                // (pose, super-tile) keys of a frame that qualifies
-constexpr int kHierChunk = 1024;                // sorted coarse elements per expansion workgroup (four waves x 256)
+// Sorted elements per expansion workgroup (four waves x chunk / 4), chosen per frame (hier_chunk): 512 below 2^21
+// instances, 1024 from there on -- measured (hier_scatter + hier_count + hier_plan, us): c3 34.9 with 1024, 31.4 with 512,
+// 39.2 with 256; c4 178 with 1024, 197 with 512, 272 with 256 (more, smaller chunks cost the plan kernel and the sums over
+// earlier chunks what they save in the walk).  The workspace is sized for the smaller one.
+constexpr int kHierChunkMin = 512, kHierChunkMax = 1024, kHierRoundsMax = kHierChunkMax / 4 / 64;
+static inline int hier_chunk(int64_t I) { return I >= (2ll << 20) ? kHierChunkMax : kHierChunkMin; }
 constexpr int kHierCopies = 16;                 // copies of the per-super-tile element counts (same-address atomics)
 static inline int64_t hier_super_tiles(int64_t gx, int64_t gy, int64_t n_poses) {
     return ((gx + kSuper - 1) / kSuper) * ((gy + kSuper - 1) / kSuper) * n_poses;
@@ -188,7 +193,7 @@ struct HierWs {
     int64_t st_count, tile_total, zero_words, tile_start, coarse_first, chunk_first, desc, counts, words;
     HierWs(int64_t gx, int64_t gy, int64_t n_poses, int64_t capacity) {
         nst = hier_super_tiles(gx, gy, n_poses);
-        chunks_max = (capacity + kHierChunk - 1) / kHierChunk + nst;
+        chunks_max = (capacity + kHierChunkMin - 1) / kHierChunkMin + nst;
         const int64_t nst_pad = (nst + 63) / 64 * 64;
         int64_t o = 64;                                              // header: [0] coarse elements, [1] chunks
         st_count = o; o += kHierCopies * nst_pad;
