@@ -1811,15 +1811,24 @@ def test_c3_full_size_vs_oracle(oracle, cam_seed):
                 sc, m, g, r, {"R": int(R), "report": {k: v for k, v in rep.items()}}, masked=(g2, r2, bounded))
 
 
-def test_c4_eight_poses_full_size_vs_oracle(oracle):
-    """BASELINE c4 itself: the c3 cloud seen from 8 virtual poses in ONE frame (8 M instances: the pair emission's
-    in-launch chained scan, depth-sort passes of 1954 blocks, 65 280 virtual tiles in strip order + queue) against the C
+@pytest.mark.parametrize("free", [False, True], ids=["x_shift_poses", "free_rotating_poses"])
+def test_c4_eight_poses_full_size_vs_oracle(oracle, free):
+    """(free_rotating_poses, round 6: the eight poses roll, pitch and yaw by 0.03 degrees each and shift, about a free 6-DoF
+    base camera -- synthetic.perturbed_poses -- with the cloud laid out in front of it.)
+    BASELINE c4 itself: the c3 cloud seen from 8 virtual poses in ONE frame (8 M instances: the hierarchical tile sort
+    over 1080 (pose, super-tile) keys -- two radix passes over 12 M elements --, depth-sort passes of 1954 blocks, 65 280
+    virtual tiles in strip order + queue) against the C
     oracle run per pose (eight host threads): per-pose structure and the sorted list of all ~54 M pairs bit for bit,
     every pose's radiance image off the differing pixels, the blurred LDR / mean radiance, all gradients (sums over the
     eight poses) on the STRICT bar for >= 90 % of the Gaussians, CRF-table and exposure gradients."""
     P, W, H, N = 1_000_000, 1920, 1080, 8
-    sc = S.make_scene(P, W, H, 3, seed=0, hdr=True)
-    cams = S.blur_poses(W, H, N)
+    if free:
+        base_cam = S.random_camera(W, H, 13)
+        sc = S.make_scene(P, W, H, 3, seed=0, hdr=True, place_in=base_cam)
+        cams = S.perturbed_poses(base_cam, N, seed=3, rot_step_deg=0.03, step=0.01)
+    else:
+        sc = S.make_scene(P, W, H, 3, seed=0, hdr=True)
+        cams = S.blur_poses(W, H, N)
     workers = min(N, os.cpu_count() or 1)
     r = Hh.run_oracle_hdr(oracle, sc, cams, "ldr", workers=workers)
     g = Hh.run_hip(sc, cameras=cams, hdr=True, blur_domain="ldr")
@@ -1850,13 +1859,14 @@ def test_c4_eight_poses_full_size_vs_oracle(oracle):
         assert not ((e > 1e-4).any(axis=0) & ~any_differs).any(), ("c4 " + name, float(e.max()))
     # (measured: 105 differing pixels over the eight poses, 93 % of the rows strict; on those <= 3e-4 of the elements beyond
     # 1e-4, worst element 9.5e-3 -- a sum over eight poses' worth of pixel terms --, relative L2 4.7e-7)
-    rep = Hh.assert_grads_close(g, r, what="c4", at_risk=m["rows"], min_strict=0.925, frac_tol=1e-3, max_tol=2e-2, l2_tol=2e-6)
+    rep = Hh.assert_grads_close(g, r, what="c4", at_risk=m["rows"], min_strict=0.925 if not free else 0.93, frac_tol=1e-3,   # (measured 0.9309 / 0.9355)
+                                max_tol=2e-2, l2_tol=2e-6)
     tab, dexp = Hh.crf_grads_given_decisions(oracle, sc, m, [f["color"] for f in r["fwd"]], list(st["pose_hdr"][:N]))
     assert Hh.rel_err(g["d_crf_table"], tab, 1e3 * Hh.grad_floor(tab))[0] <= 2e-4
     assert float(g["d_exposure"]) == pytest.approx(dexp, rel=2e-4, abs=1e-3)
     assert Hh.rel_err(g["d_crf_table"], r["dL_dcrf_table"], 1e3 * Hh.grad_floor(tab))[0] <= 2e-2
     g2, r2, bounded, rep2 = _masked_pass(oracle, sc, m, r["fwd"], "c4", cameras=cams, workers=workers, max_tol=2e-2)
-    _parity_row("c4 (c3's cloud, 8 poses per frame): HIP vs fp32 C oracle, rows off the differing pixels",
+    _parity_row("c4 (c3's cloud, 8 poses per frame" + (", free rotating poses" if free else "") + "): HIP vs fp32 C oracle, rows off the differing pixels",
                 sc, m, g, r, {"R": int(R), "report": {k: v for k, v in rep.items()}}, masked=(g2, r2, bounded))
 
 
