@@ -515,10 +515,17 @@ def test_overflow_in_a_no_grad_forward_grows_capacity_and_replays():
         assert rast.overflow_replays == 1 and np.array_equal(out2[0].cpu().numpy(), ref["color"])
 
 
-def test_overflow_in_a_training_step_raises_then_the_repeated_step_succeeds():
+@pytest.mark.parametrize("form", ["count", "hier", "radix"])
+def test_overflow_in_a_training_step_raises_then_the_repeated_step_succeeds(form):
     """A training forward does not wait for its counters; its backward finds the overflow, raises (the loss was
     computed from an empty frame) and leaves the rasterizer with a capacity that fits, so repeating the step works
-    and matches the synchronous path."""
+    and matches the synchronous path.  Through each of the three tile sorts (every one has its own verdict path: the pair
+    emission's, the hierarchical emission's, the counting scatter's)."""
+    with tile_sort(form):
+        _overflow_in_a_training_step()
+
+
+def _overflow_in_a_training_step():
     from casualhdrsplat_amd import BinningOverflow
     sc = S.make_scene(20000, 320, 200, 1, seed=5)
     ref = Hh.run_hip(sc)
