@@ -282,3 +282,46 @@ def test_kernel_register_budgets_hold():
     binn = _kernel_resources("binning.hip", "off")
     for k, v in binn.items():
         assert v.get("VGPRs Spill", 0) == 0, (k, v)
+
+
+def test_writelane_reads_no_sgpr_a_valu_instruction_just_wrote():
+    """gfx940+: a VALU instruction reading an SGPR that the VALU instruction before it wrote needs two wait states.  The
+    compiler provides them for its own instructions, NOT inside `asm` statements -- and binning.hip's hier_cover issues
+    v_writelane_b32 (no builtin in this compiler) right behind the v_cmp that produced its data: without the s_nop 1 in the
+    asm text the column masks arrived one ballot late.  Checked on the generated ISA: between a VALU write
+    of an SGPR and a v_writelane reading it lie at least two wait states (instructions or s_nop counts)."""
+    import re
+    import subprocess
+    import tempfile
+    src = os.path.join(ROOT, "casualhdrsplat_amd", "csrc", "binning.hip")
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "binning.s")
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S",
+                               "--cuda-device-only", src, "-o", out], stderr=subprocess.DEVNULL, timeout=600)
+        lines = [ln.split(";")[0].strip() for ln in open(out)]
+    lines = [ln for ln in lines if ln and not ln.startswith(".") and not ln.endswith(":")]
+    n_checked = 0
+    last_valu_write = {}          # sgpr number -> wait states since a VALU instruction wrote it
+    for ln in lines:
+        op = ln.split()[0]
+        for k in list(last_valu_write):
+            last_valu_write[k] += 1 + (int(ln.split()[1]) if op == "s_nop" else 0)
+        if op == "v_writelane_b32":
+            args = [a.strip() for a in ln[len(op):].split(",")]
+            m = re.fullmatch(r"s(\d+)", args[1])
+            if m:
+                n_checked += 1
+                since = last_valu_write.get(int(m.group(1)), 99)
+                assert since > 2, f"`{ln}` reads s{m.group(1)} {since - 1} wait state(s) after a VALU instruction wrote it"
+        if op.startswith("v_cmp") or op.startswith("v_readlane") or op.startswith("v_readfirstlane"):
+            m = re.match(r"\S+\s+s\[(\d+):(\d+)\]", ln) or re.match(r"\S+\s+s(\d+)\b", ln)
+            if m:
+                lo, hi = int(m.group(1)), int(m.group(m.lastindex))
+                for k in range(lo, hi + 1):
+                    last_valu_write[k] = 0
+        elif op.startswith("s_") and op != "s_nop":
+            m = re.match(r"\S+\s+s\[(\d+):(\d+)\]", ln) or re.match(r"\S+\s+s(\d+)\b", ln)
+            if m:      # an SALU instruction rewrote the register: no VALU-write hazard any more
+                for k in range(int(m.group(1)), int(m.group(m.lastindex)) + 1):
+                    last_valu_write.pop(k, None)
+    assert n_checked >= 64, n_checked       # 32 per instantiation of hier_cover (count + scatter kernels)
