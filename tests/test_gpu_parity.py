@@ -695,6 +695,32 @@ def test_hierarchical_tile_sort_equals_the_radix_passes_at_full_size(cfg):
             assert np.array_equal(Hh.bits(a[k]) if a[k].dtype == np.float32 else a[k], Hh.bits(b[k]) if b[k].dtype == np.float32 else b[k]), k
 
 
+@pytest.mark.parametrize("W,H,n_poses,want", [(2048, 1024, 2, 2), (2176, 2048, 1, 2), (2048, 1024, 16, 2), (2048, 1152, 16, 0)])
+def test_hierarchical_tile_sort_at_its_key_limits(W, H, n_poses, want):
+    """The (pose, super-tile) key table of the hierarchical tile sort at its edges: exactly 256 keys (the last frame whose
+    coarse sort is ONE radix pass), 272 (the first with two), exactly 2048 (the largest table: hs_common.h kHierStMax), and
+    2304 -- where HS_TILE_SORT=hier must quietly give the radix passes, as the default does.  Every array the binning stage
+    leaves, images and gradients against the radix passes, bit for bit (those are held to the oracle elsewhere)."""
+    P = 6000
+    sc = S.make_scene(P, W, H, 1, seed=61)
+    cams = S.blur_poses(W, H, n_poses, step=0.01) if n_poses > 1 else None
+    out = {}
+    for form in ("radix", "hier"):
+        with tile_sort(form):
+            out[form] = Hh.run_hip(sc, cameras=cams)
+    a, b = out["radix"], out["hier"]
+    assert int(a["state"]["tile_sort"]) == 0 and int(b["state"]["tile_sort"]) == want
+    R = a["state"]["num_rendered"]
+    assert R == b["state"]["num_rendered"] and R > 4 * P
+    for k in ("point_list", "keys_sorted"):
+        assert np.array_equal(a["state"][k][:R], b["state"][k][:R]), k
+    for k in ("ranges", "inst_sorted", "offs_sorted", "n_contrib", "final_T", "tiles_touched"):
+        assert np.array_equal(a["state"][k], b["state"][k]), k
+    for k in a:
+        if k != "state" and a[k] is not None:
+            assert np.array_equal(Hh.bits(a[k]) if a[k].dtype == np.float32 else a[k], Hh.bits(b[k]) if b[k].dtype == np.float32 else b[k]), k
+
+
 @pytest.mark.parametrize("P,W,H,n_poses", [(150000, 320, 240, 1), (3000, 1024, 1024, 1), (700, 256, 256, 16)])
 def test_counting_tile_sort_edges_vs_oracle(oracle, P, W, H, n_poses):
     """The tile sort of small frames by counting (binning.hip) at its edges: 586 emission workgroups (more than eight rows
