@@ -80,11 +80,11 @@ class hs_layout(C.Structure):
         "pair_flags", "pair_act",
         "final_T", "n_contrib", "pose_hdr", "tile_work", "tile_order",
         "pair_grads", "crf_partials", "inst_grads", "pose_partials",
-        "tile_matrix", "hier_ws")]
+        "tile_matrix", "hier_ws", "depth_ws")]
 
 
 EXPORTS = ("hs_version", "hs_last_error", "hs_plan", "hs_forward", "hs_backward", "hs_mark_visible",
-           "hs_sh_backward_views", "hs_sort_tmp_bytes", "hs_sort_pairs", "hs_render_stats", "hs_sort_tickets", "hs_spline_poses")
+           "hs_sh_backward_views", "hs_sort_tmp_bytes", "hs_sort_pairs", "hs_render_stats", "hs_sort_tickets", "hs_spline_poses", "hs_depth_sort")
 HS_RENDER_STATS = 24
 
 _lib = None
@@ -129,6 +129,8 @@ def load() -> C.CDLL:
     lib.hs_spline_poses.restype = C.c_int
     lib.hs_sort_tickets.argtypes = [C.c_int]
     lib.hs_sort_tickets.restype = C.c_int
+    lib.hs_depth_sort.argtypes = [C.c_int]
+    lib.hs_depth_sort.restype = C.c_int
     _lib = lib
     return lib
 

@@ -40,6 +40,25 @@ bool sort_tickets() {
     return v != 0;
 }
 
+// Depth sort of small frames: counting pass + range sorts (1) or the look-back passes (0); -1 = not set, the default.
+#ifndef HS_TUNE_DEPTH_MSD_DEFAULT
+#define HS_TUNE_DEPTH_MSD_DEFAULT 1
+#endif
+static std::atomic<int> g_depth_sort{-1};
+int depth_sort_mode(int64_t I) {
+    if (!depth_msd_fits(I)) return kDepthSortLsd;
+    const char* e = getenv("HS_DEPTH_SORT");   // (read at every forward: the test suite switches it inside one process)
+    if (e && e[0] == 'l') return kDepthSortLsd;
+    if (e && e[0] == 'm') return kDepthSortMsd;
+    const int v = g_depth_sort.load(std::memory_order_relaxed);
+    return v >= 0 ? v : (HS_TUNE_DEPTH_MSD_DEFAULT ? kDepthSortMsd : kDepthSortLsd);
+}
+int depth_range_cap() {
+    const char* e = getenv("HS_DEPTH_RANGE_CAP");
+    const int v = e ? atoi(e) : kMsdCap;
+    return v < 64 ? 64 : (v > kMsdCap ? kMsdCap : v);
+}
+
 bool scan_in_emission(int64_t I) {
     // (read at every forward, not once: the driver's test suite switches it inside one process)
     const char* e = getenv("HS_SCAN_IN_EMISSION");
@@ -133,6 +152,7 @@ static int plan(const hs_dims& d, hs_sizes* sz, hs_layout* L) {
     l.pairs_tmp = carve(d.capacity * 8);
     l.ranges = carve(vtiles * 8);
     l.sort_tmp = carve(sort_tmp_bytes(I));
+    l.depth_ws = carve(depth_ws_words(I) * 4);   // frames below 2^21 instances: the counting depth sort's matrix
     l.depth_pairs = carve(2 * I * 8);
     l.inst_sorted = carve(I * 4);
     l.offs_sorted = carve(I * 4);
@@ -358,6 +378,12 @@ int hs_backward(const hs_bwd_args* a, void* hip_stream) {
         if ((rc = debug_sync(a->flags, s, "preprocess backward"))) return rc;
     }
     return HS_OK;
+}
+
+int hs_depth_sort(int mode) {
+    if (mode >= 0) hs::g_depth_sort.store(mode ? 1 : 0, std::memory_order_relaxed);
+    const int v = hs::g_depth_sort.load(std::memory_order_relaxed);
+    return v >= 0 ? v : (HS_TUNE_DEPTH_MSD_DEFAULT ? 1 : 0);
 }
 
 int hs_sort_tickets(int enable) {

@@ -637,6 +637,487 @@ int radix_sort_packed(uint2* p0, uint2* p1, uint32_t* keys_out, uint32_t* vals_o
     return HS_OK;
 }
 
+// ---------------------------------------------------------------- depth sort by counting (frames below 2^21 instances)
+// Round 6.  The look-back passes above cost a frame of a million instances 63 us -- digit totals, three passes of ~18 us
+// (each a chain of ~8 dependent round trips per block), one launch that finds nothing left to do -- for 8 MB of keys.  The
+// same order (a stable sort has ONE result) from four launches without a chain between workgroups:
+//   1. depth_msd_count_kernel: per block of depth_msd_tile(I) elements, the number of keys in each of the 4096 buckets of
+//      the top kMsdBits VARYING key bits (the layout of those bits as the passes read it: DepthLayout) -- one row of u16;
+//   2. depth_msd_colscan_kernel: per bucket the exclusive prefix of the rows down the column, and the column total;
+//   3. depth_msd_scatter_kernel: block b re-reads its elements, ranks them per bucket (match-any over the twelve bits; wave
+//      w owns consecutive rounds of 64 elements, so the order inside a bucket is the input's) and writes each to
+//      start of the bucket + elements of the bucket in earlier blocks + in earlier waves + its rank: a stable counting
+//      sort by the top bits.  Culled instances (the all-ones key) are counted apart and go straight to the END of the
+//      instance list, in index order (the passes leave them among the largest visible keys; they have no pairs, so where
+//      they stand changes nothing downstream -- the order of the VISIBLE instances is the passes', bit for bit);
+//   4. depth_range_sort_kernel: workgroup k takes the buckets that START inside positions [2048 k, 2048 (k + 1)) -- whole
+//      buckets, so the range holds every key of its part of the key space -- and sorts them by all varying bits, least
+//      significant digit first, in LDS (the passes' ranking, nothing published, nothing looked up): the instance list.
+//      A range of more than 4096 elements (a bucket of more than 2048: one 4096th of the key range holds that many
+//      instances) does not fit: its workgroup then runs the same passes through memory, chunk by chunk -- correct, slow,
+//      counted in hs_counters.reserved[2] so that the host can go back to the look-back passes (hs_depth_sort).
+#ifndef HS_MSD_STOP
+#define HS_MSD_STOP 0   // timing experiments: the range sort returns after phase 1 .. 4 (wrong result)
+#endif
+#ifndef HS_ABL_MSD
+#define HS_ABL_MSD 0   // ablation switches (timing experiments only; the result is wrong with any of them set)
+#endif
+constexpr uint32_t kCulledKey = 0xFFFFFFFFu;   // depth key of a culled instance (no positive float has these bits)
+struct MsdDigit { int shift; uint32_t mask; };
+__device__ __forceinline__ MsdDigit msd_digit(const DepthLayout& L) {
+    const int nbits = L.base * L.npasses + L.rem;
+    const int w = min(kMsdBits, nbits);
+    MsdDigit D;
+    D.shift = L.lo + nbits - w;
+    D.mask = (1u << w) - 1u;
+    return D;
+}
+
+// Stable ranks of a wave's ITEMS rounds of 64 digits (round i: lane l holds element i * 64 + l of the wave's stretch):
+// rank[i] = elements of the same digit in front of it in the wave's stretch; cnt[d] (the wave's own counter row, zero on
+// entry) ends as the wave's count of digit d.  `valid`: bit i = this lane's round-i element exists (digits of the others: 0).
+template <int ITEMS, int DBITS, typename CNT>
+__device__ __forceinline__ void wave_rank(const uint32_t (&dig)[ITEMS], uint32_t valid, CNT* cnt, uint16_t (&rank)[ITEMS], int lane) {
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const bool on = (valid >> i) & 1u;
+        const uint32_t d = dig[i];
+        uint64_t peers = __ballot(on);   // match-any: lanes holding the same digit
+        if (peers == 0ull) { rank[i] = 0; continue; }   // (a round behind the end of the data: uniform, nothing to rank)
+#pragma unroll
+        for (int b = 0; b < DBITS; ++b) {
+            const uint64_t m = __ballot((d >> b) & 1u);
+            peers &= ((d >> b) & 1u) ? m : ~m;
+        }
+        const uint32_t before = cnt[d];
+        const uint32_t below = __popcll(peers & lt_mask);
+        rank[i] = (uint16_t)(before + below);
+        // the last peer publishes the new count (all peers read `before` first: same wave, in-order LDS)
+        if (on && (peers >> lane) == 1ull) cnt[d] = (CNT)(before + below + 1u);
+    }
+}
+
+template <int ITEMS>   // (per 256 threads: tiles of 4096 run 1024 threads x 4, tiles of 1024 run 256 x 4)
+__global__ void __launch_bounds__(1024) depth_msd_count_kernel(const uint2* pairs, const uint32_t* n_dev,
+                                                              const unsigned long long* bits, uint32_t tag, uint32_t* counts2,
+                                                              uint32_t* culled_rows) {
+    __shared__ uint32_t s_hist[kMsdBuckets];
+    __shared__ uint32_t s_culled;
+    for (int t = threadIdx.x; t < kMsdBuckets; t += blockDim.x) s_hist[t] = 0u;
+    if (threadIdx.x == 0) s_culled = 0u;
+    const int64_t n = *n_dev;
+    const int64_t base = (int64_t)blockIdx.x * (ITEMS * (int)blockDim.x);
+    const MsdDigit D = msd_digit(depth_layout(bits, tag));
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const int64_t k = base + i * (int)blockDim.x + threadIdx.x;
+        const uint32_t key = k < n ? pairs[k].x : 0u;
+        const bool culled = k < n && key == kCulledKey;
+        const bool valid = k < n && !culled;
+        // (neighbouring instances are not neighbours in depth: no point in looking for a wave-wide common bucket)
+        if (valid) atomicAdd(&s_hist[(key >> D.shift) & D.mask], 1u);
+        const uint64_t cm = __ballot(culled);
+        if (cm && (threadIdx.x & 63) == 0) atomicAdd(&s_culled, (uint32_t)__popcll(cm));
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) culled_rows[blockIdx.x] = s_culled;
+    uint32_t* row = counts2 + (int64_t)blockIdx.x * (kMsdBuckets / 2);   // u16 pairs: at most ITEMS * 256 = 4096 per bucket ... (*)
+    for (int t = threadIdx.x; t < kMsdBuckets / 2; t += blockDim.x) {
+        // (*) a block whose 4096 elements share ONE bucket would need 4096 = 0x1000: fits (u16 holds 65535)
+        row[t] = s_hist[2 * t] | (s_hist[2 * t + 1] << 16);
+    }
+}
+
+// 16 column pairs x 64 row slots per workgroup; a slot = up to 8 consecutive rows (<= 512 rows), kept in registers
+__global__ void __launch_bounds__(1024) depth_msd_colscan_kernel(const uint32_t* counts2, int nrows, uint2* bases2, uint2* totals2) {
+    __shared__ uint2 s_wsum[16][16];   // per wave (four row slots) and column pair
+    const int c = threadIdx.x % 16, rs = threadIdx.x / 16;
+    const int t2 = blockIdx.x * 16 + c;                                   // column pair: buckets 2 t2, 2 t2 + 1
+    const int rps = (nrows + 63) / 64;                                    // consecutive rows per slot (<= 8)
+    const int r0 = min(nrows, rs * rps), r1 = min(nrows, r0 + rps);
+    uint32_t kept[8];
+    uint2 sum = make_uint2(0u, 0u);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        kept[j] = r0 + j < r1 ? counts2[(int64_t)(r0 + j) * (kMsdBuckets / 2) + t2] : 0u;
+        sum.x += kept[j] & 0xFFFFu; sum.y += kept[j] >> 16;
+    }
+    // rows above this thread's, same column pair: lanes are (row slot % 4, column pair) = (lane / 16, lane % 16)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint2 incl = sum;
+    { const uint32_t ux = __shfl_up(incl.x, 16), uy = __shfl_up(incl.y, 16); if (lane >= 16) { incl.x += ux; incl.y += uy; } }
+    { const uint32_t ux = __shfl_up(incl.x, 32), uy = __shfl_up(incl.y, 32); if (lane >= 32) { incl.x += ux; incl.y += uy; } }
+    if (lane >= 48) s_wsum[wave][c] = incl;
+    __syncthreads();
+    uint2 run = make_uint2(incl.x - sum.x, incl.y - sum.y), total = make_uint2(0u, 0u);
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        const uint2 v = s_wsum[w][c];
+        if (w < wave) { run.x += v.x; run.y += v.y; }
+        total.x += v.x; total.y += v.y;
+    }
+    if (rs == 0) totals2[t2] = total;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (r0 + j < r1) bases2[(int64_t)(r0 + j) * (kMsdBuckets / 2) + t2] = run;
+        run.x += kept[j] & 0xFFFFu; run.y += kept[j] >> 16;
+    }
+}
+
+// Exclusive scan of the kMsdBuckets totals into `s_start` (NT threads; `s_wave`: NT / 64 words): the bucket starts
+template <int NT>
+__device__ __forceinline__ uint32_t msd_bucket_starts(const uint32_t* totals, uint32_t* s_start, uint32_t* s_wave) {
+    constexpr int E = kMsdBuckets / NT;   // consecutive buckets per thread
+    for (int k = threadIdx.x; k < kMsdBuckets; k += NT) s_start[k] = totals[k];
+    __syncthreads();
+    uint32_t mine = 0;
+#pragma unroll
+    for (int j = 0; j < E; ++j) mine += s_start[threadIdx.x * E + j];
+    uint32_t all;
+    uint32_t start = block_incl_scan<NT / 64>(mine, s_wave, &all) - mine;   // (its barriers order the reads above before the writes below)
+#pragma unroll
+    for (int j = 0; j < E; ++j) { const uint32_t tot = s_start[threadIdx.x * E + j]; s_start[threadIdx.x * E + j] = start; start += tot; }
+    __syncthreads();
+    return all;   // = the visible instances
+}
+
+// NT threads x ITEMS elements: 512 x 8 for blocks of 4096 (eight waves share the ranking: 80 KB of LDS), 256 x 4 for blocks of 1024
+template <int NT, int ITEMS>
+__global__ void __launch_bounds__(NT) depth_msd_scatter_kernel(const uint2* pairs, const uint32_t* n_dev,
+                                                                const unsigned long long* bits, uint32_t tag,
+                                                                const uint32_t* bases, const uint32_t* totals,
+                                                                const uint32_t* culled_rows, uint2* out, uint32_t* inst_sorted) {
+    constexpr int NW = NT / 64;
+    __shared__ uint16_t s_cnt[NW][kMsdBuckets];  // per-wave bucket counters -> per-wave exclusive offsets
+    __shared__ uint32_t s_base[kMsdBuckets];     // bucket start + elements of the bucket in earlier blocks
+    __shared__ uint32_t s_wave[NW], s_cwave[NW], s_cbefore[NW];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    {
+        uint32_t* z = reinterpret_cast<uint32_t*>(&s_cnt[0][0]);
+        for (int t = threadIdx.x; t < NW * kMsdBuckets / 2; t += NT) z[t] = 0u;
+    }
+    const int64_t n = *n_dev;
+    const int64_t base = (int64_t)blockIdx.x * (ITEMS * NT);
+    const MsdDigit D = msd_digit(depth_layout(bits, tag));
+    uint2 e[ITEMS];
+    uint32_t dig[ITEMS];
+    uint32_t valid = 0u, culled = 0u;
+    const int wbase = wave * (ITEMS * 64);
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const int64_t k = base + wbase + i * 64 + lane;
+        e[i] = k < n ? pairs[k] : make_uint2(0u, 0u);
+        const bool c = k < n && e[i].x == kCulledKey;
+        const bool on = k < n && !c;
+        dig[i] = on ? (e[i].x >> D.shift) & D.mask : 0u;
+        valid |= (on ? 1u : 0u) << i;
+        culled |= (c ? 1u : 0u) << i;
+    }
+    // culled instances of the blocks in front of this one (<= 512 rows)
+    uint32_t cb = 0;
+    for (int r = threadIdx.x; r < (int)blockIdx.x; r += NT) cb += culled_rows[r];
+#pragma unroll
+    for (int dd = 32; dd >= 1; dd >>= 1) cb += __shfl_xor(cb, dd);
+    if (lane == 0) s_cbefore[wave] = cb;
+    const uint32_t n_vis = msd_bucket_starts<NT>(totals, s_base, s_wave);   // (its first barrier also covers the zeroing above)
+    uint16_t rank[ITEMS];
+    if (HS_ABL_MSD & 2) {
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) rank[i] = 0;
+    } else
+    wave_rank<ITEMS, kMsdBits, uint16_t>(dig, valid, s_cnt[wave], rank, lane);
+    // Culled instances (key all ones; none of them has a pair) take no part in the sort: they go behind the visible ones at
+    // once, in index order -- a frame that sees a tenth of its cloud would otherwise carry the other nine tenths through the
+    // range sort as ONE bucket of equal keys.
+    uint32_t crank[ITEMS];
+    uint32_t cwave = 0;
+    {
+        const uint64_t lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            const uint64_t m = __ballot((culled >> i) & 1u);
+            crank[i] = cwave + (uint32_t)__popcll(m & lt_mask);
+            cwave += (uint32_t)__popcll(m);
+        }
+        if (lane == 0) s_cwave[wave] = cwave;
+    }
+    const uint32_t* brow = bases + (int64_t)blockIdx.x * kMsdBuckets;
+    __syncthreads();
+    for (int b = threadIdx.x; b < kMsdBuckets; b += NT) {
+        uint32_t run = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { const uint32_t c = s_cnt[w][b]; s_cnt[w][b] = (uint16_t)run; run += c; }
+        s_base[b] += brow[b];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i)
+        if (!(HS_ABL_MSD & 1) && ((valid >> i) & 1u)) out[s_base[dig[i]] + s_cnt[wave][dig[i]] + rank[i]] = e[i];
+    if (culled) {
+        uint32_t cfirst = n_vis;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) cfirst += s_cbefore[w] + (w < wave ? s_cwave[w] : 0u);
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i)
+            if ((culled >> i) & 1u) inst_sorted[cfirst + crank[i]] = e[i].y;
+    }
+}
+
+constexpr int kRangeThreads = 512, kRangeItems = kMsdCap / kRangeThreads;   // 8 waves, 8 elements per thread
+constexpr int kDistBits = 11, kDistBuckets = 1 << kDistBits;                 // distribution sort of a range: buckets of its relative keys' top bits
+static_assert(kRangeThreads == kDepthBins, "one digit per thread: digits of up to nine bits");
+__global__ void __launch_bounds__(kRangeThreads) depth_range_sort_kernel(const uint2* msd_sorted, uint2* scratch,
+                                                                         const unsigned long long* bits, uint32_t tag,
+                                                                         const uint32_t* totals, uint32_t* inst_sorted,
+                                                                         hs_counters* counters, int cap) {
+    constexpr int NW = kRangeThreads / 64;
+    // the passes: per-wave digit counters -> per-wave offsets [NW][512], start of each digit's run (or, off chip, its running
+    // global start) [512]; the distribution sort: members per bucket, next free slot, first slot [3][kDistBuckets]
+    __shared__ uint32_t s_work[3 * kDistBuckets];
+    static_assert(3 * kDistBuckets >= (NW + 1) * kDepthBins, "the passes' tables fit the distribution sort's");
+    uint32_t (*const s_cnt)[kDepthBins] = reinterpret_cast<uint32_t (*)[kDepthBins]>(s_work);
+    uint32_t* const s_dstart = s_work + NW * kDepthBins;
+    __shared__ uint32_t s_keys[kMsdCap], s_vals[kMsdCap];
+    __shared__ uint16_t s_pos[kMsdCap];
+    __shared__ uint32_t s_wave[NW];
+    __shared__ uint32_t s_r[2], s_b[2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x < 2) { s_r[threadIdx.x] = 0xFFFFFFFFu; s_b[threadIdx.x] = (uint32_t)kMsdBuckets; }
+    // this workgroup's range: [first bucket start >= 2048 k, first bucket start >= 2048 (k + 1)) (n_vis when there is none)
+    const uint32_t n_vis = (HS_ABL_MSD & 8) ? totals[0] * 4096u : msd_bucket_starts<kRangeThreads>(totals, s_keys, s_wave);   // (the culled ones are in place already)
+    if (!(HS_ABL_MSD & 8)) {
+        // (thresholds behind the last element mean "the end": the first bucket starting there, so that the last range's
+        // span stops with its last occupied bucket instead of running on to bucket 4095)
+        const uint32_t t0 = min(n_vis, (uint32_t)blockIdx.x * (uint32_t)kMsdRange), t1 = min(n_vis, t0 + (uint32_t)kMsdRange);
+#pragma unroll
+        for (int j = 0; j < kMsdBuckets / kRangeThreads; ++j) {
+            const int b = threadIdx.x * (kMsdBuckets / kRangeThreads) + j;
+            const uint32_t st = s_keys[b], prev = b ? s_keys[b - 1] : 0u;
+            // (the first bucket at or behind a threshold: its predecessor starts in front of it -- or it is bucket 0)
+            // (one bucket at most passes each test: plain stores)
+            if (st >= t0 && (b == 0 || prev < t0)) { s_r[0] = st; s_b[0] = (uint32_t)b; }
+            if (st >= t1 && (b == 0 || prev < t1)) { s_r[1] = st; s_b[1] = (uint32_t)b; }
+        }
+    }
+    __syncthreads();
+    uint32_t r0 = min(s_r[0], n_vis), r1 = min(s_r[1], n_vis);
+    if (HS_ABL_MSD & 8) { r0 = min(n_vis, blockIdx.x * 2048u); r1 = min(n_vis, r0 + 2048u); }
+    if (r0 >= r1) return;
+    {   // the range's first OCCUPIED bucket: the last of the buckets starting at r0 (those in front of it are empty)
+#pragma unroll
+        for (int j = 0; j < kMsdBuckets / kRangeThreads; ++j) {
+            const int b = threadIdx.x * (kMsdBuckets / kRangeThreads) + j;
+            if (s_keys[b] == r0 && (b == kMsdBuckets - 1 || s_keys[b + 1] > r0)) s_b[0] = (uint32_t)b;
+        }
+        __syncthreads();
+    }
+    const uint32_t n = r1 - r0;
+    if (HS_MSD_STOP == 1) { inst_sorted[r0 + threadIdx.x % n] = s_b[0] + s_b[1]; return; }
+    const DepthLayout L0 = depth_layout(bits, tag);
+    // The range's buckets [b0, b1) are in order already; what is left to sort are the key bits below the bucket's and the
+    // bucket number RELATIVE to b0 -- a handful of bits for a range of a few buckets: sort (key window) - (b0's first key),
+    // which has as many bits as (b1 - b0) << (bits below the bucket's) needs -- two digits instead of three at c3.
+    const MsdDigit D = msd_digit(L0);
+    const int nbits = L0.base * L0.npasses + L0.rem;
+    const int low = D.shift - L0.lo;                                        // window bits below the bucket's
+    const uint32_t b0 = s_b[0], b1 = s_b[1];
+    const uint32_t wmask = nbits >= 32 ? 0xFFFFFFFFu : (1u << nbits) - 1u;
+    const uint32_t kbase = b0 << low;                                       // window key of the range's first possible key
+    const uint64_t span = (uint64_t)(b1 - b0) << low;                       // relative keys are < span
+    DepthLayout L;
+    {
+        const int rbits = span > 1ull ? 64 - __builtin_clzll(span - 1ull) : 1;
+        L.lo = 0;
+        L.npasses = (rbits + kDepthDigitBits - 1) / kDepthDigitBits;
+        L.base = rbits / L.npasses;
+        L.rem = rbits - L.base * L.npasses;
+    }
+    const int klo = L0.lo;
+    auto rel_key = [&](uint32_t key) { return ((key >> klo) & wmask) - kbase; };
+    // a wave owns ceil(n / 512) rounds of 64 consecutive elements (not a fixed eight: a range of 2048 keeps all eight waves
+    // busy for four rounds each instead of four waves for eight)
+    const int wbase = wave * (int)((min(n, (uint32_t)kMsdCap) + kRangeThreads - 1) / kRangeThreads) * 64;
+    uint32_t key[kRangeItems], val[kRangeItems], dig[kRangeItems];
+    uint16_t rank[kRangeItems];
+    if (n <= (uint32_t)cap) {
+        const uint32_t wend = min(n, (uint32_t)wbase + ((n + kRangeThreads - 1) / kRangeThreads) * 64u);   // end of this wave's stretch
+        // ---- the range in LDS: the passes' ranking, digit after digit
+        uint32_t valid = 0u;
+#pragma unroll
+        for (int i = 0; i < kRangeItems; ++i) {
+            const uint32_t loc = wbase + i * 64 + lane;
+            const bool on = loc < wend;
+            const uint2 e = on ? msd_sorted[r0 + loc] : make_uint2(0u, 0u);
+            key[i] = on ? rel_key(e.x) : 0u; val[i] = e.y;
+            valid |= (on ? 1u : 0u) << i;
+        }
+        // Keys spread over the range's span as evenly as depths do: a distribution sort needs no pass at all.  2048 buckets
+        // of the relative key's top eleven bits (LDS atomics: the order in which a bucket's members arrive is arbitrary), then
+        // every element counts the members of ITS bucket that stand in front of it by (key, position in the input) -- a
+        // handful of LDS reads where two or three ranking passes cost ~130 vector instructions per element.  A bucket of
+        // more than kDistMax (16) members (equal keys, a cluster) would make that quadratic: such a range takes the passes below.
+        if (HS_MSD_STOP == 2) { inst_sorted[r0 + threadIdx.x % n] = key[0] + val[1] + key[7] + (uint32_t)L.npasses; return; }
+        constexpr uint32_t kDistMax = 16;
+        constexpr int E = kDistBuckets / kRangeThreads;   // consecutive buckets per thread
+        const int rbits = L.base * L.npasses + L.rem;
+        const int dsh = max(0, rbits - kDistBits);
+        uint32_t* const hist = s_work;
+        uint32_t* const cursor = s_work + kDistBuckets;
+        uint32_t* const first = s_work + 2 * kDistBuckets;
+#pragma unroll
+        for (int j = 0; j < E; ++j) hist[threadIdx.x + j * kRangeThreads] = 0u;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < kRangeItems; ++i)
+            if ((valid >> i) & 1u) atomicAdd(&hist[key[i] >> dsh], 1u);
+        __syncthreads();
+        bool dist;
+        {
+            uint32_t c[E], mine = 0, most = 0;
+#pragma unroll
+            for (int j = 0; j < E; ++j) { c[j] = hist[threadIdx.x * E + j]; mine += c[j]; most = max(most, c[j]); }
+            uint32_t total;
+            uint32_t start = block_incl_scan<NW>(mine, s_wave, &total) - mine;
+#pragma unroll
+            for (int j = 0; j < E; ++j) { first[threadIdx.x * E + j] = start; cursor[threadIdx.x * E + j] = start; start += c[j]; }
+            dist = !(HS_ABL_MSD & 32) && __syncthreads_or(most > kDistMax) == 0;
+        }
+        if (HS_MSD_STOP == 3) { inst_sorted[r0 + threadIdx.x % n] = first[threadIdx.x] + (dist ? 1u : 0u); return; }
+        if (dist) {
+#pragma unroll
+            for (int i = 0; i < kRangeItems; ++i) {
+                if ((valid >> i) & 1u) {
+                    const uint32_t p = atomicAdd(&cursor[key[i] >> dsh], 1u);
+                    s_keys[p] = key[i];
+                    s_vals[p] = val[i];
+                    s_pos[p] = (uint16_t)(wbase + i * 64 + lane);
+                }
+            }
+            __syncthreads();
+            if (HS_MSD_STOP == 4) { inst_sorted[r0 + threadIdx.x % n] = s_keys[threadIdx.x] + s_pos[threadIdx.x]; return; }
+            for (uint32_t p = threadIdx.x; p < ((HS_ABL_MSD & 128) ? 0u : n); p += kRangeThreads) {
+                const uint32_t k = s_keys[p], me = s_pos[p];
+                const uint32_t d = k >> dsh, a = first[d], cnt = hist[d];
+                uint32_t r = 0;
+                for (uint32_t q = a; q < a + cnt; ++q) {
+                    const uint32_t kq = s_keys[q], pq = s_pos[q];
+                    r += (kq < k || (kq == k && pq < me)) ? 1u : 0u;
+                }
+                inst_sorted[r0 + a + r] = s_vals[p];
+            }
+            return;
+        }
+        __syncthreads();   // (the passes' tables overlay the distribution sort's)
+        for (int pass = 0; pass < ((HS_ABL_MSD & 16) ? 0 : (HS_ABL_MSD & 4) ? 1 : L.npasses); ++pass) {
+            const int shift = L.shift(pass);
+            const uint32_t mask = (1u << L.width(pass)) - 1u;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) s_cnt[w][threadIdx.x] = 0u;
+            __syncthreads();   // (also: everybody has read the previous pass' s_keys / s_vals)
+#pragma unroll
+            for (int i = 0; i < kRangeItems; ++i) dig[i] = ((valid >> i) & 1u) ? (key[i] >> shift) & mask : 0u;
+            wave_rank<kRangeItems, kDepthDigitBits, uint32_t>(dig, valid, s_cnt[wave], rank, lane);
+            __syncthreads();
+            {
+                uint32_t my_tot = 0, run = 0;
+                uint32_t c[NW];
+#pragma unroll
+                for (int w = 0; w < NW; ++w) { c[w] = s_cnt[w][threadIdx.x]; my_tot += c[w]; }
+#pragma unroll
+                for (int w = 0; w < NW; ++w) { s_cnt[w][threadIdx.x] = run; run += c[w]; }
+                uint32_t total;
+                const uint32_t incl = block_incl_scan<NW>(my_tot, s_wave, &total);
+                s_dstart[threadIdx.x] = incl - my_tot;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < kRangeItems; ++i) {
+                if ((valid >> i) & 1u) {
+                    const uint32_t pos = s_dstart[dig[i]] + s_cnt[wave][dig[i]] + rank[i];
+                    s_keys[pos] = key[i];
+                    s_vals[pos] = val[i];
+                }
+            }
+            __syncthreads();
+            if (pass + 1 < L.npasses) {
+#pragma unroll
+                for (int i = 0; i < kRangeItems; ++i) {
+                    const uint32_t loc = wbase + i * 64 + lane;
+                    if (loc < wend) { key[i] = s_keys[loc]; val[i] = s_vals[loc]; }
+                }
+            }
+        }
+        // (a layout without a digit cannot happen: depth_layout_from gives at least one pass)
+        for (uint32_t t = threadIdx.x; t < n; t += kRangeThreads) inst_sorted[r0 + t] = s_vals[t];
+        return;
+    }
+    // ---- a range that does not fit: the same passes through memory, one chunk of kMsdCap elements after the other, this
+    // workgroup alone (source: the range's stretch of the scattered elements; ping-pong partner: the same stretch of the
+    // input buffer, which nobody reads any more).  The release / acquire pair between two passes makes this CU's L1 forget
+    // the lines of the stretch it is about to read again.
+    if (threadIdx.x == 0) atomicAdd(&counters->reserved[2], 1u);
+    const uint2* src = msd_sorted + r0;
+    uint2* dst = scratch + r0;
+    uint2* const other = const_cast<uint2*>(msd_sorted) + r0;
+    for (int pass = 0; pass < L.npasses; ++pass) {
+        const int shift = L.shift(pass);
+        const uint32_t mask = (1u << L.width(pass)) - 1u;
+        const bool last = pass == L.npasses - 1;
+        s_dstart[threadIdx.x] = 0u;
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < n; k += kRangeThreads) atomicAdd(&s_dstart[(rel_key(src[k].x) >> shift) & mask], 1u);
+        __syncthreads();
+        {
+            const uint32_t tot = s_dstart[threadIdx.x];
+            uint32_t all;
+            const uint32_t incl = block_incl_scan<NW>(tot, s_wave, &all);
+            s_dstart[threadIdx.x] = incl - tot;   // where the digit's run starts (own word: the scan's barriers are enough)
+        }
+        __syncthreads();
+        for (uint32_t c0 = 0; c0 < n; c0 += (uint32_t)kMsdCap) {
+            const uint32_t cn = min((uint32_t)kMsdCap, n - c0);
+            uint32_t valid = 0u;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) s_cnt[w][threadIdx.x] = 0u;
+#pragma unroll
+            for (int i = 0; i < kRangeItems; ++i) {
+                const uint32_t loc = wave * (kRangeItems * 64) + i * 64 + lane;   // (n > 4096 here: wbase is this)
+                const bool on = loc < cn;
+                const uint2 e = on ? src[c0 + loc] : make_uint2(0u, 0u);
+                key[i] = e.x; val[i] = e.y;
+                dig[i] = on ? (rel_key(e.x) >> shift) & mask : 0u;
+                valid |= (on ? 1u : 0u) << i;
+            }
+            __syncthreads();
+            wave_rank<kRangeItems, kDepthDigitBits, uint32_t>(dig, valid, s_cnt[wave], rank, lane);
+            __syncthreads();
+            {
+                uint32_t run = s_dstart[threadIdx.x];
+#pragma unroll
+                for (int w = 0; w < NW; ++w) { const uint32_t c = s_cnt[w][threadIdx.x]; s_cnt[w][threadIdx.x] = run; run += c; }
+                s_dstart[threadIdx.x] = run;      // the next chunk's elements of this digit go behind this chunk's
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < kRangeItems; ++i) {
+                if ((valid >> i) & 1u) {
+                    const uint32_t pos = s_cnt[wave][dig[i]] + rank[i];
+                    if (last) inst_sorted[r0 + pos] = val[i];
+                    else dst[pos] = make_uint2(key[i], val[i]);
+                }
+            }
+            __syncthreads();
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        src = dst;
+        dst = (dst == other) ? scratch + r0 : other;
+    }
+}
+
 // ---------------------------------------------------------------- split tile sort (a6 + a7)
 // Depth keys of the instances as (key, instance) elements: culled instances get the largest key so they sort to the end.
 __global__ void __launch_bounds__(256) depth_keys_kernel(int64_t I, const float* depth, const int* radii, uint2* pairs,
@@ -1756,7 +2237,24 @@ int launch_binning(const hs_fwd_args& a, const hs_layout& L, hipStream_t s, uint
     if (!prepared)
         depth_keys_kernel<<<ceil_div(I, 1024), 256, 0, s>>>(I, (const float*)(geom + L.depth), (const int*)(geom + L.radii), dp0,
                                                             depth_bits);
-    {
+    if (depth_sort_mode(I) == kDepthSortMsd) {
+        // frames below 2^21 instances: one stable counting pass over the top varying bits + range sorts in LDS (kernels above)
+        const int rows = (int)depth_msd_rows(I);
+        uint32_t* dw = (uint32_t*)(bin + L.depth_ws);
+        uint32_t* counts2 = dw;                                             // [rows][2048] u16 pairs
+        uint32_t* bases = counts2 + (int64_t)rows * (kMsdBuckets / 2);      // [rows][4096]
+        uint32_t* totals = bases + (int64_t)rows * kMsdBuckets;             // [4096]
+        uint32_t* culled_rows = totals + kMsdBuckets;                       // [rows]
+        depth_msd_count_kernel<4><<<rows, depth_msd_tile(I) / 4, 0, s>>>(dp0, n_inst, depth_bits, dtag, counts2, culled_rows);
+        depth_msd_colscan_kernel<<<kMsdBuckets / 32, 1024, 0, s>>>(counts2, rows, (uint2*)bases, (uint2*)totals);
+        if (depth_msd_tile(I) == 1024)
+            depth_msd_scatter_kernel<256, 4><<<rows, 256, 0, s>>>(dp0, n_inst, depth_bits, dtag, bases, totals, culled_rows, dp1, inst_sorted);
+        else
+            depth_msd_scatter_kernel<512, 8><<<rows, 512, 0, s>>>(dp0, n_inst, depth_bits, dtag, bases, totals, culled_rows, dp1, inst_sorted);
+        depth_range_sort_kernel<<<ceil_div(I, kMsdRange) + 1, kRangeThreads, 0, s>>>(dp1, dp0, depth_bits, dtag, totals, inst_sorted,
+                                                                                     counters, depth_range_cap());
+        HS_LAUNCH_CHECK();
+    } else {
         const int nblk = ceil_div(I, kDepthTile);
         depth_ghist_kernel<<<ceil_div(I, 4096), 1024, 0, s>>>(dp0, n_inst, depth_bits, dtag, dsc.ghist);
         const uint32_t late = fault_injection() == 3 ? 0x80000000u : 0u;

@@ -124,6 +124,24 @@ static inline int64_t sort_scratch_words(int64_t n, int passes, int tile, int bi
 // words the forward's first kernel clears for the depth sort of I instances (4 passes of 512-bin status words)
 static inline int64_t depth_scratch_words(int64_t I) { return sort_scratch_words(I, 4, kDepthTile, kDepthBins); }
 int64_t sort_tmp_bytes(int64_t n);
+// ---- depth sort of frames below 2^21 instances: ONE counting pass over the top bits + range sorts in LDS (binning.hip,
+// "depth sort by counting") instead of three or four look-back passes.  hs_layout.depth_ws, in u32 words: per block of
+// depth_msd_tile(I) instances one row of kMsdBuckets u16 bucket counts | one row of u32 prefixes down the columns | the
+// bucket totals | the culled instances per block.  Every word is written before it is read: nothing to clear.
+constexpr int kMsdBits = 12, kMsdBuckets = 1 << kMsdBits;
+constexpr int kMsdRange = 2048, kMsdCap = 4096;   // a range-sort workgroup takes the buckets starting in its 2048 positions; <= 4096 elements stay in LDS
+static inline bool depth_msd_fits(int64_t I) { return I > 0 && I < (2 << 20); }
+static inline int depth_msd_tile(int64_t I) { return I <= (1 << 18) ? 1024 : 4096; }   // (<= 512 rows either way)
+static inline int64_t depth_msd_rows(int64_t I) { return (I + depth_msd_tile(I) - 1) / depth_msd_tile(I); }
+static inline int64_t depth_ws_words(int64_t I) {
+    return depth_msd_fits(I) ? depth_msd_rows(I) * (kMsdBuckets / 2 + kMsdBuckets + 1) + kMsdBuckets : 0;   // (+ culled per row)
+}
+// Which depth sort a forward runs: HS_DEPTH_SORT=lsd / msd in the environment forces a form (read at every forward), else
+// hs_depth_sort()'s process-wide setting (the host moves it to the passes when a frame's ranges did not fit the LDS), else
+// the counting form wherever it fits.
+enum DepthSort { kDepthSortLsd = 0, kDepthSortMsd = 1 };
+int depth_sort_mode(int64_t I);
+int depth_range_cap();   // elements a range-sort workgroup keeps in LDS (kMsdCap; HS_DEPTH_RANGE_CAP lowers it: tests)
 // Scratch behind hs_layout.pair_sort_tmp: one 64-bit status word per 256-instance block of the pair emission's chained scan
 // (as u32 words), then the pair sort's scratch.  pair_scratch_words = what must be cleared before the emission runs.
 static inline int64_t emit_scan_words(int64_t I) { return 2 * ((I + 255) / 256 + 2) / 64 * 64 + 64; }

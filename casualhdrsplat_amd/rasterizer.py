@@ -182,8 +182,17 @@ class _Pending:
             self.event.synchronize()
             self.n, self.overflow = int(self.host[0]) & 0xFFFFFFFF, int(self.host[1])
             helps = int(self.host[6])   # hs_counters.reserved[4]
+            slow_ranges = int(self.host[4])   # hs_counters.reserved[2]
             _PINNED_POOL.append(self.host)
             self.host = None
+            if slow_ranges and L.load().hs_depth_sort(-1) == 1:
+                # the counting depth sort met a depth sliver holding thousands of instances (a wall of Gaussians seen head-on):
+                # its range did not fit the LDS and one workgroup sorted it through memory.  The frame is right; the look-back
+                # passes do not care how the depths are distributed
+                L.load().hs_depth_sort(0)
+                warnings.warn(f"casualhdrsplat_amd: {slow_ranges} range(s) of the counting depth sort did not fit on chip "
+                              "(many instances at one depth); using the look-back passes for the depth sort from now on",
+                              RuntimeWarning, stacklevel=3)
             if helps:
                 _HELPED_FRAMES[0] += 1
             # (the second such frame decides: one late block on a cold start is not a shared GPU)
@@ -922,6 +931,7 @@ def inspect_state(out_tensor) -> dict:
         pose_hdr=pose_hdr,
         num_rendered=R,
         look_back_helps=int(view(st.geom, lay.counters, 8, torch.int32)[6].item()),   # hs_counters.reserved[4]
+        depth_slow_ranges=int(view(st.geom, lay.counters, 8, torch.int32)[4].item()),  # reserved[2]: ranges of the counting depth sort sorted through memory
         tile_sort=int(view(st.geom, lay.counters, 8, torch.int32)[7].item()),         # reserved[5]: 0 radix, 1 counting, 2 hierarchical
         inst_sorted=view(st.binning, lay.inst_sorted, I, torch.int32), offs_sorted=view(st.binning, lay.offs_sorted, I, torch.int32),
         rec=rec, xy=rec[:, 0:2], conic_opacity=torch.stack([rec[:, 2], rec[:, 3], rec[:, 4], rec[:, 5]], 1),

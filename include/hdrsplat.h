@@ -35,7 +35,7 @@ extern "C" {
 /* libhdrsplat.so is built with -fvisibility=hidden: the hs_* entry points below are its only exported symbols */
 #define HS_API __attribute__((visibility("default")))
 
-#define HS_VERSION 307
+#define HS_VERSION 308
 
 #define HS_OK 0
 #define HS_EINVAL (-1)    /* bad argument (null pointer, bad shape, unsupported degree ...) */
@@ -108,7 +108,8 @@ typedef struct hs_counters {
     uint32_t overflow;     /* HS_STAGE_BIN: 1 = R > capacity; 2 = a radix pass gave up waiting for a predecessor's status
                               word (damaged scratch).  Either way the frame is rendered empty */
     uint32_t reserved[6];  /* [0] = pairs actually binned (R, or 0 on overflow); [1] = instance count of the depth sort;
-                              [3] = tile-queue counter of the render backward (zero between launches); [4] = times a
+                              [2] = ranges of the counting depth sort that did not fit the LDS and were sorted through
+                              memory by one workgroup (correct, slow: see hs_depth_sort); [3] = tile-queue counter of the render backward (zero between launches); [4] = times a
                               waiting workgroup of HS_STAGE_BIN had to compute a silent predecessor's counts itself
                               (non-zero: other kernels kept its blocks off the GPU -- see hs_sort_tickets); [5] = the tile
                               sort HS_STAGE_BIN ran (0 radix passes, 1 counting, 2 hierarchical); others unused */
@@ -258,6 +259,11 @@ typedef struct hs_layout {
      * HS_TILE_SORT=hier in the environment; like the counting sort it writes point_list and ranges but not keys_sorted.
      * hs_counters.reserved[5] records which tile sort a forward ran (0 radix, 1 counting, 2 hierarchical). */
     int64_t hier_ws;
+    /* (HS_VERSION 308) depth_ws (binning workspace; empty unless the frame has fewer than 2^21 instances): scratch of the
+     * depth sort such frames get instead of look-back passes -- per block of 1024 / 4096 instances a row of 4096 u16 bucket
+     * counts (top 12 varying key bits) | a row of u32 prefixes down the columns | u32 [4096] bucket totals.  Written before
+     * it is read: nothing to clear.  See hs_depth_sort. */
+    int64_t depth_ws;
 } hs_layout;
 
 HS_API int hs_version(void);
@@ -304,6 +310,18 @@ HS_API int hs_render_stats(const hs_fwd_args* fwd /* or NULL */, const hs_bwd_ar
                     uint64_t* bwd_timeline /* or NULL: per workgroup of the backward launch (tiles x poses of them)
                                               {start, end} on the 100 MHz device clock and (XCC id << 32 | HW_ID) */,
                     void* hip_stream);
+
+/* The depth sort of HS_STAGE_BIN for frames of fewer than 2^21 instances, process-wide: 1 (default) = by counting -- one
+ * stable counting pass over the top 12 varying bits of the depth keys (per-block bucket counts, a column scan, one
+ * scatter), then every run of buckets of about 2048 instances sorted to the end by one workgroup inside its LDS; 0 = the
+ * stable look-back radix passes larger frames always get.  Same result bit for bit (a stable sort has one).  The
+ * counting form assumes that no 2048 consecutive positions of the bucket order spill over 4096 instances, i.e. that no
+ * depth sliver of 1 / 4096 of the key range holds more than ~2048 instances; a range that does is sorted through memory by
+ * its one workgroup -- correct, but a frame dominated by such a range (a wall of Gaussians at one depth seen head-on)
+ * is slower than with the passes.  hs_counters.reserved[2] counts those ranges; the Python host moves the process to 0
+ * when a frame reports any.  mode < 0 only queries.  Returns the setting in force.  HS_DEPTH_SORT=lsd / msd in the
+ * environment overrides it per forward. */
+HS_API int hs_depth_sort(int mode);
 
 /* Chain positions of the radix passes of HS_STAGE_BIN, process-wide: 0 = blockIdx (default: relies on every XCD handing
  * its share of a grid out in increasing order), 1 = tickets drawn when a block STARTS (+3 % per step at c3; correct under

@@ -70,7 +70,7 @@ def test_struct_sizes_match_c(lib, tmp_path):
 
 def test_version_and_plan(lib):
     L = lib.load()
-    assert L.hs_version() == 307
+    assert L.hs_version() == 308
     d, sz, lay = lib.plan(1_000_000, 16, 3, 1920, 1080, 1, 7_000_000)
     assert sz.geom_bytes > 1_000_000 * 48 and sz.binning_bytes > 7_000_000 * 16
     assert sz.image_bytes >= 1920 * 1080 * (8 + 12) and sz.bwd_bytes >= 7_000_000 * 48
@@ -113,6 +113,33 @@ def test_plan_carries_the_hierarchical_sorts_workspace_up_to_2048_super_tile_key
     assert tail(1_000_000, 1920, 1080, 1, 7_000_000) >= chunks * (16 + 512) + 135 * 64 * 8      # descriptors + count rows + tiles
     assert tail(1_000_000, 1920, 1080, 8, 60_000_000) > 0 and tail(1_000_000, 1920, 1080, 16, 60_000_000) == 0   # 1080 / 2160 keys
     assert tail(10_000, 800, 800, 1, 0) == 0
+
+
+def test_plan_carries_the_counting_depth_sorts_matrix_below_2_21_instances(lib):
+    """hs_layout.depth_ws (HS_VERSION 308): frames of fewer than 2^21 instances carry the counting depth sort's scratch
+    behind sort_tmp -- per block of 1024 (up to 2^18 instances) or 4096 instances a row of 4096 u16 counts, a row of 4096
+    u32 prefixes and a word of culled instances, plus the 4096 bucket totals; larger frames (BASELINE c4) none."""
+    def size(P, N):
+        _, sz, lay = lib.plan(P, 1, 0, 1920, 1080, N, 1_000_000)
+        assert lay.depth_ws % 256 == 0 and lay.depth_ws >= lay.sort_tmp
+        return lay.depth_pairs - lay.depth_ws     # (depth_pairs is carved behind it)
+    row = (4096 // 2 + 4096 + 1) * 4
+    for P, N, rows in ((100_000, 1, 98), (1 << 18, 1, 256), ((1 << 18) + 1, 1, 65), (1_000_000, 1, 245), ((2 << 20) - 1, 1, 512),
+                       (200_000, 4, 196)):
+        want = rows * row + 4096 * 4
+        assert want <= size(P, N) < want + 256, (P, N)
+    assert size(2 << 20, 1) == 0 and size(1_000_000, 8) == 0
+
+
+def test_depth_sort_switch_is_process_wide_and_queryable(lib):
+    """hs_depth_sort: which depth sort frames below 2^21 instances get can be read and changed at run time (the Python host
+    goes back to the look-back passes when a frame reports ranges that did not fit on chip); no GPU involved."""
+    L = lib.load()
+    before = L.hs_depth_sort(-1)
+    assert before == 1          # by counting: the default
+    assert L.hs_depth_sort(0) == 0 and L.hs_depth_sort(-1) == 0
+    assert L.hs_depth_sort(1) == 1 and L.hs_depth_sort(-1) == 1
+    L.hs_depth_sort(before)
 
 
 def test_plan_rejects_bad_dims(lib):

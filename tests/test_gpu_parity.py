@@ -128,7 +128,7 @@ def test_ldr_forward_backward_vs_oracle(oracle, P, W, H, deg, seed, cam_seed):
 
 
 @pytest.fixture(params=["default", "tickets", "scan_in_emission", "radix_tile_sort", "scan_in_emission+counting", "hier",
-                        "hier+tickets"])
+                        "hier+tickets", "lsd_depth_sort"])
 def binning_mode(request):
     """The binning stage's alternate forms inside the driver's suite: chain positions of the radix
     passes from start-order tickets (hs_sort_tickets(1): what a process on a shared GPU runs) and the pair emission
@@ -137,10 +137,14 @@ def binning_mode(request):
     instances: most of this suite) sort their pairs by counting instead of radix passes: "tickets" and "scan_in_emission"
     keep the radix passes on them as well (HS_TILE_SORT=radix), "radix_tile_sort" only does that, and
     "scan_in_emission+counting" runs the counting sort behind the chained-scan emission.  "hier" (round 6): the hierarchical
-    tile sort -- one element per (8 x 8-tile super-tile, instance), one stable radix pass, expansion by counting."""
+    tile sort -- one element per (8 x 8-tile super-tile, instance), one stable radix pass, expansion by counting.
+    Frames below 2^21 instances sort their instances by depth by counting since round 6 (one counting pass + range sorts in
+    LDS): the "tickets" forms and "lsd_depth_sort" keep the look-back passes of the depth sort on them."""
     from casualhdrsplat_amd import _lib as L
     lib = L.load()
-    was, env = lib.hs_sort_tickets(-1), {k: os.environ.get(k) for k in ("HS_SCAN_IN_EMISSION", "HS_TILE_SORT")}
+    was, env = lib.hs_sort_tickets(-1), {k: os.environ.get(k) for k in ("HS_SCAN_IN_EMISSION", "HS_TILE_SORT", "HS_DEPTH_SORT")}
+    if request.param in ("tickets", "hier+tickets", "lsd_depth_sort"):
+        os.environ["HS_DEPTH_SORT"] = "lsd"
     if request.param in ("tickets", "hier+tickets"):
         lib.hs_sort_tickets(1)
     if request.param.startswith("hier"):   # round 6: coarse stable pass over (super-tile, instance) elements + expansion
@@ -690,6 +694,114 @@ def test_hierarchical_tile_sort_equals_the_radix_passes_at_full_size(cfg):
         assert np.array_equal(a["state"][k][:R], b["state"][k][:R]), k
     for k in ("ranges", "inst_sorted", "offs_sorted", "n_contrib", "final_T", "tiles_touched"):
         assert np.array_equal(a["state"][k], b["state"][k]), k
+    for k in a:
+        if k != "state" and a[k] is not None:
+            assert np.array_equal(Hh.bits(a[k]) if a[k].dtype == np.float32 else a[k], Hh.bits(b[k]) if b[k].dtype == np.float32 else b[k]), k
+
+
+@contextlib.contextmanager
+def environment(**kv):
+    """os.environ[k] = v for the forwards inside (the library reads these switches at every forward)."""
+    was = {k: os.environ.get(k) for k in kv}
+    os.environ.update({k: str(v) for k, v in kv.items()})
+    try:
+        yield
+    finally:
+        for k, v in was.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _depth_sort_case(name):
+    """Scenes for the depth sort by counting: (scene, cameras, hdr, extra environment, ranges expected off chip)."""
+    if name == "c2":
+        return S.make_scene(100_000, 800, 800, 0, seed=2), None, False, {}, False
+    if name == "c3":
+        return S.make_scene(1_000_000, 1920, 1080, 3, seed=0, hdr=True), None, True, {}, False
+    if name == "wild":          # culled instances (behind the camera, off screen), duplicates (equal keys), huge and tiny ones
+        return Hh.make_wild(S.make_scene(30_000, 640, 384, 1, seed=5), np.random.default_rng(3)), None, False, {}, False
+    if name == "five_poses":    # 250 000 instances: the largest frame in blocks of 1024
+        sc = S.make_scene(50_000, 480, 320, 1, seed=7, hdr=True)
+        return sc, S.blur_poses(480, 320, 5, step=0.02), True, {}, False
+    if name == "300k":          # blocks of 4096, 74 rows
+        return S.make_scene(300_000, 1024, 768, 0, seed=11), None, False, {}, False
+    if name == "tiny":
+        return S.make_scene(37, 96, 64, 2, seed=13), None, False, {}, False
+    if name == "mostly_culled":  # nine tenths of the cloud behind the camera: they must not become one bucket of the sort
+        sc = S.make_scene(200_000, 640, 480, 0, seed=17)
+        behind = torch.rand(200_000, generator=torch.Generator().manual_seed(1)) < 0.9
+        sc.means3D[behind, 2] = -sc.means3D[behind, 2]
+        return sc, None, False, {}, False
+    if name == "one_depth":     # every Gaussian at z = 5 exactly: no varying bit at all, ONE bucket of 20 000 equal keys
+        sc = S.make_scene(20_000, 320, 240, 0, seed=19)
+        k = 5.0 / sc.means3D[:, 2:3]
+        sc.means3D = sc.means3D * k
+        sc.scales = sc.scales * k
+        sc.means3D[:, 2] = 5.0
+        return sc, None, False, {}, True
+    if name == "two_depths":    # a wall at two depths 2 ulp apart: two buckets of 10 000 equal keys -> ranges that cannot fit
+        sc = S.make_scene(20_000, 320, 240, 0, seed=19)
+        k = 5.0 / sc.means3D[:, 2:3]
+        sc.means3D = sc.means3D * k
+        sc.scales = sc.scales * k
+        z = torch.full((20_000,), 5.0)
+        z[::2] = float(np.nextafter(np.nextafter(np.float32(5.0), np.float32(6.0)), np.float32(6.0)))
+        sc.means3D[:, 2] = z
+        return sc, None, False, {}, True
+    if name == "wild_cap64":    # every range of more than 64 instances goes the slow way (through memory, chunk by chunk)
+        return Hh.make_wild(S.make_scene(30_000, 640, 384, 1, seed=5), np.random.default_rng(3)), None, False, {"HS_DEPTH_RANGE_CAP": 64}, True
+    if name == "300k_cap2000":  # ... and chunks of 4096 at that: ranges of 2049 .. ~2400 instances in one chunk, none in two
+        return S.make_scene(300_000, 1024, 768, 0, seed=11), None, False, {"HS_DEPTH_RANGE_CAP": 2000}, True
+    raise KeyError(name)
+
+
+@pytest.mark.parametrize("name", ["c2", "wild", "five_poses", "300k", "tiny", "mostly_culled", "one_depth", "two_depths", "wild_cap64",
+                                  "300k_cap2000", "c3"])
+def test_depth_sort_by_counting_equals_the_look_back_passes(name):
+    """Round 6: frames below 2^21 instances sort their instances by depth with one stable counting pass over the top twelve
+    varying key bits and range sorts inside the LDS instead of three or four look-back passes.  Same order of the visible
+    instances (a stable sort has one; the culled ones, which have no pairs, stand behind them in index order instead of among
+    the largest keys), and every array downstream -- pair offsets, point_list, ranges, keys, images, gradients -- bit for bit.
+    The cases: BASELINE c2 and c3, culled instances and duplicate keys, several poses, both block sizes, a cloud smaller than a
+    wave, nine tenths culled, no varying bit, two huge buckets of equal keys (ranges that do not fit on chip: sorted through
+    memory by their workgroup, counted, and the host goes back to the passes), and the off-chip path forced onto ordinary
+    frames with one chunk and with several."""
+    from casualhdrsplat_amd import _lib as L
+    lib = L.load()
+    sc, cams, hdr, extra, off_chip = _depth_sort_case(name)
+    out = {}
+    try:
+        with environment(HS_DEPTH_SORT="lsd"):
+            out["lsd"] = Hh.run_hip(sc, cameras=cams, hdr=hdr)
+        with environment(HS_DEPTH_SORT="msd", **extra):
+            if off_chip:
+                with pytest.warns(RuntimeWarning, match="counting depth sort"):
+                    out["msd"] = Hh.run_hip(sc, cameras=cams, hdr=hdr)
+                assert lib.hs_depth_sort(-1) == 0      # the host went back to the passes for the rest of the process
+            else:
+                out["msd"] = Hh.run_hip(sc, cameras=cams, hdr=hdr)
+                assert lib.hs_depth_sort(-1) == 1
+    finally:
+        lib.hs_depth_sort(1)
+    a, b = out["lsd"], out["msd"]
+    sa, sb = a["state"], b["state"]
+    assert sa["depth_slow_ranges"] == 0 and (sb["depth_slow_ranges"] > 0) == off_chip, (sa["depth_slow_ranges"], sb["depth_slow_ranges"])
+    R = sa["num_rendered"]
+    assert R == sb["num_rendered"] and (R > 0 or name == "tiny")
+    vis = sa["radii"] > 0
+    assert np.array_equal(vis, sb["radii"] > 0)
+    ia, ib = sa["inst_sorted"].astype(np.int64), sb["inst_sorted"].astype(np.int64)
+    assert np.array_equal(np.sort(ia), np.arange(ia.size)) and np.array_equal(np.sort(ib), np.arange(ib.size))   # permutations
+    assert np.array_equal(ia[vis[ia]], ib[vis[ib]])                                  # the visible instances: the same order
+    n_vis = int(vis.sum())
+    assert vis[ib[:n_vis]].all() and np.array_equal(ib[n_vis:], np.flatnonzero(~vis))     # counting form: culled last, by index
+    assert np.array_equal(sa["offs_sorted"][vis[ia]], sb["offs_sorted"][vis[ib]])
+    for k in ("point_list", "keys_sorted"):
+        assert np.array_equal(sa[k][:R], sb[k][:R]), k
+    for k in ("ranges", "n_contrib", "final_T", "tiles_touched", "offsets"):
+        assert np.array_equal(sa[k], sb[k]), k
     for k in a:
         if k != "state" and a[k] is not None:
             assert np.array_equal(Hh.bits(a[k]) if a[k].dtype == np.float32 else a[k], Hh.bits(b[k]) if b[k].dtype == np.float32 else b[k]), k
@@ -1603,6 +1715,10 @@ def test_randomized_configurations_vs_oracle(oracle):
         os.environ.pop("HS_TILE_SORT", None)
         if case % 3:
             os.environ["HS_TILE_SORT"] = ("radix", "hier")[case % 3 - 1]
+        # (and one case in four sorts its instances by depth with the look-back passes instead of by counting)
+        os.environ.pop("HS_DEPTH_SORT", None)
+        if case % 4 == 3:
+            os.environ["HS_DEPTH_SORT"] = "lsd"
         P, W, H, n_poses, hdr, act, dom = c["P"], c["W"], c["H"], c["n_poses"], c["hdr"], c["act"], c["dom"]
         sc, cams, precomp, what = c["sc"], c["cams"], c["precomp"], c["what"]
         if hdr or n_poses > 1:
