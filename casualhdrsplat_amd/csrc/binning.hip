@@ -644,15 +644,17 @@ int radix_sort_packed(uint2* p0, uint2* p1, uint32_t* keys_out, uint32_t* vals_o
 //   1. depth_msd_count_kernel: per block of depth_msd_tile(I) elements, the number of keys in each of the 4096 buckets of
 //      the top kMsdBits VARYING key bits (the layout of those bits as the passes read it: DepthLayout) -- one row of u16;
 //   2. depth_msd_colscan_kernel: per bucket the exclusive prefix of the rows down the column, and the column total;
-//   3. depth_msd_scatter_kernel: block b re-reads its elements, ranks them per bucket (match-any over the twelve bits; wave
-//      w owns consecutive rounds of 64 elements, so the order inside a bucket is the input's) and writes each to
-//      start of the bucket + elements of the bucket in earlier blocks + in earlier waves + its rank: a stable counting
-//      sort by the top bits.  Culled instances (the all-ones key) are counted apart and go straight to the END of the
+//   3. depth_msd_scatter_kernel: block b re-reads its elements and writes each to start of its bucket + elements of the
+//      bucket in earlier blocks + the slot an LDS atomic hands it: a counting sort by the top bits, stable from block to
+//      block and in no particular order inside a (block, bucket) group -- the elements carry their instance numbers, which
+//      ARE the input order, so step 4 can put equal keys right.  Culled instances (the all-ones key) are counted apart and go straight to the END of the
 //      instance list, in index order (the passes leave them among the largest visible keys; they have no pairs, so where
 //      they stand changes nothing downstream -- the order of the VISIBLE instances is the passes', bit for bit);
 //   4. depth_range_sort_kernel: workgroup k takes the buckets that START inside positions [2048 k, 2048 (k + 1)) -- whole
-//      buckets, so the range holds every key of its part of the key space -- and sorts them by all varying bits, least
-//      significant digit first, in LDS (the passes' ranking, nothing published, nothing looked up): the instance list.
+//      buckets, so the range holds every key of its part of the key space -- and sorts them by (key, instance number) in
+//      LDS: a distribution sort when the keys spread evenly over the range's span (no bucket of its 2048 above 16 members),
+//      else stable least-significant-digit passes (the look-back passes' ranking, nothing published, nothing looked up)
+//      over instance numbers and keys: the instance list.
 //      A range of more than 4096 elements (a bucket of more than 2048: one 4096th of the key range holds that many
 //      instances) does not fit: its workgroup then runs the same passes through memory, chunk by chunk -- correct, slow,
 //      counted in hs_counters.reserved[2] so that the host can go back to the look-back passes (hs_depth_sort).
@@ -783,26 +785,26 @@ __device__ __forceinline__ uint32_t msd_bucket_starts(const uint32_t* totals, ui
     return all;   // = the visible instances
 }
 
-// NT threads x ITEMS elements: 512 x 8 for blocks of 4096 (eight waves share the ranking: 80 KB of LDS), 256 x 4 for blocks of 1024
+// NT threads x ITEMS elements: 512 x 8 for blocks of 4096, 256 x 4 for blocks of 1024.  The order in which the elements of one
+// (block, bucket) group take their slots is whatever the LDS atomics make it: every element carries its instance number,
+// instances are numbered in input order, and the range sort orders equal keys by that number -- the sort as a whole is the
+// stable one, its first pass need not be.  (Ranking the group's members by match-any over the twelve bucket bits, one
+// counter row per wave -- a stable pass -- took 6 of the kernel's 21 us at c3 plus the handling of 64 KB of counters.)
 template <int NT, int ITEMS>
 __global__ void __launch_bounds__(NT) depth_msd_scatter_kernel(const uint2* pairs, const uint32_t* n_dev,
                                                                 const unsigned long long* bits, uint32_t tag,
                                                                 const uint32_t* bases, const uint32_t* totals,
                                                                 const uint32_t* culled_rows, uint2* out, uint32_t* inst_sorted) {
     constexpr int NW = NT / 64;
-    __shared__ uint16_t s_cnt[NW][kMsdBuckets];  // per-wave bucket counters -> per-wave exclusive offsets
+    __shared__ uint32_t s_cnt[kMsdBuckets];      // slots of the bucket this block has handed out
     __shared__ uint32_t s_base[kMsdBuckets];     // bucket start + elements of the bucket in earlier blocks
     __shared__ uint32_t s_wave[NW], s_cwave[NW], s_cbefore[NW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    {
-        uint32_t* z = reinterpret_cast<uint32_t*>(&s_cnt[0][0]);
-        for (int t = threadIdx.x; t < NW * kMsdBuckets / 2; t += NT) z[t] = 0u;
-    }
+    for (int t = threadIdx.x; t < kMsdBuckets; t += NT) s_cnt[t] = 0u;
     const int64_t n = *n_dev;
     const int64_t base = (int64_t)blockIdx.x * (ITEMS * NT);
     const MsdDigit D = msd_digit(depth_layout(bits, tag));
     uint2 e[ITEMS];
-    uint32_t dig[ITEMS];
     uint32_t valid = 0u, culled = 0u;
     const int wbase = wave * (ITEMS * 64);
 #pragma unroll
@@ -810,11 +812,13 @@ __global__ void __launch_bounds__(NT) depth_msd_scatter_kernel(const uint2* pair
         const int64_t k = base + wbase + i * 64 + lane;
         e[i] = k < n ? pairs[k] : make_uint2(0u, 0u);
         const bool c = k < n && e[i].x == kCulledKey;
-        const bool on = k < n && !c;
-        dig[i] = on ? (e[i].x >> D.shift) & D.mask : 0u;
-        valid |= (on ? 1u : 0u) << i;
+        valid |= ((k < n && !c) ? 1u : 0u) << i;
         culled |= (c ? 1u : 0u) << i;
     }
+    const uint32_t* brow = bases + (int64_t)blockIdx.x * kMsdBuckets;
+    uint32_t bv[kMsdBuckets / NT];
+#pragma unroll
+    for (int j = 0; j < kMsdBuckets / NT; ++j) bv[j] = brow[threadIdx.x + j * NT];
     // culled instances of the blocks in front of this one (<= 512 rows)
     uint32_t cb = 0;
     for (int r = threadIdx.x; r < (int)blockIdx.x; r += NT) cb += culled_rows[r];
@@ -822,12 +826,8 @@ __global__ void __launch_bounds__(NT) depth_msd_scatter_kernel(const uint2* pair
     for (int dd = 32; dd >= 1; dd >>= 1) cb += __shfl_xor(cb, dd);
     if (lane == 0) s_cbefore[wave] = cb;
     const uint32_t n_vis = msd_bucket_starts<NT>(totals, s_base, s_wave);   // (its first barrier also covers the zeroing above)
-    uint16_t rank[ITEMS];
-    if (HS_ABL_MSD & 2) {
 #pragma unroll
-        for (int i = 0; i < ITEMS; ++i) rank[i] = 0;
-    } else
-    wave_rank<ITEMS, kMsdBits, uint16_t>(dig, valid, s_cnt[wave], rank, lane);
+    for (int j = 0; j < kMsdBuckets / NT; ++j) s_base[threadIdx.x + j * NT] += bv[j];
     // Culled instances (key all ones; none of them has a pair) take no part in the sort: they go behind the visible ones at
     // once, in index order -- a frame that sees a tenth of its cloud would otherwise carry the other nine tenths through the
     // range sort as ONE bucket of equal keys.
@@ -843,18 +843,14 @@ __global__ void __launch_bounds__(NT) depth_msd_scatter_kernel(const uint2* pair
         }
         if (lane == 0) s_cwave[wave] = cwave;
     }
-    const uint32_t* brow = bases + (int64_t)blockIdx.x * kMsdBuckets;
     __syncthreads();
-    for (int b = threadIdx.x; b < kMsdBuckets; b += NT) {
-        uint32_t run = 0;
 #pragma unroll
-        for (int w = 0; w < NW; ++w) { const uint32_t c = s_cnt[w][b]; s_cnt[w][b] = (uint16_t)run; run += c; }
-        s_base[b] += brow[b];
+    for (int i = 0; i < ITEMS; ++i) {
+        if (!(HS_ABL_MSD & 1) && ((valid >> i) & 1u)) {
+            const uint32_t d = (e[i].x >> D.shift) & D.mask;
+            out[s_base[d] + atomicAdd(&s_cnt[d], 1u)] = e[i];
+        }
     }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < ITEMS; ++i)
-        if (!(HS_ABL_MSD & 1) && ((valid >> i) & 1u)) out[s_base[dig[i]] + s_cnt[wave][dig[i]] + rank[i]] = e[i];
     if (culled) {
         uint32_t cfirst = n_vis;
 #pragma unroll
@@ -871,7 +867,7 @@ static_assert(kRangeThreads == kDepthBins, "one digit per thread: digits of up t
 __global__ void __launch_bounds__(kRangeThreads) depth_range_sort_kernel(const uint2* msd_sorted, uint2* scratch,
                                                                          const unsigned long long* bits, uint32_t tag,
                                                                          const uint32_t* totals, uint32_t* inst_sorted,
-                                                                         hs_counters* counters, int cap) {
+                                                                         hs_counters* counters, int cap, int ibits) {
     constexpr int NW = kRangeThreads / 64;
     // the passes: per-wave digit counters -> per-wave offsets [NW][512], start of each digit's run (or, off chip, its running
     // global start) [512]; the distribution sort: members per bucket, next free slot, first slot [3][kDistBuckets]
@@ -880,7 +876,6 @@ __global__ void __launch_bounds__(kRangeThreads) depth_range_sort_kernel(const u
     uint32_t (*const s_cnt)[kDepthBins] = reinterpret_cast<uint32_t (*)[kDepthBins]>(s_work);
     uint32_t* const s_dstart = s_work + NW * kDepthBins;
     __shared__ uint32_t s_keys[kMsdCap], s_vals[kMsdCap];
-    __shared__ uint16_t s_pos[kMsdCap];
     __shared__ uint32_t s_wave[NW];
     __shared__ uint32_t s_r[2], s_b[2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -934,6 +929,11 @@ __global__ void __launch_bounds__(kRangeThreads) depth_range_sort_kernel(const u
         L.base = rbits / L.npasses;
         L.rem = rbits - L.base * L.npasses;
     }
+    DepthLayout IL;   // digits of the instance numbers (< 2^ibits), for the ranges that take passes
+    IL.lo = 0;
+    IL.npasses = (ibits + kDepthDigitBits - 1) / kDepthDigitBits;
+    IL.base = ibits / IL.npasses;
+    IL.rem = ibits - IL.base * IL.npasses;
     const int klo = L0.lo;
     auto rel_key = [&](uint32_t key) { return ((key >> klo) & wmask) - kbase; };
     // a wave owns ceil(n / 512) rounds of 64 consecutive elements (not a fixed eight: a range of 2048 keeps all eight waves
@@ -992,32 +992,35 @@ __global__ void __launch_bounds__(kRangeThreads) depth_range_sort_kernel(const u
                     const uint32_t p = atomicAdd(&cursor[key[i] >> dsh], 1u);
                     s_keys[p] = key[i];
                     s_vals[p] = val[i];
-                    s_pos[p] = (uint16_t)(wbase + i * 64 + lane);
                 }
             }
             __syncthreads();
-            if (HS_MSD_STOP == 4) { inst_sorted[r0 + threadIdx.x % n] = s_keys[threadIdx.x] + s_pos[threadIdx.x]; return; }
+            if (HS_MSD_STOP == 4) { inst_sorted[r0 + threadIdx.x % n] = s_keys[threadIdx.x] + s_vals[threadIdx.x]; return; }
             for (uint32_t p = threadIdx.x; p < ((HS_ABL_MSD & 128) ? 0u : n); p += kRangeThreads) {
-                const uint32_t k = s_keys[p], me = s_pos[p];
+                const uint32_t k = s_keys[p], me = s_vals[p];
                 const uint32_t d = k >> dsh, a = first[d], cnt = hist[d];
                 uint32_t r = 0;
                 for (uint32_t q = a; q < a + cnt; ++q) {
-                    const uint32_t kq = s_keys[q], pq = s_pos[q];
-                    r += (kq < k || (kq == k && pq < me)) ? 1u : 0u;
+                    const uint32_t kq = s_keys[q];
+                    r += kq < k ? 1u : 0u;
+                    if (kq == k) r += s_vals[q] < me ? 1u : 0u;   // equal keys: by instance number = in input order
                 }
-                inst_sorted[r0 + a + r] = s_vals[p];
+                inst_sorted[r0 + a + r] = me;
             }
             return;
         }
         __syncthreads();   // (the passes' tables overlay the distribution sort's)
-        for (int pass = 0; pass < ((HS_ABL_MSD & 16) ? 0 : (HS_ABL_MSD & 4) ? 1 : L.npasses); ++pass) {
-            const int shift = L.shift(pass);
-            const uint32_t mask = (1u << L.width(pass)) - 1u;
+        // a clustered range: stable least-significant-digit passes -- over the instance numbers first (the scatter left the
+        // members of a bucket in no particular order), then over the relative keys
+        for (int pass = 0; pass < ((HS_ABL_MSD & 16) ? 0 : (HS_ABL_MSD & 4) ? 1 : IL.npasses + L.npasses); ++pass) {
+            const bool by_inst = pass < IL.npasses;
+            const int shift = by_inst ? IL.shift(pass) : L.shift(pass - IL.npasses);
+            const uint32_t mask = (1u << (by_inst ? IL.width(pass) : L.width(pass - IL.npasses))) - 1u;
 #pragma unroll
             for (int w = 0; w < NW; ++w) s_cnt[w][threadIdx.x] = 0u;
             __syncthreads();   // (also: everybody has read the previous pass' s_keys / s_vals)
 #pragma unroll
-            for (int i = 0; i < kRangeItems; ++i) dig[i] = ((valid >> i) & 1u) ? (key[i] >> shift) & mask : 0u;
+            for (int i = 0; i < kRangeItems; ++i) dig[i] = ((valid >> i) & 1u) ? ((by_inst ? val[i] : key[i]) >> shift) & mask : 0u;
             wave_rank<kRangeItems, kDepthDigitBits, uint32_t>(dig, valid, s_cnt[wave], rank, lane);
             __syncthreads();
             {
@@ -1041,7 +1044,7 @@ __global__ void __launch_bounds__(kRangeThreads) depth_range_sort_kernel(const u
                 }
             }
             __syncthreads();
-            if (pass + 1 < L.npasses) {
+            if (pass + 1 < IL.npasses + L.npasses) {
 #pragma unroll
                 for (int i = 0; i < kRangeItems; ++i) {
                     const uint32_t loc = wbase + i * 64 + lane;
@@ -1061,13 +1064,15 @@ __global__ void __launch_bounds__(kRangeThreads) depth_range_sort_kernel(const u
     const uint2* src = msd_sorted + r0;
     uint2* dst = scratch + r0;
     uint2* const other = const_cast<uint2*>(msd_sorted) + r0;
-    for (int pass = 0; pass < L.npasses; ++pass) {
-        const int shift = L.shift(pass);
-        const uint32_t mask = (1u << L.width(pass)) - 1u;
-        const bool last = pass == L.npasses - 1;
+    for (int pass = 0; pass < IL.npasses + L.npasses; ++pass) {
+        const bool by_inst = pass < IL.npasses;
+        const int shift = by_inst ? IL.shift(pass) : L.shift(pass - IL.npasses);
+        const uint32_t mask = (1u << (by_inst ? IL.width(pass) : L.width(pass - IL.npasses))) - 1u;
+        const bool last = pass == IL.npasses + L.npasses - 1;
+        auto digit = [&](uint2 e) { return ((by_inst ? e.y : rel_key(e.x)) >> shift) & mask; };
         s_dstart[threadIdx.x] = 0u;
         __syncthreads();
-        for (uint32_t k = threadIdx.x; k < n; k += kRangeThreads) atomicAdd(&s_dstart[(rel_key(src[k].x) >> shift) & mask], 1u);
+        for (uint32_t k = threadIdx.x; k < n; k += kRangeThreads) atomicAdd(&s_dstart[digit(src[k])], 1u);
         __syncthreads();
         {
             const uint32_t tot = s_dstart[threadIdx.x];
@@ -1087,7 +1092,7 @@ __global__ void __launch_bounds__(kRangeThreads) depth_range_sort_kernel(const u
                 const bool on = loc < cn;
                 const uint2 e = on ? src[c0 + loc] : make_uint2(0u, 0u);
                 key[i] = e.x; val[i] = e.y;
-                dig[i] = on ? (rel_key(e.x) >> shift) & mask : 0u;
+                dig[i] = on ? digit(e) : 0u;
                 valid |= (on ? 1u : 0u) << i;
             }
             __syncthreads();
@@ -2252,7 +2257,8 @@ int launch_binning(const hs_fwd_args& a, const hs_layout& L, hipStream_t s, uint
         else
             depth_msd_scatter_kernel<512, 8><<<rows, 512, 0, s>>>(dp0, n_inst, depth_bits, dtag, bases, totals, culled_rows, dp1, inst_sorted);
         depth_range_sort_kernel<<<ceil_div(I, kMsdRange) + 1, kRangeThreads, 0, s>>>(dp1, dp0, depth_bits, dtag, totals, inst_sorted,
-                                                                                     counters, depth_range_cap());
+                                                                                     counters, depth_range_cap(),
+                                                                                     max(1, tile_bits((uint32_t)(I - 1))));
         HS_LAUNCH_CHECK();
     } else {
         const int nblk = ceil_div(I, kDepthTile);
