@@ -59,6 +59,12 @@ int depth_range_cap() {
     return v < 64 ? 64 : (v > kMsdCap ? kMsdCap : v);
 }
 
+int depth_dist_max() {
+    const char* e = getenv("HS_DEPTH_DIST_MAX");
+    const int v = e ? atoi(e) : 16;
+    return v < 0 ? 0 : (v > 16 ? 16 : v);
+}
+
 bool scan_in_emission(int64_t I) {
     // (read at every forward, not once: the driver's test suite switches it inside one process)
     const char* e = getenv("HS_SCAN_IN_EMISSION");

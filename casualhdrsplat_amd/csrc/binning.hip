@@ -658,11 +658,8 @@ int radix_sort_packed(uint2* p0, uint2* p1, uint32_t* keys_out, uint32_t* vals_o
 //      A range of more than 4096 elements (a bucket of more than 2048: one 4096th of the key range holds that many
 //      instances) does not fit: its workgroup then runs the same passes through memory, chunk by chunk -- correct, slow,
 //      counted in hs_counters.reserved[2] so that the host can go back to the look-back passes (hs_depth_sort).
-#ifndef HS_MSD_STOP
-#define HS_MSD_STOP 0   // timing experiments: the range sort returns after phase 1 .. 4 (wrong result)
-#endif
 #ifndef HS_ABL_MSD
-#define HS_ABL_MSD 0   // ablation switches (timing experiments only; the result is wrong with any of them set)
+#define HS_ABL_MSD 0   // timing switch: 1 = the scatter stores nothing (wrong result)
 #endif
 constexpr uint32_t kCulledKey = 0xFFFFFFFFu;   // depth key of a culled instance (no positive float has these bits)
 struct MsdDigit { int shift; uint32_t mask; };
@@ -867,7 +864,7 @@ static_assert(kRangeThreads == kDepthBins, "one digit per thread: digits of up t
 __global__ void __launch_bounds__(kRangeThreads) depth_range_sort_kernel(const uint2* msd_sorted, uint2* scratch,
                                                                          const unsigned long long* bits, uint32_t tag,
                                                                          const uint32_t* totals, uint32_t* inst_sorted,
-                                                                         hs_counters* counters, int cap, int ibits) {
+                                                                         hs_counters* counters, int cap, int ibits, int dist_max) {
     constexpr int NW = kRangeThreads / 64;
     // the passes: per-wave digit counters -> per-wave offsets [NW][512], start of each digit's run (or, off chip, its running
     // global start) [512]; the distribution sort: members per bucket, next free slot, first slot [3][kDistBuckets]
@@ -881,8 +878,8 @@ __global__ void __launch_bounds__(kRangeThreads) depth_range_sort_kernel(const u
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x < 2) { s_r[threadIdx.x] = 0xFFFFFFFFu; s_b[threadIdx.x] = (uint32_t)kMsdBuckets; }
     // this workgroup's range: [first bucket start >= 2048 k, first bucket start >= 2048 (k + 1)) (n_vis when there is none)
-    const uint32_t n_vis = (HS_ABL_MSD & 8) ? totals[0] * 4096u : msd_bucket_starts<kRangeThreads>(totals, s_keys, s_wave);   // (the culled ones are in place already)
-    if (!(HS_ABL_MSD & 8)) {
+    const uint32_t n_vis = msd_bucket_starts<kRangeThreads>(totals, s_keys, s_wave);   // (the culled ones are in place already)
+    {
         // (thresholds behind the last element mean "the end": the first bucket starting there, so that the last range's
         // span stops with its last occupied bucket instead of running on to bucket 4095)
         const uint32_t t0 = min(n_vis, (uint32_t)blockIdx.x * (uint32_t)kMsdRange), t1 = min(n_vis, t0 + (uint32_t)kMsdRange);
@@ -897,8 +894,7 @@ __global__ void __launch_bounds__(kRangeThreads) depth_range_sort_kernel(const u
         }
     }
     __syncthreads();
-    uint32_t r0 = min(s_r[0], n_vis), r1 = min(s_r[1], n_vis);
-    if (HS_ABL_MSD & 8) { r0 = min(n_vis, blockIdx.x * 2048u); r1 = min(n_vis, r0 + 2048u); }
+    const uint32_t r0 = min(s_r[0], n_vis), r1 = min(s_r[1], n_vis);
     if (r0 >= r1) return;
     {   // the range's first OCCUPIED bucket: the last of the buckets starting at r0 (those in front of it are empty)
 #pragma unroll
@@ -909,7 +905,6 @@ __global__ void __launch_bounds__(kRangeThreads) depth_range_sort_kernel(const u
         __syncthreads();
     }
     const uint32_t n = r1 - r0;
-    if (HS_MSD_STOP == 1) { inst_sorted[r0 + threadIdx.x % n] = s_b[0] + s_b[1]; return; }
     const DepthLayout L0 = depth_layout(bits, tag);
     // The range's buckets [b0, b1) are in order already; what is left to sort are the key bits below the bucket's and the
     // bucket number RELATIVE to b0 -- a handful of bits for a range of a few buckets: sort (key window) - (b0's first key),
@@ -957,9 +952,7 @@ __global__ void __launch_bounds__(kRangeThreads) depth_range_sort_kernel(const u
         // of the relative key's top eleven bits (LDS atomics: the order in which a bucket's members arrive is arbitrary), then
         // every element counts the members of ITS bucket that stand in front of it by (key, position in the input) -- a
         // handful of LDS reads where two or three ranking passes cost ~130 vector instructions per element.  A bucket of
-        // more than kDistMax (16) members (equal keys, a cluster) would make that quadratic: such a range takes the passes below.
-        if (HS_MSD_STOP == 2) { inst_sorted[r0 + threadIdx.x % n] = key[0] + val[1] + key[7] + (uint32_t)L.npasses; return; }
-        constexpr uint32_t kDistMax = 16;
+        // more than `dist_max` (16) members (equal keys, a cluster) would make that quadratic: such a range takes the passes below.
         constexpr int E = kDistBuckets / kRangeThreads;   // consecutive buckets per thread
         const int rbits = L.base * L.npasses + L.rem;
         const int dsh = max(0, rbits - kDistBits);
@@ -982,9 +975,8 @@ __global__ void __launch_bounds__(kRangeThreads) depth_range_sort_kernel(const u
             uint32_t start = block_incl_scan<NW>(mine, s_wave, &total) - mine;
 #pragma unroll
             for (int j = 0; j < E; ++j) { first[threadIdx.x * E + j] = start; cursor[threadIdx.x * E + j] = start; start += c[j]; }
-            dist = !(HS_ABL_MSD & 32) && __syncthreads_or(most > kDistMax) == 0;
+            dist = __syncthreads_or(most > (uint32_t)dist_max) == 0;
         }
-        if (HS_MSD_STOP == 3) { inst_sorted[r0 + threadIdx.x % n] = first[threadIdx.x] + (dist ? 1u : 0u); return; }
         if (dist) {
 #pragma unroll
             for (int i = 0; i < kRangeItems; ++i) {
@@ -995,8 +987,7 @@ __global__ void __launch_bounds__(kRangeThreads) depth_range_sort_kernel(const u
                 }
             }
             __syncthreads();
-            if (HS_MSD_STOP == 4) { inst_sorted[r0 + threadIdx.x % n] = s_keys[threadIdx.x] + s_vals[threadIdx.x]; return; }
-            for (uint32_t p = threadIdx.x; p < ((HS_ABL_MSD & 128) ? 0u : n); p += kRangeThreads) {
+            for (uint32_t p = threadIdx.x; p < n; p += kRangeThreads) {
                 const uint32_t k = s_keys[p], me = s_vals[p];
                 const uint32_t d = k >> dsh, a = first[d], cnt = hist[d];
                 uint32_t r = 0;
@@ -1012,7 +1003,7 @@ __global__ void __launch_bounds__(kRangeThreads) depth_range_sort_kernel(const u
         __syncthreads();   // (the passes' tables overlay the distribution sort's)
         // a clustered range: stable least-significant-digit passes -- over the instance numbers first (the scatter left the
         // members of a bucket in no particular order), then over the relative keys
-        for (int pass = 0; pass < ((HS_ABL_MSD & 16) ? 0 : (HS_ABL_MSD & 4) ? 1 : IL.npasses + L.npasses); ++pass) {
+        for (int pass = 0; pass < IL.npasses + L.npasses; ++pass) {
             const bool by_inst = pass < IL.npasses;
             const int shift = by_inst ? IL.shift(pass) : L.shift(pass - IL.npasses);
             const uint32_t mask = (1u << (by_inst ? IL.width(pass) : L.width(pass - IL.npasses))) - 1u;
@@ -2258,7 +2249,7 @@ int launch_binning(const hs_fwd_args& a, const hs_layout& L, hipStream_t s, uint
             depth_msd_scatter_kernel<512, 8><<<rows, 512, 0, s>>>(dp0, n_inst, depth_bits, dtag, bases, totals, culled_rows, dp1, inst_sorted);
         depth_range_sort_kernel<<<ceil_div(I, kMsdRange) + 1, kRangeThreads, 0, s>>>(dp1, dp0, depth_bits, dtag, totals, inst_sorted,
                                                                                      counters, depth_range_cap(),
-                                                                                     max(1, tile_bits((uint32_t)(I - 1))));
+                                                                                     max(1, tile_bits((uint32_t)(I - 1))), depth_dist_max());
         HS_LAUNCH_CHECK();
     } else {
         const int nblk = ceil_div(I, kDepthTile);

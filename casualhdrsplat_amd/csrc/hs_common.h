@@ -142,6 +142,7 @@ static inline int64_t depth_ws_words(int64_t I) {
 enum DepthSort { kDepthSortLsd = 0, kDepthSortMsd = 1 };
 int depth_sort_mode(int64_t I);
 int depth_range_cap();   // elements a range-sort workgroup keeps in LDS (kMsdCap; HS_DEPTH_RANGE_CAP lowers it: tests)
+int depth_dist_max();    // members of a bucket up to which a range is sorted by distribution (16; HS_DEPTH_DIST_MAX lowers it: tests)
 // Scratch behind hs_layout.pair_sort_tmp: one 64-bit status word per 256-instance block of the pair emission's chained scan
 // (as u32 words), then the pair sort's scratch.  pair_scratch_words = what must be cleared before the emission runs.
 static inline int64_t emit_scan_words(int64_t I) { return 2 * ((I + 255) / 256 + 2) / 64 * 64 + 64; }

@@ -752,13 +752,17 @@ def _depth_sort_case(name):
         return sc, None, False, {}, True
     if name == "wild_cap64":    # every range of more than 64 instances goes the slow way (through memory, chunk by chunk)
         return Hh.make_wild(S.make_scene(30_000, 640, 384, 1, seed=5), np.random.default_rng(3)), None, False, {"HS_DEPTH_RANGE_CAP": 64}, True
+    if name == "c2_passes":     # no distribution sort: every range takes the passes over (instance number, key)
+        return S.make_scene(100_000, 800, 800, 0, seed=2), None, False, {"HS_DEPTH_DIST_MAX": 0}, False
+    if name == "wild_passes":
+        return Hh.make_wild(S.make_scene(30_000, 640, 384, 1, seed=5), np.random.default_rng(3)), None, False, {"HS_DEPTH_DIST_MAX": 0}, False
     if name == "300k_cap2000":  # ... and chunks of 4096 at that: ranges of 2049 .. ~2400 instances in one chunk, none in two
         return S.make_scene(300_000, 1024, 768, 0, seed=11), None, False, {"HS_DEPTH_RANGE_CAP": 2000}, True
     raise KeyError(name)
 
 
 @pytest.mark.parametrize("name", ["c2", "wild", "five_poses", "300k", "tiny", "mostly_culled", "one_depth", "two_depths", "wild_cap64",
-                                  "300k_cap2000", "c3"])
+                                  "300k_cap2000", "c2_passes", "wild_passes", "c3"])
 def test_depth_sort_by_counting_equals_the_look_back_passes(name):
     """Round 6: frames below 2^21 instances sort their instances by depth with one stable counting pass over the top twelve
     varying key bits and range sorts inside the LDS instead of three or four look-back passes.  Same order of the visible
@@ -766,8 +770,9 @@ def test_depth_sort_by_counting_equals_the_look_back_passes(name):
     the largest keys), and every array downstream -- pair offsets, point_list, ranges, keys, images, gradients -- bit for bit.
     The cases: BASELINE c2 and c3, culled instances and duplicate keys, several poses, both block sizes, a cloud smaller than a
     wave, nine tenths culled, no varying bit, two huge buckets of equal keys (ranges that do not fit on chip: sorted through
-    memory by their workgroup, counted, and the host goes back to the passes), and the off-chip path forced onto ordinary
-    frames with one chunk and with several."""
+    memory by their workgroup, counted, and the host goes back to the passes), the off-chip path forced onto ordinary
+    frames with one chunk and with several, and the in-LDS passes (what a range with clustered keys takes instead of the
+    distribution sort) forced onto every range."""
     from casualhdrsplat_amd import _lib as L
     lib = L.load()
     sc, cams, hdr, extra, off_chip = _depth_sort_case(name)
@@ -1009,7 +1014,9 @@ print("FRAME", R, h.hexdigest(), "HELPS", st["look_back_helps"])
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = {}
     for inject in ("", "late_block"):
-        env = dict(os.environ, HS_ROOT=root, HS_FAULT_INJECT=inject, HS_SORT_TICKETS="0", HS_LIB_PATH=_TEST_LIB)
+        # (a frame this small sorts its instances by counting and its pairs by counting: HS_DEPTH_SORT=lsd keeps the look-back
+        # passes of the depth sort, the only chains such a frame can have)
+        env = dict(os.environ, HS_ROOT=root, HS_FAULT_INJECT=inject, HS_SORT_TICKETS="0", HS_DEPTH_SORT="lsd", HS_LIB_PATH=_TEST_LIB)
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
         outs[inject] = [ln for ln in r.stdout.splitlines() if ln.startswith("FRAME")][0].split()
