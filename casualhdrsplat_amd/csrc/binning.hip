@@ -661,6 +661,17 @@ int radix_sort_packed(uint2* p0, uint2* p1, uint32_t* keys_out, uint32_t* vals_o
 #ifndef HS_ABL_MSD
 #define HS_ABL_MSD 0   // timing switch: 1 = the scatter stores nothing (wrong result)
 #endif
+__device__ __forceinline__ void hier_coarse_rect(uint2 rc, uint32_t& sx0, uint32_t& sy0, uint32_t& sw, uint32_t& sh);   // (below)
+// What the kernel between the depth sort and the pair / element emission used to do in a launch of its own (gather_binfo_kernel,
+// hier_gather_kernel: 15 us at c3): the tile rectangles in depth order and, per 256 consecutive instances of that order, the
+// sum of their pair counts (and of their super-tile counts: the hierarchical form).  The range sort has every instance's
+// final position in its hands: it does this on the way out.  srect == null: not asked for (the emission gathers by itself).
+#ifndef HS_TUNE_FUSE_GATHER
+#define HS_TUNE_FUSE_GATHER 1
+#endif
+struct GatherOut {
+    const uint2* binfo; uint2* srect; uint32_t* bsum; uint32_t* bcsum; uint32_t n_all;
+};
 constexpr uint32_t kCulledKey = 0xFFFFFFFFu;   // depth key of a culled instance (no positive float has these bits)
 struct MsdDigit { int shift; uint32_t mask; };
 __device__ __forceinline__ MsdDigit msd_digit(const DepthLayout& L) {
@@ -791,8 +802,13 @@ template <int NT, int ITEMS>
 __global__ void __launch_bounds__(NT) depth_msd_scatter_kernel(const uint2* pairs, const uint32_t* n_dev,
                                                                 const unsigned long long* bits, uint32_t tag,
                                                                 const uint32_t* bases, const uint32_t* totals,
-                                                                const uint32_t* culled_rows, uint2* out, uint32_t* inst_sorted) {
+                                                                const uint32_t* culled_rows, uint2* out, uint32_t* inst_sorted,
+                                                                uint32_t* zero_a, int64_t n_a, uint32_t* zero_b, int64_t n_b) {
     constexpr int NW = NT / 64;
+    // (words the kernels behind the depth sort expect cleared: the block sums the range sort adds to, the hierarchical tile
+    // sort's header and counters)
+    for (int64_t t = (int64_t)blockIdx.x * NT + threadIdx.x; t < n_a; t += (int64_t)gridDim.x * NT) zero_a[t] = 0u;
+    for (int64_t t = (int64_t)blockIdx.x * NT + threadIdx.x; t < n_b; t += (int64_t)gridDim.x * NT) zero_b[t] = 0u;
     __shared__ uint32_t s_cnt[kMsdBuckets];      // slots of the bucket this block has handed out
     __shared__ uint32_t s_base[kMsdBuckets];     // bucket start + elements of the bucket in earlier blocks
     __shared__ uint32_t s_wave[NW], s_cwave[NW], s_cbefore[NW];
@@ -864,7 +880,8 @@ static_assert(kRangeThreads == kDepthBins, "one digit per thread: digits of up t
 __global__ void __launch_bounds__(kRangeThreads) depth_range_sort_kernel(const uint2* msd_sorted, uint2* scratch,
                                                                          const unsigned long long* bits, uint32_t tag,
                                                                          const uint32_t* totals, uint32_t* inst_sorted,
-                                                                         hs_counters* counters, int cap, int ibits, int dist_max) {
+                                                                         hs_counters* counters, int cap, int ibits, int dist_max,
+                                                                         GatherOut G) {
     constexpr int NW = kRangeThreads / 64;
     // the passes: per-wave digit counters -> per-wave offsets [NW][512], start of each digit's run (or, off chip, its running
     // global start) [512]; the distribution sort: members per bucket, next free slot, first slot [3][kDistBuckets]
@@ -872,9 +889,10 @@ __global__ void __launch_bounds__(kRangeThreads) depth_range_sort_kernel(const u
     static_assert(3 * kDistBuckets >= (NW + 1) * kDepthBins, "the passes' tables fit the distribution sort's");
     uint32_t (*const s_cnt)[kDepthBins] = reinterpret_cast<uint32_t (*)[kDepthBins]>(s_work);
     uint32_t* const s_dstart = s_work + NW * kDepthBins;
-    __shared__ uint32_t s_keys[kMsdCap], s_vals[kMsdCap];
+    __shared__ uint32_t s_keys[kMsdCap], s_vals[kMsdCap], s_fin[kMsdCap];
     __shared__ uint32_t s_wave[NW];
     __shared__ uint32_t s_r[2], s_b[2];
+    __shared__ uint32_t s_bs[64];   // pair counts [0, 32) and super-tile counts [32, 64) of the range's (up to 18) blocks of 256 positions
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x < 2) { s_r[threadIdx.x] = 0xFFFFFFFFu; s_b[threadIdx.x] = (uint32_t)kMsdBuckets; }
     // this workgroup's range: [first bucket start >= 2048 k, first bucket start >= 2048 (k + 1)) (n_vis when there is none)
@@ -895,7 +913,61 @@ __global__ void __launch_bounds__(kRangeThreads) depth_range_sort_kernel(const u
     }
     __syncthreads();
     const uint32_t r0 = min(s_r[0], n_vis), r1 = min(s_r[1], n_vis);
+    if (G.srect) {   // the culled instances behind the visible ones have no rectangle: every workgroup clears a slice of that tail
+        const uint32_t tail = G.n_all - n_vis, per = (tail + gridDim.x - 1) / gridDim.x;
+        const uint32_t a = n_vis + min(tail, blockIdx.x * per), b = n_vis + min(tail, blockIdx.x * per + per);
+        for (uint32_t t = a + threadIdx.x; t < b; t += kRangeThreads) G.srect[t] = make_uint2(0u, 0u);
+    }
     if (r0 >= r1) return;
+    // On the way out: the range's instances in their final order (`fin`, LDS) -> the instance list; with G.srect also their
+    // rectangles and the block sums (see GatherOut)
+    auto epilogue = [&](const uint32_t* fin, uint32_t n) {
+        if (!G.srect) {
+            for (uint32_t t = threadIdx.x; t < n; t += kRangeThreads) inst_sorted[r0 + t] = fin[t];
+            return;
+        }
+        const bool ok = counters->overflow < 2u;
+        const uint32_t g0 = r0 >> 8, slots = ((r0 + n - 1u) >> 8) - g0 + 1u;   // <= 18
+        if (threadIdx.x < 64) s_bs[threadIdx.x] = 0u;
+        __syncthreads();
+        // (a wave's 64 consecutive positions lie in one block of 256 or two: it adds them up itself and touches the LDS
+        // counters once or twice -- 512 threads adding to a dozen addresses would queue up behind each other)
+        for (uint32_t t0 = 0; t0 < n; t0 += kRangeThreads) {
+            const uint32_t t = t0 + threadIdx.x, pos = r0 + t;
+            uint2 rc = make_uint2(0u, 0u);
+            if (t < n) {
+                const uint32_t inst = fin[t];
+                inst_sorted[pos] = inst;
+                if (ok) rc = G.binfo[inst];
+                G.srect[pos] = rc;
+            }
+            uint32_t cnt = (rc.y & 0xFFFFu) * (rc.y >> 16), ccnt = 0;
+            if (G.bcsum) {
+                uint32_t sx0, sy0, sw, sh;
+                hier_coarse_rect(rc, sx0, sy0, sw, sh);
+                ccnt = sw * sh;
+            }
+            const uint32_t first_blk = __shfl(pos, 0) >> 8;
+            const bool hi = (pos >> 8) != first_blk;
+            uint32_t lo_c = hi ? 0u : cnt, hi_c = hi ? cnt : 0u, lo_cc = hi ? 0u : ccnt, hi_cc = hi ? ccnt : 0u;
+#pragma unroll
+            for (int dd = 32; dd >= 1; dd >>= 1) {
+                lo_c += __shfl_xor(lo_c, dd); hi_c += __shfl_xor(hi_c, dd);
+                lo_cc += __shfl_xor(lo_cc, dd); hi_cc += __shfl_xor(hi_cc, dd);
+            }
+            if (lane == 0) {
+                const uint32_t sl = first_blk - g0;
+                if (lo_c) atomicAdd(&s_bs[sl], lo_c);
+                if (hi_c) atomicAdd(&s_bs[sl + 1u], hi_c);
+                if (lo_cc) atomicAdd(&s_bs[32u + sl], lo_cc);
+                if (hi_cc) atomicAdd(&s_bs[32u + sl + 1u], hi_cc);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < slots && s_bs[threadIdx.x]) atomicAdd(&G.bsum[g0 + threadIdx.x], s_bs[threadIdx.x]);
+        if (G.bcsum && threadIdx.x >= 32u && threadIdx.x < 32u + slots && s_bs[threadIdx.x])
+            atomicAdd(&G.bcsum[g0 + threadIdx.x - 32u], s_bs[threadIdx.x]);
+    };
     {   // the range's first OCCUPIED bucket: the last of the buckets starting at r0 (those in front of it are empty)
 #pragma unroll
         for (int j = 0; j < kMsdBuckets / kRangeThreads; ++j) {
@@ -996,8 +1068,10 @@ __global__ void __launch_bounds__(kRangeThreads) depth_range_sort_kernel(const u
                     r += kq < k ? 1u : 0u;
                     if (kq == k) r += s_vals[q] < me ? 1u : 0u;   // equal keys: by instance number = in input order
                 }
-                inst_sorted[r0 + a + r] = me;
+                s_fin[a + r] = me;
             }
+            __syncthreads();
+            epilogue(s_fin, n);
             return;
         }
         __syncthreads();   // (the passes' tables overlay the distribution sort's)
@@ -1044,7 +1118,7 @@ __global__ void __launch_bounds__(kRangeThreads) depth_range_sort_kernel(const u
             }
         }
         // (a layout without a digit cannot happen: depth_layout_from gives at least one pass)
-        for (uint32_t t = threadIdx.x; t < n; t += kRangeThreads) inst_sorted[r0 + t] = s_vals[t];
+        epilogue(s_vals, n);
         return;
     }
     // ---- a range that does not fit: the same passes through memory, one chunk of kMsdCap elements after the other, this
@@ -1111,6 +1185,21 @@ __global__ void __launch_bounds__(kRangeThreads) depth_range_sort_kernel(const u
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         src = dst;
         dst = (dst == other) ? scratch + r0 : other;
+    }
+    if (G.srect) {   // (the scratch stretch IS this range's stretch of the rectangle buffer: free now)
+        const bool ok = counters->overflow < 2u;
+        for (uint32_t t = threadIdx.x; t < n; t += kRangeThreads) {
+            const uint32_t pos = r0 + t;
+            const uint2 rc = ok ? G.binfo[inst_sorted[pos]] : make_uint2(0u, 0u);
+            G.srect[pos] = rc;
+            const uint32_t cnt = (rc.y & 0xFFFFu) * (rc.y >> 16);
+            if (cnt) atomicAdd(&G.bsum[pos >> 8], cnt);
+            if (G.bcsum) {
+                uint32_t sx0, sy0, sw, sh;
+                hier_coarse_rect(rc, sx0, sy0, sw, sh);
+                if (sw * sh) atomicAdd(&G.bcsum[pos >> 8], sw * sh);
+            }
+        }
     }
 }
 
@@ -2233,6 +2322,12 @@ int launch_binning(const hs_fwd_args& a, const hs_layout& L, hipStream_t s, uint
     if (!prepared)
         depth_keys_kernel<<<ceil_div(I, 1024), 256, 0, s>>>(I, (const float*)(geom + L.depth), (const int*)(geom + L.radii), dp0,
                                                             depth_bits);
+    const int mode = tile_sort_mode(I, gx, gy, d.n_poses, d.capacity);
+    const int eblk = ceil_div(I, 256);
+    // The rectangles in depth order and the sums per 256 instances of that order, which the emission's offsets come from:
+    // written by the counting depth sort's last kernel on its way out, else by gather_binfo_kernel / hier_gather_kernel
+    bool gathered = false;
+    uint32_t* bsum = (uint32_t*)(dp0 + I);   // (= dp1: free once the depth sort is done)
     if (depth_sort_mode(I) == kDepthSortMsd) {
         // frames below 2^21 instances: one stable counting pass over the top varying bits + range sorts in LDS (kernels above)
         const int rows = (int)depth_msd_rows(I);
@@ -2243,13 +2338,31 @@ int launch_binning(const hs_fwd_args& a, const hs_layout& L, hipStream_t s, uint
         uint32_t* culled_rows = totals + kMsdBuckets;                       // [rows]
         depth_msd_count_kernel<4><<<rows, depth_msd_tile(I) / 4, 0, s>>>(dp0, n_inst, depth_bits, dtag, counts2, culled_rows);
         depth_msd_colscan_kernel<<<kMsdBuckets / 32, 1024, 0, s>>>(counts2, rows, (uint2*)bases, (uint2*)totals);
+        // the emission of a frame this size takes its rectangles gathered (unless HS_SCAN_IN_EMISSION=1 asks it to gather
+        // them itself): the range sort does that on its way out, the block sums live in the count rows (dead by then)
+        GatherOut G = {nullptr, nullptr, nullptr, nullptr, (uint32_t)I};
+        uint32_t* zero_b = nullptr;
+        int64_t n_zero_b = 0;
+        if (HS_TUNE_FUSE_GATHER && (mode == kTileSortHier || !scan_in_emission(I))) {
+            gathered = true;
+            bsum = counts2;
+            G.binfo = (const uint2*)(geom + L.binfo); G.srect = dp0; G.bsum = bsum;
+            if (mode == kTileSortHier) {
+                G.bcsum = bsum + eblk;
+                zero_b = (uint32_t*)(bin + L.hier_ws);
+                n_zero_b = HierWs(gx, gy, d.n_poses, d.capacity).zero_words;
+            }
+        }
+        const int64_t n_zero_a = gathered ? 2 * (int64_t)eblk : 0;
         if (depth_msd_tile(I) == 1024)
-            depth_msd_scatter_kernel<256, 4><<<rows, 256, 0, s>>>(dp0, n_inst, depth_bits, dtag, bases, totals, culled_rows, dp1, inst_sorted);
+            depth_msd_scatter_kernel<256, 4><<<rows, 256, 0, s>>>(dp0, n_inst, depth_bits, dtag, bases, totals, culled_rows, dp1, inst_sorted,
+                                                                  bsum, n_zero_a, zero_b, n_zero_b);
         else
-            depth_msd_scatter_kernel<512, 8><<<rows, 512, 0, s>>>(dp0, n_inst, depth_bits, dtag, bases, totals, culled_rows, dp1, inst_sorted);
+            depth_msd_scatter_kernel<512, 8><<<rows, 512, 0, s>>>(dp0, n_inst, depth_bits, dtag, bases, totals, culled_rows, dp1, inst_sorted,
+                                                                  bsum, n_zero_a, zero_b, n_zero_b);
         depth_range_sort_kernel<<<ceil_div(I, kMsdRange) + 1, kRangeThreads, 0, s>>>(dp1, dp0, depth_bits, dtag, totals, inst_sorted,
                                                                                      counters, depth_range_cap(),
-                                                                                     max(1, tile_bits((uint32_t)(I - 1))), depth_dist_max());
+                                                                                     max(1, tile_bits((uint32_t)(I - 1))), depth_dist_max(), G);
         HS_LAUNCH_CHECK();
     } else {
         const int nblk = ceil_div(I, kDepthTile);
@@ -2275,21 +2388,20 @@ int launch_binning(const hs_fwd_args& a, const hs_layout& L, hipStream_t s, uint
     uint2* pA = (uint2*)(bin + L.keys_sorted);
     uint2* pB = (uint2*)(bin + L.pairs_tmp);
     // small frames: counting sort by tile id (the kernels above); the emission then always writes buffer B
-    const int mode = tile_sort_mode(I, gx, gy, d.n_poses, d.capacity);
     if (mode == kTileSortHier) {
         // hierarchical form (kernels above).  Elements start in packed buffer A when the pass count is odd, so that the
         // sorted list ends in B: A's second half is point_list, which the expansion writes while it reads the list
         const HierWs W(gx, gy, d.n_poses, d.capacity);
         uint32_t* hw = (uint32_t*)(bin + L.hier_ws);
         const int kb = tile_bits((uint32_t)W.nst), cpasses = sort_passes(kb);
-        const int eblk = ceil_div(I, 256);
         uint2* srect = dp0;
-        uint32_t* bsum = (uint32_t*)dp1;
         uint32_t* bcsum = bsum + eblk;
         const bool big = I >= (2 << 20);
         uint32_t* ssum = big ? bcsum + eblk : nullptr;     // (big frames: sums of 1024 instances too, ceil(I / 1024) words each)
         uint32_t* scsum = big ? ssum + ceil_div(I, 1024) : nullptr;
-        if (big)
+        if (gathered) {
+            // (the counting depth sort left the rectangles, the sums and the cleared words)
+        } else if (big)
             hier_gather_kernel<1024><<<ceil_div(I, 1024), 1024, 0, s>>>(I, inst_sorted, (const uint2*)(geom + L.binfo), srect, counters,
                                                                         bsum, bcsum, ssum, scsum, hw, W.zero_words);
         else
@@ -2356,14 +2468,14 @@ int launch_binning(const hs_fwd_args& a, const hs_layout& L, hipStream_t s, uint
     uint32_t* t_totals = t_bases + (int64_t)ceil_div(I, 256) * ntiles; // [key]
     // (the depth sort's two buffers are free again: they hold the gathered rectangles and their block sums when the
     // offsets are computed ahead of the emission)
-    const int eblk = ceil_div(I, 256);
     uint2* srect = nullptr;
     uint32_t* block_excl = nullptr;
     bool excl_ready = false;
     if (!scan_in_emission(I)) {
         srect = dp0;
-        block_excl = (uint32_t*)dp1;
-        gather_binfo_kernel<<<eblk, 256, 0, s>>>(I, inst_sorted, (const uint2*)(geom + L.binfo), srect, counters, block_excl);
+        block_excl = bsum;
+        if (!gathered)
+            gather_binfo_kernel<<<eblk, 256, 0, s>>>(I, inst_sorted, (const uint2*)(geom + L.binfo), srect, counters, block_excl);
         excl_ready = eblk > 8192;
         if (excl_ready) scan_spine_kernel<<<1, 256, 0, s>>>(block_excl, eblk, nullptr);
     }
