@@ -647,14 +647,15 @@ int radix_sort_packed(uint2* p0, uint2* p1, uint32_t* keys_out, uint32_t* vals_o
 //   3. depth_msd_scatter_kernel: block b re-reads its elements and writes each to start of its bucket + elements of the
 //      bucket in earlier blocks + the slot an LDS atomic hands it: a counting sort by the top bits, stable from block to
 //      block and in no particular order inside a (block, bucket) group -- the elements carry their instance numbers, which
-//      ARE the input order, so step 4 can put equal keys right.  Culled instances (the all-ones key) are counted apart and go straight to the END of the
-//      instance list, in index order (the passes leave them among the largest visible keys; they have no pairs, so where
+//      ARE the input order, so step 4 can put equal keys right.  Culled instances (the all-ones key) are counted apart and
+//      go straight to the END of the instance list, in index order (the passes leave them among the largest visible keys; they have no pairs, so where
 //      they stand changes nothing downstream -- the order of the VISIBLE instances is the passes', bit for bit);
 //   4. depth_range_sort_kernel: workgroup k takes the buckets that START inside positions [2048 k, 2048 (k + 1)) -- whole
 //      buckets, so the range holds every key of its part of the key space -- and sorts them by (key, instance number) in
 //      LDS: a distribution sort when the keys spread evenly over the range's span (no bucket of its 2048 above 16 members),
 //      else stable least-significant-digit passes (the look-back passes' ranking, nothing published, nothing looked up)
-//      over instance numbers and keys: the instance list.
+//      over instance numbers and keys: the instance list -- and, on the way out, what the emission wants next to it: the
+//      instances' tile rectangles in that order and the sums per 256 of them (GatherOut below).
 //      A range of more than 4096 elements (a bucket of more than 2048: one 4096th of the key range holds that many
 //      instances) does not fit: its workgroup then runs the same passes through memory, chunk by chunk -- correct, slow,
 //      counted in hs_counters.reserved[2] so that the host can go back to the look-back passes (hs_depth_sort).
