@@ -858,6 +858,13 @@ def main():
             n_visible = int((ist["radii"] > 0).sum())
             line["config"]["tile_sort"] = {0: "radix passes over (tile, instance) pairs", 1: "counting (small frame)",
                                            2: "hierarchical: one pass over (super-tile, instance) elements + expansion"}[int(ist["tile_sort"])]
+            # which depth sort the frame got: by counting below 2^21 instances unless the process or the
+            # environment asked for the look-back passes
+            ds_env = os.environ.get("HS_DEPTH_SORT", "")[:1]
+            by_counting = cfg[0] * cfg[5] < (2 << 20) and (ds_env == "m" or (ds_env != "l" and L.load().hs_depth_sort(-1) == 1))
+            line["config"]["depth_sort"] = ("counting pass over the top 12 varying key bits + range sorts in LDS" if by_counting
+                                            else "look-back radix passes over the varying key bits")
+            line["config"]["depth_sort_ranges_off_chip"] = int(ist["depth_slow_ranges"])
             step_bytes = whole_step_bytes(cfg, R, Rp, vtiles, n_visible)
             step_gbs = step_bytes["total"] / (ms_per_step * 1e-3) / 1e9
             line["roofline"] = {
