@@ -882,7 +882,7 @@ __global__ void __launch_bounds__(kRangeThreads) depth_range_sort_kernel(const u
                                                                          const unsigned long long* bits, uint32_t tag,
                                                                          const uint32_t* totals, uint32_t* inst_sorted,
                                                                          hs_counters* counters, int cap, int ibits, int dist_max,
-                                                                         GatherOut G) {
+                                                                         GatherOut G, int range) {
     constexpr int NW = kRangeThreads / 64;
     // the passes: per-wave digit counters -> per-wave offsets [NW][512], start of each digit's run (or, off chip, its running
     // global start) [512]; the distribution sort: members per bucket, next free slot, first slot [3][kDistBuckets]
@@ -901,7 +901,7 @@ __global__ void __launch_bounds__(kRangeThreads) depth_range_sort_kernel(const u
     {
         // (thresholds behind the last element mean "the end": the first bucket starting there, so that the last range's
         // span stops with its last occupied bucket instead of running on to bucket 4095)
-        const uint32_t t0 = min(n_vis, (uint32_t)blockIdx.x * (uint32_t)kMsdRange), t1 = min(n_vis, t0 + (uint32_t)kMsdRange);
+        const uint32_t t0 = min(n_vis, (uint32_t)blockIdx.x * (uint32_t)range), t1 = min(n_vis, t0 + (uint32_t)range);
 #pragma unroll
         for (int j = 0; j < kMsdBuckets / kRangeThreads; ++j) {
             const int b = threadIdx.x * (kMsdBuckets / kRangeThreads) + j;
@@ -2361,9 +2361,10 @@ int launch_binning(const hs_fwd_args& a, const hs_layout& L, hipStream_t s, uint
         else
             depth_msd_scatter_kernel<512, 8><<<rows, 512, 0, s>>>(dp0, n_inst, depth_bits, dtag, bases, totals, culled_rows, dp1, inst_sorted,
                                                                   bsum, n_zero_a, zero_b, n_zero_b);
-        depth_range_sort_kernel<<<ceil_div(I, kMsdRange) + 1, kRangeThreads, 0, s>>>(dp1, dp0, depth_bits, dtag, totals, inst_sorted,
-                                                                                     counters, depth_range_cap(),
-                                                                                     max(1, tile_bits((uint32_t)(I - 1))), depth_dist_max(), G);
+        const int range = depth_msd_range(I);
+        depth_range_sort_kernel<<<ceil_div(I, range) + 1, kRangeThreads, 0, s>>>(dp1, dp0, depth_bits, dtag, totals, inst_sorted,
+                                                                                 counters, depth_range_cap(),
+                                                                                 max(1, tile_bits((uint32_t)(I - 1))), depth_dist_max(), G, range);
         HS_LAUNCH_CHECK();
     } else {
         const int nblk = ceil_div(I, kDepthTile);

@@ -129,7 +129,16 @@ int64_t sort_tmp_bytes(int64_t n);
 // depth_msd_tile(I) instances one row of kMsdBuckets u16 bucket counts | one row of u32 prefixes down the columns | the
 // bucket totals | the culled instances per block.  Every word is written before it is read: nothing to clear.
 constexpr int kMsdBits = 12, kMsdBuckets = 1 << kMsdBits;
-constexpr int kMsdRange = 2048, kMsdCap = 4096;   // a range-sort workgroup takes the buckets starting in its 2048 positions; <= 4096 elements stay in LDS
+#ifndef HS_TUNE_MSD_RANGE
+#define HS_TUNE_MSD_RANGE 2048
+#endif
+constexpr int kMsdRange = HS_TUNE_MSD_RANGE, kMsdCap = 4096;   // a range-sort workgroup takes the buckets starting in its 2048 positions; <= 4096 elements stay in LDS
+#ifndef HS_TUNE_MSD_SMALL_RANGE
+#define HS_TUNE_MSD_SMALL_RANGE 512
+#endif
+// (small frames: shorter ranges, i.e. more workgroups with less to do each -- 49 workgroups of 2048 instances leave most of the
+// GPU idle at BASELINE c2 while each walks its phases alone)
+static inline int depth_msd_range(int64_t I) { return I <= (1 << 18) ? HS_TUNE_MSD_SMALL_RANGE : kMsdRange; }
 static inline bool depth_msd_fits(int64_t I) { return I > 0 && I < (2 << 20); }
 static inline int depth_msd_tile(int64_t I) { return I <= (1 << 18) ? 1024 : 4096; }   // (<= 512 rows either way)
 static inline int64_t depth_msd_rows(int64_t I) { return (I + depth_msd_tile(I) - 1) / depth_msd_tile(I); }

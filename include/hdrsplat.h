@@ -313,7 +313,8 @@ HS_API int hs_render_stats(const hs_fwd_args* fwd /* or NULL */, const hs_bwd_ar
 
 /* The depth sort of HS_STAGE_BIN for frames of fewer than 2^21 instances, process-wide: 1 (default) = by counting -- one
  * stable counting pass over the top 12 varying bits of the depth keys (per-block bucket counts, a column scan, one
- * scatter), then every run of buckets of about 2048 instances sorted to the end by one workgroup inside its LDS; 0 = the
+ * scatter), then every run of buckets of about 2048 instances (512 up to 2^18 instances) sorted to the end by one workgroup
+ * inside its LDS; 0 = the
  * stable look-back radix passes larger frames always get.  Same result bit for bit (a stable sort has one).  The
  * counting form assumes that no 2048 consecutive positions of the bucket order spill over 4096 instances, i.e. that no
  * depth sliver of 1 / 4096 of the key range holds more than ~2048 instances; a range that does is sorted through memory by
