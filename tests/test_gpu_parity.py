@@ -734,6 +734,10 @@ def _depth_sort_case(name):
         behind = torch.rand(200_000, generator=torch.Generator().manual_seed(1)) < 0.9
         sc.means3D[behind, 2] = -sc.means3D[behind, 2]
         return sc, None, False, {}, False
+    if name == "all_culled":    # the camera looks away: no visible instance, no varying bit, nothing to sort
+        sc = S.make_scene(5_000, 320, 240, 0, seed=17)
+        sc.means3D[:, 2] = -sc.means3D[:, 2]
+        return sc, None, False, {}, False
     if name == "one_depth":     # every Gaussian at z = 5 exactly: no varying bit at all, ONE bucket of 20 000 equal keys
         sc = S.make_scene(20_000, 320, 240, 0, seed=19)
         k = 5.0 / sc.means3D[:, 2:3]
@@ -761,7 +765,7 @@ def _depth_sort_case(name):
     raise KeyError(name)
 
 
-@pytest.mark.parametrize("name", ["c2", "wild", "five_poses", "300k", "tiny", "mostly_culled", "one_depth", "two_depths", "wild_cap64",
+@pytest.mark.parametrize("name", ["c2", "wild", "five_poses", "300k", "tiny", "mostly_culled", "all_culled", "one_depth", "two_depths", "wild_cap64",
                                   "300k_cap2000", "c2_passes", "wild_passes", "c3"])
 def test_depth_sort_by_counting_equals_the_look_back_passes(name):
     """Round 6: frames below 2^21 instances sort their instances by depth with one stable counting pass over the top twelve
@@ -794,7 +798,7 @@ def test_depth_sort_by_counting_equals_the_look_back_passes(name):
     sa, sb = a["state"], b["state"]
     assert sa["depth_slow_ranges"] == 0 and (sb["depth_slow_ranges"] > 0) == off_chip, (sa["depth_slow_ranges"], sb["depth_slow_ranges"])
     R = sa["num_rendered"]
-    assert R == sb["num_rendered"] and (R > 0 or name == "tiny")
+    assert R == sb["num_rendered"] and (R > 0) == (name != "all_culled")
     vis = sa["radii"] > 0
     assert np.array_equal(vis, sb["radii"] > 0)
     ia, ib = sa["inst_sorted"].astype(np.int64), sb["inst_sorted"].astype(np.int64)
