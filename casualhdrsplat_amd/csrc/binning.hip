@@ -1696,7 +1696,7 @@ __global__ void __launch_bounds__(256) tile_keys_kernel(const uint2* ranges, int
 //   5. hier_count_kernel, one workgroup per chunk: pairs per tile of the super-tile and per wave (a wave takes 256
 //      consecutive elements: four +-1 corner marks per element into a 9 x 9 grid, then a 2-D prefix sum), and the tile
 //      totals (atomics: a dozen per address);
-//   6. hier_tiles_kernel (one workgroup): exclusive scan of the tile totals in tile-id order = ranges, first positions;
+//   6. hier_tiles_kernel (one workgroup per 1024 tiles): exclusive scan of the tile totals in tile-id order = ranges, first positions;
 //   7. hier_scatter_kernel, one workgroup per chunk: first position of (wave, tile) = start of the tile + pairs of the
 //      tile in the super-tile's earlier chunks (summed here from their rows) + in earlier waves; the waves then walk the
 //      pairs of their elements in element order (row-major inside the clipped rectangle) and hand out positions by
@@ -2033,9 +2033,13 @@ __global__ void __launch_bounds__(256) hier_count_kernel(const uint32_t* hier, c
 
 // ranges = exclusive scan of the tile totals in tile-id order (pose, row, column); tiles without pairs keep the (0, 0) they
 // were cleared to.  tile_start[(pose, super-tile) key * 64 + tile inside it] = first sorted position.  One workgroup per
-// 8192 tiles (BASELINE c3: one); a workgroup adds up the totals in front of its tiles itself (c4: 65 280 tiles, eight
-// workgroups, at most 56 gathered loads per thread) -- no chain, no second kernel.
-constexpr int kHierTilesPerThread = 8, kHierTilesPerBlock = 1024 * kHierTilesPerThread;
+// 1024 tiles (BASELINE c3: eight; one workgroup per 8192 took 10.5 us there against 6.1: the launch is all latency, and a
+// thread with one tile has one load and one store on its critical path); a workgroup adds up the totals in front of its tiles
+// itself (c4: 65 280 tiles, 64 workgroups, at most 63 gathered loads per thread) -- no chain, no second kernel.
+#ifndef HS_TUNE_HIER_TILES_E
+#define HS_TUNE_HIER_TILES_E 1   // tiles per thread (measured, kernel us at c3 / c4: 8 -> 10.5 / 28.4, 2 -> 6.6 / 24.3, 1 -> 6.1 / 23.5)
+#endif
+constexpr int kHierTilesPerThread = HS_TUNE_HIER_TILES_E, kHierTilesPerBlock = 1024 * kHierTilesPerThread;
 __device__ __forceinline__ uint32_t hier_tile_slot(uint32_t t, uint32_t tpp, uint32_t gx, int sgx, int sgy) {
     const uint32_t pose = t / tpp, rem = t - pose * tpp, ty = rem / gx, tx = rem - ty * gx;
     return (pose * (uint32_t)(sgx * sgy) + (ty / kSuper) * (uint32_t)sgx + tx / kSuper) * 64u + (ty % kSuper) * 8u + tx % kSuper;
